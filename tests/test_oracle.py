@@ -1,0 +1,124 @@
+"""CPU tests (-m "not gpu"): the oracle against the committed golden vectors.
+
+oracle/pasta.py (big-int) is pinned to the published pasta_curves constants; oracle/cpu_ref.cpp
+(4 x u64 Montgomery restatement of best_multiexp / best_fft) is pinned to pasta.py through the
+golden vectors.  The reference's own tests hold no value-level vectors for this path
+(/root/reference/src/test_utils.rs:6-71 asserts only that the verifier accepts).
+"""
+import numpy as np
+import pytest
+
+import cpu_ref
+import pasta as o
+from common import load_json, load_npz, unhex, unhex_rows
+
+FIELDS = ["fp", "fq"]
+CURVES = ["pallas", "vesta"]
+
+
+def test_published_constants():
+    o.check_published_constants()
+    for c in o.CURVES.values():
+        assert c.is_on_curve(c.generator)
+        assert c.mul(c.scalar.m, c.generator) is None
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_field_kat_cpu_ref(field):
+    kat = load_json("field_kat.json")[field]
+    f = o.FIELDS[field]
+    a = unhex_rows([r["a"] for r in kat["rows"]])
+    b = unhex_rows([r["b"] for r in kat["rows"]])
+    for op in ("add", "sub", "mul"):
+        got = cpu_ref.field_op(field, op, a, b)
+        assert (got == unhex_rows([r[op] for r in kat["rows"]])).all(), op
+    for op in ("sqr", "neg", "inv"):
+        got = cpu_ref.field_op(field, op, a)
+        assert (got == unhex_rows([r[op] for r in kat["rows"]])).all(), op
+    # to_repr(): Montgomery -> canonical limbs and back
+    can = cpu_ref.field_op(field, "from_mont", a)
+    assert (can == unhex_rows([r["a_canonical"] for r in kat["rows"]])).all()
+    assert (cpu_ref.field_op(field, "to_mont", can) == a).all()
+    # the big-int oracle reproduces its own fixtures (guards against fixture rot)
+    for r in kat["rows"][:8]:
+        x, y = f.from_limbs(unhex(r["a"])), f.from_limbs(unhex(r["b"]))
+        assert f.limbs(f.mul(x, y)) == [int(v) for v in unhex(r["mul"])]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_curve_kat_cpu_ref(curve):
+    kat = load_json("curve_kat.json")[curve]
+    for case in kat["add_cases"]:
+        pj, qj = unhex(case["p_jac"]), unhex(case["q_jac"])
+        want = unhex(case["sum_affine"])
+        assert (cpu_ref.to_affine(curve, cpu_ref.point_op(curve, "add", pj, qj)) == want).all()
+        assert (cpu_ref.to_affine(curve, cpu_ref.point_op(curve, "madd", pj, unhex(case["q_affine"]))) == want).all()
+        assert (cpu_ref.to_affine(curve, cpu_ref.point_op(curve, "dbl", pj)) == unhex(case["dbl_p_affine"])).all()
+        assert (cpu_ref.to_affine(curve, pj) == unhex(case["p_affine"])).all()
+    for case in kat["mul_cases"]:
+        got = cpu_ref.scalar_mul(curve, unhex(case["base"]), unhex(case["k_canonical"]))
+        assert (cpu_ref.to_affine(curve, got) == unhex(case["result_affine"])).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_msm_kat_cpu_ref(curve, threads):
+    kat = load_json("msm_kat.json")[curve]
+    for case in kat["cases"]:
+        got = cpu_ref.best_multiexp(curve, unhex_rows(case["scalars"]), unhex_rows(case["bases"]), threads)
+        assert (cpu_ref.to_affine(curve, got) == unhex(case["result_affine"])).all(), case["n"]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_recipes_cpu_ref(curve):
+    import importlib
+    synth = importlib.import_module("tiny_ram_halo2_amd.synth")
+    kat = load_json("msm_kat.json")[curve]
+    for rec in kat["recipes"]:
+        sc = synth.field_elements(rec["seed"], rec["n"])
+        bases = cpu_ref.gen_bases(curve, rec["s0"], rec["d"], rec["n"], threads=4)
+        got = cpu_ref.best_multiexp(curve, sc, bases, threads=4)
+        assert (cpu_ref.to_affine(curve, got) == unhex(rec["result_affine"])).all(), rec["n"]
+
+
+def test_msm_length_mismatch_asserts():
+    # reference: assert_eq!(coeffs.len(), bases.len()) panics
+    with pytest.raises(AssertionError):
+        cpu_ref.best_multiexp("pallas", np.zeros((3, 4), np.uint64), np.zeros((2, 8), np.uint64))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("threads", [1, 8])
+def test_ntt_kat_cpu_ref(field, threads):
+    arr, meta = load_npz("ntt_kat.npz"), load_json("ntt_kat.json")
+    for log_n in (0, 1, 2, 3, 4, 10):
+        key = f"{field}_{log_n}"
+        fwd = cpu_ref.best_fft(field, arr[key + "_in"], unhex(meta[key]["omega"]), log_n, threads)
+        assert (fwd == arr[key + "_fwd"].reshape(-1, 4)).all(), key
+        inv = cpu_ref.best_fft(field, fwd, unhex(meta[key]["omega_inv"]), log_n, threads)
+        assert (inv == arr[key + "_inv_unscaled"].reshape(-1, 4)).all(), key
+        n = 1 << log_n
+        ninv = np.tile(unhex(meta[key]["n_inv"]), (n, 1))
+        assert (cpu_ref.field_op(field, "mul", inv, ninv) == arr[key + "_in"].reshape(-1, 4)).all()
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_roundtrip_and_horner_2_16(field):
+    """size-independent properties at a larger size: inverse(forward(a)) * n^-1 == a and
+    a'[i] == poly(omega^i) by Horner at a few i (big-int)."""
+    import importlib
+    synth = importlib.import_module("tiny_ram_halo2_amd.synth")
+    f = o.FIELDS[field]
+    log_n = 16
+    a = synth.ntt_input(log_n)
+    w = f.omega(log_n)
+    fwd = cpu_ref.best_fft(field, a, np.array(f.limbs(w), np.uint64), log_n, threads=8)
+    coeffs = [f.from_limbs(r) for r in a]
+    for i in (0, 1, 12345, (1 << log_n) - 1):
+        x, acc = pow(w, i, f.m), 0
+        for cf in reversed(coeffs):
+            acc = (acc * x + cf) % f.m
+        assert f.from_limbs(fwd[i]) == acc
+    inv = cpu_ref.best_fft(field, fwd, np.array(f.limbs(f.inv(w)), np.uint64), log_n, threads=8)
+    ninv = np.tile(np.array(f.limbs(f.inv(1 << log_n)), np.uint64), (1 << log_n, 1))
+    assert (cpu_ref.field_op(field, "mul", inv, ninv) == a).all()
