@@ -1,0 +1,25 @@
+# Builds libtrh.so (HIP kernels + C ABI, gfx950 only) and the oracle's C++ restatement.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+PKG := tiny-ram-halo2_amd
+CSRC := $(PKG)/csrc
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-result
+OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o
+HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h include/trh.h
+
+all: $(PKG)/libtrh.so oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PKG)/libtrh.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+oracle:
+	$(MAKE) -s -C oracle libtrh_oracle.so
+
+clean:
+	rm -f $(OBJS) $(PKG)/libtrh.so
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,144 @@
+/* trh.h -- C ABI of libtrh.so, the MI355X (gfx950) backend for the MSM / NTT / IPA-commitment
+ * hot path of halo2_proofs as driven by the tiny-ram-halo2 TinyRAM circuit.
+ *
+ * The reference has no FFI of its own: the seam is the set of Rust functions that
+ * `halo2_proofs::plonk::create_proof` calls (reference call sites
+ * /root/reference/src/test_utils.rs:21, 23-25, 41-49, 89-104; crate pinned at
+ * /root/reference/Cargo.lock:619-621, pasta_curves at :847-858).  Each entry point below names
+ * the Rust interface it replaces.  INTEGRATION.md shows the `extern "C"` block a maintainer
+ * adds to the halo2_proofs fork.
+ *
+ * Data formats (identical to the Rust in-memory layout, so slices cross without repacking):
+ *   field element  4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced
+ *                  -- `pasta_curves::Fp` / `Fq`.
+ *   affine base    8 x u64: x[4], y[4]; the all-zero pattern is the identity.  (pasta's
+ *                  `Affine` carries a separate flag: the Rust shim repacks, see INTEGRATION.md.)
+ *   point result   12 x u64: Jacobian X[4], Y[4], Z[4] as in pasta's `Point`, normalised to
+ *                  Z = 1; the identity is all-zero.
+ * Curves: pallas (base Fp, scalar Fq), vesta (base Fq, scalar Fp; `EqAffine`, the curve the
+ * reference proves over).  Fields: fp, fq.
+ *
+ * Errors: every function returns 0 on success or a negative TRH_E* code; the message is
+ * available from trh_last_error() (thread-local).  Nothing aborts or throws across the ABI;
+ * the Rust shim maps a non-zero return to the panic the reference would raise.
+ * Threading: entry points may be called concurrently from several host threads; calls are
+ * serialised per device context.
+ * There is no CPU fallback: without a usable HIP device trh_init() fails and every compute
+ * entry point returns TRH_ENODEV.
+ */
+#ifndef TRH_H
+#define TRH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRH_OK 0
+#define TRH_EINVAL (-1)   /* bad argument (the Rust side panics on these: length mismatch, n != 1<<log_n) */
+#define TRH_ENODEV (-2)   /* no HIP device / trh_init not called */
+#define TRH_EHIP (-3)     /* HIP runtime error */
+#define TRH_ENOMEM (-4)
+
+#define TRH_PALLAS 0
+#define TRH_VESTA 1
+#define TRH_FP 0
+#define TRH_FQ 1
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int trh_init(int device);            /* binds the calling process to one GPU; idempotent */
+void trh_shutdown(void);
+const char* trh_last_error(void);
+int trh_device_count(void);
+const char* trh_version(void);
+
+/* ---- halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------------
+ * coeffs: n x 4 u64 (scalar field, Montgomery -- the memory image of `&[C::Scalar]`),
+ * bases: n x 8 u64 affine, out: 12 u64.  Host pointers; data is copied to the device.     */
+int trh_best_multiexp_pallas(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
+int trh_best_multiexp_vesta(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
+
+/* ---- halo2_proofs::arithmetic::best_fft(a, omega, log_n) ---------------------------------
+ * a: 2^log_n x 4 u64 in place, natural order in and out; omega: 4 u64 Montgomery, must be a
+ * primitive 2^log_n-th root of unity (what EvaluationDomain passes).  Host pointers.       */
+int trh_best_fft_fp(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+int trh_best_fft_fq(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+
+/* ---- device-resident base sets: poly::commitment::Params { g, g_lagrange, w } -------------
+ * `Params::commit` / `commit_lagrange` run hundreds of MSMs over the same bases; upload once. */
+typedef struct trh_bases* trh_bases_t;
+int trh_bases_create_pallas(const uint64_t* xy_host, size_t n, trh_bases_t* out);
+int trh_bases_create_vesta(const uint64_t* xy_host, size_t n, trh_bases_t* out);
+/* wrap n bases already in device memory (no copy, not owned) */
+int trh_bases_wrap_device(int curve, const void* xy_dev, size_t n, trh_bases_t* out);
+/* synthetic set P_i = (s0 + (first + i) * d) * G, G = (-1, 2), generated on the device */
+int trh_bases_generate(int curve, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out);
+int trh_bases_download(trh_bases_t b, size_t offset, size_t n, uint64_t* xy_host);
+const void* trh_bases_device_ptr(trh_bases_t b);
+size_t trh_bases_len(trh_bases_t b);
+void trh_bases_destroy(trh_bases_t b);
+
+/* MSM over bases[offset .. offset+n) with host scalars (Params::commit / commit_lagrange) */
+int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n,
+            int scalars_are_montgomery, uint64_t out_xyz[12]);
+/* same with scalars already in device memory, enqueued on `stream` (a hipStream_t, may be 0);
+ * synchronises the stream before returning the point to the host.                           */
+int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
+                int scalars_are_montgomery, void* stream, uint64_t out_xyz[12]);
+/* asynchronous halves of trh_msm_dev: enqueue leaves the per-window sums on the device,
+ * finish synchronises, folds the windows on the host and returns the point.                 */
+int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
+                        int scalars_are_montgomery, void* stream);
+int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
+/* batch of MSMs over the same bases (one per column): scalars_dev holds batch x n x 4 u64 */
+int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch,
+                      int scalars_are_montgomery, void* stream, uint64_t* out_xyz /* batch x 12 */);
+/* window width override for tuning (0 = automatic) */
+int trh_msm_set_window_bits(int c);
+
+/* sum of `count` points (Jacobian 12 x u64 each) on the host: combines the per-GPU partial
+ * results of a range-sharded MSM after the all-gather.                                       */
+int trh_point_sum(int curve, const uint64_t* points_xyz, size_t count, uint64_t out_xyz[12]);
+
+/* ---- NTT on device memory (EvaluationDomain call sites) ----------------------------------- */
+int trh_ntt_dev(int field, void* a_dev, uint32_t log_n, const uint64_t omega[4], size_t batch, void* stream);
+/* a[i] *= factor (e.g. n^-1 after an inverse transform), device memory */
+int trh_field_scale_dev(int field, void* a_dev, size_t n, const uint64_t factor[4], void* stream);
+/* a[i] *= factors[i % period] (factors: period x 4 u64, host memory, period <= 64).  Covers
+ * halo2's `distribute_powers_zeta` coset shift (period 3: 1, zeta, zeta^2) and
+ * `divide_by_vanishing_poly` (period 2^(extended_k - k) table of (X^n - 1)^-1 values).        */
+int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_t* factors, uint32_t period, void* stream);
+
+/* ---- element-wise field / group ops on device memory (parity tests of the device arithmetic;
+ *      op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv, 6 to_mont, 7 from_mont) ------------------ */
+int trh_field_op_dev(int field, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);
+/* op: 0 out = p + q (both Jacobian 12 x u64), 1 out = p + q (q affine 8 x u64), 2 out = 2p;
+ * out Jacobian normalised */
+int trh_point_op_dev(int curve, int op, const void* p_dev, const void* q_dev, void* out_dev, size_t n, void* stream);
+
+/* ---- plain device memory helpers so that non-HIP hosts (Rust, ctypes) can stage buffers ---- */
+int trh_malloc(void** dev, size_t bytes);
+int trh_free(void* dev);
+int trh_memcpy_h2d(void* dev, const void* host, size_t bytes);
+int trh_memcpy_d2h(void* host, const void* dev, size_t bytes);
+int trh_stream_synchronize(void* stream);
+
+/* ---- timing of the last MSM / NTT on this context (HIP events on the launch stream) -------- */
+typedef struct trh_timing {
+    float total_ms;        /* first kernel start -> last kernel end */
+    float digits_ms;       /* MSM: scalar recode + histogram */
+    float sort_ms;         /* MSM: bucket offsets + scatter */
+    float accumulate_ms;   /* MSM: bucket accumulation (the dominant kernel) */
+    float reduce_ms;       /* MSM: bucket reduction + window sums */
+    int window_bits;
+    int windows;
+} trh_timing_t;
+int trh_set_timing(int enabled);
+int trh_last_timing(trh_timing_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRH_H */

@@ -1,0 +1,299 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libtrh.so, against the
+oracle (oracle/pasta.py big-int, oracle/cpu_ref.cpp restatement of best_multiexp / best_fft) and
+the committed golden vectors.  Bit-exact: every comparison is limb-for-limb equality.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import cpu_ref
+import pasta as o
+from common import load_json, load_npz, unhex, unhex_rows
+from tiny_ram_halo2_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["fp", "fq"]
+CURVES = ["pallas", "vesta"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    api.init(0)
+    yield
+
+
+def aff(curve, jac):
+    return cpu_ref.to_affine(curve, jac)
+
+
+# ---------------------------------------------------------------------------------------
+# K1 / K2: field and group arithmetic on the device
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("field", FIELDS)
+def test_field_ops_golden(field):
+    kat = load_json("field_kat.json")[field]
+    a = unhex_rows([r["a"] for r in kat["rows"]])
+    b = unhex_rows([r["b"] for r in kat["rows"]])
+    for op in ("add", "sub", "mul"):
+        assert (api.field_op_dev(field, op, a, b) == unhex_rows([r[op] for r in kat["rows"]])).all(), op
+    for op in ("sqr", "neg", "inv"):
+        assert (api.field_op_dev(field, op, a) == unhex_rows([r[op] for r in kat["rows"]])).all(), op
+    can = api.field_op_dev(field, "from_mont", a)
+    assert (can == unhex_rows([r["a_canonical"] for r in kat["rows"]])).all()
+    assert (api.field_op_dev(field, "to_mont", can) == a).all()
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_field_ops_random_vs_cpu(field):
+    n = 1 << 16
+    f = o.FIELDS[field]
+    a = synth.field_elements(0xF1E1D + f.m % 97, n)
+    b = synth.field_elements(0xF1E1E + f.m % 97, n)
+    # make them proper residues (< m) -- the stream is < 2^254 < m already
+    for op in ("add", "sub", "mul"):
+        assert (api.field_op_dev(field, op, a, b) == cpu_ref.field_op(field, op, a, b)).all(), op
+    for op in ("sqr", "neg", "from_mont", "to_mont"):
+        assert (api.field_op_dev(field, op, a) == cpu_ref.field_op(field, op, a)).all(), op
+    assert (api.field_op_dev(field, "inv", a[:2048]) == cpu_ref.field_op(field, "inv", a[:2048])).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_point_ops_golden(curve):
+    kat = load_json("curve_kat.json")[curve]
+    pj = unhex_rows([c["p_jac"] for c in kat["add_cases"]])
+    qj = unhex_rows([c["q_jac"] for c in kat["add_cases"]])
+    qa = unhex_rows([c["q_affine"] for c in kat["add_cases"]])
+    want = unhex_rows([c["sum_affine"] for c in kat["add_cases"]])
+    want_dbl = unhex_rows([c["dbl_p_affine"] for c in kat["add_cases"]])
+    assert (api.point_op_dev(curve, "add", pj, qj)[:, :8] == want).all()
+    assert (api.point_op_dev(curve, "madd", pj, qa)[:, :8] == want).all()
+    assert (api.point_op_dev(curve, "dbl", pj)[:, :8] == want_dbl).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_bases_generate(curve):
+    n = 3000
+    b = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n, first=5)
+    got = b.download()
+    want = cpu_ref.gen_bases(curve, synth.BASE_S0 + 5 * synth.BASE_D, synth.BASE_D, n, threads=4)
+    assert (got == want).all()
+
+
+# ---------------------------------------------------------------------------------------
+# K3: MSM
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_golden_cases(curve):
+    kat = load_json("msm_kat.json")[curve]
+    for case in kat["cases"]:
+        got = api.best_multiexp(curve, unhex_rows(case["scalars"]), unhex_rows(case["bases"]))
+        assert (got[:8] == unhex(case["result_affine"])).all(), case["n"]
+    for rec in kat["recipes"]:
+        sc = synth.field_elements(rec["seed"], rec["n"])
+        bases = api.Bases.generate(curve, rec["s0"], rec["d"], rec["n"])
+        got = bases.msm(sc)
+        assert (got[:8] == unhex(rec["result_affine"])).all(), rec["n"]
+
+
+def test_msm_empty():
+    got = api.best_multiexp("pallas", np.zeros((0, 4), np.uint64), np.zeros((0, 8), np.uint64))
+    assert (got == 0).all()
+
+
+def test_msm_length_mismatch_asserts():
+    with pytest.raises(AssertionError):
+        api.best_multiexp("pallas", np.zeros((3, 4), np.uint64), np.zeros((2, 8), np.uint64))
+
+
+def _edge_inputs(curve, n, seed):
+    """random scalars/bases with the reference-relevant edge cases mixed in"""
+    f = o.CURVES[curve].scalar
+    sc = synth.field_elements(seed, n)
+    bases = cpu_ref.gen_bases(curve, 0xABCDEF + seed % 1000, 0x1357, n, threads=4)
+    if n >= 16:
+        sc[0] = 0                                                   # zero scalar (Montgomery 0)
+        sc[1] = np.array(f.limbs(f.m - 1), np.uint64)               # -1
+        sc[2] = np.array(f.limbs(1), np.uint64)                     # 1
+        bases[3] = 0                                                # identity base
+        bases[5] = bases[4]; sc[5] = sc[4]                          # duplicate pair, same scalar
+        bases[7] = bases[6]; bases[7][4:] = cpu_ref.field_op(o.CURVES[curve].base.name, "neg", bases[6][4:].reshape(1, 4))[0]
+        sc[7] = sc[6]                                               # P and -P cancel
+        sc[9] = sc[2]; sc[10] = sc[2]; bases[10] = bases[9]         # 1*P + 1*P: doubling inside a bucket
+    return sc, bases
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 1000, 4097, 1 << 14])
+def test_msm_vs_cpu_ref(curve, n):
+    sc, bases = _edge_inputs(curve, n, 0x5EED + n)
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
+    got = api.best_multiexp(curve, sc, bases)
+    assert (got[:8] == want).all()
+    one = np.array(o.CURVES[curve].base.limbs(1), np.uint64)
+    assert (got[8:] == (one if want.any() else 0)).all()
+
+
+@pytest.mark.parametrize("cbits", [2, 3, 5, 8, 11, 13, 15, 16])
+def test_msm_window_widths(cbits):
+    """every window width must give the same group element (exercises the signed recoding,
+    including widths that divide 255 and leave a carry-only top window)"""
+    curve, n = "pallas", 3000
+    sc, bases = _edge_inputs(curve, n, 0xC0FFEE)
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
+    try:
+        api.set_window_bits(cbits)
+        got = api.best_multiexp(curve, sc, bases)
+    finally:
+        api.set_window_bits(0)
+    assert (got[:8] == want).all()
+
+
+def test_msm_canonical_scalars_and_offset():
+    curve, n = "vesta", 2048
+    sc, bases = _edge_inputs(curve, n, 0xCA11)
+    can = cpu_ref.field_op("fp", "from_mont", sc)
+    b = api.Bases.from_host(curve, bases)
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc[100:1100], bases[100:1100], threads=8))
+    assert (b.msm(can[100:1100], offset=100, montgomery=False)[:8] == want).all()
+    assert (b.msm(sc[100:1100], offset=100, montgomery=True)[:8] == want).all()
+    with pytest.raises(api.TrhError):
+        b.msm(sc, offset=1)  # range exceeds the resident bases
+
+
+def test_msm_all_same_base_skewed():
+    """all scalars small and all bases equal: every pair lands in a handful of buckets"""
+    curve, n = "pallas", 5000
+    f = o.CURVES[curve].scalar
+    vals = [(i % 3) for i in range(n)]
+    sc = np.array([f.limbs(v) for v in vals], np.uint64)
+    g = np.array(o.CURVES[curve].affine_limbs(o.CURVES[curve].generator), np.uint64)
+    bases = np.tile(g, (n, 1))
+    got = api.best_multiexp(curve, sc, bases)
+    want = o.CURVES[curve].mul(sum(vals), o.CURVES[curve].generator)
+    assert o.CURVES[curve].affine_from_limbs(got[:8]) == want
+
+
+@pytest.mark.parametrize("log_n", [16, 20])
+def test_msm_closed_form(log_n):
+    """BASELINE config 2 (2^20 Pallas MSM): bases P_i = (s0 + i d) G so the expected result is
+    (sum_i s_i (s0 + i d) mod q) G -- a size-independent check; at 2^16 also vs the CPU restatement."""
+    curve = "pallas"
+    n = 1 << log_n
+    f = o.CURVES[curve].scalar
+    sc = synth.msm_scalars(log_n)
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+    got = bases.msm(sc)
+    can = cpu_ref.field_op("fq", "from_mont", sc)
+    total = synth.weighted_scalar_sum(can, synth.BASE_S0, synth.BASE_D) % f.m
+    g = np.array(o.CURVES[curve].affine_limbs(o.CURVES[curve].generator), np.uint64)
+    want = aff(curve, cpu_ref.scalar_mul(curve, g, np.array(o.int_to_limbs(total), np.uint64)))
+    assert (got[:8] == want).all()
+    if log_n <= 16:
+        want2 = aff(curve, cpu_ref.best_multiexp(curve, sc, bases.download(), threads=8))
+        assert (got[:8] == want2).all()
+
+
+def test_msm_batch_dev():
+    curve, n, batch = "vesta", 1500, 5
+    bases_h = cpu_ref.gen_bases(curve, 77, 3, n, threads=4)
+    b = api.Bases.from_host(curve, bases_h)
+    sc = synth.field_elements(0xBA7C4, n * batch).reshape(batch, n, 4)
+    d = api.DeviceBuffer.from_host(sc)
+    got = b.msm_batch_dev(d, n, batch)
+    for k in range(batch):
+        want = aff(curve, cpu_ref.best_multiexp(curve, sc[k], bases_h, threads=8))
+        assert (got[k, :8] == want).all(), k
+
+
+def test_point_sum_shards_equal_whole():
+    """range-sharded MSM (the multi-GPU decomposition) == whole MSM"""
+    curve, n, g = "pallas", 6000, 4
+    sc, bases = _edge_inputs(curve, n, 0x5A4D)
+    b = api.Bases.from_host(curve, bases)
+    whole = b.msm(sc)
+    per = n // g
+    parts = np.stack([b.msm(sc[r * per:(r + 1) * per], offset=r * per) for r in range(g)])
+    assert (api.point_sum(curve, parts) == whole).all()
+
+
+# ---------------------------------------------------------------------------------------
+# K4: NTT
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_golden(field):
+    arr, meta = load_npz("ntt_kat.npz"), load_json("ntt_kat.json")
+    for log_n in (0, 1, 2, 3, 4, 10):
+        key = f"{field}_{log_n}"
+        fwd = api.best_fft(field, arr[key + "_in"], unhex(meta[key]["omega"]), log_n)
+        assert (fwd == arr[key + "_fwd"].reshape(-1, 4)).all(), key
+        inv = api.best_fft(field, fwd, unhex(meta[key]["omega_inv"]), log_n)
+        assert (inv == arr[key + "_inv_unscaled"].reshape(-1, 4)).all(), key
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 11, 12, 13, 16, 18, 19, 20])
+def test_ntt_vs_cpu_ref(field, log_n):
+    f = o.FIELDS[field]
+    a = synth.field_elements(0x4E5454 + log_n, 1 << log_n)
+    w = np.array(f.limbs(f.omega(log_n)), np.uint64)
+    got = api.best_fft(field, a, w, log_n)
+    want = cpu_ref.best_fft(field, a, w, log_n, threads=8)
+    assert (got == want).all()
+
+
+def test_ntt_2_22_roundtrip_and_spot_values():
+    """BASELINE config 3 (2^22 Fp NTT): bit-exact vs the CPU restatement, inverse round trip and
+    Horner spot checks against the big-int oracle."""
+    field, log_n = "fp", 22
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    a = synth.ntt_input(log_n)
+    w = f.omega(log_n)
+    wl = np.array(f.limbs(w), np.uint64)
+    d = api.DeviceBuffer.from_host(a)
+    api.ntt_dev(field, d, log_n, wl)
+    fwd = d.to_host(shape=(-1, 4))
+    assert (fwd == cpu_ref.best_fft(field, a, wl, log_n, threads=8)).all()
+    coeffs = [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in a[:]]
+    rinv = pow(f.R, -1, f.m)
+    coeffs = [c * rinv % f.m for c in coeffs]
+    for i in (0, 1, 3 * 2 ** 20 + 17):
+        x, acc = pow(w, i, f.m), 0
+        for cf in reversed(coeffs):
+            acc = (acc * x + cf) % f.m
+        assert f.from_limbs(fwd[i]) == acc
+    api.ntt_dev(field, d, log_n, np.array(f.limbs(f.inv(w)), np.uint64))
+    api.field_scale_dev(field, d, n, np.array(f.limbs(f.inv(n)), np.uint64))
+    api.lib().trh_stream_synchronize(None)
+    assert (d.to_host(shape=(-1, 4)) == a).all()
+
+
+def test_ntt_batch_and_linearity():
+    field, log_n, batch = "fq", 13, 6
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    a = synth.field_elements(0xBA7C5, n * batch).reshape(batch, n, 4)
+    w = np.array(f.limbs(f.omega(log_n)), np.uint64)
+    d = api.DeviceBuffer.from_host(a)
+    api.ntt_dev(field, d, log_n, w, batch=batch)
+    got = d.to_host(shape=(batch, n, 4))
+    for k in range(batch):
+        assert (got[k] == cpu_ref.best_fft(field, a[k], w, log_n, threads=8)).all(), k
+    # linearity: NTT(a0 + a1) == NTT(a0) + NTT(a1)
+    s = cpu_ref.field_op(field, "add", a[0], a[1])
+    lhs = api.best_fft(field, s, w, log_n)
+    rhs = cpu_ref.field_op(field, "add", got[0], got[1])
+    assert (lhs == rhs).all()
+
+
+def test_scale_periodic():
+    field, n = "fp", 1000
+    f = o.FIELDS[field]
+    a = synth.field_elements(0x5CA1E, n)
+    facs = np.array([f.limbs(1), f.limbs(f.ZETA), f.limbs(f.ZETA * f.ZETA % f.m)], np.uint64)
+    d = api.DeviceBuffer.from_host(a)
+    api.field_scale_periodic_dev(field, d, n, facs)
+    api.lib().trh_stream_synchronize(None)
+    want = cpu_ref.field_op(field, "mul", a, facs[np.arange(n) % 3])
+    assert (d.to_host(shape=(-1, 4)) == want).all()

@@ -1,0 +1,330 @@
+"""ctypes binding of libtrh.so plus a host-side mirror of the halo2_proofs interface for the
+MSM / NTT / commitment hot path (same names and argument meaning as the Rust functions the
+reference reaches through create_proof, /root/reference/src/test_utils.rs:21-49):
+
+    best_multiexp(coeffs, bases)            halo2_proofs::arithmetic::best_multiexp
+    best_fft(a, omega, log_n)               halo2_proofs::arithmetic::best_fft
+    Params(curve, g, g_lagrange, w, u)      halo2_proofs::poly::commitment::Params
+        .commit(poly, r) / .commit_lagrange(poly, r)
+    EvaluationDomain(field, k, j)           halo2_proofs::poly::EvaluationDomain
+        .lagrange_to_coeff / .coeff_to_extended / .extended_to_coeff
+
+Arrays are numpy uint64 (little-endian limbs, Montgomery form) on the host, or raw device
+pointers (ints / torch tensors' data_ptr()) for the *_dev forms.  The library has no CPU
+fallback: loading fails loudly if libtrh.so is missing, and every compute call raises
+TrhError when no MI355X is bound.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrh.so")
+
+PALLAS, VESTA = 0, 1
+FP, FQ = 0, 1
+CURVE_ID = {"pallas": PALLAS, "vesta": VESTA}
+FIELD_ID = {"fp": FP, "fq": FQ}
+# scalar field of each curve (pallas: base Fp / scalar Fq; vesta: base Fq / scalar Fp)
+SCALAR_FIELD = {"pallas": "fq", "vesta": "fp"}
+BASE_FIELD = {"pallas": "fp", "vesta": "fq"}
+FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "inv": 5, "to_mont": 6, "from_mont": 7}
+POINT_OPS = {"add": 0, "madd": 1, "dbl": 2}
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+
+
+class TrhError(RuntimeError):
+    pass
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_float), ("digits_ms", ctypes.c_float), ("sort_ms", ctypes.c_float),
+                ("accumulate_ms", ctypes.c_float), ("reduce_ms", ctypes.c_float),
+                ("window_bits", ctypes.c_int), ("windows", ctypes.c_int)]
+
+
+_SIGNATURES = {
+    "trh_init": ([ctypes.c_int], ctypes.c_int),
+    "trh_shutdown": ([], None),
+    "trh_last_error": ([], ctypes.c_char_p),
+    "trh_device_count": ([], ctypes.c_int),
+    "trh_version": ([], ctypes.c_char_p),
+    "trh_best_multiexp_pallas": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
+    "trh_best_multiexp_vesta": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
+    "trh_best_fft_fp": ([_u64p, _u64p, ctypes.c_uint32], ctypes.c_int),
+    "trh_best_fft_fq": ([_u64p, _u64p, ctypes.c_uint32], ctypes.c_int),
+    "trh_bases_create_pallas": ([_u64p, ctypes.c_size_t, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_bases_create_vesta": ([_u64p, ctypes.c_size_t, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_bases_wrap_device": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_bases_generate": ([ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_size_t, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_bases_download": ([_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p], ctypes.c_int),
+    "trh_bases_device_ptr": ([_vp], _vp),
+    "trh_bases_len": ([_vp], ctypes.c_size_t),
+    "trh_bases_destroy": ([_vp], None),
+    "trh_msm": ([_vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_int, _u64p], ctypes.c_int),
+    "trh_msm_dev": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp, _u64p], ctypes.c_int),
+    "trh_msm_dev_enqueue": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp], ctypes.c_int),
+    "trh_msm_dev_finish": ([_vp, _vp, _u64p], ctypes.c_int),
+    "trh_msm_batch_dev": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _vp, _u64p], ctypes.c_int),
+    "trh_msm_set_window_bits": ([ctypes.c_int], ctypes.c_int),
+    "trh_point_sum": ([ctypes.c_int, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
+    "trh_ntt_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_field_scale_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
+    "trh_field_scale_periodic_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp], ctypes.c_int),
+    "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
+    "trh_free": ([_vp], ctypes.c_int),
+    "trh_memcpy_h2d": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
+    "trh_memcpy_d2h": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
+    "trh_stream_synchronize": ([_vp], ctypes.c_int),
+    "trh_set_timing": ([ctypes.c_int], ctypes.c_int),
+    "trh_last_timing": ([ctypes.POINTER(Timing)], ctypes.c_int),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Loads libtrh.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrhError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback for the MSM/NTT path")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise TrhError(f"libtrh error {rc}: {lib().trh_last_error().decode()}")
+
+
+def init(device: int = 0):
+    _check(lib().trh_init(device))
+
+
+def shutdown():
+    lib().trh_shutdown()
+
+
+def _c(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a if cols is None else a.reshape(-1, cols)
+
+
+def _p(a):
+    return a.ctypes.data_as(_u64p)
+
+
+# ---------------------------------------------------------------------------------------
+# halo2_proofs::arithmetic
+# ---------------------------------------------------------------------------------------
+def best_multiexp(curve: str, coeffs, bases) -> np.ndarray:
+    """coeffs: (n, 4) Montgomery scalars, bases: (n, 8) affine.  Returns Jacobian (12,) with Z = 1."""
+    c, b = _c(coeffs, 4), _c(bases, 8)
+    assert c.shape[0] == b.shape[0]  # reference: assert_eq!(coeffs.len(), bases.len())
+    out = np.zeros(12, dtype=np.uint64)
+    fn = lib().trh_best_multiexp_pallas if curve == "pallas" else lib().trh_best_multiexp_vesta
+    _check(fn(_p(c), _p(b), c.shape[0], _p(out)))
+    return out
+
+
+def best_fft(field: str, a, omega, log_n: int) -> np.ndarray:
+    """In-place semantics of the Rust function; returns the transformed copy."""
+    a = _c(a, 4).copy()
+    assert a.shape[0] == 1 << log_n  # reference: assert_eq!(a.len(), 1 << log_n)
+    w = _c(omega).reshape(4)
+    fn = lib().trh_best_fft_fp if field == "fp" else lib().trh_best_fft_fq
+    _check(fn(_p(a), _p(w), log_n))
+    return a
+
+
+def point_sum(curve: str, points) -> np.ndarray:
+    pts = _c(points, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    _check(lib().trh_point_sum(CURVE_ID[curve], _p(pts), pts.shape[0], _p(out)))
+    return out
+
+
+def affine_of(jac) -> np.ndarray:
+    """Normalised Jacobian (Z = 1 or identity) -> 8-limb affine POD."""
+    return np.ascontiguousarray(jac, dtype=np.uint64).reshape(12)[:8].copy()
+
+
+# ---------------------------------------------------------------------------------------
+# device memory helpers
+# ---------------------------------------------------------------------------------------
+class DeviceBuffer:
+    def __init__(self, nbytes: int):
+        self.ptr = _vp()
+        self.nbytes = nbytes
+        _check(lib().trh_malloc(ctypes.byref(self.ptr), nbytes))
+
+    @classmethod
+    def from_host(cls, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        if a.nbytes:
+            _check(lib().trh_memcpy_h2d(buf.ptr, a.ctypes.data_as(_vp), a.nbytes))
+        return buf
+
+    def to_host(self, dtype=np.uint64, shape=None) -> np.ndarray:
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        if self.nbytes:
+            _check(lib().trh_memcpy_d2h(out.ctypes.data_as(_vp), self.ptr, self.nbytes))
+        return out if shape is None else out.reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            lib().trh_free(self.ptr)
+            self.ptr = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _devptr(x):
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return _vp(x.data_ptr())
+    return _vp(int(x))
+
+
+def field_op_dev(field: str, op: str, a, b=None) -> np.ndarray:
+    a = _c(a, 4)
+    da = DeviceBuffer.from_host(a)
+    db = DeviceBuffer.from_host(_c(b, 4)) if b is not None else None
+    do = DeviceBuffer(a.nbytes)
+    _check(lib().trh_field_op_dev(FIELD_ID[field], FIELD_OPS[op], da.ptr, db.ptr if db else None, do.ptr, a.shape[0], None))
+    _check(lib().trh_stream_synchronize(None))
+    return do.to_host(shape=(-1, 4))
+
+
+def point_op_dev(curve: str, op: str, p, q=None) -> np.ndarray:
+    p = _c(p, 12)
+    dp = DeviceBuffer.from_host(p)
+    dq = DeviceBuffer.from_host(_c(q)) if q is not None else None
+    do = DeviceBuffer(p.nbytes)
+    _check(lib().trh_point_op_dev(CURVE_ID[curve], POINT_OPS[op], dp.ptr, dq.ptr if dq else None, do.ptr, p.shape[0], None))
+    _check(lib().trh_stream_synchronize(None))
+    return do.to_host(shape=(-1, 12))
+
+
+def ntt_dev(field: str, a_dev, log_n: int, omega, batch: int = 1, stream=None):
+    w = _c(omega).reshape(4)
+    _check(lib().trh_ntt_dev(FIELD_ID[field], _devptr(a_dev), log_n, _p(w), batch, stream))
+
+
+def field_scale_dev(field: str, a_dev, n: int, factor, stream=None):
+    f = _c(factor).reshape(4)
+    _check(lib().trh_field_scale_dev(FIELD_ID[field], _devptr(a_dev), n, _p(f), stream))
+
+
+def field_scale_periodic_dev(field: str, a_dev, n: int, factors, stream=None):
+    f = _c(factors, 4)
+    _check(lib().trh_field_scale_periodic_dev(FIELD_ID[field], _devptr(a_dev), n, _p(f), f.shape[0], stream))
+
+
+def set_timing(on: bool):
+    _check(lib().trh_set_timing(1 if on else 0))
+
+
+def last_timing() -> dict:
+    t = Timing()
+    _check(lib().trh_last_timing(ctypes.byref(t)))
+    return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+
+def set_window_bits(c: int):
+    _check(lib().trh_msm_set_window_bits(c))
+
+
+# ---------------------------------------------------------------------------------------
+# device-resident bases + MSM
+# ---------------------------------------------------------------------------------------
+class Bases:
+    """Device-resident affine base set (Params.g / Params.g_lagrange)."""
+
+    def __init__(self, curve: str, handle):
+        self.curve = curve
+        self.handle = handle
+
+    @classmethod
+    def from_host(cls, curve: str, xy) -> "Bases":
+        xy = _c(xy, 8)
+        h = _vp()
+        fn = lib().trh_bases_create_pallas if curve == "pallas" else lib().trh_bases_create_vesta
+        _check(fn(_p(xy), xy.shape[0], ctypes.byref(h)))
+        return cls(curve, h)
+
+    @classmethod
+    def wrap_device(cls, curve: str, dev_ptr, n: int) -> "Bases":
+        h = _vp()
+        _check(lib().trh_bases_wrap_device(CURVE_ID[curve], _devptr(dev_ptr), n, ctypes.byref(h)))
+        return cls(curve, h)
+
+    @classmethod
+    def generate(cls, curve: str, s0: int, d: int, n: int, first: int = 0) -> "Bases":
+        h = _vp()
+        _check(lib().trh_bases_generate(CURVE_ID[curve], s0, d, first, n, ctypes.byref(h)))
+        return cls(curve, h)
+
+    def __len__(self):
+        return int(lib().trh_bases_len(self.handle))
+
+    def download(self, offset: int = 0, n: int | None = None) -> np.ndarray:
+        n = len(self) - offset if n is None else n
+        out = np.empty((n, 8), dtype=np.uint64)
+        _check(lib().trh_bases_download(self.handle, offset, n, _p(out)))
+        return out
+
+    def msm(self, scalars, offset: int = 0, montgomery: bool = True) -> np.ndarray:
+        s = _c(scalars, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().trh_msm(self.handle, offset, _p(s), s.shape[0], 1 if montgomery else 0, _p(out)))
+        return out
+
+    def msm_dev(self, scalars_dev, n: int, offset: int = 0, montgomery: bool = True, stream=None) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().trh_msm_dev(self.handle, offset, _devptr(scalars_dev), n, 1 if montgomery else 0, stream, _p(out)))
+        return out
+
+    def msm_dev_enqueue(self, scalars_dev, n: int, offset: int = 0, montgomery: bool = True, stream=None):
+        _check(lib().trh_msm_dev_enqueue(self.handle, offset, _devptr(scalars_dev), n, 1 if montgomery else 0, stream))
+
+    def msm_dev_finish(self, stream=None) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().trh_msm_dev_finish(self.handle, stream, _p(out)))
+        return out
+
+    def msm_batch_dev(self, scalars_dev, n: int, batch: int, offset: int = 0, montgomery: bool = True, stream=None) -> np.ndarray:
+        out = np.zeros((batch, 12), dtype=np.uint64)
+        _check(lib().trh_msm_batch_dev(self.handle, offset, _devptr(scalars_dev), n, batch, 1 if montgomery else 0, stream, _p(out)))
+        return out
+
+    def destroy(self):
+        if self.handle:
+            lib().trh_bases_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,377 @@
+// C ABI of libtrh.so (include/trh.h): argument checking, staging of host buffers, context.
+#include <string.h>
+
+#include "ctx.h"
+
+namespace trh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+Ctx& ctx() {
+    static Ctx c;
+    return c;
+}
+
+int require_init() {
+    if (!ctx().inited) {
+        set_error("trh_init() has not succeeded: no HIP device bound (libtrh has no CPU fallback)");
+        return TRH_ENODEV;
+    }
+    return TRH_OK;
+}
+
+int field_scale_periodic(int field, void* a_dev, size_t n, const void* factors_dev, u32 period, hipStream_t s);
+
+namespace {
+
+template <class F>
+__global__ void __launch_bounds__(256) field_op_kernel(int op, const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> x, y = fe_zero<F>(), r;
+    {
+        uint4 lo = a[2 * i], hi = a[2 * i + 1];
+        x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w; x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+    }
+    if (b) {
+        uint4 lo = b[2 * i], hi = b[2 * i + 1];
+        y.l[0] = lo.x; y.l[1] = lo.y; y.l[2] = lo.z; y.l[3] = lo.w; y.l[4] = hi.x; y.l[5] = hi.y; y.l[6] = hi.z; y.l[7] = hi.w;
+    }
+    switch (op) {
+        case 0: r = fe_add(x, y); break;
+        case 1: r = fe_sub(x, y); break;
+        case 2: r = fe_mul(x, y); break;
+        case 3: r = fe_sqr(x); break;
+        case 4: r = fe_neg(x); break;
+        case 5: r = fe_inv(x); break;
+        case 6: r = fe_to_mont(x); break;
+        default: r = fe_from_mont(x); break;
+    }
+    out[2 * i] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
+    out[2 * i + 1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) point_op_kernel(int op, const u32* __restrict__ p, const u32* __restrict__ q, u32* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jacobian<F> pj;
+    for (int k = 0; k < 24; ++k) ((u32*)&pj)[k] = p[24 * i + k];
+    XYZZ<F> a = xyzz_from_jacobian(pj), r;
+    if (op == 0) {
+        Jacobian<F> qj;
+        for (int k = 0; k < 24; ++k) ((u32*)&qj)[k] = q[24 * i + k];
+        r = xyzz_add(a, xyzz_from_jacobian(qj));
+    } else if (op == 1) {
+        Affine<F> qa;
+        for (int k = 0; k < 16; ++k) ((u32*)&qa)[k] = q[16 * i + k];
+        r = a;
+        xyzz_madd(r, qa);
+    } else {
+        r = xyzz_dbl(a);
+    }
+    Jacobian<F> o = jac_from_affine(xyzz_to_affine(r));
+    for (int k = 0; k < 24; ++k) out[24 * i + k] = ((u32*)&o)[k];
+}
+
+int check_curve(int curve) {
+    if (curve != TRH_PALLAS && curve != TRH_VESTA) { set_error("unknown curve id %d", curve); return TRH_EINVAL; }
+    return TRH_OK;
+}
+int check_field(int field) {
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    return TRH_OK;
+}
+
+int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t* out) {
+    TRH_TRY(require_init());
+    if (!out || (n && (!coeffs || !bases))) { set_error("best_multiexp: null pointer"); return TRH_EINVAL; }
+    if (n >= ((size_t)1 << 31)) { set_error("best_multiexp: n too large"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    DevBuf bbuf;
+    TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
+    int rc = bbuf.ensure(n * 64 + 64);
+    if (rc != TRH_OK) return rc;
+    hipError_t e = hipSuccess;
+    if (n) {
+        e = hipMemcpy(c.msm.scalars.p, coeffs, n * 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bbuf.p, bases, n * 64, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { bbuf.release(); set_error("best_multiexp: upload failed: %s", hipGetErrorString(e)); return TRH_EHIP; }
+    rc = msm_enqueue(curve, bbuf.p, c.msm.scalars.p, n, 1, n, 1, 0);
+    if (rc == TRH_OK) rc = msm_finish(curve, 0, out, 1);
+    bbuf.release();
+    return rc;
+}
+
+int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n) {
+    TRH_TRY(require_init());
+    if (!a || !omega) { set_error("best_fft: null pointer"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (log_n > 27) { set_error("best_fft: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    const size_t bytes = (size_t)32 << log_n;
+    TRH_TRY(c.io.ensure(bytes));
+    TRH_HIP_TRY(hipMemcpy(c.io.p, a, bytes, hipMemcpyHostToDevice));
+    TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, 0));
+    TRH_HIP_TRY(hipMemcpy(a, c.io.p, bytes, hipMemcpyDeviceToHost));
+    return TRH_OK;
+}
+
+int bases_create(int curve, const uint64_t* xy, size_t n, trh_bases_t* out) {
+    TRH_TRY(require_init());
+    if (!out || (n && !xy)) { set_error("bases_create: null pointer"); return TRH_EINVAL; }
+    trh_bases* b = new trh_bases{curve, nullptr, n, true};
+    hipError_t e = hipMalloc(&b->d_xy, n * 64 + 64);
+    if (e == hipSuccess && n) e = hipMemcpy(b->d_xy, xy, n * 64, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (b->d_xy) (void)hipFree(b->d_xy);
+        delete b;
+        set_error("bases_create: %s", hipGetErrorString(e));
+        return TRH_EHIP;
+    }
+    *out = b;
+    return TRH_OK;
+}
+
+}  // namespace
+}  // namespace trh
+
+using namespace trh;
+
+extern "C" {
+
+const char* trh_version(void) { return "trh 0.1.0 (gfx950)"; }
+const char* trh_last_error(void) { return g_err; }
+
+int trh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int trh_init(int device) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.inited) {
+        if (c.device == device) return TRH_OK;
+        set_error("trh_init: already bound to device %d", c.device);
+        return TRH_EINVAL;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("trh_init: no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e)); return TRH_ENODEV; }
+    if (device < 0 || device >= n) { set_error("trh_init: device %d out of range [0, %d)", device, n); return TRH_EINVAL; }
+    TRH_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TRH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("trh_init: device is %s, libtrh is built for gfx950 only", prop.gcnArchName); return TRH_ENODEV; }
+    c.device = device;
+    c.inited = true;
+    return TRH_OK;
+}
+
+void trh_shutdown(void) {
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.inited) return;
+    (void)hipDeviceSynchronize();
+    msm_release();
+    ntt_release_tables();
+    c.io.release();
+    c.inited = false;
+    c.device = -1;
+}
+
+int trh_best_multiexp_pallas(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out[12]) { return best_multiexp_host(TRH_PALLAS, coeffs, bases, n, out); }
+int trh_best_multiexp_vesta(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out[12]) { return best_multiexp_host(TRH_VESTA, coeffs, bases, n, out); }
+int trh_best_fft_fp(uint64_t* a, const uint64_t omega[4], uint32_t log_n) { return best_fft_host(TRH_FP, a, omega, log_n); }
+int trh_best_fft_fq(uint64_t* a, const uint64_t omega[4], uint32_t log_n) { return best_fft_host(TRH_FQ, a, omega, log_n); }
+
+int trh_bases_create_pallas(const uint64_t* xy, size_t n, trh_bases_t* out) { return bases_create(TRH_PALLAS, xy, n, out); }
+int trh_bases_create_vesta(const uint64_t* xy, size_t n, trh_bases_t* out) { return bases_create(TRH_VESTA, xy, n, out); }
+
+int trh_bases_wrap_device(int curve, const void* xy_dev, size_t n, trh_bases_t* out) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_curve(curve));
+    if (!out || (n && !xy_dev)) { set_error("bases_wrap_device: null pointer"); return TRH_EINVAL; }
+    *out = new trh_bases{curve, (void*)xy_dev, n, false};
+    return TRH_OK;
+}
+
+int trh_bases_generate(int curve, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_curve(curve));
+    if (!out) { set_error("bases_generate: null pointer"); return TRH_EINVAL; }
+    trh_bases* b = new trh_bases{curve, nullptr, n, true};
+    hipError_t e = hipMalloc(&b->d_xy, n * 64 + 64);
+    if (e != hipSuccess) { delete b; set_error("bases_generate: %s", hipGetErrorString(e)); return TRH_ENOMEM; }
+    int rc = bases_generate_device(curve, s0, d, first, n, b->d_xy, 0);
+    if (rc == TRH_OK && hipStreamSynchronize(0) != hipSuccess) { set_error("bases_generate: kernel failed"); rc = TRH_EHIP; }
+    if (rc != TRH_OK) { (void)hipFree(b->d_xy); delete b; return rc; }
+    *out = b;
+    return TRH_OK;
+}
+
+int trh_bases_download(trh_bases_t b, size_t offset, size_t n, uint64_t* xy_host) {
+    TRH_TRY(require_init());
+    if (!b || !xy_host || offset + n > b->n) { set_error("bases_download: bad range"); return TRH_EINVAL; }
+    TRH_HIP_TRY(hipMemcpy(xy_host, (const char*)b->d_xy + offset * 64, n * 64, hipMemcpyDeviceToHost));
+    return TRH_OK;
+}
+const void* trh_bases_device_ptr(trh_bases_t b) { return b ? b->d_xy : nullptr; }
+size_t trh_bases_len(trh_bases_t b) { return b ? b->n : 0; }
+void trh_bases_destroy(trh_bases_t b) {
+    if (!b) return;
+    if (b->owned && b->d_xy) (void)hipFree(b->d_xy);
+    delete b;
+}
+
+static int msm_args(trh_bases_t bases, size_t offset, const void* scalars, size_t n, size_t batch, void* out) {
+    TRH_TRY(require_init());
+    if (!bases || !out || (n && !scalars)) { set_error("msm: null pointer"); return TRH_EINVAL; }
+    if (offset + n > bases->n || offset + n < offset) { set_error("msm: range [%zu, %zu) exceeds the %zu resident bases", offset, offset + n, bases->n); return TRH_EINVAL; }
+    if (n >= ((size_t)1 << 31)) { set_error("msm: n too large"); return TRH_EINVAL; }
+    if (batch == 0) { set_error("msm: batch == 0"); return TRH_EINVAL; }
+    return TRH_OK;
+}
+
+int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n, int mont, uint64_t out[12]) {
+    TRH_TRY(msm_args(bases, offset, scalars_host, n, 1, out));
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
+    if (n) TRH_HIP_TRY(hipMemcpy(c.msm.scalars.p, scalars_host, n * 32, hipMemcpyHostToDevice));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, c.msm.scalars.p, n, 1, n, mont, 0));
+    return msm_finish(bases->curve, 0, out, 1);
+}
+
+int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream) {
+    uint64_t dummy;
+    TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, &dummy));
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, 1, n, mont, (hipStream_t)stream);
+}
+int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out[12]) {
+    TRH_TRY(require_init());
+    if (!bases || !out) { set_error("msm_dev_finish: null pointer"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
+}
+int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream, uint64_t out[12]) {
+    TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, out));
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, 1, n, mont, (hipStream_t)stream));
+    return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
+}
+int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch, int mont, void* stream, uint64_t* out) {
+    TRH_TRY(msm_args(bases, offset, scalars_dev, n, batch, out));
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, batch, n, mont, (hipStream_t)stream));
+    return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
+}
+int trh_msm_set_window_bits(int cbits) {
+    if (cbits != 0 && (cbits < 2 || cbits > 16)) { set_error("window bits must be 0 or in [2, 16]"); return TRH_EINVAL; }
+    ctx().window_override = cbits;
+    return TRH_OK;
+}
+
+int trh_point_sum(int curve, const uint64_t* pts, size_t count, uint64_t out[12]) {
+    TRH_TRY(check_curve(curve));
+    if (!out || (count && !pts)) { set_error("point_sum: null pointer"); return TRH_EINVAL; }
+    return point_sum_host(curve, pts, count, out);
+}
+
+int trh_ntt_dev(int field, void* a_dev, uint32_t log_n, const uint64_t omega[4], size_t batch, void* stream) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_field(field));
+    if (!a_dev || !omega) { set_error("ntt_dev: null pointer"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return ntt_device(field, a_dev, log_n, omega, batch, (hipStream_t)stream);
+}
+
+int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_t* factors, uint32_t period, void* stream) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_field(field));
+    if (!a_dev || !factors || period == 0 || period > 64) { set_error("field_scale_periodic: bad arguments"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_TRY(c.io.ensure(64 * 32));
+    TRH_HIP_TRY(hipMemcpyAsync(c.io.p, factors, (size_t)period * 32, hipMemcpyHostToDevice, (hipStream_t)stream));
+    TRH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return field_scale_periodic(field, a_dev, n, c.io.p, period, (hipStream_t)stream);
+}
+int trh_field_scale_dev(int field, void* a_dev, size_t n, const uint64_t factor[4], void* stream) {
+    return trh_field_scale_periodic_dev(field, a_dev, n, factor, 1, stream);
+}
+
+int trh_field_op_dev(int field, int op, const void* a, const void* b, void* out, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_field(field));
+    if (!n) return TRH_OK;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (field == TRH_FP) hipLaunchKernelGGL((field_op_kernel<FpParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, op, (const uint4*)a, (const uint4*)b, (uint4*)out, n);
+    else hipLaunchKernelGGL((field_op_kernel<FqParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, op, (const uint4*)a, (const uint4*)b, (uint4*)out, n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    TRH_TRY(check_curve(curve));
+    if (!n) return TRH_OK;
+    const unsigned gb = (unsigned)((n + 63) / 64);
+    if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_kernel<FpParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const u32*)p, (const u32*)q, (u32*)out, n);
+    else hipLaunchKernelGGL((point_op_kernel<FqParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const u32*)p, (const u32*)q, (u32*)out, n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+int trh_malloc(void** dev, size_t bytes) {
+    TRH_TRY(require_init());
+    if (!dev) { set_error("trh_malloc: null pointer"); return TRH_EINVAL; }
+    hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
+    return TRH_OK;
+}
+int trh_free(void* dev) {
+    TRH_TRY(require_init());
+    TRH_HIP_TRY(hipFree(dev));
+    return TRH_OK;
+}
+int trh_memcpy_h2d(void* dev, const void* host, size_t bytes) {
+    TRH_TRY(require_init());
+    TRH_HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return TRH_OK;
+}
+int trh_memcpy_d2h(void* host, const void* dev, size_t bytes) {
+    TRH_TRY(require_init());
+    TRH_HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return TRH_OK;
+}
+int trh_stream_synchronize(void* stream) {
+    TRH_TRY(require_init());
+    TRH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return TRH_OK;
+}
+
+int trh_set_timing(int enabled) { ctx().timing = enabled; return TRH_OK; }
+int trh_last_timing(trh_timing_t* out) {
+    if (!out) { set_error("last_timing: null pointer"); return TRH_EINVAL; }
+    *out = ctx().last;
+    return TRH_OK;
+}
+
+}  // extern "C"

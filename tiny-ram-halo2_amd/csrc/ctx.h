@@ -1,0 +1,113 @@
+// Process-wide device context of libtrh: error reporting, grow-only scratch buffers, timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/trh.h"
+#include "curve.h"
+
+namespace trh {
+
+void set_error(const char* fmt, ...);
+
+#define TRH_HIP_TRY(expr)                                                                    \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::trh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TRH_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+#define TRH_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != TRH_OK) return _rc; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return TRH_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); p = nullptr; return TRH_ENOMEM; }
+        cap = want;
+        return TRH_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct TwiddleEntry {
+    int field, log_n;
+    u64 omega[4];
+    DevBuf lo, hi;  // lo[i] = omega^i (i < 2^lo_bits), hi[i] = omega^(i << lo_bits)
+    int lo_bits, hi_bits;
+    u64 stamp;
+};
+
+struct MsmScratch {
+    DevBuf scalars;      // host-scalar entry points stage here
+    DevBuf digits;       // W x n u32: bucket id | sign << 31
+    DevBuf sorted;       // W x n u32: point index | sign << 31, grouped by bucket
+    DevBuf counts;       // W x (NB + 1) u32 histogram, then running cursor / bucket end
+    DevBuf starts;       // W x (NB + 1) u32 bucket start offsets
+    DevBuf buckets;      // W x NB XYZZ
+    DevBuf partials;     // W x blocks XYZZ
+    DevBuf window_sums;  // batch x W XYZZ
+    void* host_sums = nullptr;  // pinned mirror of window_sums
+    size_t host_sums_cap = 0;
+    // state of the enqueued-but-not-finished MSM
+    int pending_curve = -1, pending_windows = 0, pending_c = 0;
+    size_t pending_batch = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+struct Ctx {
+    std::mutex mu;
+    bool inited = false;
+    int device = -1;
+    int timing = 0;
+    int window_override = 0;
+    trh_timing_t last{};
+    MsmScratch msm;
+    DevBuf ntt_tmp;
+    DevBuf io;  // staging for host-pointer NTT entry points
+    std::vector<TwiddleEntry*> twiddles;
+    u64 stamp = 0;
+};
+
+Ctx& ctx();
+int require_init();
+
+// ntt.hip
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s);
+void ntt_release_tables();
+// msm.hip
+int msm_enqueue(int curve, const void* bases_dev, const void* scalars_dev, size_t n, size_t batch,
+                size_t scalar_stride_elems, int mont, hipStream_t s);
+int msm_finish(int curve, hipStream_t s, u64* out_xyz, size_t batch);
+int point_sum_host(int curve, const u64* pts, size_t count, u64* out);
+int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* out_dev, hipStream_t s);
+void msm_release();
+
+}  // namespace trh
+
+struct trh_bases {
+    int curve;
+    void* d_xy;
+    size_t n;
+    bool owned;
+};

@@ -1,0 +1,157 @@
+// Pallas / Vesta group law for gfx950 (y^2 = x^3 + 5 over Fp / Fq).
+//
+// Replaces pasta_curves 0.4.1 `pallas::{Affine,Point}` / `vesta::{Affine,Point}` (curves.rs)
+// on the paths halo2_proofs' best_multiexp and the IPA commitment use (reference call sites
+// /root/reference/src/test_utils.rs:12, 21, 40-49).
+//
+// Device accumulators use extended-Jacobian XYZZ coordinates (x = X/ZZ, y = Y/ZZZ,
+// ZZ^3 = ZZZ^2): a mixed add is 8M + 2S with no field inversion and the accumulator never
+// has to be renormalised; identity is ZZ = 0.  Results cross the C ABI as Jacobian
+// (X, Y, Z) -- the layout of pasta's `Point` -- normalised to Z = 1 (identity: all zero), so
+// the bytes are unique and comparable limb-for-limb with the CPU path after `to_affine()`.
+//
+// Every formula carries the complete case analysis (identity operands, P + P, P + (-P)): the
+// exceptional branches are taken for duplicate bases and in bucket running sums.
+#pragma once
+#include "field.h"
+
+namespace trh {
+
+// 64-byte POD used for bases: x, y Montgomery; the all-zero pattern (not on the curve) is the identity
+template <class F>
+struct Affine {
+    Fe<F> x, y;
+};
+template <class F>
+struct XYZZ {
+    Fe<F> x, y, zz, zzz;
+};
+template <class F>
+struct Jacobian {
+    Fe<F> x, y, z;
+};
+
+template <class F> TRH_HD bool aff_is_identity(const Affine<F>& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
+template <class F> TRH_HD XYZZ<F> xyzz_identity() {
+    XYZZ<F> r; r.x = fe_zero<F>(); r.y = fe_zero<F>(); r.zz = fe_zero<F>(); r.zzz = fe_zero<F>(); return r;
+}
+template <class F> TRH_HD bool xyzz_is_identity(const XYZZ<F>& p) { return fe_is_zero(p.zz); }
+template <class F> TRH_HD XYZZ<F> xyzz_from_affine(const Affine<F>& p) {
+    XYZZ<F> r;
+    if (aff_is_identity(p)) return xyzz_identity<F>();
+    r.x = p.x; r.y = p.y; r.zz = fe_one<F>(); r.zzz = fe_one<F>();
+    return r;
+}
+
+// 2 * affine point (mdbl-2008-s-1), p != identity
+template <class F> TRH_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
+    XYZZ<F> r;
+    Fe<F> U = fe_dbl(p.y);
+    if (fe_is_zero(U)) return xyzz_identity<F>();  // order-2 point (none on these curves)
+    Fe<F> V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.x, V);
+    Fe<F> xx = fe_sqr(p.x), M = fe_add(fe_dbl(xx), xx);
+    r.x = fe_sub(fe_sqr(M), fe_dbl(S));
+    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.zz = V; r.zzz = W;
+    return r;
+}
+
+// 2 * P (dbl-2008-s-1, a = 0)
+template <class F> TRH_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+    if (xyzz_is_identity(p)) return p;
+    XYZZ<F> r;
+    Fe<F> U = fe_dbl(p.y);
+    Fe<F> V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.x, V);
+    Fe<F> xx = fe_sqr(p.x), M = fe_add(fe_dbl(xx), xx);
+    r.x = fe_sub(fe_sqr(M), fe_dbl(S));
+    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.zz = fe_mul(V, p.zz);
+    r.zzz = fe_mul(W, p.zzz);
+    return r;
+}
+
+// acc += p (madd-2008-s: 8M + 2S), p affine
+template <class F> TRH_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
+    if (aff_is_identity(p)) return;
+    if (xyzz_is_identity(acc)) { acc = xyzz_from_affine(p); return; }
+    Fe<F> U2 = fe_mul(p.x, acc.zz), S2 = fe_mul(p.y, acc.zzz);
+    Fe<F> P = fe_sub(U2, acc.x), R = fe_sub(S2, acc.y);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) acc = xyzz_dbl_affine(p);  // acc == p
+        else acc = xyzz_identity<F>();                // acc == -p
+        return;
+    }
+    Fe<F> PP = fe_sqr(P), PPP = fe_mul(P, PP), Q = fe_mul(acc.x, PP);
+    Fe<F> x3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    acc.y = fe_sub(fe_mul(R, fe_sub(Q, x3)), fe_mul(acc.y, PPP));
+    acc.x = x3;
+    acc.zz = fe_mul(acc.zz, PP);
+    acc.zzz = fe_mul(acc.zzz, PPP);
+}
+
+// a + b (add-2008-s: 12M + 2S)
+template <class F> TRH_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if (xyzz_is_identity(a)) return b;
+    if (xyzz_is_identity(b)) return a;
+    Fe<F> U1 = fe_mul(a.x, b.zz), U2 = fe_mul(b.x, a.zz);
+    Fe<F> S1 = fe_mul(a.y, b.zzz), S2 = fe_mul(b.y, a.zzz);
+    Fe<F> P = fe_sub(U2, U1), R = fe_sub(S2, S1);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) return xyzz_dbl(a);
+        return xyzz_identity<F>();
+    }
+    Fe<F> PP = fe_sqr(P), PPP = fe_mul(P, PP), Q = fe_mul(U1, PP);
+    XYZZ<F> r;
+    r.x = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    r.y = fe_sub(fe_mul(R, fe_sub(Q, r.x)), fe_mul(S1, PPP));
+    r.zz = fe_mul(fe_mul(a.zz, b.zz), PP);
+    r.zzz = fe_mul(fe_mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
+template <class F> TRH_HD Affine<F> aff_neg(const Affine<F>& p) {
+    Affine<F> r; r.x = p.x; r.y = fe_neg(p.y);  // identity (0,0) stays (0,0)
+    return r;
+}
+template <class F> TRH_HD XYZZ<F> xyzz_neg(const XYZZ<F>& p) {
+    XYZZ<F> r = p; r.y = fe_neg(p.y);
+    return r;
+}
+
+// k * p for a small non-negative integer k (double-and-add, variable time)
+template <class F> TRH_HD XYZZ<F> xyzz_mul_small(const XYZZ<F>& p, u32 k) {
+    XYZZ<F> acc = xyzz_identity<F>();
+    for (int i = 31; i >= 0; --i) {
+        acc = xyzz_dbl(acc);
+        if ((k >> i) & 1u) acc = xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+// XYZZ -> affine (one inversion)
+template <class F> TRH_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+    Affine<F> r;
+    if (xyzz_is_identity(p)) { r.x = fe_zero<F>(); r.y = fe_zero<F>(); return r; }
+    // 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2  (ZZ^3 = ZZZ^2)
+    Fe<F> zzz_inv = fe_inv(p.zzz);
+    Fe<F> zz_inv = fe_mul(fe_sqr(zzz_inv), fe_sqr(p.zz));
+    r.x = fe_mul(p.x, zz_inv);
+    r.y = fe_mul(p.y, zzz_inv);
+    return r;
+}
+// Jacobian with Z = 1 (identity: all zero) -- the normalised ABI output
+template <class F> TRH_HD Jacobian<F> jac_from_affine(const Affine<F>& a) {
+    Jacobian<F> j;
+    j.x = a.x; j.y = a.y;
+    j.z = aff_is_identity(a) ? fe_zero<F>() : fe_one<F>();
+    return j;
+}
+// Jacobian (any Z) -> XYZZ: ZZ = Z^2, ZZZ = Z^3
+template <class F> TRH_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F>& j) {
+    XYZZ<F> r;
+    if (fe_is_zero(j.z)) return xyzz_identity<F>();
+    r.x = j.x; r.y = j.y; r.zz = fe_sqr(j.z); r.zzz = fe_mul(r.zz, j.z);
+    return r;
+}
+
+}  // namespace trh

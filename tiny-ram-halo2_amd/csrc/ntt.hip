@@ -1,0 +1,292 @@
+// Radix-2 number-theoretic transform over Fp / Fq for gfx950.
+//
+// Replaces halo2_proofs 0.2.0 `arithmetic::best_fft` (arithmetic.rs; crate pinned at
+// /root/reference/Cargo.lock:619-621) as called by `poly::EvaluationDomain::{lagrange_to_coeff,
+// coeff_to_extended, extended_to_coeff}` inside keygen_* / create_proof
+// (/root/reference/src/test_utils.rs:23-25, 41-49).  Same contract: in place, natural order in
+// and out, a'[i] = sum_j a[j] omega^(i j), omega a primitive 2^log_n-th root of unity.
+//
+// Schedule (Stockham auto-sort, so no bit-reversal pass over HBM): log_n is split into passes of
+// s <= 9 stages.  One workgroup owns a tile of R = 2^s rows x C columns (R*C = 2048 elements =
+// 64 KiB of LDS): it reads C-element runs at stride N/R, applies the inter-pass twiddle
+// omega^(k r), runs the s radix-2 stages entirely in LDS with an LDS-resident table of the R/2
+// in-tile twiddles, and writes C-element runs to the auto-sorted position.  Passes ping-pong
+// between the buffer and a scratch buffer; the last pass of an odd count is in place (its tile
+// reads and writes the same addresses).  Twiddles omega^e come from two L2-resident tables
+// (omega^lo, omega^(hi << lo_bits)) built on the device per (field, log_n, omega).
+//
+// Integer work, no MFMA.  Algorithmic HBM bytes: 32 B read + 32 B write per element.
+#include <string.h>
+
+#include "ctx.h"
+
+namespace trh {
+
+namespace {
+
+constexpr int TILE_LOG = 11;
+constexpr int TILE = 1 << TILE_LOG;
+constexpr int NTT_THREADS = TILE / 4;
+constexpr int MAX_PASS_LOG = 9;
+
+struct alignas(16) Half {  // 16 bytes of a field element
+    u32 w[4];
+};
+
+template <class F>
+__device__ __forceinline__ Fe<F> load_fe(const uint4* __restrict__ p) {
+    uint4 a = p[0], b = p[1];
+    Fe<F> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void store_fe(uint4* __restrict__ p, const Fe<F>& v) {
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+// LDS holds each element as two 16-byte halves in separate planes: consecutive lanes touch
+// consecutive 16-byte slots, which ds_read_b128 / ds_write_b128 serve without bank conflicts
+template <class F>
+__device__ __forceinline__ Fe<F> lds_load(const uint4* lo, const uint4* hi, int idx) {
+    uint4 a = lo[idx], b = hi[idx];
+    Fe<F> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_store(uint4* lo, uint4* hi, int idx, const Fe<F>& v) {
+    lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// omega^e from the two-level tables
+template <class F>
+__device__ __forceinline__ Fe<F> twiddle(const uint4* __restrict__ t_lo, const uint4* __restrict__ t_hi, u32 e, int lo_bits) {
+    const u32 el = e & ((1u << lo_bits) - 1u), eh = e >> lo_bits;
+    Fe<F> w = load_fe<F>(t_lo + 2 * (size_t)el);
+    if (eh) w = fe_mul(w, load_fe<F>(t_hi + 2 * (size_t)eh));
+    return w;
+}
+
+// tables: lo[i] = omega^i, hi[i] = omega^(i << lo_bits); pw[b] = omega^(2^b) supplied by the host
+template <class F>
+__global__ void __launch_bounds__(256) ntt_tables_kernel(const uint4* __restrict__ pw, uint4* __restrict__ t_lo, uint4* __restrict__ t_hi, int lo_bits, int hi_bits) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nlo = 1u << lo_bits, nhi = 1u << hi_bits;
+    if (i < nlo) {
+        Fe<F> r = fe_one<F>();
+        for (int b = 0; b < lo_bits; ++b)
+            if ((i >> b) & 1u) r = fe_mul(r, load_fe<F>(pw + 2 * b));
+        store_fe<F>(t_lo + 2 * (size_t)i, r);
+    }
+    if (i < nhi) {
+        Fe<F> r = fe_one<F>();
+        for (int b = 0; b < hi_bits; ++b)
+            if ((i >> b) & 1u) r = fe_mul(r, load_fe<F>(pw + 2 * (b + lo_bits)));
+        store_fe<F>(t_hi + 2 * (size_t)i, r);
+    }
+}
+
+// One Stockham pass: R = 2^s, Ns = 2^log_ns (size of the sub-transforms already done).
+template <class F>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
+                                                               const uint4* __restrict__ t_lo, const uint4* __restrict__ t_hi, int lo_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = 1 << s;
+    const int log_c = (log_n < TILE_LOG ? log_n : TILE_LOG) - s;  // columns per tile
+    const int C = 1 << log_c;
+    const int E = R << log_c;  // elements in this tile
+    uint4* lds_lo = (uint4*)smem;
+    uint4* lds_hi = lds_lo + E;
+    uint4* tw_lo = lds_hi + E;        // R/2 in-tile twiddles omega_R^i, same split layout
+    uint4* tw_hi = tw_lo + (R >> 1);
+
+    const size_t N = (size_t)1 << log_n;
+    const size_t batch_off = (size_t)blockIdx.y * N * 2;  // in uint4 units
+    in += batch_off;
+    out += batch_off;
+    const u32 j0 = blockIdx.x << log_c;
+    const u32 ns_mask = (1u << log_ns) - 1u;
+    const int tid = threadIdx.x;
+    const size_t row_stride = N >> s;  // N / R
+
+    // in-tile twiddle table: omega_R^i = omega^(i << (log_n - s))
+    for (int i = tid; i < (R >> 1); i += NTT_THREADS) {
+        Fe<F> w = twiddle<F>(t_lo, t_hi, (u32)i << (log_n - s), lo_bits);
+        lds_store<F>(tw_lo, tw_hi, i, w);
+    }
+    // load + inter-pass twiddle + bit-reversed row placement
+    const int tw_shift = log_n - log_ns - s;  // exponent scale N / (Ns R)
+    for (int e = tid; e < E; e += NTT_THREADS) {
+        const u32 c = e & (C - 1), r = e >> log_c;
+        const u32 j = j0 + c, k = j & ns_mask;
+        Fe<F> x = load_fe<F>(in + 2 * ((size_t)j + (size_t)r * row_stride));
+        if (log_ns > 0) {
+            const u32 ex = (k * r) << tw_shift;
+            if (ex) x = fe_mul(x, twiddle<F>(t_lo, t_hi, ex, lo_bits));
+        }
+        const u32 rr = __brev(r) >> (32 - s);
+        lds_store<F>(lds_lo, lds_hi, (int)((rr << log_c) | c), x);
+    }
+    __syncthreads();
+    // s radix-2 DIT stages in LDS
+    for (int st = 0; st < s; ++st) {
+        const int half = 1 << st;
+        for (int bf = tid; bf < (E >> 1); bf += NTT_THREADS) {
+            const int c = bf & (C - 1), p = bf >> log_c;
+            const int pos = p & (half - 1);
+            const int r0 = ((p >> st) << (st + 1)) | pos;
+            const int i0 = (r0 << log_c) | c, i1 = i0 + (half << log_c);
+            Fe<F> a = lds_load<F>(lds_lo, lds_hi, i0);
+            Fe<F> b = lds_load<F>(lds_lo, lds_hi, i1);
+            if (pos) b = fe_mul(b, lds_load<F>(tw_lo, tw_hi, pos << (s - 1 - st)));
+            lds_store<F>(lds_lo, lds_hi, i0, fe_add(a, b));
+            lds_store<F>(lds_lo, lds_hi, i1, fe_sub(a, b));
+        }
+        __syncthreads();
+    }
+    // store to the auto-sorted position
+    for (int e = tid; e < E; e += NTT_THREADS) {
+        const u32 c = e & (C - 1), r = e >> log_c;
+        const u32 j = j0 + c, k = j & ns_mask;
+        const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)r << log_ns);
+        store_fe<F>(out + 2 * dst, lds_load<F>(lds_lo, lds_hi, e));
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t n, const uint4* __restrict__ factors, u32 period) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> f = load_fe<F>(factors + 2 * (i % period));
+    store_fe<F>(a + 2 * i, fe_mul(load_fe<F>(a + 2 * i), f));
+}
+
+TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
+    Ctx& c = ctx();
+    for (TwiddleEntry* t : c.twiddles)
+        if (t->field == field && t->log_n == log_n && memcmp(t->omega, omega, 32) == 0) { t->stamp = ++c.stamp; return t; }
+    return nullptr;
+}
+
+template <class F>
+int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** out) {
+    Ctx& c = ctx();
+    if (c.twiddles.size() >= 16) {  // evict the least recently used entry
+        size_t victim = 0;
+        for (size_t i = 1; i < c.twiddles.size(); ++i)
+            if (c.twiddles[i]->stamp < c.twiddles[victim]->stamp) victim = i;
+        TRH_HIP_TRY(hipDeviceSynchronize());
+        c.twiddles[victim]->lo.release(); c.twiddles[victim]->hi.release();
+        delete c.twiddles[victim];
+        c.twiddles.erase(c.twiddles.begin() + victim);
+    }
+    TwiddleEntry* t = new TwiddleEntry();
+    t->field = F::ID; t->log_n = log_n; memcpy(t->omega, omega, 32);
+    t->lo_bits = (log_n + 1) / 2; t->hi_bits = log_n - t->lo_bits;
+    if (t->lo_bits < 1) t->lo_bits = 1;
+    t->stamp = ++c.stamp;
+    int rc = t->lo.ensure(((size_t)32 << t->lo_bits) + 32 * 64);
+    if (rc == TRH_OK) rc = t->hi.ensure((size_t)32 << t->hi_bits);
+    if (rc != TRH_OK) { delete t; return rc; }
+    // omega^(2^b) on the host (shared field code), staged behind the lo table
+    Fe<F> pw[32];
+    memcpy(&pw[0], omega, 32);
+    for (int b = 1; b < 32; ++b) pw[b] = fe_sqr(pw[b - 1]);
+    uint4* d_pw = t->lo.as<uint4>() + ((size_t)2 << t->lo_bits);
+    TRH_HIP_TRY(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
+    const u32 cnt = 1u << (t->lo_bits > t->hi_bits ? t->lo_bits : t->hi_bits);
+    hipLaunchKernelGGL((ntt_tables_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, s, d_pw, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits, t->hi_bits);
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // pw is a stack buffer
+    c.twiddles.push_back(t);
+    *out = t;
+    return TRH_OK;
+}
+
+template <class F>
+int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s) {
+    if (log_n == 0 || batch == 0) return TRH_OK;
+    Ctx& c = ctx();
+    TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega);
+    if (!t) TRH_TRY(build_tables<F>((int)log_n, omega, s, &t));
+
+    // pass plan
+    int sizes[8], P = 0;
+    if ((int)log_n <= TILE_LOG) { sizes[P++] = (int)log_n; }
+    else {
+        P = ((int)log_n + MAX_PASS_LOG - 1) / MAX_PASS_LOG;
+        if (P < 2) P = 2;
+        int rem = (int)log_n;
+        for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
+    }
+    const size_t N = (size_t)1 << log_n;
+    uint4* a = (uint4*)a_dev;
+    uint4* tmp = nullptr;
+    size_t chunk = batch;
+    if (P > 1) {
+        const size_t max_tmp = (size_t)2 << 30;  // cap the scratch at 2 GiB per call
+        chunk = max_tmp / (N * 32);
+        if (chunk < 1) chunk = 1;
+        if (chunk > batch) chunk = batch;
+        TRH_TRY(c.ntt_tmp.ensure(chunk * N * 32));
+        tmp = c.ntt_tmp.as<uint4>();
+    }
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (b0 + chunk <= batch) ? chunk : batch - b0;
+        uint4* base = a + b0 * N * 2;
+        uint4* src = base;
+        uint4* dst = tmp;
+        int log_ns = 0;
+        for (int p = 0; p < P; ++p) {
+            const int sp = sizes[p];
+            const bool in_place = (P == 1) || ((P & 1) && p == P - 1);
+            uint4* o = in_place ? src : dst;
+            const int tile_log = (int)log_n < TILE_LOG ? (int)log_n : TILE_LOG;
+            const size_t tiles = N >> tile_log;
+            const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
+            hipLaunchKernelGGL((ntt_pass_kernel<F>), dim3((unsigned)tiles, (unsigned)nb), dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns,
+                               t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+            if (!in_place) { uint4* x = src; src = dst; dst = x; }
+            log_ns += sp;
+        }
+    }
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+}  // namespace
+
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s) {
+    if (log_n > 27) { set_error("ntt: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        attr_set = true;
+    }
+    if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s);
+    return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s);
+}
+
+int field_scale_periodic(int field, void* a_dev, size_t n, const void* factors_dev, u32 period, hipStream_t s) {
+    if (!n) return TRH_OK;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (field == TRH_FP) hipLaunchKernelGGL((field_scale_periodic_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, n, (const uint4*)factors_dev, period);
+    else hipLaunchKernelGGL((field_scale_periodic_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, n, (const uint4*)factors_dev, period);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+void ntt_release_tables() {
+    Ctx& c = ctx();
+    for (TwiddleEntry* t : c.twiddles) { t->lo.release(); t->hi.release(); delete t; }
+    c.twiddles.clear();
+    c.ntt_tmp.release();
+}
+
+}  // namespace trh
