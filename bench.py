@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Pallas MSM pairs/s @ 2^24 (+ Fp NTT elems/s @ 2^22) on 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path: a Pallas multi-scalar multiplication over 2^24 (scalar, base)
+pairs per GPU, inputs already resident in HBM.  With N GPUs the global MSM has N * 2^24 pairs,
+range-sharded across ranks (weak scaling); each rank runs its local Pippenger to one partial
+point, the 96-byte partials are all-gathered over RCCL and summed on every rank (EC addition is
+not an RCCL reduce op).  Rank 0 prints ONE JSON line.
+
+`roofline` is for the dominant kernel (msm_accumulate_kernel): algorithmic bytes = 96 B per pair
+(32 B scalar + 64 B base) x pairs per launch, divided by that kernel's average duration measured
+with HIP events on the launch stream inside the timed region (libtrh's timing hooks).
+`cpu_baseline` times oracle/cpu_ref.cpp (the C++ restatement of halo2_proofs' rayon
+best_multiexp; kind "port") on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "Pallas MSM pairs/s @ 2^24 + Fp NTT elems/s @ 2^22; 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline_msm(curve: str, log_cap: int = 22):
+    """oracle leg: chunk-per-thread Pippenger restatement on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_ref  # oracle -- the thing timed here, never the product path
+    from tiny_ram_halo2_amd import synth
+
+    threads = cpu_ref.hardware_threads()
+    # calibrate on 2^16 pairs, then size the sample for ~15 s
+    n0 = 1 << 16
+    bases0 = cpu_ref.gen_bases(curve, synth.BASE_S0, synth.BASE_D, n0, threads)
+    sc0 = synth.msm_scalars(16)
+    t = time.perf_counter()
+    cpu_ref.best_multiexp(curve, sc0, bases0, threads)
+    dt0 = time.perf_counter() - t
+    rate0 = n0 / dt0
+    log_n = 16
+    while log_n < log_cap and (1 << (log_n + 1)) / rate0 < 12.0:
+        log_n += 1
+    n = 1 << log_n
+    bases = cpu_ref.gen_bases(curve, synth.BASE_S0, synth.BASE_D, n, threads)
+    sc = synth.msm_scalars(log_n)
+    t = time.perf_counter()
+    cpu_ref.best_multiexp(curve, sc, bases, threads)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"one 2^{log_n} Pallas best_multiexp (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}
+
+
+def cpu_baseline_ntt(field: str, log_n: int):
+    import cpu_ref
+    import pasta as o
+    from tiny_ram_halo2_amd import synth
+
+    threads = cpu_ref.hardware_threads()
+    f = o.FIELDS[field]
+    a = synth.ntt_input(log_n)
+    w = np.array(f.limbs(f.omega(log_n)), np.uint64)
+    t = time.perf_counter()
+    cpu_ref.best_fft(field, a, w, log_n, threads)
+    dt = time.perf_counter() - t
+    return {"value": (1 << log_n) / dt, "unit": "elems/s", "cores": threads, "kind": "port",
+            "sample": f"one 2^{log_n} Fp best_fft (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}
+
+
+def load_traffic(name: str):
+    """PMC-derived HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(name)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=24, help="log2 of MSM pairs per GPU")
+    ap.add_argument("--ntt-log-n", type=int, default=22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tiny_ram_halo2_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libtrh has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    api.init(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    curve = "pallas"
+    log_n = args.log_n
+    n = 1 << log_n
+    first = rank * n  # this rank's slice of the global (scalar, base) range
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n, first=first)
+    sc_host = synth.field_elements(synth.SEED_MSM | log_n, n, start=first)
+    d_sc = torch.from_numpy(sc_host.view(np.int64)).to(dev)
+    partial = torch.zeros(12, dtype=torch.int64, device=dev)
+    gathered = [torch.zeros(12, dtype=torch.int64, device=dev) for _ in range(world)]
+
+    def step():
+        p = bases.msm_dev(d_sc, n, stream=stream)  # local Pippenger -> one Jacobian point (host)
+        if world == 1:
+            return p
+        partial.copy_(torch.from_numpy(p.view(np.int64)))
+        dist.all_gather(gathered, partial)
+        pts = torch.stack(gathered).cpu().numpy().view(np.uint64)
+        return api.point_sum(curve, pts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        result = step()
+    api.set_timing(True)
+    acc_ms, phase = [], {"digits_ms": 0.0, "sort_ms": 0.0, "accumulate_ms": 0.0, "reduce_ms": 0.0, "total_ms": 0.0}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        tm = api.last_timing()
+        acc_ms.append(tm["accumulate_ms"])
+        for k in phase:
+            phase[k] += tm[k] / args.steps
+    fence()
+    elapsed = time.perf_counter() - t0
+    api.set_timing(False)
+    tm = api.last_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # closed-form check of the whole (global) MSM: bases are (s0 + i d) G with known logs
+    check = None
+    if rank == 0:
+        d_can = torch.empty_like(d_sc)
+        api._check(api.lib().trh_field_op_dev(api.FQ, api.FIELD_OPS["from_mont"], api._devptr(d_sc), None, api._devptr(d_can), n, stream))
+        torch.cuda.synchronize()
+        can = d_can.cpu().numpy().view(np.uint64)
+        q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+        total = synth.weighted_scalar_sum(can, synth.BASE_S0, synth.BASE_D, start=first) % q
+        if world == 1:
+            R = (1 << 256) % q
+            g = api.Bases.generate(curve, 1, 0, 1)  # the generator itself
+            want = g.msm(synth.ints_to_limbs([total * R % q]))
+            check = "closed-form ok" if (want == result).all() else "MISMATCH"
+        else:
+            check = "rank-0 shard only (global closed form covered by tests)"
+
+    # ---- secondary: Fp NTT @ 2^22 (same process, outside the MSM timed region) ----
+    ntt = None
+    if rank == 0:
+        ln = args.ntt_log_n
+        P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+        root = 0x2BCE74DEAC30EBDA362120830561F81AEA322BF2B7BB7584BDAD6FABD87EA32F
+        omega = pow(root, 1 << (32 - ln), P)
+        w = synth.ints_to_limbs([omega * ((1 << 256) % P) % P])[0]
+        a = synth.ntt_input(ln)
+        d_a = torch.from_numpy(a.view(np.int64).copy()).to(dev)
+        for _ in range(max(args.warmup, 2)):
+            api.ntt_dev("fp", d_a, ln, w, stream=stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(args.steps, 5) * 4
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            api.ntt_dev("fp", d_a, ln, w, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        ach = 64.0 * (1 << ln) / (ms * 1e-3) / 1e9
+        ntt = {"metric": f"Fp NTT elems/s @ 2^{ln}", "value": (1 << ln) / (ms * 1e-3), "unit": "elems/s", "ms_per_transform": ms,
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": load_traffic(f"ntt_fp_2^{ln}")}}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            ntt["cpu_baseline"] = cpu_baseline_ntt("fp", ln)
+
+    if rank == 0:
+        acc = float(np.mean(acc_ms))
+        ach = 96.0 * n / (acc * 1e-3) / 1e9
+        out = {
+            "metric": METRIC,
+            "value": world * n * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"Pallas MSM, 2^{log_n} pairs per GPU, random 254-bit scalars, distinct bases (s0+i*d)G, "
+                                   f"inputs resident in HBM; global size {world}*2^{log_n}", "curve": curve,
+                       "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
+                       "parallelism": f"range-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(f"msm_accumulate_2^{log_n}"),
+                         "kernel_ms": acc, "algorithmic_bytes": 96 * n},
+            "phases_ms": phase,
+            "check": check,
+            "secondary": ntt,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_msm(curve)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

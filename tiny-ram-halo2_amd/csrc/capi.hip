@@ -38,11 +38,11 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint4* __re
     Fe<F> x, y = fe_zero<F>(), r;
     {
         uint4 lo = a[2 * i], hi = a[2 * i + 1];
-        x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w; x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+        x = fe_load<F>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
     }
     if (b) {
         uint4 lo = b[2 * i], hi = b[2 * i + 1];
-        y.l[0] = lo.x; y.l[1] = lo.y; y.l[2] = lo.z; y.l[3] = lo.w; y.l[4] = hi.x; y.l[5] = hi.y; y.l[6] = hi.z; y.l[7] = hi.w;
+        y = fe_load<F>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
     }
     switch (op) {
         case 0: r = fe_add(x, y); break;
@@ -54,31 +54,26 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint4* __re
         case 6: r = fe_to_mont(x); break;
         default: r = fe_from_mont(x); break;
     }
-    out[2 * i] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
-    out[2 * i + 1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+    u32 w[8];
+    fe_store(r, w);
+    out[2 * i] = make_uint4(w[0], w[1], w[2], w[3]);
+    out[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 template <class F>
-__global__ void __launch_bounds__(64) point_op_kernel(int op, const u32* __restrict__ p, const u32* __restrict__ q, u32* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(64) point_op_kernel(int op, const JacobianMem* __restrict__ p, const void* __restrict__ q, JacobianMem* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Jacobian<F> pj;
-    for (int k = 0; k < 24; ++k) ((u32*)&pj)[k] = p[24 * i + k];
-    XYZZ<F> a = xyzz_from_jacobian(pj), r;
+    XYZZ<F> a = xyzz_from_jacobian(jac_load<F>(p[i])), r;
     if (op == 0) {
-        Jacobian<F> qj;
-        for (int k = 0; k < 24; ++k) ((u32*)&qj)[k] = q[24 * i + k];
-        r = xyzz_add(a, xyzz_from_jacobian(qj));
+        r = xyzz_add(a, xyzz_from_jacobian(jac_load<F>(((const JacobianMem*)q)[i])));
     } else if (op == 1) {
-        Affine<F> qa;
-        for (int k = 0; k < 16; ++k) ((u32*)&qa)[k] = q[16 * i + k];
         r = a;
-        xyzz_madd(r, qa);
+        xyzz_madd(r, aff_load<F>(((const AffineMem*)q)[i]));
     } else {
         r = xyzz_dbl(a);
     }
-    Jacobian<F> o = jac_from_affine(xyzz_to_affine(r));
-    for (int k = 0; k < 24; ++k) out[24 * i + k] = ((u32*)&o)[k];
+    jac_store(jac_from_affine(xyzz_to_affine(r)), out[i]);
 }
 
 int check_curve(int curve) {
@@ -333,8 +328,8 @@ int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out,
     TRH_TRY(check_curve(curve));
     if (!n) return TRH_OK;
     const unsigned gb = (unsigned)((n + 63) / 64);
-    if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_kernel<FpParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const u32*)p, (const u32*)q, (u32*)out, n);
-    else hipLaunchKernelGGL((point_op_kernel<FqParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const u32*)p, (const u32*)q, (u32*)out, n);
+    if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_kernel<FpParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
+    else hipLaunchKernelGGL((point_op_kernel<FqParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }

@@ -60,9 +60,12 @@ struct TwiddleEntry {
 struct MsmScratch {
     DevBuf scalars;      // host-scalar entry points stage here
     DevBuf digits;       // W x n u32: bucket id | sign << 31
+    DevBuf parted;       // W x n u32: entries grouped by level-1 bin (index | low bucket bits | sign)
     DevBuf sorted;       // W x n u32: point index | sign << 31, grouped by bucket
-    DevBuf counts;       // W x (NB + 1) u32 histogram, then running cursor / bucket end
+    DevBuf counts;       // W x nbins u32 level-1 histogram, then running cursor / bin end
+    DevBuf bin_starts;   // W x nbins u32 level-1 bin start offsets
     DevBuf starts;       // W x (NB + 1) u32 bucket start offsets
+    DevBuf ends;         // W x (NB + 1) u32 bucket end offsets
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
     DevBuf window_sums;  // batch x W XYZZ

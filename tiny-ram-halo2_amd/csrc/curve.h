@@ -17,7 +17,18 @@
 
 namespace trh {
 
-// 64-byte POD used for bases: x, y Montgomery; the all-zero pattern (not on the curve) is the identity
+// Memory-format PODs (what crosses the C ABI and what kernels keep in HBM / LDS): each field
+// element is eight 32-bit words = pasta's [u64; 4].  AffineMem is the 64-byte base POD (the
+// all-zero pattern, not on the curve, is the identity); JacobianMem is pasta's `Point` layout.
+struct alignas(16) FeMem { u32 w[8]; };
+struct alignas(16) AffineMem { FeMem x, y; };
+struct alignas(16) XYZZMem { FeMem x, y, zz, zzz; };
+struct alignas(16) JacobianMem { FeMem x, y, z; };
+
+template <class F> TRH_HD Fe<F> fe_load(const FeMem& m) { return fe_load<F>(m.w); }
+template <class F> TRH_HD void fe_store(const Fe<F>& a, FeMem& m) { fe_store(a, m.w); }
+
+// register-form points
 template <class F>
 struct Affine {
     Fe<F> x, y;
@@ -153,5 +164,20 @@ template <class F> TRH_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F>& j) {
     r.x = j.x; r.y = j.y; r.zz = fe_sqr(j.z); r.zzz = fe_mul(r.zz, j.z);
     return r;
 }
+
+template <class F> TRH_HD Affine<F> aff_load(const AffineMem& m) {
+    Affine<F> r; r.x = fe_load<F>(m.x); r.y = fe_load<F>(m.y); return r;
+}
+template <class F> TRH_HD void aff_store(const Affine<F>& a, AffineMem& m) { fe_store(a.x, m.x); fe_store(a.y, m.y); }
+template <class F> TRH_HD XYZZ<F> xyzz_load(const XYZZMem& m) {
+    XYZZ<F> r; r.x = fe_load<F>(m.x); r.y = fe_load<F>(m.y); r.zz = fe_load<F>(m.zz); r.zzz = fe_load<F>(m.zzz); return r;
+}
+template <class F> TRH_HD void xyzz_store(const XYZZ<F>& a, XYZZMem& m) {
+    fe_store(a.x, m.x); fe_store(a.y, m.y); fe_store(a.zz, m.zz); fe_store(a.zzz, m.zzz);
+}
+template <class F> TRH_HD Jacobian<F> jac_load(const JacobianMem& m) {
+    Jacobian<F> r; r.x = fe_load<F>(m.x); r.y = fe_load<F>(m.y); r.z = fe_load<F>(m.z); return r;
+}
+template <class F> TRH_HD void jac_store(const Jacobian<F>& a, JacobianMem& m) { fe_store(a.x, m.x); fe_store(a.y, m.y); fe_store(a.z, m.z); }
 
 }  // namespace trh

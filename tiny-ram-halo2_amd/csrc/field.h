@@ -1,17 +1,25 @@
-// Pasta field arithmetic for gfx950: 255-bit Montgomery (R = 2^256) on 8 x u32 limbs.
+// Pasta field arithmetic for gfx950: 255-bit Montgomery (R = 2^256), nine 30-bit limbs in
+// registers.
 //
 // Replaces pasta_curves 0.4.1 `Fp` / `Fq` (fields/fp.rs, fields/fq.rs; pinned at
 // /root/reference/Cargo.lock:847-858, used by the reference at src/test_utils.rs:2 and
-// src/circuits/tables/even_bits.rs:250-262).  Memory format is identical to the Rust one:
-// four u64 little-endian limbs, Montgomery form, fully reduced -- the same bytes read as
-// eight u32 limbs here, so buffers cross the C ABI without repacking.
+// src/circuits/tables/even_bits.rs:250-262).  The MEMORY format is identical to the Rust one
+// (four u64 little-endian limbs, Montgomery form with R = 2^256, fully reduced), so buffers
+// cross the C ABI without repacking; fe_load / fe_store convert between those eight 32-bit
+// words and the register form.
 //
-// Both moduli have the shape  m = 2^254 + t,  t < 2^126,  m = 1 (mod 2^32):
-//   limbs(m) = [1, M1, M2, M3, 0, 0, 0, 0x40000000]
-// so in word-serial Montgomery reduction the quotient digit is  q = -T[i] mod 2^32  (no
-// multiply: -m^-1 = -1 mod 2^32), q*m needs only three 32x32 multiplies (M1..M3), the low word
-// is a pure carry and the top word is a shift by 30.  A field multiply is therefore
-// 64 (product) + 24 (reduction) v_mad_u64_u32 instead of 64 + 72.
+// Why 30-bit limbs.  gfx950 has no 64x64 multiplier; its widest integer multiply is
+// v_mad_u64_u32 (32x32 + 64 -> 64, half rate -- measured 32 Tops/s vs 65 for v_add_u32, the same
+// rate as a carry-chained v_addc_co_u32).  With saturated 32-bit limbs every partial product
+// needs carry handling and 64-bit operand pairs must be re-formed (the compiler emitted 211
+// v_mov + 94 v_lshl_add_u64 around the 88 multiplies).  With limbs < 2^30 a column of the
+// schoolbook product holds at most 9 products + 4 reduction terms < 13 * 2^60 < 2^64, so the
+// whole multiply is `acc[i+j] += a[i] * b[j]` -- in-place v_mad_u64_u32 chains with no carries.
+//
+// Both moduli are m = 2^254 + t with t < 2^126 and m = 1 (mod 2^30): in radix 2^30 the limbs are
+// [1, P1, P2, P3, P4, 0, 0, 0, 2^14].  The Montgomery quotient digit is q = -T_i mod 2^30 (no
+// multiply), q*m costs four multiplies and one shift.  R stays 2^256 = 2^(8*30 + 16): eight
+// 30-bit rounds, one 16-bit round, and a 16-bit realignment of the result.
 //
 // The same source is compiled for the host (final window combine, affine normalisation).
 #pragma once
@@ -28,192 +36,238 @@ namespace trh {
 
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int32_t i32;
 
-struct FpParams {  // Pallas base field = Vesta scalar field
-    static constexpr u32 M1 = 0x992d30edu, M2 = 0x094cf91bu, M3 = 0x224698fcu;
-    static constexpr int ID = 0;
-    TRH_HD static constexpr u32 one(int i) {  // R = 2^256 mod p
-        constexpr u32 v[8] = {0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-        return v[i];
-    }
-    TRH_HD static constexpr u32 r2(int i) {  // R^2 mod p
-        constexpr u32 v[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};
-        return v[i];
-    }
-};
-struct FqParams {  // Vesta base field = Pallas scalar field
-    static constexpr u32 M1 = 0x8c46eb21u, M2 = 0x0994a8ddu, M3 = 0x224698fcu;
-    static constexpr int ID = 1;
-    TRH_HD static constexpr u32 one(int i) {
-        constexpr u32 v[8] = {0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-        return v[i];
-    }
-    TRH_HD static constexpr u32 r2(int i) {
-        constexpr u32 v[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
-        return v[i];
-    }
-};
+constexpr u32 LIMB_BITS = 30;
+constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;
+constexpr int NLIMBS = 9;
 
-template <class F>
-TRH_HD constexpr u32 mod_limb(int i) {
-    return i == 0 ? 1u : i == 1 ? F::M1 : i == 2 ? F::M2 : i == 3 ? F::M3 : i == 7 ? 0x40000000u : 0u;
+// 30-bit limb k of a 256-bit value given as eight 32-bit words (compile-time helper)
+constexpr u32 limb30_of(const u32 (&w)[8], int k) {
+    const int bit = 30 * k, word = bit >> 5, sh = bit & 31;
+    u64 v = w[word];
+    if (word + 1 < 8) v |= (u64)w[word + 1] << 32;
+    return (u32)(v >> sh) & LIMB_MASK;
 }
 
+struct FpParams {  // Pallas base field = Vesta scalar field
+    static constexpr int ID = 0;
+    static constexpr u32 MOD[8] = {0x00000001u, 0x992d30edu, 0x094cf91bu, 0x224698fcu, 0u, 0u, 0u, 0x40000000u};
+    static constexpr u32 ONE[8] = {0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // R mod p
+    static constexpr u32 R2[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};   // R^2 mod p
+};
+struct FqParams {  // Vesta base field = Pallas scalar field
+    static constexpr int ID = 1;
+    static constexpr u32 MOD[8] = {0x00000001u, 0x8c46eb21u, 0x0994a8ddu, 0x224698fcu, 0u, 0u, 0u, 0x40000000u};
+    static constexpr u32 ONE[8] = {0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+    static constexpr u32 R2[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
+};
+
+template <class F, int K> struct ModLimb { static constexpr u32 v = limb30_of(F::MOD, K); };
+template <class F, int K> struct OneLimb { static constexpr u32 v = limb30_of(F::ONE, K); };
+template <class F, int K> struct R2Limb { static constexpr u32 v = limb30_of(F::R2, K); };
+
+template <class F> TRH_HD constexpr u32 mod_limb(int k) {
+    return k == 0 ? ModLimb<F, 0>::v : k == 1 ? ModLimb<F, 1>::v : k == 2 ? ModLimb<F, 2>::v : k == 3 ? ModLimb<F, 3>::v :
+           k == 4 ? ModLimb<F, 4>::v : k == 5 ? ModLimb<F, 5>::v : k == 6 ? ModLimb<F, 6>::v : k == 7 ? ModLimb<F, 7>::v : ModLimb<F, 8>::v;
+}
+template <class F> TRH_HD constexpr u32 one_limb(int k) {
+    return k == 0 ? OneLimb<F, 0>::v : k == 1 ? OneLimb<F, 1>::v : k == 2 ? OneLimb<F, 2>::v : k == 3 ? OneLimb<F, 3>::v :
+           k == 4 ? OneLimb<F, 4>::v : k == 5 ? OneLimb<F, 5>::v : k == 6 ? OneLimb<F, 6>::v : k == 7 ? OneLimb<F, 7>::v : OneLimb<F, 8>::v;
+}
+template <class F> TRH_HD constexpr u32 r2_limb(int k) {
+    return k == 0 ? R2Limb<F, 0>::v : k == 1 ? R2Limb<F, 1>::v : k == 2 ? R2Limb<F, 2>::v : k == 3 ? R2Limb<F, 3>::v :
+           k == 4 ? R2Limb<F, 4>::v : k == 5 ? R2Limb<F, 5>::v : k == 6 ? R2Limb<F, 6>::v : k == 7 ? R2Limb<F, 7>::v : R2Limb<F, 8>::v;
+}
+static_assert(ModLimb<FpParams, 0>::v == 1 && ModLimb<FpParams, 5>::v == 0 && ModLimb<FpParams, 6>::v == 0 &&
+              ModLimb<FpParams, 7>::v == 0 && ModLimb<FpParams, 8>::v == (1u << 14), "Fp modulus shape");
+static_assert(ModLimb<FqParams, 0>::v == 1 && ModLimb<FqParams, 5>::v == 0 && ModLimb<FqParams, 6>::v == 0 &&
+              ModLimb<FqParams, 7>::v == 0 && ModLimb<FqParams, 8>::v == (1u << 14), "Fq modulus shape");
+
+// register form: l[k] < 2^30, value = sum l[k] 2^(30k) < m
 template <class F>
 struct Fe {
-    u32 l[8];
+    u32 l[NLIMBS];
 };
+
+// ---- memory <-> register form (eight 32-bit words, little endian) -----------------------
+template <class F> TRH_HD Fe<F> fe_load(u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5, u32 w6, u32 w7) {
+    Fe<F> r;
+    r.l[0] = w0 & LIMB_MASK;
+    r.l[1] = ((w0 >> 30) | (w1 << 2)) & LIMB_MASK;
+    r.l[2] = ((w1 >> 28) | (w2 << 4)) & LIMB_MASK;
+    r.l[3] = ((w2 >> 26) | (w3 << 6)) & LIMB_MASK;
+    r.l[4] = ((w3 >> 24) | (w4 << 8)) & LIMB_MASK;
+    r.l[5] = ((w4 >> 22) | (w5 << 10)) & LIMB_MASK;
+    r.l[6] = ((w5 >> 20) | (w6 << 12)) & LIMB_MASK;
+    r.l[7] = ((w6 >> 18) | (w7 << 14)) & LIMB_MASK;
+    r.l[8] = w7 >> 16;
+    return r;
+}
+template <class F> TRH_HD Fe<F> fe_load(const u32* w) { return fe_load<F>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]); }
+template <class F> TRH_HD void fe_store(const Fe<F>& a, u32* w) {
+    w[0] = a.l[0] | (a.l[1] << 30);
+    w[1] = (a.l[1] >> 2) | (a.l[2] << 28);
+    w[2] = (a.l[2] >> 4) | (a.l[3] << 26);
+    w[3] = (a.l[3] >> 6) | (a.l[4] << 24);
+    w[4] = (a.l[4] >> 8) | (a.l[5] << 22);
+    w[5] = (a.l[5] >> 10) | (a.l[6] << 20);
+    w[6] = (a.l[6] >> 12) | (a.l[7] << 18);
+    w[7] = (a.l[7] >> 14) | (a.l[8] << 16);
+}
 
 template <class F> TRH_HD Fe<F> fe_zero() {
     Fe<F> r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = 0;
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = 0;
     return r;
 }
 template <class F> TRH_HD Fe<F> fe_one() {
     Fe<F> r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = F::one(i);
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = one_limb<F>(i);
     return r;
 }
 template <class F> TRH_HD Fe<F> fe_r2() {
     Fe<F> r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = F::r2(i);
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = r2_limb<F>(i);
     return r;
 }
 template <class F> TRH_HD bool fe_is_zero(const Fe<F>& a) {
     u32 o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.l[i];
+    for (int i = 0; i < NLIMBS; ++i) o |= a.l[i];
     return o == 0;
 }
 template <class F> TRH_HD bool fe_eq(const Fe<F>& a, const Fe<F>& b) {
     u32 o = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o |= a.l[i] ^ b.l[i];
+    for (int i = 0; i < NLIMBS; ++i) o |= a.l[i] ^ b.l[i];
     return o == 0;
 }
 
-// r = a - m if a >= m else a   (a < 2m)
+// a in [0, 2m) with normalised limbs -> a mod m
 template <class F> TRH_HD void fe_cond_sub(Fe<F>& a) {
-    u32 t[8];
-    u32 borrow = 0;
+    u32 t[NLIMBS];
+    i32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = __builtin_subc(a.l[i], mod_limb<F>(i), borrow, &borrow);
+    for (int i = 0; i < NLIMBS; ++i) {
+        i32 v = (i32)a.l[i] - (i32)mod_limb<F>(i) + c;
+        t[i] = (u32)v & LIMB_MASK;
+        c = v >> 30;  // arithmetic: 0 or -1
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a.l[i] = borrow ? a.l[i] : t[i];
+    for (int i = 0; i < NLIMBS; ++i) a.l[i] = c ? a.l[i] : t[i];
 }
 
 template <class F> TRH_HD Fe<F> fe_add(const Fe<F>& a, const Fe<F>& b) {
     Fe<F> r;
     u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
-    fe_cond_sub(r);  // a + b < 2m < 2^256: no carry out
+    for (int i = 0; i < NLIMBS; ++i) {
+        u32 v = a.l[i] + b.l[i] + c;
+        r.l[i] = v & LIMB_MASK;
+        c = v >> 30;
+    }
+    fe_cond_sub(r);  // a + b < 2m < 2^256 fits nine limbs
     return r;
 }
 template <class F> TRH_HD Fe<F> fe_sub(const Fe<F>& a, const Fe<F>& b) {
     Fe<F> r;
-    u32 bw = 0;
+    i32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_subc(a.l[i], b.l[i], bw, &bw);
-    u32 mask = 0u - bw, c = 0;
+    for (int i = 0; i < NLIMBS; ++i) {
+        i32 v = (i32)a.l[i] - (i32)b.l[i] + c;
+        r.l[i] = (u32)v & LIMB_MASK;
+        c = v >> 30;
+    }
+    const u32 mask = (u32)c;  // all ones when a < b: add m back
+    u32 cc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_addc(r.l[i], mod_limb<F>(i) & mask, c, &c);
+    for (int i = 0; i < NLIMBS; ++i) {
+        u32 v = r.l[i] + (mod_limb<F>(i) & mask) + cc;
+        r.l[i] = v & LIMB_MASK;
+        cc = v >> 30;
+    }
     return r;
 }
 template <class F> TRH_HD Fe<F> fe_neg(const Fe<F>& a) { return fe_sub(fe_zero<F>(), a); }
 template <class F> TRH_HD Fe<F> fe_dbl(const Fe<F>& a) { return fe_add(a, a); }
 
-// Word-serial Montgomery reduction of a 16-word value T < m * 2^256; returns T / 2^256 mod m.
-template <class F> TRH_HD Fe<F> fe_mont_reduce(u32 (&t)[16]) {
-    u32 hi = 0;  // deferred carry into word i+9
+// Montgomery reduction of 18 lazy 64-bit columns (value < m * 2^256): returns value / 2^256 mod m.
+template <class F> TRH_HD Fe<F> fe_mont_reduce(u64 (&acc)[18]) {
+    constexpr u32 P1 = ModLimb<F, 1>::v, P2 = ModLimb<F, 2>::v, P3 = ModLimb<F, 3>::v, P4 = ModLimb<F, 4>::v;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32 q = 0u - t[i];
-        u64 uv;
-        u32 c = (t[i] != 0) ? 1u : 0u;  // t[i] + q*1 = 2^32 or 0
-        uv = (u64)q * F::M1 + t[i + 1] + c; t[i + 1] = (u32)uv; c = (u32)(uv >> 32);
-        uv = (u64)q * F::M2 + t[i + 2] + c; t[i + 2] = (u32)uv; c = (u32)(uv >> 32);
-        uv = (u64)q * F::M3 + t[i + 3] + c; t[i + 3] = (u32)uv; c = (u32)(uv >> 32);
-        t[i + 4] = __builtin_addc(t[i + 4], 0u, c, &c);
-        t[i + 5] = __builtin_addc(t[i + 5], 0u, c, &c);
-        t[i + 6] = __builtin_addc(t[i + 6], 0u, c, &c);
-        t[i + 7] = __builtin_addc(t[i + 7], q << 30, c, &c);
-        uv = (u64)t[i + 8] + (q >> 2) + c + hi;
-        t[i + 8] = (u32)uv;
-        hi = (u32)(uv >> 32);
+    for (int i = 0; i < 8; ++i) {  // eight 30-bit rounds
+        const u32 q = (0u - (u32)acc[i]) & LIMB_MASK;
+        // column i becomes a multiple of 2^30: acc[i] + q = ((acc[i] + 2^30 - 1) >> 30) << 30
+        acc[i + 1] += ((acc[i] + LIMB_MASK) >> 30) + (u64)q * P1;
+        acc[i + 2] += (u64)q * P2;
+        acc[i + 3] += (u64)q * P3;
+        acc[i + 4] += (u64)q * P4;
+        acc[i + 8] += (u64)q << 14;
     }
-    // hi == 0 here: (T + Q*m) / 2^256 < 2m < 2^256
+    {  // one 16-bit round: 256 = 8 * 30 + 16
+        const u32 q = (0u - (u32)acc[8]) & 0xffffu;
+        acc[8] += q;
+        acc[9] += (u64)q * P1;
+        acc[10] += (u64)q * P2;
+        acc[11] += (u64)q * P3;
+        acc[12] += (u64)q * P4;
+        acc[16] += (u64)q << 14;
+    }
+    // normalise columns 8..17 (low 16 bits of column 8 are zero) and realign by 16 bits
+    u32 n[10];
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        c += acc[8 + k];
+        n[k] = (u32)c & LIMB_MASK;
+        c >>= 30;
+    }
     Fe<F> r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = t[i + 8];
-    fe_cond_sub(r);
+    for (int k = 0; k < NLIMBS; ++k) r.l[k] = ((n[k] >> 16) | (n[k + 1] << 14)) & LIMB_MASK;
+    fe_cond_sub(r);  // (T + Q m) / 2^256 < 2m
     return r;
 }
 
 template <class F> TRH_HD Fe<F> fe_mul(const Fe<F>& a, const Fe<F>& b) {
-    u32 t[16];
+    u64 acc[18];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u32 c = 0;
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            u64 uv = (u64)a.l[i] * b.l[j] + (i ? t[i + j] : 0u) + c;
-            t[i + j] = (u32)uv;
-            c = (u32)(uv >> 32);
-        }
-        t[i + 8] = c;
-    }
-    return fe_mont_reduce<F>(t);
+    for (int i = 0; i < NLIMBS; ++i)
+#pragma unroll
+        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (u64)a.l[i] * b.l[j];
+    return fe_mont_reduce<F>(acc);
 }
 
 template <class F> TRH_HD Fe<F> fe_sqr(const Fe<F>& a) {
-    // off-diagonal products once, doubled, plus the diagonal: 36 multiplies instead of 64
-    u32 t[16];
+    u64 acc[18];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = 0;
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        u32 c = 0;
+    for (int i = 0; i < NLIMBS; ++i) {
+        acc[2 * i] += (u64)a.l[i] * a.l[i];
+        const u32 a2 = a.l[i] << 1;  // < 2^31: 4 doubled pairs + 1 square per column stay < 9 * 2^60
 #pragma unroll
-        for (int j = i + 1; j < 8; ++j) {
-            u64 uv = (u64)a.l[i] * a.l[j] + t[i + j] + c;
-            t[i + j] = (u32)uv;
-            c = (u32)(uv >> 32);
-        }
-        t[i + 8] = c;
+        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (u64)a2 * a.l[j];
     }
-    // double
-    u32 top = 0;
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-        u32 nt = t[i] >> 31;
-        t[i] = (t[i] << 1) | top;
-        top = nt;
-    }
-    // add diagonal
-    u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u64 d = (u64)a.l[i] * a.l[i];
-        t[2 * i] = __builtin_addc(t[2 * i], (u32)d, c, &c);
-        t[2 * i + 1] = __builtin_addc(t[2 * i + 1], (u32)(d >> 32), c, &c);
-    }
-    return fe_mont_reduce<F>(t);
+    return fe_mont_reduce<F>(acc);
 }
 
 // Montgomery -> canonical (pasta `to_repr()` as limbs): multiply by 1
 template <class F> TRH_HD Fe<F> fe_from_mont(const Fe<F>& a) {
-    u32 t[16];
+    u64 acc[18];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { t[i] = a.l[i]; t[i + 8] = 0; }
-    return fe_mont_reduce<F>(t);
+    for (int k = 0; k < 18; ++k) acc[k] = k < NLIMBS ? a.l[k] : 0;
+    return fe_mont_reduce<F>(acc);
 }
 template <class F> TRH_HD Fe<F> fe_to_mont(const Fe<F>& a) { return fe_mul(a, fe_r2<F>()); }
 
-// a^e, e given as 8 u32 limbs (variable time; host-side use and table setup)
+// a^e, e given as 32-bit words (variable time; host-side use and table setup)
 template <class F> TRH_HD Fe<F> fe_pow(const Fe<F>& a, const u32* e, int nbits) {
     Fe<F> r = fe_one<F>();
     for (int i = nbits - 1; i >= 0; --i) {
@@ -226,9 +280,9 @@ template <class F> TRH_HD Fe<F> fe_pow(const Fe<F>& a, const u32* e, int nbits) 
 template <class F> TRH_HD Fe<F> fe_inv(const Fe<F>& a) {
     u32 e[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = mod_limb<F>(i);
-    e[0] = 0xffffffffu;  // m - 2: limb0 = 1 - 2 borrows from limb1
-    e[1] = mod_limb<F>(1) - 1u;
+    for (int i = 0; i < 8; ++i) e[i] = F::MOD[i];
+    e[0] = 0xffffffffu;  // m - 2: word0 = 1 - 2 borrows from word1
+    e[1] = F::MOD[1] - 1u;
     return fe_pow(a, e, 255);
 }
 

@@ -45,44 +45,53 @@ inline int choose_window_bits(size_t n) {
 inline int num_windows(int c) { return 255 / c + 1; }
 
 // ---------------------------------------------------------------------------------------
-// 1. recode
+// 1. recode: one thread per scalar (grid-stride).  Writes digits[j][i] = bucket | sign << 31
+//    (bucket 0 = nothing to add) and a histogram over level-1 bins
+//    bin = (bucket - 1) >> k2, accumulated in LDS and flushed once per workgroup.
 // ---------------------------------------------------------------------------------------
 template <class SF>
 __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W,
-                                                         u32* __restrict__ digits, u32* __restrict__ counts, u32 nb1) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
-    Fe<SF> s;
-    s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
-    s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-    if (mont) s = fe_from_mont(s);
+                                                         u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds) {
+    extern __shared__ u32 lhist[];  // W * nbins counters when use_lds
+    const u32 total = (u32)W * nbins;
+    if (use_lds) {
+        for (u32 k = threadIdx.x; k < total; k += blockDim.x) lhist[k] = 0;
+        __syncthreads();
+    }
     const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
-    u32 carry = 0;
-    for (int j = 0; j < W; ++j) {
-        u32 raw = (s.l[0] & mask) + carry;
-        // shift the 256-bit value right by c (static register indexing)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
+        u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (mont) fe_store(fe_from_mont(fe_load<SF>(w)), w);
+        u32 carry = 0;
+        for (int j = 0; j < W; ++j) {
+            u32 raw = (w[0] & mask) + carry;
+            // shift the 256-bit value right by c (static register indexing)
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
-        s.l[7] >>= c;
-        u32 entry = 0;
-        if (raw > half) {  // negative digit raw - 2^c, borrow from the next window
-            u32 b = (1u << c) - raw;
-            carry = 1;
-            entry = b | SIGN_BIT;
-            if (b) atomicAdd(&counts[(size_t)j * nb1 + b], 1u);
-            else entry = 0;  // raw == 2^c: digit 0 with carry
-        } else {
-            carry = 0;
-            entry = raw;
-            if (raw) atomicAdd(&counts[(size_t)j * nb1 + raw], 1u);
+            for (int k = 0; k < 7; ++k) w[k] = (w[k] >> c) | (w[k + 1] << (32 - c));
+            w[7] >>= c;
+            u32 bucket, sign = 0;
+            if (raw > half) { bucket = (1u << c) - raw; carry = 1; sign = SIGN_BIT; }  // digit raw - 2^c
+            else { bucket = raw; carry = 0; }
+            digits[(size_t)j * n + i] = bucket ? (bucket | sign) : 0u;
+            if (bucket) {
+                const u32 bin = (bucket - 1u) >> k2;
+                if (use_lds) atomicAdd(&lhist[(u32)j * nbins + bin], 1u);
+                else atomicAdd(&bin_counts[(size_t)j * nbins + bin], 1u);
+            }
         }
-        digits[(size_t)j * n + i] = entry;
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < total; k += blockDim.x) {
+            const u32 v = lhist[k];
+            if (v) atomicAdd(&bin_counts[k], v);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// 2. offsets: per window exclusive scan of counts[0..nb1) -> starts; counts becomes the cursor
+// 2. exclusive scan per window of cnt[0..len) -> starts; cnt becomes the running cursor
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1) {
     __shared__ u32 part[1024];
@@ -90,7 +99,7 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
     u32* cnt = counts + (size_t)j * nb1;
     u32* st = starts + (size_t)j * nb1;
     const u32 per = (nb1 + 1023u) / 1024u;
-    const u32 lo = t * per, hi = (lo + per < nb1) ? lo + per : nb1;
+    const u32 lo = t * per < nb1 ? t * per : nb1, hi = (lo + per < nb1) ? lo + per : nb1;
     u32 sum = 0;
     for (u32 b = lo; b < hi; ++b) sum += cnt[b];
     part[t] = sum;
@@ -105,24 +114,95 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
     for (u32 b = lo; b < hi; ++b) {
         u32 cv = cnt[b];
         st[b] = run;
-        cnt[b] = run;  // cursor starts at the bucket start
+        cnt[b] = run;  // cursor starts at the bin start
         run += cv;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// 3. scatter
+// 3a. partition: workgroup (tile, window) groups a tile of PART_TILE digits by level-1 bin.
+//     LDS histogram of the tile -> one global atomicAdd per (workgroup, bin) reserves a run in the
+//     bin's region -> entries are written into that run (rank from an LDS atomic), so each
+//     workgroup writes ~PART_TILE / nbins consecutive entries per bin.
+//     entry = point index | low k2 bucket bits << idx_bits | sign << 31
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const u32* __restrict__ digits, u32* __restrict__ cursor,
-                                                          u32* __restrict__ sorted, size_t n, u32 nb1) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int PART_TILE = 16384;
+__global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
+                                                            u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
+    extern __shared__ u32 lds[];  // [nbins] counts / cursors, [nbins] global run base
+    u32* cnt = lds;
+    u32* base = lds + nbins;
     const int j = blockIdx.y;
-    if (i >= n) return;
-    u32 e = digits[(size_t)j * n + i];
-    u32 b = e & ~SIGN_BIT;
-    if (!b) return;
-    u32 pos = atomicAdd(&cursor[(size_t)j * nb1 + b], 1u);
-    sorted[(size_t)j * n + pos] = (u32)i | (e & SIGN_BIT);
+    const size_t t0 = (size_t)blockIdx.x * PART_TILE;
+    const size_t t1 = t0 + PART_TILE < n ? t0 + PART_TILE : n;
+    const u32* dg = digits + (size_t)j * n;
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    for (size_t i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
+        const u32 b = dg[i] & ~SIGN_BIT;
+        if (b) atomicAdd(&cnt[(b - 1u) >> k2], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const u32 v = cnt[k];
+        base[k] = v ? atomicAdd(&bin_cursor[(size_t)j * nbins + k], v) : 0u;
+        cnt[k] = 0;
+    }
+    __syncthreads();
+    u32* out = parted + (size_t)j * n;
+    const u32 low_mask = (1u << k2) - 1u;
+    for (size_t i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
+        const u32 e = dg[i];
+        const u32 b = e & ~SIGN_BIT;
+        if (b) {
+            const u32 bm = b - 1u, bin = bm >> k2;
+            const u32 r = atomicAdd(&cnt[bin], 1u);
+            out[base[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3b. bucket sort: workgroup (bin, window) orders its bin's entries by the low k2 bucket bits
+//     (LDS histogram + scan + LDS cursors) and publishes the bucket ranges.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
+                                                              const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
+                                                              u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
+                                                              u32 nbins, int idx_bits, u32 nbk) {
+    __shared__ u32 cnt[128], off[128];
+    const int j = blockIdx.y;
+    const u32 bin = blockIdx.x;
+    const u32 lo = bin_starts[(size_t)j * nbins + bin], hi = bin_ends[(size_t)j * nbins + bin];
+    const u32 nsub = 1u << k2, low_mask = nsub - 1u;
+    const u32* src = parted + (size_t)j * n;
+    u32* dst = sorted + (size_t)j * n;
+    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&cnt[(src[i] >> idx_bits) & low_mask], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (u32 k = 0; k < nsub; ++k) { off[k] = run; run += cnt[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nsub) {
+        const u32 bucket = (bin << k2) + threadIdx.x + 1u;  // 1-based bucket id
+        if (bucket <= nbk) {
+            starts[(size_t)j * (nbk + 1) + bucket] = lo + off[threadIdx.x];
+            ends[(size_t)j * (nbk + 1) + bucket] = lo + off[threadIdx.x] + cnt[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 idx_mask = (1u << idx_bits) - 1u;
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const u32 e = src[i];
+        const u32 sub = (e >> idx_bits) & low_mask;
+        const u32 r = atomicAdd(&cnt[sub], 1u);
+        dst[lo + off[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -133,37 +213,39 @@ __device__ __forceinline__ Affine<BF> load_affine(const uint4* __restrict__ base
     const uint4* p = bases + (size_t)idx * 4;
     uint4 a = p[0], b = p[1], c = p[2], d = p[3];
     Affine<BF> r;
-    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w;
-    r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
-    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w;
-    r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
+    r.x = fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    r.y = fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w);
     return r;
 }
-
 template <class BF>
-__device__ __forceinline__ void store_xyzz(XYZZ<BF>* dst, const XYZZ<BF>& v) {
-    uint4* p = (uint4*)dst;
-    const u32* w = (const u32*)&v;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+__device__ __forceinline__ void store_fe4(uint4* p, const Fe<BF>& v) {
+    u32 w[8];
+    fe_store(v, w);
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 template <class BF>
-__device__ __forceinline__ XYZZ<BF> load_xyzz(const XYZZ<BF>* src) {
+__device__ __forceinline__ Fe<BF> load_fe4(const uint4* p) {
+    uint4 a = p[0], b = p[1];
+    return fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+template <class BF>
+__device__ __forceinline__ void store_xyzz(XYZZMem* dst, const XYZZ<BF>& v) {
+    uint4* p = (uint4*)dst;
+    store_fe4(p, v.x); store_fe4(p + 2, v.y); store_fe4(p + 4, v.zz); store_fe4(p + 6, v.zzz);
+}
+template <class BF>
+__device__ __forceinline__ XYZZ<BF> load_xyzz(const XYZZMem* src) {
     const uint4* p = (const uint4*)src;
     XYZZ<BF> v;
-    u32* w = (u32*)&v;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        uint4 q = p[k];
-        w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
-    }
+    v.x = load_fe4<BF>(p); v.y = load_fe4<BF>(p + 2); v.zz = load_fe4<BF>(p + 4); v.zzz = load_fe4<BF>(p + 6);
     return v;
 }
 
 template <class BF>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint4* __restrict__ bases, const u32* __restrict__ sorted,
                                                              const u32* __restrict__ starts, const u32* __restrict__ ends,
-                                                             XYZZ<BF>* __restrict__ buckets, size_t n, u32 nbk) {
+                                                             XYZZMem* __restrict__ buckets, size_t n, u32 nbk) {
     // thread -> bucket id 1..nbk of window blockIdx.y
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y;
@@ -194,17 +276,17 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint4* __rest
 //    thread t of a window owns buckets t*m+1 .. (t+1)*m; blocks of 256 threads tree-add in LDS.
 // ---------------------------------------------------------------------------------------
 template <class BF>
-__global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZ<BF>* __restrict__ buckets, XYZZ<BF>* __restrict__ partials,
+__global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZMem* __restrict__ buckets, XYZZMem* __restrict__ partials,
                                                          u32 nbk, u32 m, u32 threads_per_window) {
-    __shared__ XYZZ<BF> sh[256];
+    __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
     const int j = blockIdx.y;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     XYZZ<BF> total = xyzz_identity<BF>();
     if (t < threads_per_window) {
-        const XYZZ<BF>* bk = buckets + (size_t)j * nbk + (size_t)t * m;
+        const XYZZMem* bk = buckets + (size_t)j * nbk + (size_t)t * m;
         XYZZ<BF> run = xyzz_identity<BF>(), acc = xyzz_identity<BF>();
         for (int k = (int)m - 1; k >= 0; --k) {
-            XYZZ<BF> v = load_xyzz(&bk[k]);
+            XYZZ<BF> v = load_xyzz<BF>(&bk[k]);
             run = xyzz_add(run, v);
             acc = xyzz_add(acc, run);
         }
@@ -232,11 +314,11 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZ<BF>* __restr
 
 // one block per window: sum `count` partials
 template <class BF>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZ<BF>* __restrict__ partials, XYZZ<BF>* __restrict__ window_sums, u32 count) {
-    __shared__ XYZZ<BF> sh[256];
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+    __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
     const int j = blockIdx.x;
     XYZZ<BF> v = xyzz_identity<BF>();
-    for (u32 k = threadIdx.x; k < count; k += 256) v = xyzz_add(v, load_xyzz(&partials[(size_t)j * count + k]));
+    for (u32 k = threadIdx.x; k < count; k += 256) v = xyzz_add(v, load_xyzz<BF>(&partials[(size_t)j * count + k]));
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -263,10 +345,9 @@ __global__ void __launch_bounds__(256) bases_generate_kernel(u64 s0, u64 d, u64 
         if ((k >> bit) & 1ull) xyzz_madd(acc, G);
     }
     Affine<BF> a = xyzz_to_affine(acc);
-    const u32* w = (const u32*)&a;
     uint4* p = out + i * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    store_fe4(p, a.x);
+    store_fe4(p + 2, a.y);
 }
 
 template <class SF, class BF>
@@ -276,6 +357,15 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     const int cb = choose_window_bits(n);
     const int W = num_windows(cb);
     const u32 nbk = 1u << (cb - 1), nb1 = nbk + 1;
+    // sort geometry: bucket - 1 = bin << k2 | sub; the partitioned entry packs sub above the index
+    int idx_bits = 1;
+    while (((size_t)1 << idx_bits) < n) ++idx_bits;
+    int k2 = cb - 1 < 7 ? cb - 1 : 7;
+    if (k2 > 31 - idx_bits) k2 = 31 - idx_bits;
+    const int k1 = cb - 1 - k2;
+    const u32 nbins = 1u << k1;
+    const size_t recode_lds = (size_t)W * nbins * 4;
+    const int recode_use_lds = recode_lds <= 64 * 1024;
     // reduce geometry
     u32 tpw = nbk < 2048 ? nbk : 2048;  // threads per window
     if (tpw > nbk) tpw = nbk;
@@ -283,13 +373,16 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     const u32 rblocks = (tpw + 255) / 256;
 
     TRH_TRY(m.digits.ensure((size_t)W * n * 4 + 16));
+    TRH_TRY(m.parted.ensure((size_t)W * n * 4 + 16));
     TRH_TRY(m.sorted.ensure((size_t)W * n * 4 + 16));
-    TRH_TRY(m.counts.ensure((size_t)W * nb1 * 4));
+    TRH_TRY(m.counts.ensure((size_t)W * nbins * 4));
+    TRH_TRY(m.bin_starts.ensure((size_t)W * nbins * 4));
     TRH_TRY(m.starts.ensure((size_t)W * nb1 * 4));
-    TRH_TRY(m.buckets.ensure((size_t)W * nbk * sizeof(XYZZ<BF>)));
-    TRH_TRY(m.partials.ensure((size_t)W * rblocks * sizeof(XYZZ<BF>)));
-    TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZ<BF>)));
-    const size_t hs = batch * W * sizeof(XYZZ<BF>);
+    TRH_TRY(m.ends.ensure((size_t)W * nb1 * 4));
+    TRH_TRY(m.buckets.ensure((size_t)W * nbk * sizeof(XYZZMem)));
+    TRH_TRY(m.partials.ensure((size_t)W * rblocks * sizeof(XYZZMem)));
+    TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
+    const size_t hs = batch * W * sizeof(XYZZMem);
     if (hs > m.host_sums_cap) {
         if (m.host_sums) (void)hipHostFree(m.host_sums);
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
@@ -302,20 +395,25 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
         const uint4* sc = (const uint4*)((const char*)scalars_dev + bi * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
         if (n) {
-            TRH_HIP_TRY(hipMemsetAsync(m.counts.p, 0, (size_t)W * nb1 * 4, s));
-            const unsigned gb = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb), dim3(256), 0, s, sc, n, mont, cb, W, m.digits.as<u32>(), m.counts.as<u32>(), nb1);
+            TRH_HIP_TRY(hipMemsetAsync(m.counts.p, 0, (size_t)W * nbins * 4, s));
+            unsigned gb = (unsigned)((n + 255) / 256);
+            if (gb > 2048) gb = 2048;
+            hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
+                               m.digits.as<u32>(), m.counts.as<u32>(), k2, nbins, recode_use_lds);
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-            hipLaunchKernelGGL(msm_offsets_kernel, dim3(W), dim3(1024), 0, s, m.counts.as<u32>(), m.starts.as<u32>(), nb1);
-            hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb, W), dim3(256), 0, s, m.digits.as<u32>(), m.counts.as<u32>(), m.sorted.as<u32>(), n, nb1);
+            hipLaunchKernelGGL(msm_offsets_kernel, dim3(W), dim3(1024), 0, s, m.counts.as<u32>(), m.bin_starts.as<u32>(), nbins);
+            hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W), dim3(256), (size_t)nbins * 8, s,
+                               m.digits.as<u32>(), m.counts.as<u32>(), m.parted.as<u32>(), n, k2, nbins, idx_bits);
+            hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W), dim3(256), 0, s, m.parted.as<u32>(), m.bin_starts.as<u32>(),
+                               m.counts.as<u32>(), m.sorted.as<u32>(), m.starts.as<u32>(), m.ends.as<u32>(), n, k2, nbins, idx_bits, nbk);
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
             hipLaunchKernelGGL((msm_accumulate_kernel<BF>), dim3((nbk + 255) / 256, W), dim3(256), 0, s, (const uint4*)bases_dev, m.sorted.as<u32>(),
-                               m.starts.as<u32>(), m.counts.as<u32>(), m.buckets.as<XYZZ<BF>>(), n, nbk);
+                               m.starts.as<u32>(), m.ends.as<u32>(), m.buckets.as<XYZZMem>(), n, nbk);
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
-            hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W), dim3(256), 0, s, m.buckets.as<XYZZ<BF>>(), m.partials.as<XYZZ<BF>>(), nbk, slice, tpw);
-            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W), dim3(256), 0, s, m.partials.as<XYZZ<BF>>(), m.window_sums.as<XYZZ<BF>>() + bi * W, rblocks);
+            hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W), dim3(256), 0, s, m.buckets.as<XYZZMem>(), m.partials.as<XYZZMem>(), nbk, slice, tpw);
+            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W), dim3(256), 0, s, m.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + bi * W, rblocks);
         } else {
-            TRH_HIP_TRY(hipMemsetAsync(m.window_sums.as<XYZZ<BF>>() + bi * W, 0, W * sizeof(XYZZ<BF>), s));
+            TRH_HIP_TRY(hipMemsetAsync(m.window_sums.as<XYZZMem>() + bi * W, 0, W * sizeof(XYZZMem), s));
             if (timing) for (int k = 1; k <= 3; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
@@ -332,13 +430,14 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
 
 // host: Horner over windows, normalise
 template <class BF>
-void combine_windows_host(const XYZZ<BF>* ws, int W, int cb, u64* out_xyz) {
+void combine_windows_host(const XYZZMem* ws, int W, int cb, u64* out_xyz) {
     XYZZ<BF> acc = xyzz_identity<BF>();
     for (int j = W - 1; j >= 0; --j) {
         for (int k = 0; k < cb; ++k) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, ws[j]);
+        acc = xyzz_add(acc, xyzz_load<BF>(ws[j]));
     }
-    Jacobian<BF> r = jac_from_affine(xyzz_to_affine(acc));
+    JacobianMem r;
+    jac_store(jac_from_affine(xyzz_to_affine(acc)), r);
     memcpy(out_xyz, &r, 96);
 }
 
@@ -348,7 +447,7 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     MsmScratch& m = c.msm;
     if (m.pending_curve != BF::ID || m.pending_batch != batch) { set_error("msm_finish: no matching MSM enqueued"); return TRH_EINVAL; }
     TRH_HIP_TRY(hipStreamSynchronize(s));
-    const XYZZ<BF>* ws = (const XYZZ<BF>*)m.host_sums;
+    const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     for (size_t bi = 0; bi < batch; ++bi) combine_windows_host<BF>(ws + bi * m.pending_windows, m.pending_windows, m.pending_c, out_xyz + 12 * bi);
     if (m.ev_valid) {
         float t01, t12, t23, t34, tt;
@@ -369,11 +468,12 @@ template <class BF>
 int point_sum_host_t(const u64* pts, size_t count, u64* out) {
     XYZZ<BF> acc = xyzz_identity<BF>();
     for (size_t i = 0; i < count; ++i) {
-        Jacobian<BF> j;
+        JacobianMem j;
         memcpy(&j, pts + 12 * i, 96);
-        acc = xyzz_add(acc, xyzz_from_jacobian(j));
+        acc = xyzz_add(acc, xyzz_from_jacobian(jac_load<BF>(j)));
     }
-    Jacobian<BF> r = jac_from_affine(xyzz_to_affine(acc));
+    JacobianMem r;
+    jac_store(jac_from_affine(xyzz_to_affine(acc)), r);
     memcpy(out, &r, 96);
     return TRH_OK;
 }
@@ -403,7 +503,7 @@ int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* o
 }
 void msm_release() {
     MsmScratch& m = ctx().msm;
-    m.scalars.release(); m.digits.release(); m.sorted.release(); m.counts.release(); m.starts.release();
+    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release();
     m.buckets.release(); m.partials.release(); m.window_sums.release();
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;

@@ -36,30 +36,28 @@ struct alignas(16) Half {  // 16 bytes of a field element
 template <class F>
 __device__ __forceinline__ Fe<F> load_fe(const uint4* __restrict__ p) {
     uint4 a = p[0], b = p[1];
-    Fe<F> r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
+    return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
 }
 template <class F>
 __device__ __forceinline__ void store_fe(uint4* __restrict__ p, const Fe<F>& v) {
-    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    u32 w[8];
+    fe_store(v, w);
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// LDS holds each element as two 16-byte halves in separate planes: consecutive lanes touch
-// consecutive 16-byte slots, which ds_read_b128 / ds_write_b128 serve without bank conflicts
+// LDS holds each element in memory format as two 16-byte halves in separate planes: consecutive
+// lanes touch consecutive 16-byte slots, which ds_read_b128 / ds_write_b128 serve conflict-free
 template <class F>
 __device__ __forceinline__ Fe<F> lds_load(const uint4* lo, const uint4* hi, int idx) {
     uint4 a = lo[idx], b = hi[idx];
-    Fe<F> r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
+    return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
 }
 template <class F>
 __device__ __forceinline__ void lds_store(uint4* lo, uint4* hi, int idx, const Fe<F>& v) {
-    lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    u32 w[8];
+    fe_store(v, w);
+    lo[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+    hi[idx] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // omega^e from the two-level tables
@@ -193,9 +191,9 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     if (rc == TRH_OK) rc = t->hi.ensure((size_t)32 << t->hi_bits);
     if (rc != TRH_OK) { delete t; return rc; }
     // omega^(2^b) on the host (shared field code), staged behind the lo table
-    Fe<F> pw[32];
+    FeMem pw[32];
     memcpy(&pw[0], omega, 32);
-    for (int b = 1; b < 32; ++b) pw[b] = fe_sqr(pw[b - 1]);
+    for (int b = 1; b < 32; ++b) fe_store(fe_sqr(fe_load<F>(pw[b - 1])), pw[b]);
     uint4* d_pw = t->lo.as<uint4>() + ((size_t)2 << t->lo_bits);
     TRH_HIP_TRY(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
     const u32 cnt = 1u << (t->lo_bits > t->hi_bits ? t->lo_bits : t->hi_bits);

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for the headline bench on the GPU box.
+#   tools/profile.sh <tag>     -> gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}
+# Kernel trace/stats and PMC counters are collected in separate runs (never combined).
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- python3 $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -20
