@@ -32,13 +32,25 @@ METRIC = "Pallas MSM pairs/s @ 2^24 + Fp NTT elems/s @ 2^22; 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def usable_cores() -> int:
+    """cores this process may actually run on (affinity mask and cgroup quota), not the box total"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline_msm(curve: str, log_cap: int = 22):
     """oracle leg: chunk-per-thread Pippenger restatement on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_ref  # oracle -- the thing timed here, never the product path
     from tiny_ram_halo2_amd import synth
 
-    threads = cpu_ref.hardware_threads()
+    threads = usable_cores()
     # calibrate on 2^16 pairs, then size the sample for ~15 s
     n0 = 1 << 16
     bases0 = cpu_ref.gen_bases(curve, synth.BASE_S0, synth.BASE_D, n0, threads)
@@ -65,7 +77,7 @@ def cpu_baseline_ntt(field: str, log_n: int):
     import pasta as o
     from tiny_ram_halo2_amd import synth
 
-    threads = cpu_ref.hardware_threads()
+    threads = usable_cores()
     f = o.FIELDS[field]
     a = synth.ntt_input(log_n)
     w = np.array(f.limbs(f.omega(log_n)), np.uint64)
@@ -94,11 +106,12 @@ def main():
     ap.add_argument("--log-n", type=int, default=24, help="log2 of MSM pairs per GPU")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (keeps profiles free of the extra 1-pair MSM)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from tiny_ram_halo2_amd import api, synth
+    from tiny_ram_halo2_amd import api, sharded, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,17 +135,10 @@ def main():
     bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n, first=first)
     sc_host = synth.field_elements(synth.SEED_MSM | log_n, n, start=first)
     d_sc = torch.from_numpy(sc_host.view(np.int64)).to(dev)
-    partial = torch.zeros(12, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(12, dtype=torch.int64, device=dev) for _ in range(world)]
 
     def step():
-        p = bases.msm_dev(d_sc, n, stream=stream)  # local Pippenger -> one Jacobian point (host)
-        if world == 1:
-            return p
-        partial.copy_(torch.from_numpy(p.view(np.int64)))
-        dist.all_gather(gathered, partial)
-        pts = torch.stack(gathered).cpu().numpy().view(np.uint64)
-        return api.point_sum(curve, pts)
+        # local Pippenger -> one Jacobian point; all-gather of the 96-byte partials + host add when world > 1
+        return sharded.sharded_msm(curve, lambda: bases.msm_dev(d_sc, n, stream=stream), device=dev)
 
     def fence():
         if world > 1:
@@ -162,7 +168,7 @@ def main():
 
     # closed-form check of the whole (global) MSM: bases are (s0 + i d) G with known logs
     check = None
-    if rank == 0:
+    if rank == 0 and not args.no_check:
         d_can = torch.empty_like(d_sc)
         api._check(api.lib().trh_field_op_dev(api.FQ, api.FIELD_OPS["from_mont"], api._devptr(d_sc), None, api._devptr(d_can), n, stream))
         torch.cuda.synchronize()

@@ -102,6 +102,72 @@ __global__ void k_mad24(u64* out, u32 a, u32 b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+__global__ void k_add64(u64* out, u32 a, u32 b) {  // 64-bit add (v_lshl_add_u64 / add_co+addc)
+    u64 x[8];
+    for (int k = 0; k < 8; ++k) x[k] = threadIdx.x + k;
+    u64 bb = ((u64)b << 33) + threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = x[k] + bb;
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    u64 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_shr64(u64* out, u32 a, u32 b) {  // v_lshrrev_b64 by a constant
+    u64 x[8];
+    for (int k = 0; k < 8; ++k) x[k] = ((u64)threadIdx.x << 40) + k + ((u64)a << 50);
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (x[k] >> 30) | 0x8000000000000000ull;
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    u64 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_alignbit(u64* out, u32 a, u32 b) {
+    u32 x[8];
+    for (int k = 0; k < 8; ++k) x[k] = threadIdx.x + k;
+    u32 bb = b + threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = __builtin_amdgcn_alignbit(bb, x[k], 30);
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    u32 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_add3(u64* out, u32 a, u32 b) {
+    u32 x[8];
+    for (int k = 0; k < 8; ++k) x[k] = threadIdx.x + k;
+    u32 bb = b + threadIdx.x, cc = a ^ threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = x[k] + bb + cc;
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    u32 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_addco(u64* out, u32 a, u32 b) {  // independent add_co + addc pairs (no long chain)
+    u32 x[8], y[8];
+    for (int k = 0; k < 8; ++k) { x[k] = threadIdx.x + k; y[k] = k; }
+    u32 bb = b + threadIdx.x + 0xfff00000u;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { u32 c = 0; x[k] = __builtin_addc(x[k], bb, 0u, &c); y[k] = __builtin_addc(y[k], 0u, c, &c); }
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+        asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+    }
+    u32 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= x[k] ^ y[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 constexpr int FITERS = 512;
 template <int MODE>
 __global__ void __launch_bounds__(256) k_field(u64* out, u32 seed) {
@@ -157,6 +223,11 @@ int main() {
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_addc, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "v_addc_co chain (per limb)", 8.0 * ITERS);
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_fma64, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "v_fma_f64", 8.0 * ITERS);
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_mad24, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "v_mul_u32_u24 (+add)", 8.0 * ITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_add64, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "64-bit add", 8.0 * ITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_shr64, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "64-bit shr 30 (+or)", 8.0 * ITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_alignbit, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "v_alignbit_b32", 8.0 * ITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_add3, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "v_add3_u32", 8.0 * ITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_addco, dim3(b), dim3(t), 0, 0, o, 3u, 5u); }, B, T, d_out, "add_co+addc pair (x2 ops)", 16.0 * ITERS);
     for (int blocks : {256 * 2, 256 * 4, 256 * 8}) {
         run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<0>, dim3(b), dim3(t), 0, 0, o, 1u); }, blocks, T, d_out, "fe_mul", FITERS);
         run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<1>, dim3(b), dim3(t), 0, 0, o, 1u); }, blocks, T, d_out, "fe_sqr", FITERS);
