@@ -66,6 +66,10 @@ struct MsmScratch {
     DevBuf bin_starts;   // W x nbins u32 level-1 bin start offsets
     DevBuf starts;       // W x (NB + 1) u32 bucket start offsets
     DevBuf ends;         // W x (NB + 1) u32 bucket end offsets
+    DevBuf seg_bucket;   // W x nseg u32: bucket holding the first entry of each segment
+    DevBuf first, last;  // W x nseg raw lazy XYZZ: first run / unfinished last run of each segment
+    DevBuf direct;       // W x (NB + 1) raw lazy XYZZ: buckets that lie inside one segment
+    DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
     DevBuf window_sums;  // batch x W XYZZ

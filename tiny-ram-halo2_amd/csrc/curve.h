@@ -165,6 +165,77 @@ template <class F> TRH_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F>& j) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------
+// Lazy-domain points (field.h "Lazy domain"): MSM bucket accumulation only.
+// Invariants of a stored XYZZz: x < 8m, y < 8m, zz < 1.01m, zzz < 1.01m; identity <=> zz is
+// exactly zero.  AffineZ coordinates are < 1.01m; identity <=> x and y exactly zero.
+// The exceptional cases (P + P, P + (-P)) go through the canonical formulas above.
+// ---------------------------------------------------------------------------------------
+template <class F>
+struct AffineZ {
+    Fz<F> x, y;
+};
+template <class F>
+struct XYZZz {
+    Fz<F> x, y, zz, zzz;
+};
+struct alignas(16) XYZZzMem { u32 w[36]; };  // raw limbs of x, y, zz, zzz (accumulate -> combine scratch)
+
+template <class F> TRH_HD XYZZz<F> xyzzz_identity() {
+    XYZZz<F> r; r.x = fz_zero<F>(); r.y = fz_zero<F>(); r.zz = fz_zero<F>(); r.zzz = fz_zero<F>(); return r;
+}
+template <class F> TRH_HD bool xyzzz_is_identity(const XYZZz<F>& p) { return fz_is_exact_zero(p.zz); }
+template <class F> TRH_HD XYZZ<F> xyzzz_to_canonical(const XYZZz<F>& p) {
+    XYZZ<F> r;
+    if (xyzzz_is_identity(p)) return xyzz_identity<F>();
+    r.x = fz_to_fe(p.x); r.y = fz_to_fe(p.y); r.zz = fz_to_fe(p.zz); r.zzz = fz_to_fe(p.zzz);
+    return r;
+}
+template <class F> TRH_HD XYZZz<F> xyzzz_from_canonical(const XYZZ<F>& p) {
+    XYZZz<F> r;
+    if (xyzz_is_identity(p)) return xyzzz_identity<F>();
+    r.x = fz_from_fe(p.x); r.y = fz_from_fe(p.y); r.zz = fz_from_fe(p.zz); r.zzz = fz_from_fe(p.zzz);
+    return r;
+}
+
+// acc += p, p affine in the lazy domain
+template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
+    if (fz_is_exact_zero(p.x) && fz_is_exact_zero(p.y)) return;
+    if (xyzzz_is_identity(acc)) { acc.x = p.x; acc.y = p.y; acc.zz = fz_one<F>(); acc.zzz = fz_one<F>(); return; }
+    const Fz<F> U2 = fz_mul(p.x, acc.zz), S2 = fz_mul(p.y, acc.zzz);
+    const Fz<F> P = fz_sub<F, 8>(U2, acc.x), R = fz_sub<F, 8>(S2, acc.y);  // < 9.01m
+    if (fz_is_zero_mod(P)) {  // same x: doubling or cancellation, through the canonical formulas
+        XYZZ<F> c = xyzzz_to_canonical(acc);
+        Affine<F> q; q.x = fz_to_fe(p.x); q.y = fz_to_fe(p.y);
+        xyzz_madd(c, q);
+        acc = xyzzz_from_canonical(c);
+        return;
+    }
+    const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(acc.x, PP);
+    const Fz<F> x3 = fz_sub<F, 4>(fz_sqr(R), fz_add(PPP, fz_add(Q, Q)));             // < 5.01m
+    acc.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, x3)), fz_mul(acc.y, PPP));         // < 3.01m
+    acc.x = x3;
+    acc.zz = fz_mul(acc.zz, PP);
+    acc.zzz = fz_mul(acc.zzz, PPP);
+}
+
+// a + b, both lazy XYZZ
+template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& b) {
+    if (xyzzz_is_identity(a)) return b;
+    if (xyzzz_is_identity(b)) return a;
+    const Fz<F> U1 = fz_mul(a.x, b.zz), U2 = fz_mul(b.x, a.zz);
+    const Fz<F> S1 = fz_mul(a.y, b.zzz), S2 = fz_mul(b.y, a.zzz);
+    const Fz<F> P = fz_sub<F, 2>(U2, U1), R = fz_sub<F, 2>(S2, S1);  // < 3.01m
+    if (fz_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
+    const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(U1, PP);
+    XYZZz<F> r;
+    r.x = fz_sub<F, 4>(fz_sqr(R), fz_add(PPP, fz_add(Q, Q)));
+    r.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, r.x)), fz_mul(S1, PPP));
+    r.zz = fz_mul(fz_mul(a.zz, b.zz), PP);
+    r.zzz = fz_mul(fz_mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
 template <class F> TRH_HD Affine<F> aff_load(const AffineMem& m) {
     Affine<F> r; r.x = fe_load<F>(m.x); r.y = fe_load<F>(m.y); return r;
 }

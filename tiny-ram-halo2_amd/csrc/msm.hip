@@ -10,8 +10,10 @@
 //                base-2^c digits (buckets 1..2^(c-1)), per-window bucket histogram
 //   2. offsets   exclusive scan of the histogram per window
 //   3. scatter   counting sort: point indices grouped by (window, bucket)
-//   4. accumulate one thread per (window, bucket): XYZZ accumulator += affine base (8M + 2S),
-//                coalesced 16-byte loads of the 64-byte base, next base prefetched
+//   4. accumulate bases converted once to the lazy Montgomery domain (R' = 2^270, no modular
+//                reduction in add/sub); one thread per fixed-length SEGMENT of the sorted list, so
+//                every lane does the same number of XYZZ mixed adds (8M + 2S) whatever the bucket
+//                sizes; per-bucket pieces are combined by one thread per bucket
 //   5. reduce    sum_b b * B_b per window: per-thread running sums over a slice of buckets,
 //                slice offset by a short double-and-add, LDS tree across the workgroup
 //   6. combine   per-window sums -> host (W x 128 B), Horner over windows on the host
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restric
 __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
                                                               const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
                                                               u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
-                                                              u32 nbins, int idx_bits, u32 nbk) {
+                                                              u32 nbins, int idx_bits, u32 nbk, u32* __restrict__ seg_bucket, u32 nseg, u32 seg_len) {
     __shared__ u32 cnt[128], off[128];
     const int j = blockIdx.y;
     const u32 bin = blockIdx.x;
@@ -189,8 +191,12 @@ __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restr
     if (threadIdx.x < nsub) {
         const u32 bucket = (bin << k2) + threadIdx.x + 1u;  // 1-based bucket id
         if (bucket <= nbk) {
-            starts[(size_t)j * (nbk + 1) + bucket] = lo + off[threadIdx.x];
-            ends[(size_t)j * (nbk + 1) + bucket] = lo + off[threadIdx.x] + cnt[threadIdx.x];
+            const u32 S = lo + off[threadIdx.x], E = S + cnt[threadIdx.x];
+            starts[(size_t)j * (nbk + 1) + bucket] = S;
+            ends[(size_t)j * (nbk + 1) + bucket] = E;
+            // segments whose first entry lies in this bucket
+            if (E > S)
+                for (u32 t = (S + seg_len - 1) / seg_len; t * seg_len < E; ++t) seg_bucket[(size_t)j * nseg + t] = bucket;
         }
     }
     __syncthreads();
@@ -242,33 +248,119 @@ __device__ __forceinline__ XYZZ<BF> load_xyzz(const XYZZMem* src) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------
+// 4. balanced accumulation in the lazy domain.
+//   convert   bases (Montgomery R = 2^256) -> lazy domain (R' = 2^270), once per MSM
+//   segments  thread (segment, window) walks seg_len consecutive entries of the bucket-sorted
+//             list: every lane does the same number of mixed adds whatever the bucket sizes.
+//             At a bucket boundary the raw accumulator (36 limbs) is stored -- the first run of a
+//             segment to first[], a run that ends past the segment to last[], a bucket that lies
+//             inside the segment to direct[] -- and the accumulator restarts.
+//   combine   thread per bucket: adds the pieces of its bucket (first[] of every segment it
+//             covers, plus last[] / direct[] of the segment it starts in), converts to the
+//             canonical Montgomery form and writes the bucket for the reduction kernels.
+// ---------------------------------------------------------------------------------------
 template <class BF>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint4* __restrict__ bases, const u32* __restrict__ sorted,
-                                                             const u32* __restrict__ starts, const u32* __restrict__ ends,
-                                                             XYZZMem* __restrict__ buckets, size_t n, u32 nbk) {
-    // thread -> bucket id 1..nbk of window blockIdx.y
+__global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* p = in + i * 4;
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    u32 wx[8], wy[8];
+    fz_store(fz_from_fe(fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)), wx);  // 0 -> 0: identity stays (0, 0)
+    fz_store(fz_from_fe(fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w)), wy);
+    uint4* q = out + i * 4;
+    q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
+    q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+}
+
+template <class BF>
+__device__ __forceinline__ void store_raw(XYZZzMem* dst, const XYZZz<BF>& v) {
+    uint4* p = (uint4*)dst;
+    const u32* w = (const u32*)&v;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+template <class BF>
+__device__ __forceinline__ XYZZz<BF> load_raw(const XYZZzMem* src) {
+    const uint4* p = (const uint4*)src;
+    XYZZz<BF> v;
+    u32* w = (u32*)&v;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        uint4 q = p[k];
+        w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+    }
+    return v;
+}
+
+template <class BF>
+__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
+                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                                                                 XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
+                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (t >= nseg) return;
+    const u32 nb1 = nbk + 1;
+    const u32* en = ends + (size_t)j * nb1;
+    const u32 total = en[nbk];  // entries of this window (zero digits are not listed)
+    u32 pos = t * seg_len;
+    if (pos >= total) return;
+    const u32 stop = pos + seg_len < total ? pos + seg_len : total;
+    u32 B = seg_bucket[(size_t)j * nseg + t];
+    u32 cur_end = en[B];
+    const u32* lst = sorted + (size_t)j * n;
+    XYZZzMem* my_first = first + (size_t)j * nseg + t;
+    XYZZz<BF> acc = xyzzz_identity<BF>();
+    bool is_first = true;
+    u32 e = lst[pos];
+    const uint4* bp = bases_z + (size_t)(e & ~SIGN_BIT) * 4;
+    uint4 na = bp[0], nb = bp[1], nc = bp[2], nd = bp[3];
+    for (; pos < stop; ++pos) {
+        if (pos == cur_end) {  // bucket finished: publish its run and start the next bucket
+            store_raw(is_first ? my_first : direct + (size_t)j * nb1 + B, acc);
+            is_first = false;
+            acc = xyzzz_identity<BF>();
+            do { ++B; cur_end = en[B]; } while (cur_end <= pos);
+        }
+        const u32 ce = e;
+        AffineZ<BF> cur;
+        cur.x = fz_load<BF>(na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w);
+        cur.y = fz_load<BF>(nc.x, nc.y, nc.z, nc.w, nd.x, nd.y, nd.z, nd.w);
+        if (pos + 1 < stop) {  // prefetch the next base while this add runs
+            e = lst[pos + 1];
+            bp = bases_z + (size_t)(e & ~SIGN_BIT) * 4;
+            na = bp[0]; nb = bp[1]; nc = bp[2]; nd = bp[3];
+        }
+        if ((ce & SIGN_BIT) && !(fz_is_exact_zero(cur.x) && fz_is_exact_zero(cur.y))) cur.y = fz_sub<BF, 2>(fz_zero<BF>(), cur.y);
+        xyzzz_madd(acc, cur);
+    }
+    if (is_first) store_raw(my_first, acc);
+    else if (cur_end == stop) store_raw(direct + (size_t)j * nb1 + B, acc);
+    else store_raw(last + (size_t)j * nseg + t, acc);
+}
+
+template <class BF>
+__global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
+                                                          const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
+                                                          const XYZZzMem* __restrict__ direct, XYZZMem* __restrict__ buckets,
+                                                          u32 nbk, u32 nseg, u32 seg_len) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y;
     if (b > nbk) return;
     const u32 nb1 = nbk + 1;
-    const u32 lo = starts[(size_t)j * nb1 + b], hi = ends[(size_t)j * nb1 + b];
-    const u32* lst = sorted + (size_t)j * n;
-    XYZZ<BF> acc = xyzz_identity<BF>();
-    if (lo < hi) {
-        u32 e = lst[lo];
-        Affine<BF> nxt = load_affine<BF>(bases, e & ~SIGN_BIT);
-        for (u32 k = lo; k < hi; ++k) {
-            Affine<BF> cur = nxt;
-            const u32 ce = e;
-            if (k + 1 < hi) {  // prefetch the next base while this add runs
-                e = lst[k + 1];
-                nxt = load_affine<BF>(bases, e & ~SIGN_BIT);
-            }
-            if (ce & SIGN_BIT) cur.y = fe_neg(cur.y);
-            xyzz_madd(acc, cur);
-        }
+    const u32 S = starts[(size_t)j * nb1 + b], E = ends[(size_t)j * nb1 + b];
+    XYZZz<BF> acc = xyzzz_identity<BF>();
+    if (E > S) {
+        const u32 t_lo = S / seg_len, t_hi = (E - 1) / seg_len;
+        const XYZZzMem* fj = first + (size_t)j * nseg;
+        if (S == t_lo * seg_len) acc = load_raw<BF>(fj + t_lo);
+        else if (E <= (t_lo + 1) * seg_len) acc = load_raw<BF>(direct + (size_t)j * nb1 + b);
+        else acc = load_raw<BF>(last + (size_t)j * nseg + t_lo);
+        for (u32 t = t_lo + 1; t <= t_hi; ++t) acc = xyzzz_add(acc, load_raw<BF>(fj + t));
     }
-    store_xyzz(&buckets[(size_t)j * nbk + (b - 1)], acc);
+    store_xyzz(&buckets[(size_t)j * nbk + (b - 1)], xyzzz_to_canonical(acc));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -379,6 +471,13 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     TRH_TRY(m.bin_starts.ensure((size_t)W * nbins * 4));
     TRH_TRY(m.starts.ensure((size_t)W * nb1 * 4));
     TRH_TRY(m.ends.ensure((size_t)W * nb1 * 4));
+    const u32 seg_len = n >= ((size_t)1 << 18) ? 64u : n >= ((size_t)1 << 16) ? 32u : 16u;
+    const u32 nseg = (u32)((n + seg_len - 1) / seg_len);
+    TRH_TRY(m.seg_bucket.ensure((size_t)W * nseg * 4 + 16));
+    TRH_TRY(m.first.ensure((size_t)W * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(m.last.ensure((size_t)W * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(m.direct.ensure((size_t)W * nb1 * sizeof(XYZZzMem)));
+    TRH_TRY(m.bases_z.ensure(n * 64 + 64));
     TRH_TRY(m.buckets.ensure((size_t)W * nbk * sizeof(XYZZMem)));
     TRH_TRY(m.partials.ensure((size_t)W * rblocks * sizeof(XYZZMem)));
     TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
@@ -405,10 +504,15 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
             hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W), dim3(256), (size_t)nbins * 8, s,
                                m.digits.as<u32>(), m.counts.as<u32>(), m.parted.as<u32>(), n, k2, nbins, idx_bits);
             hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W), dim3(256), 0, s, m.parted.as<u32>(), m.bin_starts.as<u32>(),
-                               m.counts.as<u32>(), m.sorted.as<u32>(), m.starts.as<u32>(), m.ends.as<u32>(), n, k2, nbins, idx_bits, nbk);
+                               m.counts.as<u32>(), m.sorted.as<u32>(), m.starts.as<u32>(), m.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
+                               m.seg_bucket.as<u32>(), nseg, seg_len);
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
-            hipLaunchKernelGGL((msm_accumulate_kernel<BF>), dim3((nbk + 255) / 256, W), dim3(256), 0, s, (const uint4*)bases_dev, m.sorted.as<u32>(),
-                               m.starts.as<u32>(), m.ends.as<u32>(), m.buckets.as<XYZZMem>(), n, nbk);
+            if (bi == 0)
+                hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
+            hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W), dim3(256), 0, s, m.bases_z.as<uint4>(), m.sorted.as<u32>(),
+                               m.ends.as<u32>(), m.seg_bucket.as<u32>(), m.first.as<XYZZzMem>(), m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
+            hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W), dim3(256), 0, s, m.starts.as<u32>(), m.ends.as<u32>(), m.first.as<XYZZzMem>(),
+                               m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len);
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W), dim3(256), 0, s, m.buckets.as<XYZZMem>(), m.partials.as<XYZZMem>(), nbk, slice, tpw);
             hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W), dim3(256), 0, s, m.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + bi * W, rblocks);
@@ -503,7 +607,7 @@ int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* o
 }
 void msm_release() {
     MsmScratch& m = ctx().msm;
-    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release();
+    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release(); m.seg_bucket.release(); m.first.release(); m.last.release(); m.direct.release(); m.bases_z.release();
     m.buckets.release(); m.partials.release(); m.window_sums.release();
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
