@@ -110,6 +110,11 @@ int trh_field_scale_dev(int field, void* a_dev, size_t n, const uint64_t factor[
  * halo2's `distribute_powers_zeta` coset shift (period 3: 1, zeta, zeta^2) and
  * `divide_by_vanishing_poly` (period 2^(extended_k - k) table of (X^n - 1)^-1 values).        */
 int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_t* factors, uint32_t period, void* stream);
+/* same for `rows` polynomials stored back to back (row_len elements each): only the first
+ * active_len elements of each row are scaled and the period restarts with each row, i.e.
+ * a[r][c] *= factors[c % period] for c < active_len (a batch of coeff_to_extended inputs).     */
+int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len,
+                             const uint64_t* factors, uint32_t period, void* stream);
 
 /* ---- element-wise field / group ops on device memory (parity tests of the device arithmetic;
  *      op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv, 6 to_mont, 7 from_mont) ------------------ */

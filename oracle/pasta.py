@@ -401,6 +401,64 @@ def synth_base(curve: Curve, s0: int, d: int, i: int) -> Affine:
     return curve.mul(s0 + i * d, curve.generator)
 
 
+# --------------------------------------------------------------------------------------
+# poly::EvaluationDomain restatement (halo2_proofs 0.2.0 src/poly/domain.rs; SURVEY.md section
+# 8 row a5; reached via keygen_* / create_proof at src/test_utils.rs:23-25, 41-49).
+# Values are canonical ints; vectors are Python lists.
+# --------------------------------------------------------------------------------------
+class EvaluationDomain:
+    def __init__(self, field: Field, j: int, k: int):
+        m = field.m
+        self.field, self.k, self.n = field, k, 1 << k
+        self.quotient_poly_degree = j - 1
+        ek = k
+        while (1 << ek) < self.n * self.quotient_poly_degree:
+            ek += 1
+        self.extended_k = ek
+        self.extended_omega = field.omega(ek)
+        self.omega = field.omega(k)
+        assert pow(self.extended_omega, 1 << (ek - k), m) == self.omega
+        self.omega_inv = field.inv(self.omega)
+        self.extended_omega_inv = field.inv(self.extended_omega)
+        self.g_coset = field.ZETA
+        self.g_coset_inv = field.sqr(field.ZETA)
+        self.ifft_divisor = field.inv(1 << k)
+        self.extended_ifft_divisor = field.inv(1 << ek)
+        # t(X) = X^n - 1 evaluated on the coset zeta * extended_omega^i, inverted
+        self.t_evaluations = [field.inv((pow(self.g_coset * pow(self.extended_omega, i, m) % m, self.n, m) - 1) % m)
+                              for i in range(1 << (ek - k))]
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def lagrange_to_coeff(self, a: List[int]) -> List[int]:
+        assert len(a) == self.n
+        m = self.field.m
+        return [v * self.ifft_divisor % m for v in best_fft(self.field, a, self.omega_inv, self.k)]
+
+    def _distribute_powers_zeta(self, a: List[int], into_coset: bool) -> List[int]:
+        powers = [self.g_coset, self.g_coset_inv] if into_coset else [self.g_coset_inv, self.g_coset]
+        m = self.field.m
+        return [v if i % 3 == 0 else v * powers[i % 3 - 1] % m for i, v in enumerate(a)]
+
+    def coeff_to_extended(self, a: List[int]) -> List[int]:
+        assert len(a) == self.n
+        a = self._distribute_powers_zeta(list(a), True) + [0] * (self.extended_len() - self.n)
+        return best_fft(self.field, a, self.extended_omega, self.extended_k)
+
+    def extended_to_coeff(self, a: List[int]) -> List[int]:
+        assert len(a) == self.extended_len()
+        m = self.field.m
+        a = [v * self.extended_ifft_divisor % m for v in best_fft(self.field, a, self.extended_omega_inv, self.extended_k)]
+        a = self._distribute_powers_zeta(a, False)
+        return a[: self.n * self.quotient_poly_degree]
+
+    def divide_by_vanishing_poly(self, a: List[int]) -> List[int]:
+        assert len(a) == self.extended_len()
+        t, m = self.t_evaluations, self.field.m
+        return [v * t[i % len(t)] % m for i, v in enumerate(a)]
+
+
 if __name__ == "__main__":
     check_published_constants()
     for c in CURVES.values():

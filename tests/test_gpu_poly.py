@@ -1,0 +1,114 @@
+"""GPU parity tests (-m gpu) for the EvaluationDomain / Params mirrors:
+device results vs the big-int restatement in oracle/pasta.py, plus the algebraic properties the
+domain offers (coset round trip; division by the vanishing polynomial inverts multiplication)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ref
+import pasta as o
+from tiny_ram_halo2_amd import api, poly, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    api.init(0)
+    yield
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy()).cuda()
+
+
+def to_host(t):
+    torch.cuda.synchronize()
+    return t.contiguous().cpu().numpy().view(np.uint64)
+
+
+def limbs(f, vals):
+    return np.array([f.limbs(v) for v in vals], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+@pytest.mark.parametrize("k,j", [(4, 4), (6, 7), (8, 3)])
+def test_domain_vs_oracle(field, k, j):
+    f = o.FIELDS[field]
+    rng = random.Random(k * 100 + j)
+    dom, ref = poly.EvaluationDomain(field, j, k), o.EvaluationDomain(f, j, k)
+    assert dom.extended_k == ref.extended_k and dom.omega == ref.omega and dom.t_evaluations == ref.t_evaluations
+    batch = 3
+    vals = [[rng.randrange(f.m) for _ in range(dom.n)] for _ in range(batch)]
+    a = to_dev(np.stack([limbs(f, v) for v in vals]))
+    # lagrange_to_coeff
+    coeff = dom.lagrange_to_coeff(a.clone())
+    want = [ref.lagrange_to_coeff(v) for v in vals]
+    got = to_host(coeff)
+    for b in range(batch):
+        assert [f.from_limbs(r) for r in got[b]] == want[b]
+    # coeff_to_extended
+    ext = dom.coeff_to_extended(coeff)
+    want_ext = [ref.coeff_to_extended(w) for w in want]
+    got = to_host(ext)
+    for b in range(batch):
+        assert [f.from_limbs(r) for r in got[b]] == want_ext[b]
+    # divide_by_vanishing_poly
+    div = dom.divide_by_vanishing_poly(ext.clone())
+    got = to_host(div)
+    want_div = [ref.divide_by_vanishing_poly(w) for w in want_ext]
+    for b in range(batch):
+        assert [f.from_limbs(r) for r in got[b]] == want_div[b]
+    # extended_to_coeff (of the undivided evaluations: must give back the coefficients, zero-padded)
+    back = dom.extended_to_coeff(ext.clone())
+    got = to_host(back)
+    for b in range(batch):
+        w = ref.extended_to_coeff(want_ext[b])
+        assert [f.from_limbs(r) for r in got[b]] == w
+        assert w[: dom.n] == want[b] and all(v == 0 for v in w[dom.n:])
+
+
+def test_domain_roundtrip_k14():
+    """size-independent property at a create_proof-like size: extended_to_coeff(coeff_to_extended(a)) == a ‖ 0"""
+    field, k, j = "fp", 14, 7
+    dom = poly.EvaluationDomain(field, j, k)
+    a = synth.field_elements(0xD0, 2 * dom.n).reshape(2, dom.n, 4)
+    d = to_dev(a)
+    ext = dom.coeff_to_extended(d)
+    assert ext.shape == (2, dom.extended_len(), 4)
+    back = to_host(dom.extended_to_coeff(ext))
+    assert (back[:, : dom.n] == a).all() and (back[:, dom.n:] == 0).all()
+    # lagrange_to_coeff inverts coeff_to_lagrange
+    lag = dom.coeff_to_lagrange(d.clone())
+    assert (to_host(dom.lagrange_to_coeff(lag)) == a).all()
+
+
+@pytest.mark.parametrize("curve", ["vesta", "pallas"])
+def test_params_commit(curve):
+    k = 8
+    n = 1 << k
+    sf = api.SCALAR_FIELD[curve]
+    g = cpu_ref.gen_bases(curve, 11, 3, n, threads=4)
+    gl = cpu_ref.gen_bases(curve, 1234567, 5, n, threads=4)
+    w = cpu_ref.gen_bases(curve, 999, 1, 1, threads=1)
+    params = poly.Params(curve, k, g, gl, w)
+    p = synth.field_elements(0xC0, n)
+    r = synth.field_elements(0xC1, 1)[0]
+    want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([p, r[None]]), np.concatenate([g, w]), threads=4))
+    assert (params.commit(p, r)[:8] == want).all()
+    assert (params.commit(to_dev(p), r)[:8] == want).all()
+    want_l = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([p, r[None]]), np.concatenate([gl, w]), threads=4))
+    assert (params.commit_lagrange(p, r)[:8] == want_l).all()
+    # batch of columns
+    batch = 4
+    ps = synth.field_elements(0xC2, n * batch).reshape(batch, n, 4)
+    rs = synth.field_elements(0xC3, batch)
+    got = params.commit_lagrange_batch(to_dev(ps), rs)
+    for i in range(batch):
+        wl = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([ps[i], rs[i][None]]), np.concatenate([gl, w]), threads=4))
+        assert (got[i, :8] == wl).all()
+    # commit(a) == commit_lagrange(lagrange form of a) when g_lagrange is the Lagrange basis of g is a
+    # property of Params::new (a "next" row); here the two base sets are independent.
+    del sf

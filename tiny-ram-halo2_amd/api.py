@@ -76,6 +76,7 @@ _SIGNATURES = {
     "trh_ntt_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_scale_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_field_scale_periodic_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp], ctypes.c_int),
+    "trh_field_scale_rows_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
@@ -239,6 +240,11 @@ def field_scale_dev(field: str, a_dev, n: int, factor, stream=None):
 def field_scale_periodic_dev(field: str, a_dev, n: int, factors, stream=None):
     f = _c(factors, 4)
     _check(lib().trh_field_scale_periodic_dev(FIELD_ID[field], _devptr(a_dev), n, _p(f), f.shape[0], stream))
+
+
+def field_scale_rows_dev(field: str, a_dev, rows: int, row_len: int, active_len: int, factors, stream=None):
+    f = _c(factors, 4)
+    _check(lib().trh_field_scale_rows_dev(FIELD_ID[field], _devptr(a_dev), rows, row_len, active_len, _p(f), f.shape[0], stream))
 
 
 def set_timing(on: bool):

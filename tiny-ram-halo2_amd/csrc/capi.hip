@@ -27,7 +27,7 @@ int require_init() {
     return TRH_OK;
 }
 
-int field_scale_periodic(int field, void* a_dev, size_t n, const void* factors_dev, u32 period, hipStream_t s);
+int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s);
 
 namespace {
 
@@ -182,6 +182,7 @@ void trh_shutdown(void) {
     msm_release();
     ntt_release_tables();
     c.io.release();
+    c.factors.release();
     c.inited = false;
     c.device = -1;
 }
@@ -298,16 +299,22 @@ int trh_ntt_dev(int field, void* a_dev, uint32_t log_n, const uint64_t omega[4],
     return ntt_device(field, a_dev, log_n, omega, batch, (hipStream_t)stream);
 }
 
-int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_t* factors, uint32_t period, void* stream) {
+int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const uint64_t* factors, uint32_t period, void* stream) {
     TRH_TRY(require_init());
     TRH_TRY(check_field(field));
-    if (!a_dev || !factors || period == 0 || period > 64) { set_error("field_scale_periodic: bad arguments"); return TRH_EINVAL; }
+    if (!a_dev || !factors || period == 0 || period > 64 || active_len > row_len) { set_error("field_scale: bad arguments"); return TRH_EINVAL; }
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    TRH_TRY(c.io.ensure(64 * 32));
-    TRH_HIP_TRY(hipMemcpyAsync(c.io.p, factors, (size_t)period * 32, hipMemcpyHostToDevice, (hipStream_t)stream));
-    TRH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return field_scale_periodic(field, a_dev, n, c.io.p, period, (hipStream_t)stream);
+    // factors are staged in a small ring so that back-to-back calls on one stream do not overwrite
+    // a table a queued kernel still reads
+    TRH_TRY(c.factors.ensure(16 * 64 * 32));
+    char* slot = (char*)c.factors.p + (size_t)(c.factor_slot++ & 15) * 64 * 32;
+    TRH_HIP_TRY(hipMemcpyAsync(slot, factors, (size_t)period * 32, hipMemcpyHostToDevice, (hipStream_t)stream));
+    TRH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // `factors` is caller memory
+    return field_scale_periodic(field, a_dev, rows, row_len, active_len, slot, period, (hipStream_t)stream);
+}
+int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_t* factors, uint32_t period, void* stream) {
+    return trh_field_scale_rows_dev(field, a_dev, 1, n, n, factors, period, stream);
 }
 int trh_field_scale_dev(int field, void* a_dev, size_t n, const uint64_t factor[4], void* stream) {
     return trh_field_scale_periodic_dev(field, a_dev, n, factor, 1, stream);

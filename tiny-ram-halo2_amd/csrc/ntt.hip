@@ -252,11 +252,14 @@ __global__ void __launch_bounds__(256) ntt_pass8_kernel(const uint4* __restrict_
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t n, const uint4* __restrict__ factors, u32 period) {
+__global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t rows, size_t row_len, size_t active_len,
+                                                                   const uint4* __restrict__ factors, u32 period) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<F> f = load_fe<F>(factors + 2 * (i % period));
-    store_fe<F>(a + 2 * i, fe_mul(load_fe<F>(a + 2 * i), f));
+    if (i >= rows * active_len) return;
+    const size_t r = i / active_len, c = i - r * active_len;
+    uint4* p = a + 2 * (r * row_len + c);
+    Fe<F> f = load_fe<F>(factors + 2 * (c % period));
+    store_fe<F>(p, fe_mul(load_fe<F>(p), f));
 }
 
 TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
@@ -373,11 +376,12 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
     return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s);
 }
 
-int field_scale_periodic(int field, void* a_dev, size_t n, const void* factors_dev, u32 period, hipStream_t s) {
+int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s) {
+    const size_t n = rows * active_len;
     if (!n) return TRH_OK;
     const unsigned gb = (unsigned)((n + 255) / 256);
-    if (field == TRH_FP) hipLaunchKernelGGL((field_scale_periodic_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, n, (const uint4*)factors_dev, period);
-    else hipLaunchKernelGGL((field_scale_periodic_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, n, (const uint4*)factors_dev, period);
+    if (field == TRH_FP) hipLaunchKernelGGL((field_scale_periodic_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, rows, row_len, active_len, (const uint4*)factors_dev, period);
+    else hipLaunchKernelGGL((field_scale_periodic_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, rows, row_len, active_len, (const uint4*)factors_dev, period);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }

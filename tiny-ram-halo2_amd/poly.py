@@ -1,0 +1,184 @@
+"""Host-side mirror of `halo2_proofs::poly::{EvaluationDomain, commitment::Params}` for the
+MSM / NTT call sites of `create_proof` (reference: /root/reference/src/test_utils.rs:21-49 reaches
+them through keygen_vk / keygen_pk / create_proof; crate pinned at Cargo.lock:619-621).
+
+Polynomials live in device memory as torch int64 tensors of shape (..., n, 4) holding the
+u64 Montgomery limbs (torch is used for allocation, zero-padding and slicing only -- every field
+operation is a libtrh kernel on the tensor's stream).  Same method names, argument meaning and
+assertions as the Rust types:
+
+    EvaluationDomain(field, j, k)          EvaluationDomain::new(j, k)
+        .lagrange_to_coeff(a)              iFFT with omega^-1, then * n^-1
+        .coeff_to_extended(a)              zeta-coset shift, zero-pad to 2^extended_k, FFT
+        .extended_to_coeff(a)              iFFT, * 2^-extended_k, inverse coset shift, truncate
+        .divide_by_vanishing_poly(a)       pointwise * (X^n - 1)^-1 on the coset (period 2^(ek-k))
+    Params(curve, k, g, g_lagrange, w, u)  commitment::Params
+        .commit(poly, r) / .commit_lagrange(poly, r)      MSM over (g | g_lagrange) ‖ w, n + 1 pairs
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import api
+
+_MODULUS = {
+    "fp": 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001,
+    "fq": 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001,
+}
+_ROOT_OF_UNITY = {  # pasta_curves ROOT_OF_UNITY (2^32-th root), canonical
+    "fp": 0x2BCE74DEAC30EBDA362120830561F81AEA322BF2B7BB7584BDAD6FABD87EA32F,
+    "fq": 0x2DE6A9B8746D3F589E5C4DFD492AE26E9BB97EA3C106F049A70E2C1102B6D05F,
+}
+_ZETA = {  # pasta_curves ZETA (cube root of unity), canonical
+    "fp": 0x12CCCA834ACDBA712CAAD5DC57AAB1B01D1F8BD237AD31491DAD5EBDFDFE4AB9,
+    "fq": 0x06819A58283E528E511DB4D81CF70F5A0FED467D47C033AF2AA9D2E050AA0E4F,
+}
+S = 32
+
+
+def _mont(field: str, x: int) -> np.ndarray:
+    m = _MODULUS[field]
+    v = x % m * ((1 << 256) % m) % m
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def _stream(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class EvaluationDomain:
+    def __init__(self, field: str, j: int, k: int):
+        m = _MODULUS[field]
+        self.field, self.k, self.n = field, k, 1 << k
+        self.quotient_poly_degree = j - 1
+        ek = k
+        while (1 << ek) < self.n * self.quotient_poly_degree:
+            ek += 1
+        self.extended_k = ek
+        ext_omega = _ROOT_OF_UNITY[field]
+        for _ in range(ek, S):
+            ext_omega = ext_omega * ext_omega % m
+        omega = ext_omega
+        for _ in range(k, ek):
+            omega = omega * omega % m
+        self.omega, self.omega_inv = omega, pow(omega, -1, m)
+        self.extended_omega, self.extended_omega_inv = ext_omega, pow(ext_omega, -1, m)
+        self.g_coset = _ZETA[field]
+        self.g_coset_inv = self.g_coset * self.g_coset % m
+        self.ifft_divisor = pow(2, -k, m)
+        self.extended_ifft_divisor = pow(2, -ek, m)
+        # t(X) = X^n - 1 on the coset zeta * extended_omega^i: period 2^(ek - k), inverted
+        orig = pow(self.g_coset, self.n, m)
+        step = pow(ext_omega, self.n, m)
+        t_eval, cur = [], orig
+        while True:
+            t_eval.append(cur)
+            cur = cur * step % m
+            if cur == orig:
+                break
+        assert len(t_eval) == 1 << (ek - k)
+        self.t_evaluations = [pow((t - 1) % m, -1, m) for t in t_eval]
+        # limb forms
+        self._w = {name: _mont(field, getattr(self, name)) for name in ("omega", "omega_inv", "extended_omega", "extended_omega_inv",
+                                                                        "ifft_divisor", "extended_ifft_divisor")}
+        self._into_coset = np.stack([_mont(field, 1), _mont(field, self.g_coset), _mont(field, self.g_coset_inv)])
+        self._from_coset = np.stack([_mont(field, 1), _mont(field, self.g_coset_inv), _mont(field, self.g_coset)])
+        self._t_inv = np.stack([_mont(field, t) for t in self.t_evaluations])
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    @staticmethod
+    def _batch(a):
+        assert a.shape[-1] == 4
+        b = 1
+        for d in a.shape[:-2]:
+            b *= d
+        return b
+
+    def _ifft(self, a, omega_inv, log_n, divisor):
+        b = self._batch(a)
+        api.ntt_dev(self.field, a, log_n, omega_inv, batch=b, stream=_stream(a))
+        api.field_scale_dev(self.field, a, b << log_n, divisor, stream=_stream(a))
+
+    def lagrange_to_coeff(self, a):
+        """in place on a (..., n, 4) device tensor; returns a"""
+        assert a.shape[-2] == self.n
+        self._ifft(a, self._w["omega_inv"], self.k, self._w["ifft_divisor"])
+        return a
+
+    def coeff_to_lagrange(self, a):
+        assert a.shape[-2] == self.n
+        api.ntt_dev(self.field, a, self.k, self._w["omega"], batch=self._batch(a), stream=_stream(a))
+        return a
+
+    def coeff_to_extended(self, a):
+        """(..., n, 4) coefficients -> new (..., 2^extended_k, 4) tensor of coset evaluations"""
+        import torch
+        assert a.shape[-2] == self.n
+        b = self._batch(a)
+        ext = torch.zeros(a.shape[:-2] + (self.extended_len(), 4), dtype=a.dtype, device=a.device)
+        ext[..., : self.n, :] = a
+        # distribute_powers_zeta(into_coset): only the first n coefficients are non-zero, and the
+        # period-3 pattern restarts with each polynomial (index counts from 0 per polynomial)
+        api.field_scale_rows_dev(self.field, ext, b, self.extended_len(), self.n, self._into_coset, stream=_stream(ext))
+        api.ntt_dev(self.field, ext, self.extended_k, self._w["extended_omega"], batch=b, stream=_stream(ext))
+        return ext
+
+    def extended_to_coeff(self, a):
+        """in place iFFT + inverse coset shift on (..., 2^extended_k, 4); returns the truncated view
+        of length n * quotient_poly_degree"""
+        assert a.shape[-2] == self.extended_len()
+        b = self._batch(a)
+        self._ifft(a, self._w["extended_omega_inv"], self.extended_k, self._w["extended_ifft_divisor"])
+        api.field_scale_rows_dev(self.field, a, b, self.extended_len(), self.extended_len(), self._from_coset, stream=_stream(a))
+        return a[..., : self.n * self.quotient_poly_degree, :]
+
+    def divide_by_vanishing_poly(self, a):
+        assert a.shape[-2] == self.extended_len()
+        b = self._batch(a)
+        # the period 2^(ek-k) divides 2^extended_k, so the batch can be scaled as one long vector
+        api.field_scale_periodic_dev(self.field, a, b * self.extended_len(), self._t_inv, stream=_stream(a))
+        return a
+
+
+class Params:
+    """commitment::Params with device-resident bases: g ‖ w and g_lagrange ‖ w (n + 1 points each)."""
+
+    def __init__(self, curve: str, k: int, g, g_lagrange, w, u=None):
+        self.curve, self.k, self.n = curve, k, 1 << k
+        g = np.ascontiguousarray(g, dtype=np.uint64).reshape(-1, 8)
+        gl = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(-1, 8)
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(1, 8)
+        assert g.shape[0] == self.n and gl.shape[0] == self.n
+        self.w, self.u = w, u
+        self._g = api.Bases.from_host(curve, np.concatenate([g, w]))
+        self._g_lagrange = api.Bases.from_host(curve, np.concatenate([gl, w]))
+
+    def _commit(self, bases, poly, r):
+        import torch
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        if isinstance(poly, np.ndarray):
+            sc = np.concatenate([poly.astype(np.uint64).reshape(-1, 4), r.reshape(1, 4)])
+            assert sc.shape[0] == self.n + 1
+            return bases.msm(sc)
+        assert poly.shape[-2] == self.n
+        sc = torch.cat([poly.reshape(self.n, 4), torch.from_numpy(r.view(np.int64)).to(poly.device).reshape(1, 4)])
+        return bases.msm_dev(sc, self.n + 1, stream=_stream(sc))
+
+    def commit(self, poly, r):
+        """poly in coefficient form (host numpy (n, 4) or device tensor), r the blind: MSM of n + 1 pairs"""
+        return self._commit(self._g, poly, r)
+
+    def commit_lagrange(self, poly, r):
+        return self._commit(self._g_lagrange, poly, r)
+
+    def commit_lagrange_batch(self, polys, blinds):
+        """polys: device tensor (batch, n, 4); blinds: (batch, 4) host limbs -> (batch, 12) points"""
+        import torch
+        batch = polys.shape[0]
+        assert polys.shape[1] == self.n
+        bl = torch.from_numpy(np.ascontiguousarray(blinds, dtype=np.uint64).reshape(batch, 1, 4).view(np.int64)).to(polys.device)
+        sc = torch.cat([polys, bl], dim=1).contiguous()
+        return self._g_lagrange.msm_batch_dev(sc, self.n + 1, batch, stream=_stream(sc))
