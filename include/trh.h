@@ -116,6 +116,19 @@ int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_
 int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len,
                              const uint64_t* factors, uint32_t period, void* stream);
 
+/* ---- IPA opening rounds: poly::commitment::prover::create_proof (device memory) ---------------
+ * The two half-size MSMs of a round run through trh_msm_dev on the live G' buffer
+ * (trh_bases_wrap_device + offset); these are the remaining per-round primitives.            */
+/* halo2_proofs::arithmetic::compute_inner_product(a, b): sum a[i] * b[i] -> out (Montgomery) */
+int trh_field_inner_product_dev(int field, const void* a_dev, const void* b_dev, size_t n, void* stream, uint64_t out[4]);
+/* y[i] += c * x[i]: the folds p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] */
+int trh_field_axpy_dev(int field, void* y_dev, const void* x_dev, size_t n, const uint64_t c_mont[4], void* stream);
+/* out[i] = x^i for i < n: the evaluation vector b = (1, x3, x3^2, ...) */
+int trh_field_powers_dev(int field, void* out_dev, size_t n, const uint64_t x_mont[4], void* stream);
+/* parallel_generator_collapse: g_lo[i] = g_lo[i] + u * g_hi[i], normalised to affine (u: scalar
+ * field element, Montgomery; g_*: `half` 64-byte affine PODs)                                   */
+int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t half, const uint64_t u_mont[4], void* stream);
+
 /* ---- element-wise field / group ops on device memory (parity tests of the device arithmetic;
  *      op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv, 6 to_mont, 7 from_mont) ------------------ */
 int trh_field_op_dev(int field, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);

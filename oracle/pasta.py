@@ -459,6 +459,64 @@ class EvaluationDomain:
         return [v * t[i % len(t)] % m for i, v in enumerate(a)]
 
 
+# --------------------------------------------------------------------------------------
+# IPA opening restatement (halo2_proofs 0.2.0 src/poly/commitment/prover.rs create_proof;
+# SURVEY.md section 8 row a7; reached via create_proof at src/test_utils.rs:41-49).
+# Transcript and randomness are injected (the reference feeds OsRng and a BLAKE2b transcript).
+# --------------------------------------------------------------------------------------
+def ipa_create_proof(curve: Curve, k: int, g: List[Affine], w: Affine, u: Affine, rng, transcript,
+                     p_poly: List[int], p_blind: int, x3: int, s_poly: List[int], s_blind: int):
+    f_, m, n = curve.scalar, curve.scalar.m, 1 << k
+    assert len(p_poly) == n and len(g) == n and len(s_poly) == n
+
+    def commit(poly, r):
+        return best_multiexp(curve, list(poly) + [r], list(g) + [w])
+
+    def eval_poly(poly, x):
+        acc = 0
+        for c in reversed(poly):
+            acc = (acc * x + c) % m
+        return acc
+
+    s_poly = list(s_poly)
+    s_poly[0] = (s_poly[0] - eval_poly(s_poly, x3)) % m      # s(x3) = 0
+    transcript.write_point(commit(s_poly, s_blind))
+    xi = transcript.squeeze_challenge_scalar()
+    z = transcript.squeeze_challenge_scalar()
+    p_prime = [(s * xi + p) % m for s, p in zip(s_poly, p_poly)]
+    v = eval_poly(p_prime, x3)
+    p_prime[0] = (p_prime[0] - v) % m
+    f = (s_blind * xi + p_blind) % m
+    b, cur = [], 1
+    for _ in range(n):
+        b.append(cur)
+        cur = cur * x3 % m
+    g_prime = list(g)
+    for j in range(k):
+        half = 1 << (k - j - 1)
+        l_j = best_multiexp(curve, p_prime[half:], g_prime[:half])
+        r_j = best_multiexp(curve, p_prime[:half], g_prime[half:])
+        value_l = sum(x * y for x, y in zip(p_prime[half:], b[:half])) % m
+        value_r = sum(x * y for x, y in zip(p_prime[:half], b[half:])) % m
+        l_rand, r_rand = rng(), rng()
+        l_j = curve.add(l_j, best_multiexp(curve, [value_l * z % m, l_rand], [u, w]))
+        r_j = curve.add(r_j, best_multiexp(curve, [value_r * z % m, r_rand], [u, w]))
+        transcript.write_point(l_j)
+        transcript.write_point(r_j)
+        u_j = transcript.squeeze_challenge_scalar()
+        u_inv = f_.inv(u_j)
+        for i in range(half):
+            p_prime[i] = (p_prime[i] + p_prime[i + half] * u_inv) % m
+            b[i] = (b[i] + b[i + half] * u_j) % m
+        p_prime, b = p_prime[:half], b[:half]
+        g_prime = [curve.add(g_prime[i], curve.mul(u_j, g_prime[i + half])) for i in range(half)]  # parallel_generator_collapse
+        f = (f + l_rand * u_inv + r_rand * u_j) % m
+    c = p_prime[0]
+    transcript.write_scalar(c)
+    transcript.write_scalar(f)
+    return c, f
+
+
 if __name__ == "__main__":
     check_published_constants()
     for c in CURVES.values():

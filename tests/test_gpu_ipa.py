@@ -1,0 +1,140 @@
+"""GPU parity tests (-m gpu) for the IPA opening: the device primitives
+against the oracle, then the whole k-round prover replayed with an injected transcript and randomness
+against the big-int restatement oracle/pasta.py::ipa_create_proof -- every L_j, R_j, c and f identical."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ref
+import pasta as o
+from tiny_ram_halo2_amd import api, ipa, poly, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    api.init(0)
+    yield
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy()).cuda()
+
+
+def to_host(t):
+    torch.cuda.synchronize()
+    return t.contiguous().cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_inner_product_axpy_powers(field):
+    f = o.FIELDS[field]
+    for n in (1, 7, 1000, 70000):
+        a, b = synth.field_elements(0x1A, n), synth.field_elements(0x1B, n)
+        da, db = to_dev(a), to_dev(b)
+        got = api.inner_product_dev(field, da, db, n)
+        prod = cpu_ref.field_op(field, "mul", a, b)
+        want = 0
+        for r in prod:
+            want = (want + f.from_limbs(r)) % f.m
+        assert f.from_limbs(got) == want
+        c = np.array(f.limbs(0xC0FFEE + n), np.uint64)
+        api.axpy_dev(field, da, db, n, c)
+        wanty = cpu_ref.field_op(field, "add", a, cpu_ref.field_op(field, "mul", b, np.tile(c, (n, 1))))
+        assert (to_host(da) == wanty).all()
+    x = 0x123456789ABCDEF % f.m
+    out = torch.empty((5000, 4), dtype=torch.int64, device="cuda")
+    api.powers_dev(field, out, 5000, np.array(f.limbs(x), np.uint64))
+    got = to_host(out)
+    for i in (0, 1, 2, 63, 64, 4999):
+        assert f.from_limbs(got[i]) == pow(x, i, f.m)
+
+
+@pytest.mark.parametrize("curve", ["pallas", "vesta"])
+def test_bases_fold(curve):
+    cv = o.CURVES[curve]
+    half = 300
+    g = cpu_ref.gen_bases(curve, 17, 5, 2 * half, threads=4)
+    g[3] = 0                       # identity in the low half
+    g[half + 5] = 0                # identity in the high half
+    g[half + 7] = g[7]             # lo == hi: lo + u * lo
+    u = 0x1D0F5A7E9B3C2468ACE13579BDF02468ACE13579BDF0246 % cv.scalar.m
+    d = to_dev(g)
+    api.bases_fold_dev(curve, d[:half], d[half:], half, np.array(cv.scalar.limbs(u), np.uint64))
+    got = to_host(d)[:half]
+    for i in (0, 1, 3, 5, 7, 150, 299):
+        want = cv.add(cv.affine_from_limbs(g[i]), cv.mul(u, cv.affine_from_limbs(g[half + i])))
+        assert cv.affine_from_limbs(got[i]) == want, i
+    # u = -1 on equal points cancels to the identity
+    d2 = to_dev(np.concatenate([g[:half], g[:half]]))
+    api.bases_fold_dev(curve, d2[:half], d2[half:], half, np.array(cv.scalar.limbs(cv.scalar.m - 1), np.uint64))
+    assert (to_host(d2)[:half] == 0).all()
+
+
+class HashTranscript:
+    """stand-in for Blake2bWrite: challenges are a hash of everything written so far"""
+
+    def __init__(self, modulus):
+        self.h, self.m, self.log = hashlib.blake2b(b"trh-test-transcript"), modulus, []
+
+    def _absorb(self, tag, data):
+        self.h.update(tag + bytes(data))
+        self.log.append((tag, bytes(data)))
+
+    def squeeze_challenge_scalar(self):
+        self.h.update(b"challenge")
+        return int.from_bytes(self.h.digest(), "little") % self.m
+
+
+class DeviceTranscript(HashTranscript):
+    def write_point(self, jac):
+        self._absorb(b"P", np.ascontiguousarray(jac, dtype=np.uint64)[:8].tobytes())
+
+    def write_scalar(self, limbs):
+        self._absorb(b"S", np.ascontiguousarray(limbs, dtype=np.uint64).tobytes())
+
+
+class OracleTranscript(HashTranscript):
+    def __init__(self, curve):
+        super().__init__(curve.scalar.m)
+        self.curve = curve
+
+    def write_point(self, pt):
+        self._absorb(b"P", np.array(self.curve.affine_limbs(pt), dtype=np.uint64).tobytes())
+
+    def write_scalar(self, v):
+        self._absorb(b"S", np.array(self.curve.scalar.limbs(v), dtype=np.uint64).tobytes())
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 3), ("vesta", 6), ("pallas", 5)])
+def test_ipa_create_proof_vs_oracle(curve, k):
+    cv = o.CURVES[curve]
+    sfn = api.SCALAR_FIELD[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0x1FA + k)
+    g_l = cpu_ref.gen_bases(curve, 31, 7, n, threads=4)
+    gl_l = cpu_ref.gen_bases(curve, 99991, 3, n, threads=4)
+    w_l = cpu_ref.gen_bases(curve, 424242, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 737373, 1, 1, threads=1)
+    params = poly.Params(curve, k, g_l, gl_l, w_l, u=u_l)
+    p_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    s_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    draws = [rnd.randrange(fs.m) for _ in range(2 * k)]
+
+    it1, it2 = iter(draws), iter(draws)
+    t_dev, t_ref = DeviceTranscript(fs.m), OracleTranscript(cv)
+    c_dev, f_dev = ipa.create_proof(params, lambda: next(it1), t_dev, to_dev(np.array([fs.limbs(v) for v in p_poly], np.uint64)),
+                                    p_blind, x3, s_poly=np.array([fs.limbs(v) for v in s_poly], np.uint64), s_blind=s_blind)
+    c_ref, f_ref = o.ipa_create_proof(cv, k, [cv.affine_from_limbs(r) for r in g_l], cv.affine_from_limbs(w_l[0]),
+                                      cv.affine_from_limbs(u_l[0]), lambda: next(it2), t_ref, p_poly, p_blind, x3, s_poly, s_blind)
+    assert (c_dev, f_dev) == (c_ref, f_ref)
+    assert len(t_dev.log) == len(t_ref.log) == 1 + 2 * k + 2
+    for a, b in zip(t_dev.log, t_ref.log):
+        assert a == b
+    del sfn

@@ -77,6 +77,10 @@ _SIGNATURES = {
     "trh_field_scale_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_field_scale_periodic_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp], ctypes.c_int),
     "trh_field_scale_rows_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _u64p, ctypes.c_uint32, _vp], ctypes.c_int),
+    "trh_field_inner_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp, _u64p], ctypes.c_int),
+    "trh_field_axpy_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
+    "trh_field_powers_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
+    "trh_bases_fold_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
@@ -245,6 +249,28 @@ def field_scale_periodic_dev(field: str, a_dev, n: int, factors, stream=None):
 def field_scale_rows_dev(field: str, a_dev, rows: int, row_len: int, active_len: int, factors, stream=None):
     f = _c(factors, 4)
     _check(lib().trh_field_scale_rows_dev(FIELD_ID[field], _devptr(a_dev), rows, row_len, active_len, _p(f), f.shape[0], stream))
+
+
+def inner_product_dev(field: str, a_dev, b_dev, n: int, stream=None) -> np.ndarray:
+    """halo2_proofs::arithmetic::compute_inner_product on device vectors -> (4,) Montgomery limbs"""
+    out = np.zeros(4, dtype=np.uint64)
+    _check(lib().trh_field_inner_product_dev(FIELD_ID[field], _devptr(a_dev), _devptr(b_dev), n, stream, _p(out)))
+    return out
+
+
+def axpy_dev(field: str, y_dev, x_dev, n: int, c, stream=None):
+    cc = _c(c).reshape(4)
+    _check(lib().trh_field_axpy_dev(FIELD_ID[field], _devptr(y_dev), _devptr(x_dev), n, _p(cc), stream))
+
+
+def powers_dev(field: str, out_dev, n: int, x, stream=None):
+    xx = _c(x).reshape(4)
+    _check(lib().trh_field_powers_dev(FIELD_ID[field], _devptr(out_dev), n, _p(xx), stream))
+
+
+def bases_fold_dev(curve: str, g_lo_dev, g_hi_dev, half: int, u, stream=None):
+    uu = _c(u).reshape(4)
+    _check(lib().trh_bases_fold_dev(CURVE_ID[curve], _devptr(g_lo_dev), _devptr(g_hi_dev), half, _p(uu), stream))
 
 
 def set_timing(on: bool):
