@@ -1,0 +1,38 @@
+"""GPU test (-m gpu): the create_proof schedule replay at k = 10 (WORD_BITS = 16, BASELINE config 1's
+circuit size) with the first items of every primitive kind compared against the oracle."""
+import numpy as np
+import pytest
+
+import cpu_ref
+import pasta as o
+from tiny_ram_halo2_amd import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def test_replay_k10_matches_oracle():
+    seen = {}
+
+    def hook(kind, inp, out):
+        seen[kind] = seen.get(kind, 0) + 1
+        if kind in ("commit_lagrange", "commit"):
+            bases = inp["bases"].download()
+            want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], bases, threads=8))
+            assert (np.asarray(out)[:8] == want).all(), kind
+            return
+        field, j, k = inp["domain"]
+        f = o.FIELDS[field]
+        dom = o.EvaluationDomain(f, j, k)
+        a = [f.from_limbs(r) for r in np.asarray(inp["a"]).reshape(-1, 4)]
+        if kind == "lagrange_to_coeff":
+            want = dom.lagrange_to_coeff(a)
+        elif kind == "coeff_to_extended":
+            want = dom.coeff_to_extended(a)
+        else:
+            want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
+        assert [f.from_limbs(r) for r in np.asarray(out).reshape(-1, 4)] == want, kind
+
+    res = replay.run(16, batch=32, hook=hook, verbose=False)
+    assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
+    assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
+    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "commit": 1, "divide_and_extended_to_coeff": 1}

@@ -1,0 +1,189 @@
+"""Replay of the arithmetic schedule `halo2_proofs::plonk::create_proof` issues for the reference's
+TinyRamCircuit<WORD_BITS, REG_COUNT = 8> (the reference call
+site is /root/reference/src/test_utils.rs:41-49 with k = 2 + WORD_BITS / 2 from :20).
+
+The Rust prover cannot run here (no toolchain), so this driver issues the same primitive kinds, sizes
+and counts against libtrh with synthetic column data: per column a `commit_lagrange` (MSM of n + 1
+pairs over the resident Lagrange bases), `lagrange_to_coeff` (iNTT n) and `coeff_to_extended` (coset NTT
+8n); the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
+and one IPA opening (k rounds).  Column / lookup / permutation counts are derived from the reference's
+`configure` code (Appendix B): 94 instance + 263 advice columns, 31 lookups, 47 permutation products,
+quotient degree 5 => extended_k = k + 3.  Witness generation, the quotient evaluation h(X) itself and
+the transcript stay on the host in the real prover and are not part of the replay.
+
+    python -m tiny_ram_halo2_amd.replay --word-bits 32           # k = 18, the 2^14-cycle configuration
+    python -m tiny_ram_halo2_amd.replay --word-bits 16           # k = 10 (BASELINE config 1's circuit size)
+
+`run(..., hook=f)` calls f(kind, inputs, outputs) on the first items of every primitive kind so that a test
+can compare them with the oracle (tests/test_gpu_replay.py); the module itself never touches the oracle.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+
+import numpy as np
+
+from . import api, ipa, poly, synth
+
+# Appendix B counts for TinyRamCircuit<WB, 8>
+N_INSTANCE, N_ADVICE, N_LOOKUPS, N_PERM_PRODUCTS, N_H_PIECES = 94, 263, 31, 47, 5
+QUOTIENT_J = 6  # cs.degree() = 6 => EvaluationDomain::new(6, k): quotient_poly_degree 5, extended_k = k + 3
+
+
+def schedule(k: int) -> dict:
+    lag_cols = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS
+    return {
+        "k": k, "n": 1 << k, "extended_k": k + 3,
+        "msm_n_plus_1": N_INSTANCE + N_ADVICE + 2 * N_LOOKUPS + N_LOOKUPS + N_PERM_PRODUCTS + 1 + N_H_PIECES + 1,
+        "intt_n": lag_cols, "ntt_extended": lag_cols, "intt_extended": 1, "ipa_openings": 1,
+    }
+
+
+class _FixedTranscript:
+    """challenge source standing in for the host's BLAKE2b transcript"""
+
+    def __init__(self, m, seed=0x7E57):
+        self.m, self.ctr, self.seed = m, 0, seed
+
+    def write_point(self, p):
+        pass
+
+    def write_scalar(self, s):
+        pass
+
+    def squeeze_challenge_scalar(self):
+        self.ctr += 1
+        w = [int(v) for v in synth.splitmix64_stream(self.seed, 4 * self.ctr, 4)]
+        return (w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192) % self.m
+
+
+def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bool = True) -> dict:
+    import torch
+
+    k = 2 + word_bits // 2
+    sch = schedule(k)
+    n, ek = sch["n"], sch["extended_k"]
+    curve, field = "vesta", "fp"  # the reference proves over Fp with Params<EqAffine> (test_utils.rs:8, 21)
+    api.init(device)
+    dev = torch.device("cuda", device)
+    dom = poly.EvaluationDomain(field, QUOTIENT_J, k)
+    assert dom.extended_k == ek, (dom.extended_k, ek)
+
+    # Params: synthetic resident bases (Params::new's hash-to-curve generators are a setup cost, a "next" row)
+    g = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n + 1)
+    gl = api.Bases.generate(curve, synth.BASE_S0 + 77, synth.BASE_D + 2, n + 1)
+    g_host = g.download()
+    params = poly.Params.__new__(poly.Params)
+    params.curve, params.k, params.n = curve, k, n
+    params._g, params._g_lagrange = g, gl
+    params.w = g_host[n:n + 1]
+    params.u = api.Bases.generate(curve, 4242, 1, 1).download()
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "commit": 0.0,
+             "extended_to_coeff": 0.0, "ipa": 0.0}
+    counts = {kk: 0 for kk in times}
+    checked = 0
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter()
+
+    # --- Lagrange-basis columns: instance, advice, lookup permuted x2 + z, permutation z ---
+    lag_total = sch["intt_n"]
+    done = 0
+    seed = 0xC01
+    while done < lag_total:
+        b = min(batch, lag_total - done)
+        cols_h = synth.field_elements(seed + done, b * n).reshape(b, n, 4)
+        blinds = synth.field_elements(seed + 0x100000 + done, b)
+        cols = torch.from_numpy(cols_h.view(np.int64)).to(dev)
+        e0 = ev()
+        pts = params.commit_lagrange_batch(cols, blinds)
+        e1 = ev()
+        coeff = dom.lagrange_to_coeff(cols)
+        e2 = ev()
+        ext = dom.coeff_to_extended(coeff)
+        e3 = ev()
+        torch.cuda.synchronize()
+        times["commit_lagrange"] += e0.elapsed_time(e1)
+        times["lagrange_to_coeff"] += e1.elapsed_time(e2)
+        times["coeff_to_extended"] += e2.elapsed_time(e3)
+        counts["commit_lagrange"] += b
+        counts["lagrange_to_coeff"] += b
+        counts["coeff_to_extended"] += b
+        if hook is not None and done == 0:
+            torch.cuda.synchronize()
+            for i in range(min(b, 3)):
+                hook("commit_lagrange", dict(scalars=np.concatenate([cols_h[i], blinds[i][None]]), bases=gl), pts[i])
+                hook("lagrange_to_coeff", dict(a=cols_h[i], domain=(field, QUOTIENT_J, k)), coeff[i].cpu().numpy().view(np.uint64))
+                hook("coeff_to_extended", dict(a=coeff[i].cpu().numpy().view(np.uint64), domain=(field, QUOTIENT_J, k)), ext[i].cpu().numpy().view(np.uint64))
+                checked += 3
+        del ext, coeff, cols
+        done += b
+
+    # --- coefficient-basis commits: vanishing random poly, h pieces ---
+    ncoef = 1 + N_H_PIECES
+    cols_h = synth.field_elements(0xABC, ncoef * n).reshape(ncoef, n, 4)
+    blinds = synth.field_elements(0xABD, ncoef)
+    cols = torch.from_numpy(cols_h.view(np.int64)).to(dev)
+    e0 = ev()
+    sc = torch.cat([cols, torch.from_numpy(blinds.reshape(ncoef, 1, 4).view(np.int64)).to(dev)], dim=1).contiguous()
+    pts = g.msm_batch_dev(sc, n + 1, ncoef, stream=torch.cuda.current_stream().cuda_stream)
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["commit"] += e0.elapsed_time(e1)
+    counts["commit"] += ncoef
+    if hook is not None:
+        hook("commit", dict(scalars=np.concatenate([cols_h[0], blinds[0][None]]), bases=g), pts[0])
+        checked += 1
+
+    # --- h(X): one extended iNTT ---
+    h_h = synth.field_elements(0xEE, 1 << ek)
+    h = torch.from_numpy(h_h.view(np.int64)).to(dev).reshape(1, 1 << ek, 4)
+    e0 = ev()
+    dom.divide_by_vanishing_poly(h)
+    hc = dom.extended_to_coeff(h)
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["extended_to_coeff"] += e0.elapsed_time(e1)
+    counts["extended_to_coeff"] += 1
+    if hook is not None:
+        hook("divide_and_extended_to_coeff", dict(a=h_h, domain=(field, QUOTIENT_J, k)), hc[0].cpu().numpy().view(np.uint64))
+        checked += 1
+
+    # --- IPA opening of the final polynomial ---
+    m = poly._MODULUS[field]
+    p_h = synth.field_elements(0x1FA, n)
+    p_dev = torch.from_numpy(p_h.view(np.int64)).to(dev)
+    draws = iter(range(7, 10 ** 9, 13))
+    e0 = ev()
+    ipa.create_proof(params, lambda: next(draws), _FixedTranscript(m), p_dev, 0x1234, 0x77777, s_poly=synth.field_elements(0x5A, n), s_blind=0x99)
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["ipa"] += e0.elapsed_time(e1)
+    counts["ipa"] += 1
+
+    wall = time.perf_counter() - t_wall
+    out = {"word_bits": word_bits, "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
+           "gpu_ms_total": round(sum(times.values()), 3), "wall_s_including_host_input_generation": round(wall, 3),
+           "checked_against_oracle": checked}
+    if verbose:
+        print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--word-bits", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    run(a.word_bits, a.batch)
+
+
+if __name__ == "__main__":
+    main()
