@@ -297,3 +297,17 @@ def test_scale_periodic():
     api.lib().trh_stream_synchronize(None)
     want = cpu_ref.field_op(field, "mul", a, facs[np.arange(n) % 3])
     assert (d.to_host(shape=(-1, 4)) == want).all()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_heavy_buckets(curve):
+    """skewed scalars (values 0..3, as witness columns of flags and small words produce): a handful of
+    buckets hold thousands of entries each and go through the workgroup-per-bucket combine"""
+    n = 40000
+    f = o.CURVES[curve].scalar
+    vals = (np.arange(n) * 2654435761 >> 7) % 4
+    table = np.array([f.limbs(v) for v in range(4)], np.uint64)
+    sc = table[vals]
+    bases = cpu_ref.gen_bases(curve, 0xFEED, 0x35, n, threads=4)
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
+    assert (api.best_multiexp(curve, sc, bases)[:8] == want).all()

@@ -70,6 +70,7 @@ struct MsmScratch {
     DevBuf first, last;  // W x nseg raw lazy XYZZ: first run / unfinished last run of each segment
     DevBuf direct;       // W x (NB + 1) raw lazy XYZZ: buckets that lie inside one segment
     DevBuf bases_z;      // n affine bases converted to the lazy domain
+    DevBuf heavy;        // [0] count + list of (window, bucket) ids whose pieces a whole workgroup combines
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
     DevBuf window_sums;  // batch x W XYZZ

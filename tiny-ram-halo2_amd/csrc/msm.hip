@@ -341,11 +341,42 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     else store_raw(last + (size_t)j * nseg + t, acc);
 }
 
+constexpr u32 HEAVY_PIECES = 16;
+
+// buckets spanning more than HEAVY_PIECES segments (skewed scalars; the short top window of 255-bit
+// scalars): one workgroup per listed bucket, threads stride over the pieces, LDS tree at the end
+template <class BF>
+__global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
+                                                                const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
+                                                                XYZZMem* __restrict__ buckets, u32 nbk, u32 nseg, u32 seg_len,
+                                                                const u32* __restrict__ heavy) {
+    __shared__ XYZZz<BF> sh[256];
+    const u32 count = heavy[0];
+    const u32 nb1 = nbk + 1;
+    for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
+        const u32 id = heavy[1 + h], j = id / nb1, b = id - j * nb1;
+        const u32 S = starts[id], E = ends[id];
+        const u32 t_lo = S / seg_len, t_hi = (E - 1) / seg_len;
+        const XYZZzMem* fj = first + (size_t)j * nseg;
+        XYZZz<BF> acc = xyzzz_identity<BF>();
+        if (threadIdx.x == 0) acc = (S == t_lo * seg_len) ? load_raw<BF>(fj + t_lo) : load_raw<BF>(last + (size_t)j * nseg + t_lo);
+        for (u32 t = t_lo + 1 + threadIdx.x; t <= t_hi; t += blockDim.x) acc = xyzzz_add(acc, load_raw<BF>(fj + t));
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) store_xyzz(&buckets[(size_t)j * nbk + (b - 1)], xyzzz_to_canonical(sh[0]));
+        __syncthreads();
+    }
+}
+
 template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                           const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                           const XYZZzMem* __restrict__ direct, XYZZMem* __restrict__ buckets,
-                                                          u32 nbk, u32 nseg, u32 seg_len) {
+                                                          u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y;
     if (b > nbk) return;
@@ -354,6 +385,10 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
     XYZZz<BF> acc = xyzzz_identity<BF>();
     if (E > S) {
         const u32 t_lo = S / seg_len, t_hi = (E - 1) / seg_len;
+        if (t_hi - t_lo > HEAVY_PIECES) {  // skewed bucket: a whole workgroup adds its pieces (msm_combine_heavy_kernel)
+            heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)j * nb1 + b;
+            return;
+        }
         const XYZZzMem* fj = first + (size_t)j * nseg;
         if (S == t_lo * seg_len) acc = load_raw<BF>(fj + t_lo);
         else if (E <= (t_lo + 1) * seg_len) acc = load_raw<BF>(direct + (size_t)j * nb1 + b);
@@ -478,6 +513,10 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     TRH_TRY(m.last.ensure((size_t)W * nseg * sizeof(XYZZzMem)));
     TRH_TRY(m.direct.ensure((size_t)W * nb1 * sizeof(XYZZzMem)));
     TRH_TRY(m.bases_z.ensure(n * 64 + 64));
+    // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
+    const size_t max_heavy = (size_t)W * nseg / HEAVY_PIECES + 1;
+    TRH_TRY(m.heavy.ensure((max_heavy + 1) * 4));
+    const unsigned heavy_blocks = (unsigned)(max_heavy < 1024 ? max_heavy : 1024);
     TRH_TRY(m.buckets.ensure((size_t)W * nbk * sizeof(XYZZMem)));
     TRH_TRY(m.partials.ensure((size_t)W * rblocks * sizeof(XYZZMem)));
     TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
@@ -495,6 +534,7 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
         if (n) {
             TRH_HIP_TRY(hipMemsetAsync(m.counts.p, 0, (size_t)W * nbins * 4, s));
+            TRH_HIP_TRY(hipMemsetAsync(m.heavy.p, 0, 4, s));
             unsigned gb = (unsigned)((n + 255) / 256);
             if (gb > 2048) gb = 2048;
             hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
@@ -512,7 +552,9 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
             hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W), dim3(256), 0, s, m.bases_z.as<uint4>(), m.sorted.as<u32>(),
                                m.ends.as<u32>(), m.seg_bucket.as<u32>(), m.first.as<XYZZzMem>(), m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W), dim3(256), 0, s, m.starts.as<u32>(), m.ends.as<u32>(), m.first.as<XYZZzMem>(),
-                               m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len);
+                               m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len, m.heavy.as<u32>());
+            hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks), dim3(256), 0, s, m.starts.as<u32>(), m.ends.as<u32>(), m.first.as<XYZZzMem>(),
+                               m.last.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len, m.heavy.as<u32>());
             if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W), dim3(256), 0, s, m.buckets.as<XYZZMem>(), m.partials.as<XYZZMem>(), nbk, slice, tpw);
             hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W), dim3(256), 0, s, m.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + bi * W, rblocks);
@@ -607,7 +649,7 @@ int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* o
 }
 void msm_release() {
     MsmScratch& m = ctx().msm;
-    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release(); m.seg_bucket.release(); m.first.release(); m.last.release(); m.direct.release(); m.bases_z.release();
+    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release(); m.seg_bucket.release(); m.first.release(); m.last.release(); m.direct.release(); m.bases_z.release(); m.heavy.release();
     m.buckets.release(); m.partials.release(); m.window_sums.release();
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
