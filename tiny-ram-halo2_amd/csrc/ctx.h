@@ -57,23 +57,26 @@ struct TwiddleEntry {
     u64 stamp;
 };
 
-struct MsmScratch {
-    DevBuf scalars;      // host-scalar entry points stage here
+struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: batch item)
     DevBuf digits;       // W x n u32: bucket id | sign << 31
     DevBuf parted;       // W x n u32: entries grouped by level-1 bin (index | low bucket bits | sign)
     DevBuf sorted;       // W x n u32: point index | sign << 31, grouped by bucket
     DevBuf counts;       // W x nbins u32 level-1 histogram, then running cursor / bin end
     DevBuf bin_starts;   // W x nbins u32 level-1 bin start offsets
-    DevBuf starts;       // W x (NB + 1) u32 bucket start offsets
-    DevBuf ends;         // W x (NB + 1) u32 bucket end offsets
+    DevBuf starts, ends; // W x (NB + 1) u32 bucket ranges in `sorted`
     DevBuf seg_bucket;   // W x nseg u32: bucket holding the first entry of each segment
     DevBuf first, last;  // W x nseg raw lazy XYZZ: first run / unfinished last run of each segment
     DevBuf direct;       // W x (NB + 1) raw lazy XYZZ: buckets that lie inside one segment
-    DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf heavy;        // [0] count + list of (window, bucket) ids whose pieces a whole workgroup combines
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
+};
+
+struct MsmScratch {
+    DevBuf scalars;      // host-scalar entry points stage here
+    DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf window_sums;  // batch x W XYZZ
+    MsmLane lane;
     void* host_sums = nullptr;  // pinned mirror of window_sums
     size_t host_sums_cap = 0;
     // state of the enqueued-but-not-finished MSM

@@ -39,10 +39,10 @@ inline int ilog2_floor(size_t n) {
 inline int choose_window_bits(size_t n) {
     int o = ctx().window_override;
     if (o >= 2 && o <= MAX_C) return o;
-    int c = ilog2_floor(n ? n : 1) / 2 + 4;
-    if (c > MAX_C) c = MAX_C;
-    if (c < 2) c = 2;
-    return c;
+    // measured on MI355X (tools/window_sweep.py): below 2^15 pairs an MSM is latency-bound and the width
+    // hardly matters; from 2^16 the wide windows win (fewer mixed adds, more level-1 sort bins)
+    const int l = ilog2_floor(n ? n : 1);
+    return l < 9 ? 4 : l < 11 ? 5 : l < 13 ? 8 : l < 15 ? 9 : l < 16 ? 10 : l < 19 ? 15 : 16;
 }
 inline int num_windows(int c) { return 255 / c + 1; }
 
@@ -53,7 +53,9 @@ inline int num_windows(int c) { return 255 / c + 1; }
 // ---------------------------------------------------------------------------------------
 template <class SF>
 __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W,
-                                                         u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds) {
+                                                         u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds, size_t sstride) {
+    const size_t z = blockIdx.z;  // batch item
+    scalars += z * sstride * 2; digits += z * (size_t)W * n; bin_counts += z * (size_t)W * nbins;
     extern __shared__ u32 lhist[];  // W * nbins counters when use_lds
     const u32 total = (u32)W * nbins;
     if (use_lds) {
@@ -96,6 +98,8 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
 // 2. exclusive scan per window of cnt[0..len) -> starts; cnt becomes the running cursor
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1) {
+    const size_t z = blockIdx.z;  // batch item
+    counts += z * (size_t)gridDim.x * nb1; starts += z * (size_t)gridDim.x * nb1;
     __shared__ u32 part[1024];
     const int j = blockIdx.x, t = threadIdx.x;
     u32* cnt = counts + (size_t)j * nb1;
@@ -131,6 +135,8 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
 constexpr int PART_TILE = 16384;
 __global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
                                                             u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
+    const size_t z = blockIdx.z;  // batch item
+    digits += z * (size_t)gridDim.y * n; parted += z * (size_t)gridDim.y * n; bin_cursor += z * (size_t)gridDim.y * nbins;
     extern __shared__ u32 lds[];  // [nbins] counts / cursors, [nbins] global run base
     u32* cnt = lds;
     u32* base = lds + nbins;
@@ -172,6 +178,12 @@ __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restr
                                                               const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
                                                               u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
                                                               u32 nbins, int idx_bits, u32 nbk, u32* __restrict__ seg_bucket, u32 nseg, u32 seg_len) {
+    const size_t z = blockIdx.z;  // batch item
+    {
+        const size_t Wz = gridDim.y;
+        parted += z * Wz * n; sorted += z * Wz * n; bin_starts += z * Wz * nbins; bin_ends += z * Wz * nbins;
+        starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); seg_bucket += z * Wz * nseg;
+    }
     __shared__ u32 cnt[128], off[128];
     const int j = blockIdx.y;
     const u32 bin = blockIdx.x;
@@ -299,6 +311,12 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
                                                                  const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
                                                                  XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
                                                                  XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+    const size_t z = blockIdx.z;  // batch item
+    {
+        const size_t Wz = gridDim.y;
+        sorted += z * Wz * n; ends += z * Wz * (nbk + 1); seg_bucket += z * Wz * nseg;
+        first += z * Wz * nseg; last += z * Wz * nseg; direct += z * Wz * (nbk + 1);
+    }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (t >= nseg) return;
@@ -349,7 +367,13 @@ template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                                 const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                                 XYZZMem* __restrict__ buckets, u32 nbk, u32 nseg, u32 seg_len,
-                                                                const u32* __restrict__ heavy) {
+                                                                const u32* __restrict__ heavy, u32 W, u32 heavy_stride) {
+    const size_t z = blockIdx.z;  // batch item
+    {
+        const size_t Wz = W;
+        starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
+        buckets += z * Wz * nbk; heavy += z * heavy_stride;
+    }
     __shared__ XYZZz<BF> sh[256];
     const u32 count = heavy[0];
     const u32 nb1 = nbk + 1;
@@ -376,7 +400,13 @@ template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                           const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                           const XYZZzMem* __restrict__ direct, XYZZMem* __restrict__ buckets,
-                                                          u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */) {
+                                                          u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride) {
+    const size_t z = blockIdx.z;  // batch item
+    {
+        const size_t Wz = gridDim.y;
+        starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
+        direct += z * Wz * (nbk + 1); buckets += z * Wz * nbk; heavy += z * heavy_stride;
+    }
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int j = blockIdx.y;
     if (b > nbk) return;
@@ -405,6 +435,8 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
 template <class BF>
 __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZMem* __restrict__ buckets, XYZZMem* __restrict__ partials,
                                                          u32 nbk, u32 m, u32 threads_per_window) {
+    const size_t z = blockIdx.z;  // batch item
+    buckets += z * (size_t)gridDim.y * nbk; partials += z * (size_t)gridDim.y * gridDim.x;
     __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
     const int j = blockIdx.y;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,6 +474,8 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZMem* __restri
 // one block per window: sum `count` partials
 template <class BF>
 __global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+    const size_t z = blockIdx.z;  // batch item
+    partials += z * (size_t)gridDim.x * count; window_sums += z * (size_t)gridDim.x;
     __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
     const int j = blockIdx.x;
     XYZZ<BF> v = xyzz_identity<BF>();
@@ -481,6 +515,7 @@ template <class SF, class BF>
 int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
+    MsmLane& L = m.lane;
     const int cb = choose_window_bits(n);
     const int W = num_windows(cb);
     const u32 nbk = 1u << (cb - 1), nb1 = nbk + 1;
@@ -495,30 +530,42 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     const int recode_use_lds = recode_lds <= 64 * 1024;
     // reduce geometry
     u32 tpw = nbk < 2048 ? nbk : 2048;  // threads per window
-    if (tpw > nbk) tpw = nbk;
     const u32 slice = nbk / tpw;
     const u32 rblocks = (tpw + 255) / 256;
-
-    TRH_TRY(m.digits.ensure((size_t)W * n * 4 + 16));
-    TRH_TRY(m.parted.ensure((size_t)W * n * 4 + 16));
-    TRH_TRY(m.sorted.ensure((size_t)W * n * 4 + 16));
-    TRH_TRY(m.counts.ensure((size_t)W * nbins * 4));
-    TRH_TRY(m.bin_starts.ensure((size_t)W * nbins * 4));
-    TRH_TRY(m.starts.ensure((size_t)W * nb1 * 4));
-    TRH_TRY(m.ends.ensure((size_t)W * nb1 * 4));
-    const u32 seg_len = n >= ((size_t)1 << 18) ? 64u : n >= ((size_t)1 << 16) ? 32u : 16u;
+    // independent batch items (one MSM per column of create_proof, same bases) are processed
+    // `chunk` at a time by the SAME launches (blockIdx.z = item), so the latency-bound sort and
+    // reduction phases of one item are hidden behind the work of the others
+    size_t chunk = batch;
+    {
+        const size_t per_item = (size_t)W * n * 12 + 1;  // digits + parted + sorted dominate
+        const size_t cap = ((size_t)4 << 30) / per_item;
+        if (chunk > cap) chunk = cap ? cap : 1;
+        if (chunk > 64) chunk = 64;
+    }
+    // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 64 entries each
+    u32 seg_len = 64;
+    while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
     const u32 nseg = (u32)((n + seg_len - 1) / seg_len);
-    TRH_TRY(m.seg_bucket.ensure((size_t)W * nseg * 4 + 16));
-    TRH_TRY(m.first.ensure((size_t)W * nseg * sizeof(XYZZzMem)));
-    TRH_TRY(m.last.ensure((size_t)W * nseg * sizeof(XYZZzMem)));
-    TRH_TRY(m.direct.ensure((size_t)W * nb1 * sizeof(XYZZzMem)));
-    TRH_TRY(m.bases_z.ensure(n * 64 + 64));
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
     const size_t max_heavy = (size_t)W * nseg / HEAVY_PIECES + 1;
-    TRH_TRY(m.heavy.ensure((max_heavy + 1) * 4));
-    const unsigned heavy_blocks = (unsigned)(max_heavy < 1024 ? max_heavy : 1024);
-    TRH_TRY(m.buckets.ensure((size_t)W * nbk * sizeof(XYZZMem)));
-    TRH_TRY(m.partials.ensure((size_t)W * rblocks * sizeof(XYZZMem)));
+    const u32 heavy_stride = (u32)(max_heavy + 1);
+    const unsigned heavy_blocks = (unsigned)(max_heavy < 256 ? max_heavy : 256);
+
+    TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
+    TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
+    TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
+    TRH_TRY(L.counts.ensure(chunk * W * nbins * 4));
+    TRH_TRY(L.bin_starts.ensure(chunk * W * nbins * 4));
+    TRH_TRY(L.starts.ensure(chunk * W * nb1 * 4));
+    TRH_TRY(L.ends.ensure(chunk * W * nb1 * 4));
+    TRH_TRY(L.seg_bucket.ensure(chunk * W * nseg * 4 + 16));
+    TRH_TRY(L.first.ensure(chunk * W * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(L.last.ensure(chunk * W * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(L.direct.ensure(chunk * W * nb1 * sizeof(XYZZzMem)));
+    TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
+    TRH_TRY(L.buckets.ensure(chunk * W * nbk * sizeof(XYZZMem)));
+    TRH_TRY(L.partials.ensure(chunk * W * rblocks * sizeof(XYZZMem)));
+    TRH_TRY(m.bases_z.ensure(n * 64 + 64));
     TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
     const size_t hs = batch * W * sizeof(XYZZMem);
     if (hs > m.host_sums_cap) {
@@ -529,39 +576,39 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     const bool timing = c.timing && batch == 1;
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
 
-    for (size_t bi = 0; bi < batch; ++bi) {
-        const uint4* sc = (const uint4*)((const char*)scalars_dev + bi * stride * 32);
+    if (!n) {
+        TRH_HIP_TRY(hipMemsetAsync(m.window_sums.p, 0, hs, s));
+        if (timing) for (int k = 0; k <= 4; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
+    }
+    for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
+        const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
+        const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
-        if (n) {
-            TRH_HIP_TRY(hipMemsetAsync(m.counts.p, 0, (size_t)W * nbins * 4, s));
-            TRH_HIP_TRY(hipMemsetAsync(m.heavy.p, 0, 4, s));
-            unsigned gb = (unsigned)((n + 255) / 256);
-            if (gb > 2048) gb = 2048;
-            hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
-                               m.digits.as<u32>(), m.counts.as<u32>(), k2, nbins, recode_use_lds);
-            if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-            hipLaunchKernelGGL(msm_offsets_kernel, dim3(W), dim3(1024), 0, s, m.counts.as<u32>(), m.bin_starts.as<u32>(), nbins);
-            hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W), dim3(256), (size_t)nbins * 8, s,
-                               m.digits.as<u32>(), m.counts.as<u32>(), m.parted.as<u32>(), n, k2, nbins, idx_bits);
-            hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W), dim3(256), 0, s, m.parted.as<u32>(), m.bin_starts.as<u32>(),
-                               m.counts.as<u32>(), m.sorted.as<u32>(), m.starts.as<u32>(), m.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
-                               m.seg_bucket.as<u32>(), nseg, seg_len);
-            if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
-            if (bi == 0)
-                hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-            hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W), dim3(256), 0, s, m.bases_z.as<uint4>(), m.sorted.as<u32>(),
-                               m.ends.as<u32>(), m.seg_bucket.as<u32>(), m.first.as<XYZZzMem>(), m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
-            hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W), dim3(256), 0, s, m.starts.as<u32>(), m.ends.as<u32>(), m.first.as<XYZZzMem>(),
-                               m.last.as<XYZZzMem>(), m.direct.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len, m.heavy.as<u32>());
-            hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks), dim3(256), 0, s, m.starts.as<u32>(), m.ends.as<u32>(), m.first.as<XYZZzMem>(),
-                               m.last.as<XYZZzMem>(), m.buckets.as<XYZZMem>(), nbk, nseg, seg_len, m.heavy.as<u32>());
-            if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
-            hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W), dim3(256), 0, s, m.buckets.as<XYZZMem>(), m.partials.as<XYZZMem>(), nbk, slice, tpw);
-            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W), dim3(256), 0, s, m.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + bi * W, rblocks);
-        } else {
-            TRH_HIP_TRY(hipMemsetAsync(m.window_sums.as<XYZZMem>() + bi * W, 0, W * sizeof(XYZZMem), s));
-            if (timing) for (int k = 1; k <= 3; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
-        }
+        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * W * nbins * 4, s));
+        TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
+        unsigned gb = (unsigned)((n + 255) / 256);
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
+                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride);
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
+        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(256), (size_t)nbins * 8, s,
+                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), n, k2, nbins, idx_bits);
+        hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W, nb), dim3(256), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(),
+                           L.counts.as<u32>(), L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
+                           L.seg_bucket.as<u32>(), nseg, seg_len);
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
+        if (b0 == 0)
+            hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
+        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W, nb), dim3(256), 0, s, m.bases_z.as<uint4>(), L.sorted.as<u32>(),
+                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
+        hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
+                           L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
+        hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
+                           L.last.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)W, heavy_stride);
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
+        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W, nb), dim3(256), 0, s, L.buckets.as<XYZZMem>(), L.partials.as<XYZZMem>(), nbk, slice, tpw);
+        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W, 1, nb), dim3(256), 0, s, L.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + b0 * W, rblocks);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
     }
     TRH_HIP_TRY(hipGetLastError());
@@ -649,8 +696,10 @@ int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* o
 }
 void msm_release() {
     MsmScratch& m = ctx().msm;
-    m.scalars.release(); m.digits.release(); m.parted.release(); m.sorted.release(); m.counts.release(); m.bin_starts.release(); m.starts.release(); m.ends.release(); m.seg_bucket.release(); m.first.release(); m.last.release(); m.direct.release(); m.bases_z.release(); m.heavy.release();
-    m.buckets.release(); m.partials.release(); m.window_sums.release();
+    m.scalars.release(); m.bases_z.release(); m.window_sums.release();
+    MsmLane& L = m.lane;
+    L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release();
+    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release();
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
     for (int k = 0; k < 6; ++k) if (m.ev[k]) { (void)hipEventDestroy(m.ev[k]); m.ev[k] = nullptr; }
