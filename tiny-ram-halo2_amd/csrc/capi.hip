@@ -101,7 +101,7 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
         if (e == hipSuccess) e = hipMemcpy(bbuf.p, bases, n * 64, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { bbuf.release(); set_error("best_multiexp: upload failed: %s", hipGetErrorString(e)); return TRH_EHIP; }
-    rc = msm_enqueue(curve, bbuf.p, c.msm.scalars.p, n, 1, n, 1, 0);
+    rc = msm_enqueue(curve, bbuf.p, nullptr, c.msm.scalars.p, n, 1, n, 1, 0);
     if (rc == TRH_OK) rc = msm_finish(curve, 0, out, 1);
     bbuf.release();
     return rc;
@@ -228,7 +228,20 @@ size_t trh_bases_len(trh_bases_t b) { return b ? b->n : 0; }
 void trh_bases_destroy(trh_bases_t b) {
     if (!b) return;
     if (b->owned && b->d_xy) (void)hipFree(b->d_xy);
+    if (b->d_z) (void)hipFree(b->d_z);
     delete b;
+}
+
+// owned base sets are immutable: convert them to the lazy Montgomery domain once and keep the copy
+static const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
+    if (!b->owned || b->n == 0) return nullptr;
+    if (!b->d_z) {
+        void* z = nullptr;
+        if (hipMalloc(&z, b->n * 64 + 64) != hipSuccess) return nullptr;  // fall back to per-call conversion
+        if (msm_convert_bases(b->curve, b->d_xy, z, b->n, s) != TRH_OK || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(z); return nullptr; }
+        b->d_z = z;
+    }
+    return (const char*)b->d_z + offset * 64;
 }
 
 static int msm_args(trh_bases_t bases, size_t offset, const void* scalars, size_t n, size_t batch, void* out) {
@@ -246,7 +259,7 @@ int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size
     std::lock_guard<std::mutex> lk(c.mu);
     TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
     if (n) TRH_HIP_TRY(hipMemcpy(c.msm.scalars.p, scalars_host, n * 32, hipMemcpyHostToDevice));
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, c.msm.scalars.p, n, 1, n, mont, 0));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, 0), c.msm.scalars.p, n, 1, n, mont, 0));
     return msm_finish(bases->curve, 0, out, 1);
 }
 
@@ -255,7 +268,7 @@ int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_de
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, &dummy));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, 1, n, mont, (hipStream_t)stream);
+    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream);
 }
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out[12]) {
     TRH_TRY(require_init());
@@ -268,14 +281,14 @@ int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, out));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, 1, n, mont, (hipStream_t)stream));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream));
     return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
 }
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch, int mont, void* stream, uint64_t* out) {
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, batch, out));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, scalars_dev, n, batch, n, mont, (hipStream_t)stream));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, batch, n, mont, (hipStream_t)stream));
     return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
 }
 int trh_msm_set_window_bits(int cbits) {

@@ -109,8 +109,9 @@ int require_init();
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s);
 void ntt_release_tables();
 // msm.hip
-int msm_enqueue(int curve, const void* bases_dev, const void* scalars_dev, size_t n, size_t batch,
+int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
                 size_t scalar_stride_elems, int mont, hipStream_t s);
+int msm_convert_bases(int curve, const void* in_dev, void* out_dev, size_t n, hipStream_t s);
 int msm_finish(int curve, hipStream_t s, u64* out_xyz, size_t batch);
 int point_sum_host(int curve, const u64* pts, size_t count, u64* out);
 int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* out_dev, hipStream_t s);
@@ -123,4 +124,5 @@ struct trh_bases {
     void* d_xy;
     size_t n;
     bool owned;
+    void* d_z = nullptr;  // owned (immutable) sets: the bases converted once to the lazy Montgomery domain
 };

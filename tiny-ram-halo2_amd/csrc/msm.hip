@@ -19,6 +19,7 @@
 //   6. combine   per-window sums -> host (W x 128 B), Horner over windows on the host
 //
 // Integer work, no MFMA.  Algorithmic HBM bytes: 32 B scalar + 64 B base per pair.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -133,13 +134,20 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
 //     entry = point index | low k2 bucket bits << idx_bits | sign << 31
 // ---------------------------------------------------------------------------------------
 constexpr int PART_TILE = 16384;
-__global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
-                                                            u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
+constexpr int PART_THREADS = 512;
+__global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
+                                                                     u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
     const size_t z = blockIdx.z;  // batch item
     digits += z * (size_t)gridDim.y * n; parted += z * (size_t)gridDim.y * n; bin_cursor += z * (size_t)gridDim.y * nbins;
-    extern __shared__ u32 lds[];  // [nbins] counts / cursors, [nbins] global run base
-    u32* cnt = lds;
-    u32* base = lds + nbins;
+    // LDS: the tile's entries staged in bin order (so that every bin's run leaves as one coalesced
+    // store instead of PART_TILE scattered 4-byte writes), then per bin: count / cursor, start inside
+    // the stage, start of the reserved run in HBM
+    extern __shared__ u32 lds[];
+    u32* stage = lds;
+    u32* cnt = lds + PART_TILE;
+    u32* lbase = cnt + nbins;
+    u32* gbase = lbase + nbins;
+    __shared__ u32 scan[PART_THREADS];
     const int j = blockIdx.y;
     const size_t t0 = (size_t)blockIdx.x * PART_TILE;
     const size_t t1 = t0 + PART_TILE < n ? t0 + PART_TILE : n;
@@ -151,13 +159,30 @@ __global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restric
         if (b) atomicAdd(&cnt[(b - 1u) >> k2], 1u);
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) {
-        const u32 v = cnt[k];
-        base[k] = v ? atomicAdd(&bin_cursor[(size_t)j * nbins + k], v) : 0u;
-        cnt[k] = 0;
+    {   // exclusive scan of cnt over the bins -> lbase; one global atomic per bin reserves its run
+        const u32 per = (nbins + PART_THREADS - 1) / PART_THREADS;
+        const u32 lo = threadIdx.x * per < nbins ? threadIdx.x * per : nbins, hi = lo + per < nbins ? lo + per : nbins;
+        u32 sum = 0;
+        for (u32 k = lo; k < hi; ++k) sum += cnt[k];
+        scan[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < PART_THREADS; off <<= 1) {
+            const u32 v = ((int)threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        u32 run = scan[threadIdx.x] - sum;
+        for (u32 k = lo; k < hi; ++k) {
+            const u32 v = cnt[k];
+            lbase[k] = run;
+            gbase[k] = v ? atomicAdd(&bin_cursor[(size_t)j * nbins + k], v) : 0u;
+            run += v;
+        }
     }
     __syncthreads();
-    u32* out = parted + (size_t)j * n;
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
     const u32 low_mask = (1u << k2) - 1u;
     for (size_t i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
         const u32 e = dg[i];
@@ -165,8 +190,16 @@ __global__ void __launch_bounds__(256) msm_partition_kernel(const u32* __restric
         if (b) {
             const u32 bm = b - 1u, bin = bm >> k2;
             const u32 r = atomicAdd(&cnt[bin], 1u);
-            out[base[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
+            stage[lbase[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
         }
+    }
+    __syncthreads();
+    // copy out: one wave per bin, lanes cover consecutive entries of the run
+    u32* out = parted + (size_t)j * n;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (u32 bin = wave; bin < nbins; bin += PART_THREADS / 64) {
+        const u32 c = cnt[bin], lb = lbase[bin], gb = gbase[bin];
+        for (u32 k = lane; k < c; k += 64) out[gb + k] = stage[lb + k];
     }
 }
 
@@ -359,7 +392,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     else store_raw(last + (size_t)j * nseg + t, acc);
 }
 
-constexpr u32 HEAVY_PIECES = 16;
+constexpr u32 HEAVY_PIECES = 64;
 
 // buckets spanning more than HEAVY_PIECES segments (skewed scalars; the short top window of 255-bit
 // scalars): one workgroup per listed bucket, threads stride over the pieces, LDS tree at the end
@@ -512,7 +545,7 @@ __global__ void __launch_bounds__(256) bases_generate_kernel(u64 s0, u64 d, u64 
 }
 
 template <class SF, class BF>
-int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
+int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
     MsmLane& L = m.lane;
@@ -545,6 +578,7 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 64 entries each
     u32 seg_len = 64;
     while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+    if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len = (u32)v; }  // tuning knob
     const u32 nseg = (u32)((n + seg_len - 1) / seg_len);
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
     const size_t max_heavy = (size_t)W * nseg / HEAVY_PIECES + 1;
@@ -565,13 +599,19 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
     TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
     TRH_TRY(L.buckets.ensure(chunk * W * nbk * sizeof(XYZZMem)));
     TRH_TRY(L.partials.ensure(chunk * W * rblocks * sizeof(XYZZMem)));
-    TRH_TRY(m.bases_z.ensure(n * 64 + 64));
+    if (!bases_z) TRH_TRY(m.bases_z.ensure(n * 64 + 64));
+    const uint4* bz = bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
     TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
     const size_t hs = batch * W * sizeof(XYZZMem);
     if (hs > m.host_sums_cap) {
         if (m.host_sums) (void)hipHostFree(m.host_sums);
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
         m.host_sums_cap = hs + 4096;
+    }
+    static bool part_attr = false;
+    if (!part_attr) {
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
+        part_attr = true;
     }
     const bool timing = c.timing && batch == 1;
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
@@ -592,15 +632,15 @@ int msm_enqueue_t(const void* bases_dev, const void* scalars_dev, size_t n, size
                            L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
-        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(256), (size_t)nbins * 8, s,
+        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), n, k2, nbins, idx_bits);
         hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W, nb), dim3(256), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(),
                            L.counts.as<u32>(), L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
                            L.seg_bucket.as<u32>(), nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
-        if (b0 == 0)
+        if (b0 == 0 && !bases_z)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W, nb), dim3(256), 0, s, m.bases_z.as<uint4>(), L.sorted.as<u32>(),
+        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
         hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
                            L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
@@ -673,10 +713,18 @@ int point_sum_host_t(const u64* pts, size_t count, u64* out) {
 
 }  // namespace
 
-int msm_enqueue(int curve, const void* bases_dev, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
+int msm_enqueue(int curve, const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
     // pallas: base Fp, scalar Fq; vesta: base Fq, scalar Fp
-    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, scalars_dev, n, batch, stride, mont, s);
-    return msm_enqueue_t<FpParams, FqParams>(bases_dev, scalars_dev, n, batch, stride, mont, s);
+    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s);
+    return msm_enqueue_t<FpParams, FqParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s);
+}
+int msm_convert_bases(int curve, const void* in_dev, void* out_dev, size_t n, hipStream_t s) {
+    if (!n) return TRH_OK;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (curve == TRH_PALLAS) hipLaunchKernelGGL((msm_convert_bases_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)in_dev, (uint4*)out_dev, n);
+    else hipLaunchKernelGGL((msm_convert_bases_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)in_dev, (uint4*)out_dev, n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
 }
 int msm_finish(int curve, hipStream_t s, u64* out_xyz, size_t batch) {
     if (curve == TRH_PALLAS) return msm_finish_t<FpParams>(s, out_xyz, batch);
