@@ -67,12 +67,12 @@ def main():
             f = v.get("FETCH_SIZE", (0, 0.0)); w = v.get("WRITE_SIZE", (0, 0.0))
             hbm = (2 * f[1] + w[1]) * 1024
             lines.append(f"| {name} | {grid} | {max(f[0], w[0])} | {f[1]:.0f} | {w[1]:.0f} | {hbm:.3e} |")
-            if name.startswith("msm_accumulate_kernel") and hbm > traffic.get(f"msm_accumulate_2^{msm_log_n}", 0):
+            if name.startswith("msm_accumulate") and hbm > traffic.get(f"msm_accumulate_2^{msm_log_n}", 0):
                 traffic[f"msm_accumulate_2^{msm_log_n}"] = hbm  # the full-size launches (largest group)
         # the NTT is several launches of one kernel per transform: sum over the passes of one transform
         passes = 1 if ntt_log_n <= 11 else max(2, -(-ntt_log_n // 9))  # mirrors the pass plan in csrc/ntt.hip
         ntt_total = passes * max([(2 * v.get("FETCH_SIZE", (0, 0.0))[1] + v.get("WRITE_SIZE", (0, 0.0))[1]) * 1024
-                                  for (name, grid), v in pmc.items() if name.startswith("ntt_pass_kernel")] or [0])
+                                  for (name, grid), v in pmc.items() if name.startswith("ntt_pass")] or [0])
         if ntt_total:
             traffic[f"ntt_fp_2^{ntt_log_n}"] = ntt_total
             lines += ["", f"NTT 2^{ntt_log_n}: HBM bytes per transform ({passes} passes x per-launch average) = {ntt_total:.3e} "
