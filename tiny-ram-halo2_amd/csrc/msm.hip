@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
 // 3b. bucket sort: workgroup (bin, window) orders its bin's entries by the low k2 bucket bits
 //     (LDS histogram + scan + LDS cursors) and publishes the bucket ranges.
 // ---------------------------------------------------------------------------------------
+constexpr int BS_TILE = 8192;
 __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
                                                               const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
                                                               u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
@@ -245,14 +246,40 @@ __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restr
         }
     }
     __syncthreads();
-    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
-    __syncthreads();
+    // second pass: tiles of BS_TILE entries are staged in LDS in sub-bucket order, so that every
+    // sub-bucket's piece leaves as a coalesced store (wave per sub-bucket) instead of scattered words
+    __shared__ u32 tcnt[128], tbase[128], run[128];
+    __shared__ u32 stage[BS_TILE];
+    if (threadIdx.x < 128) run[threadIdx.x] = 0;
     const u32 idx_mask = (1u << idx_bits) - 1u;
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const u32 e = src[i];
-        const u32 sub = (e >> idx_bits) & low_mask;
-        const u32 r = atomicAdd(&cnt[sub], 1u);
-        dst[lo + off[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (u32 t0 = lo; t0 < hi; t0 += BS_TILE) {
+        const u32 t1 = t0 + BS_TILE < hi ? t0 + BS_TILE : hi;
+        if (threadIdx.x < 128) tcnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (u32 i = t0 + threadIdx.x; i < t1; i += blockDim.x) atomicAdd(&tcnt[(src[i] >> idx_bits) & low_mask], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 r = 0;
+            for (u32 k = 0; k < nsub; ++k) { tbase[k] = r; r += tcnt[k]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) tcnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (u32 i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
+            const u32 e = src[i];
+            const u32 sub = (e >> idx_bits) & low_mask;
+            const u32 r = atomicAdd(&tcnt[sub], 1u);
+            stage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+        }
+        __syncthreads();
+        for (u32 sub = wave; sub < nsub; sub += 4) {
+            const u32 c = tcnt[sub], sb = tbase[sub], gb = lo + off[sub] + run[sub];
+            for (u32 k = lane; k < c; k += 64) dst[gb + k] = stage[sb + k];
+        }
+        __syncthreads();
+        if (threadIdx.x < nsub) run[threadIdx.x] += tcnt[threadIdx.x];
+        __syncthreads();
     }
 }
 
