@@ -174,13 +174,39 @@ __global__ void __launch_bounds__(256) k_field(u64* out, u32 seed) {
     Fe<FpParams> x = fe_one<FpParams>(), y = fe_r2<FpParams>();
     x.l[0] += threadIdx.x + seed; y.l[1] ^= blockIdx.x;
     for (int i = 0; i < FITERS; ++i) {
-        if (MODE == 0) x = fe_mul(x, y);
+        if (MODE == 0) { const Fe<FpParams> t = fe_mul(x, y); x = y; y = t; }  // both operands vary
         else if (MODE == 1) x = fe_sqr(x);
         else if (MODE == 2) x = fe_add(x, y);
         else x = fe_sub(x, y);
     }
     u64 r = 0;
     for (int k = 0; k < 8; ++k) r ^= x.l[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_lazy(u64* out, u32 seed) {
+    Fz<FpParams> x = fz_one<FpParams>(), y = fz_one<FpParams>();
+    x.l[0] += threadIdx.x + seed; y.l[1] ^= blockIdx.x;
+    for (int i = 0; i < FITERS; ++i) {
+        if (MODE == 0) { const Fz<FpParams> t = fz_mul(x, y); x = y; y = t; }  // both operands vary
+        else if (MODE == 1) x = fz_sqr(x);
+        else if (MODE == 2) x = fz_add(x, y);
+        else x = fz_sub<FpParams, 8>(x, y);
+        if (MODE >= 2) { x.l[8] &= 0xffff; }
+    }
+    u64 r = 0;
+    for (int k = 0; k < 9; ++k) r ^= x.l[k] ^ y.l[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_madd_lazy(u64* out, u32 seed) {
+    AffineZ<FpParams> g;
+    g.x = fz_one<FpParams>(); g.y = fz_one<FpParams>(); g.x.l[0] += 5; g.y.l[1] += 7;   // not a curve point: timing only
+    XYZZz<FpParams> acc;
+    acc.x = g.y; acc.y = g.x; acc.zz = fz_one<FpParams>(); acc.zzz = fz_one<FpParams>();
+    acc.x.l[2] += threadIdx.x + seed;
+    for (int i = 0; i < FITERS; ++i) xyzzz_madd(acc, g);
+    u64 r = 0;
+    for (int k = 0; k < 9; ++k) r ^= acc.x.l[k] ^ acc.zz.l[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 __global__ void __launch_bounds__(256) k_madd(u64* out, u32 seed) {
@@ -234,6 +260,12 @@ int main() {
     }
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<2>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fe_add", FITERS);
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<3>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fe_sub", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<0>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_mul (lazy R'=2^270)", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<1>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_sqr", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<2>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_add", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<3>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_sub", FITERS);
+    for (int blocks : {256 * 3, 256 * 6})
+        run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_madd_lazy, dim3(b), dim3(t), 0, 0, o, 1u); }, blocks, T, d_out, "xyzzz_madd (lazy)", FITERS);
     for (int blocks : {256 * 2, 256 * 4, 256 * 8})
         run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_madd, dim3(b), dim3(t), 0, 0, o, 1u); }, blocks, T, d_out, "xyzz_madd", FITERS);
     return 0;
