@@ -129,6 +129,14 @@ int trh_field_powers_dev(int field, void* out_dev, size_t n, const uint64_t x_mo
  * field element, Montgomery; g_*: `half` 64-byte affine PODs)                                   */
 int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t half, const uint64_t u_mont[4], void* stream);
 
+/* ---- best_fft over curve points: Params::new's g -> g_lagrange -----------------------------
+ * halo2_proofs::arithmetic::best_fft::<C::Curve>(a, omega, log_n): a'[i] = sum_j [omega^(i j)] a[j].
+ * points_dev: 2^log_n affine PODs in device memory, transformed in place (natural order in and out)
+ * and normalised to affine; omega: scalar field element, Montgomery, primitive 2^log_n-th root;
+ * scale_or_null: when non-NULL every output is multiplied by this scalar (Params::new uses n^-1).  */
+int trh_point_fft_dev(int curve, void* points_dev, uint32_t log_n, const uint64_t omega[4],
+                      const uint64_t* scale_or_null, void* stream);
+
 /* ---- element-wise field / group ops on device memory (parity tests of the device arithmetic;
  *      op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv, 6 to_mont, 7 from_mont) ------------------ */
 int trh_field_op_dev(int field, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);

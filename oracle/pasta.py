@@ -460,6 +460,41 @@ class EvaluationDomain:
 
 
 # --------------------------------------------------------------------------------------
+# best_fft over curve points (arithmetic.rs best_fft::<C::Curve>, as Params::new builds g_lagrange:
+# g_lagrange = batch_normalize(n^-1 * best_fft(g, omega^-1, k)); src/test_utils.rs:21, 89).
+# --------------------------------------------------------------------------------------
+def best_fft_points(curve: Curve, a: List[Affine], omega: int, log_n: int) -> List[Affine]:
+    n = len(a)
+    assert n == 1 << log_n
+    m = curve.scalar.m
+    a = list(a)
+    for k in range(n):
+        rk = bitreverse(k, log_n)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    half = 1
+    while half < n:
+        w_m = pow(omega, n // (2 * half), m)
+        for start in range(0, n, 2 * half):
+            w = 1
+            for j in range(half):
+                t = curve.mul(w, a[start + half + j])
+                u = a[start + j]
+                a[start + j] = curve.add(u, t)
+                a[start + half + j] = curve.add(u, curve.neg(t))
+                w = w * w_m % m
+        half *= 2
+    return a
+
+
+def params_g_lagrange(curve: Curve, g: List[Affine], k: int) -> List[Affine]:
+    """the Lagrange-basis generators Params::new derives from g"""
+    f = curve.scalar
+    n_inv = f.inv(1 << k)
+    return [curve.mul(n_inv, p) for p in best_fft_points(curve, g, f.inv(f.omega(k)), k)]
+
+
+# --------------------------------------------------------------------------------------
 # IPA opening restatement (halo2_proofs 0.2.0 src/poly/commitment/prover.rs create_proof;
 # SURVEY.md section 8 row a7; reached via create_proof at src/test_utils.rs:41-49).
 # Transcript and randomness are injected (the reference feeds OsRng and a BLAKE2b transcript).

@@ -112,3 +112,28 @@ def test_params_commit(curve):
     # commit(a) == commit_lagrange(lagrange form of a) when g_lagrange is the Lagrange basis of g is a
     # property of Params::new (a "next" row); here the two base sets are independent.
     del sf
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 1), ("vesta", 4), ("pallas", 6)])
+def test_params_g_lagrange_point_fft(curve, k):
+    """Params::new's curve-point FFT (SURVEY 8f-3): device g_lagrange vs the big-int restatement, and the
+    defining property commit(coeffs) == commit_lagrange(evaluations) for a random polynomial."""
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    g_l = cpu_ref.gen_bases(curve, 0xBEEF + k, 11, n, threads=2)
+    g_l[n - 1] = 0 if k >= 4 else g_l[n - 1]          # an identity generator must survive the transform
+    got = to_host(poly.Params.g_lagrange_from_g(curve, k, to_dev(g_l)))
+    want = o.params_g_lagrange(cv, [cv.affine_from_limbs(r) for r in g_l], k)
+    for i in range(n):
+        assert cv.affine_from_limbs(got[i]) == want[i], i
+    # commit(a) with g == commit_lagrange(a evaluated on the domain) with g_lagrange (blind 0)
+    rnd = random.Random(k)
+    coeffs = [rnd.randrange(fs.m) for _ in range(n)]
+    evals = o.best_fft(fs, coeffs, fs.omega(k), k)
+    w = cpu_ref.gen_bases(curve, 5, 1, 1, threads=1)
+    params = poly.Params(curve, k, g_l, got, w)
+    zero = np.zeros(4, np.uint64)
+    c1 = params.commit(limbs(fs, coeffs), zero)
+    c2 = params.commit_lagrange(limbs(fs, evals), zero)
+    assert (c1 == c2).all()

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "trh_field_axpy_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_field_powers_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_bases_fold_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
+    "trh_point_fft_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, _u64p, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
@@ -271,6 +272,13 @@ def powers_dev(field: str, out_dev, n: int, x, stream=None):
 def bases_fold_dev(curve: str, g_lo_dev, g_hi_dev, half: int, u, stream=None):
     uu = _c(u).reshape(4)
     _check(lib().trh_bases_fold_dev(CURVE_ID[curve], _devptr(g_lo_dev), _devptr(g_hi_dev), half, _p(uu), stream))
+
+
+def point_fft_dev(curve: str, points_dev, log_n: int, omega, scale=None, stream=None):
+    """best_fft over curve points (Params::new's g -> g_lagrange); `scale` multiplies every output (n^-1)"""
+    w = _c(omega).reshape(4)
+    sc = None if scale is None else _c(scale).reshape(4)
+    _check(lib().trh_point_fft_dev(CURVE_ID[curve], _devptr(points_dev), log_n, _p(w), None if sc is None else _p(sc), stream))
 
 
 def set_timing(on: bool):

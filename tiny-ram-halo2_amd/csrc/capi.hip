@@ -183,6 +183,7 @@ void trh_shutdown(void) {
     ntt_release_tables();
     c.io.release();
     c.factors.release();
+    c.pfft.release();
     c.inited = false;
     c.device = -1;
 }

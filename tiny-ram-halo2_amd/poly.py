@@ -156,6 +156,20 @@ class Params:
         self._g = api.Bases.from_host(curve, np.concatenate([g, w]))
         self._g_lagrange = api.Bases.from_host(curve, np.concatenate([gl, w]))
 
+    @staticmethod
+    def g_lagrange_from_g(curve: str, k: int, g_dev):
+        """The heavy step of `Params::new(k)`: g_lagrange = batch_normalize(n^-1 * best_fft(g, omega^-1, k)) with
+        best_fft over curve points.  g_dev: device tensor (n, 8) of affine generators; returns a new tensor.
+        (The hash-to-curve derivation of g itself stays on the host.)"""
+        sf = api.SCALAR_FIELD[curve]
+        m = _MODULUS[sf]
+        omega = _ROOT_OF_UNITY[sf]
+        for _ in range(k, S):
+            omega = omega * omega % m
+        out = g_dev.clone()
+        api.point_fft_dev(curve, out, k, _mont(sf, pow(omega, -1, m)), scale=_mont(sf, pow(1 << k, -1, m)), stream=_stream(out))
+        return out
+
     def _commit(self, bases, poly, r):
         import torch
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
