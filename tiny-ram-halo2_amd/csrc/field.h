@@ -151,6 +151,16 @@ template <class F> TRH_HD bool fe_eq(const Fe<F>& a, const Fe<F>& b) {
     return o == 0;
 }
 
+// 2^14 in a register the compiler cannot see through: `q * two14 + acc` then stays ONE v_mad_u64_u32
+// instead of a 64-bit shift plus a 64-bit add (the top modulus limb is 2^14)
+TRH_HD u32 opaque_two14() {
+    u32 v = 1u << 14;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 // a in [0, 2m) with normalised limbs -> a mod m
 template <class F> TRH_HD void fe_cond_sub(Fe<F>& a) {
     u32 t[NLIMBS];
@@ -345,6 +355,7 @@ template <class F> TRH_HD bool fz_is_exact_zero(const Fz<F>& a) {
 // nine uniform 30-bit rounds; result = value / 2^270 (mod m), < m (1 + 2^-8) for inputs < 2^8 m^2
 template <class F> TRH_HD Fz<F> fz_reduce(u64 (&acc)[18]) {
     constexpr u32 P1 = ModLimb<F, 1>::v, P2 = ModLimb<F, 2>::v, P3 = ModLimb<F, 3>::v, P4 = ModLimb<F, 4>::v;
+    const u32 two14 = opaque_two14();
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const u32 q = (0u - (u32)acc[i]) & LIMB_MASK;
@@ -352,7 +363,7 @@ template <class F> TRH_HD Fz<F> fz_reduce(u64 (&acc)[18]) {
         acc[i + 2] += (u64)q * P2;
         acc[i + 3] += (u64)q * P3;
         acc[i + 4] += (u64)q * P4;
-        acc[i + 8] += (u64)q << 14;
+        acc[i + 8] += (u64)q * two14;
     }
     Fz<F> r;
     u64 c = 0;
