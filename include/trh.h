@@ -116,6 +116,23 @@ int trh_field_scale_periodic_dev(int field, void* a_dev, size_t n, const uint64_
 int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len,
                              const uint64_t* factors, uint32_t period, void* stream);
 
+/* ---- halo2_proofs::poly::EvaluationDomain on device polynomials -------------------------------
+ * trh_domain_create(field, j, k) mirrors EvaluationDomain::new(j, k): quotient_poly_degree = j - 1,
+ * extended_k = smallest e with 2^e >= 2^k (j - 1); omega / extended_omega from ROOT_OF_UNITY, coset
+ * generator ZETA, t_evaluations = (X^n - 1)^-1 on the coset.  Polynomials are `batch` rows of 2^k
+ * (or 2^extended_k) field elements stored back to back in device memory.                        */
+typedef struct trh_domain* trh_domain_t;
+int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain_t* out);
+void trh_domain_destroy(trh_domain_t d);
+uint32_t trh_domain_extended_k(trh_domain_t d);
+/* which: 0 omega, 1 omega_inv, 2 extended_omega, 3 extended_omega_inv, 4 ifft_divisor,
+ *        5 extended_ifft_divisor, 6 g_coset (zeta), 7 g_coset_inv (zeta^2); Montgomery limbs */
+int trh_domain_constant(trh_domain_t d, int which, uint64_t out[4]);
+int trh_domain_lagrange_to_coeff(trh_domain_t d, void* a_dev, size_t batch, void* stream);            /* in place */
+int trh_domain_coeff_to_extended(trh_domain_t d, const void* coeff_dev, void* ext_dev, size_t batch, void* stream);
+int trh_domain_extended_to_coeff(trh_domain_t d, void* a_dev, size_t batch, void* stream);            /* in place; caller truncates */
+int trh_domain_divide_by_vanishing_poly(trh_domain_t d, void* a_dev, size_t batch, void* stream);     /* in place */
+
 /* ---- IPA opening rounds: poly::commitment::prover::create_proof (device memory) ---------------
  * The two half-size MSMs of a round run through trh_msm_dev on the live G' buffer
  * (trh_bases_wrap_device + offset); these are the remaining per-round primitives.            */

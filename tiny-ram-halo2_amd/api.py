@@ -82,6 +82,14 @@ _SIGNATURES = {
     "trh_field_powers_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_bases_fold_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _u64p, _vp], ctypes.c_int),
     "trh_point_fft_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, _u64p, _vp], ctypes.c_int),
+    "trh_domain_create": ([ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_domain_destroy": ([_vp], None),
+    "trh_domain_extended_k": ([_vp], ctypes.c_uint32),
+    "trh_domain_constant": ([_vp, ctypes.c_int, _u64p], ctypes.c_int),
+    "trh_domain_lagrange_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_domain_coeff_to_extended": ([_vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_domain_extended_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_domain_divide_by_vanishing_poly": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),

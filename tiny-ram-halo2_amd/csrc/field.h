@@ -57,6 +57,9 @@ struct FpParams {  // Pallas base field = Vesta scalar field
     static constexpr u32 R2[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};   // R^2 mod p
     static constexpr u32 TO_LAZY[8] = {0xc0000001u, 0x592d30ecu, 0x2301ace0u, 0x1ff35ab5u, 0xf76e59c1u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};   // 2^284 mod p
     static constexpr u32 LAZY_ONE[8] = {0xffff0001u, 0x684030ecu, 0x10315feeu, 0x894a8fafu, 0xffffddb9u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // 2^270 mod p
+    // pasta_curves ROOT_OF_UNITY (primitive 2^32-th root) and ZETA (cube root of unity), Montgomery form
+    static constexpr u32 ROOT_OF_UNITY[8] = {0xbad6dbf0u, 0xa28db849u, 0xd3b539dfu, 0x9083cd03u, 0x9dc8448eu, 0xfba6b9cau, 0x7b89c6dau, 0x3ec92874u};
+    static constexpr u32 ZETA[8] = {0x619a153du, 0x02021cf6u, 0x4980b78eu, 0x9e8c2697u, 0xc87a4666u, 0x2a676d5cu, 0xa7a17876u, 0x15d8049du};
 };
 struct FqParams {  // Vesta base field = Pallas scalar field
     static constexpr int ID = 1;
@@ -65,6 +68,8 @@ struct FqParams {  // Vesta base field = Pallas scalar field
     static constexpr u32 R2[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
     static constexpr u32 TO_LAZY[8] = {0xc0000001u, 0x4c46eb20u, 0xa682ee15u, 0x1fe16ec4u, 0xf76e59c1u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
     static constexpr u32 LAZY_ONE[8] = {0xffff0001u, 0xa125eb20u, 0x60b71c96u, 0x894a8f67u, 0xffffddb9u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+    static constexpr u32 ROOT_OF_UNITY[8] = {0x8c9942deu, 0x21807742u, 0x21b60494u, 0xcc495789u, 0xb2efbee2u, 0xac2e5d27u, 0x7f2db056u, 0x0b79fa89u};
+    static constexpr u32 ZETA[8] = {0x80111122u, 0x7c541a84u, 0x56ed29dau, 0x40630b9cu, 0x135b2b29u, 0x02c275fbu, 0x88245b10u, 0x121d29f8u};
 };
 
 template <class F, int K> struct ModLimb { static constexpr u32 v = limb30_of(F::MOD, K); };

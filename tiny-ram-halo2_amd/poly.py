@@ -97,15 +97,33 @@ class EvaluationDomain:
             b *= d
         return b
 
-    def _ifft(self, a, omega_inv, log_n, divisor):
-        b = self._batch(a)
-        api.ntt_dev(self.field, a, log_n, omega_inv, batch=b, stream=_stream(a))
-        api.field_scale_dev(self.field, a, b << log_n, divisor, stream=_stream(a))
+    # The transforms run through libtrh's C++ EvaluationDomain (csrc/domain.hip), which derives the same
+    # constants from ROOT_OF_UNITY / ZETA; the big-int values above are kept for inspection and are
+    # cross-checked against the library in handle().
+    def handle(self):
+        if getattr(self, "_h", None) is None:
+            import ctypes
+            h = ctypes.c_void_p()
+            api._check(api.lib().trh_domain_create(api.FIELD_ID[self.field], self.quotient_poly_degree + 1, self.k, ctypes.byref(h)))
+            assert api.lib().trh_domain_extended_k(h) == self.extended_k
+            out = np.zeros(4, dtype=np.uint64)
+            for which, name in enumerate(("omega", "omega_inv", "extended_omega", "extended_omega_inv", "ifft_divisor", "extended_ifft_divisor")):
+                api._check(api.lib().trh_domain_constant(h, which, api._p(out)))
+                assert (out == self._w[name]).all(), name
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                api.lib().trh_domain_destroy(self._h)
+        except Exception:
+            pass
 
     def lagrange_to_coeff(self, a):
         """in place on a (..., n, 4) device tensor; returns a"""
         assert a.shape[-2] == self.n
-        self._ifft(a, self._w["omega_inv"], self.k, self._w["ifft_divisor"])
+        api._check(api.lib().trh_domain_lagrange_to_coeff(self.handle(), api._devptr(a), self._batch(a), _stream(a)))
         return a
 
     def coeff_to_lagrange(self, a):
@@ -117,29 +135,21 @@ class EvaluationDomain:
         """(..., n, 4) coefficients -> new (..., 2^extended_k, 4) tensor of coset evaluations"""
         import torch
         assert a.shape[-2] == self.n
-        b = self._batch(a)
-        ext = torch.zeros(a.shape[:-2] + (self.extended_len(), 4), dtype=a.dtype, device=a.device)
-        ext[..., : self.n, :] = a
-        # distribute_powers_zeta(into_coset): only the first n coefficients are non-zero, and the
-        # period-3 pattern restarts with each polynomial (index counts from 0 per polynomial)
-        api.field_scale_rows_dev(self.field, ext, b, self.extended_len(), self.n, self._into_coset, stream=_stream(ext))
-        api.ntt_dev(self.field, ext, self.extended_k, self._w["extended_omega"], batch=b, stream=_stream(ext))
+        a = a.contiguous()
+        ext = torch.empty(a.shape[:-2] + (self.extended_len(), 4), dtype=a.dtype, device=a.device)
+        api._check(api.lib().trh_domain_coeff_to_extended(self.handle(), api._devptr(a), api._devptr(ext), self._batch(a), _stream(a)))
         return ext
 
     def extended_to_coeff(self, a):
         """in place iFFT + inverse coset shift on (..., 2^extended_k, 4); returns the truncated view
         of length n * quotient_poly_degree"""
         assert a.shape[-2] == self.extended_len()
-        b = self._batch(a)
-        self._ifft(a, self._w["extended_omega_inv"], self.extended_k, self._w["extended_ifft_divisor"])
-        api.field_scale_rows_dev(self.field, a, b, self.extended_len(), self.extended_len(), self._from_coset, stream=_stream(a))
+        api._check(api.lib().trh_domain_extended_to_coeff(self.handle(), api._devptr(a), self._batch(a), _stream(a)))
         return a[..., : self.n * self.quotient_poly_degree, :]
 
     def divide_by_vanishing_poly(self, a):
         assert a.shape[-2] == self.extended_len()
-        b = self._batch(a)
-        # the period 2^(ek-k) divides 2^extended_k, so the batch can be scaled as one long vector
-        api.field_scale_periodic_dev(self.field, a, b * self.extended_len(), self._t_inv, stream=_stream(a))
+        api._check(api.lib().trh_domain_divide_by_vanishing_poly(self.handle(), api._devptr(a), self._batch(a), _stream(a)))
         return a
 
 
