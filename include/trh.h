@@ -146,6 +146,26 @@ int trh_field_powers_dev(int field, void* out_dev, size_t n, const uint64_t x_mo
  * field element, Montgomery; g_*: `half` 64-byte affine PODs)                                   */
 int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t half, const uint64_t u_mont[4], void* stream);
 
+/* The whole opening in one call: poly::commitment::prover::create_proof(params, rng, transcript,
+ * p_poly, p_blind, x_3).  p', b and G' never leave the device; per round only L_j, R_j and the
+ * challenge cross the boundary, through the caller's transcript (BLAKE2b on the Rust side) and
+ * randomness callbacks.  g_w: resident bases g (2^k points) followed by w; u_xy: Params.u;
+ * p_poly_dev / s_poly_dev: 2^k coefficients in device memory (s_poly: the caller's random polynomial,
+ * its constant term is adjusted here so that s(x3) = 0); scalars are Montgomery limbs.
+ * Writes to the transcript exactly what the Rust prover writes: S, then L_j, R_j per round, then c, f. */
+typedef struct trh_transcript {
+    void* ctx;
+    void (*write_point)(void* ctx, const uint64_t xyz[12]);           /* normalised Jacobian, Z = 1 */
+    void (*write_scalar)(void* ctx, const uint64_t s_mont[4]);
+    void (*squeeze_challenge_scalar)(void* ctx, uint64_t out_mont[4]);
+} trh_transcript_t;
+typedef void (*trh_rng_scalar_fn)(void* ctx, uint64_t out_mont[4]);    /* C::Scalar::random(rng) */
+int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, const void* p_poly_dev,
+                         const uint64_t p_blind[4], const uint64_t x3[4], const void* s_poly_dev,
+                         const uint64_t s_blind[4], const trh_transcript_t* transcript,
+                         trh_rng_scalar_fn rng, void* rng_ctx, void* stream,
+                         uint64_t out_c[4], uint64_t out_f[4]);
+
 /* ---- best_fft over curve points: Params::new's g -> g_lagrange -----------------------------
  * halo2_proofs::arithmetic::best_fft::<C::Curve>(a, omega, log_n): a'[i] = sum_j [omega^(i j)] a[j].
  * points_dev: 2^log_n affine PODs in device memory, transformed in place (natural order in and out)

@@ -137,4 +137,11 @@ def test_ipa_create_proof_vs_oracle(curve, k):
     assert len(t_dev.log) == len(t_ref.log) == 1 + 2 * k + 2
     for a, b in zip(t_dev.log, t_ref.log):
         assert a == b
+    # the single-call C++ prover (trh_ipa_create_proof) writes the same transcript
+    it3 = iter(draws)
+    t_nat = DeviceTranscript(fs.m)
+    c_nat, f_nat = ipa.create_proof_native(params, lambda: next(it3), t_nat, to_dev(np.array([fs.limbs(v) for v in p_poly], np.uint64)),
+                                           p_blind, x3, np.array([fs.limbs(v) for v in s_poly], np.uint64), s_blind)
+    assert (c_nat, f_nat) == (c_ref, f_ref)
+    assert t_nat.log == t_ref.log
     del sfn

@@ -42,6 +42,17 @@ class TrhError(RuntimeError):
     pass
 
 
+WRITE_POINT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64))
+WRITE_SCALAR_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64))
+SQUEEZE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64))
+RNG_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64))
+
+
+class Transcript(ctypes.Structure):
+    _fields_ = [("ctx", ctypes.c_void_p), ("write_point", WRITE_POINT_FN), ("write_scalar", WRITE_SCALAR_FN),
+                ("squeeze_challenge_scalar", SQUEEZE_FN)]
+
+
 class Timing(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("digits_ms", ctypes.c_float), ("sort_ms", ctypes.c_float),
                 ("accumulate_ms", ctypes.c_float), ("reduce_ms", ctypes.c_float),
@@ -90,6 +101,7 @@ _SIGNATURES = {
     "trh_domain_coeff_to_extended": ([_vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_domain_extended_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_domain_divide_by_vanishing_poly": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_ipa_create_proof": ([_vp, _u64p, ctypes.c_uint32, _vp, _u64p, _u64p, _vp, _u64p, ctypes.POINTER(Transcript), RNG_FN, _vp, _vp, _u64p, _u64p], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),

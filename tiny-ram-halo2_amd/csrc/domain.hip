@@ -128,9 +128,9 @@ void trh_domain_destroy(trh_domain* d) {
     if (d->d_tables) (void)hipFree(d->d_tables);
     delete d;
 }
-uint32_t trh_domain_extended_k(const trh_domain* d) { return d ? d->extended_k : 0; }
+uint32_t trh_domain_extended_k(trh_domain* d) { return d ? d->extended_k : 0; }
 /* which: 0 omega, 1 omega_inv, 2 extended_omega, 3 extended_omega_inv, 4 ifft_divisor, 5 extended_ifft_divisor, 6 g_coset, 7 g_coset_inv */
-int trh_domain_constant(const trh_domain* d, int which, uint64_t out[4]) {
+int trh_domain_constant(trh_domain* d, int which, uint64_t out[4]) {
     if (!d || !out || which < 0 || which > 7) { set_error("domain_constant: bad arguments"); return TRH_EINVAL; }
     const FeMem* src[8] = {&d->omega, &d->omega_inv, &d->extended_omega, &d->extended_omega_inv, &d->ifft_divisor, &d->extended_ifft_divisor,
                            &d->into_coset[1], &d->into_coset[2]};
@@ -139,7 +139,7 @@ int trh_domain_constant(const trh_domain* d, int which, uint64_t out[4]) {
 }
 
 /* EvaluationDomain::lagrange_to_coeff: iFFT with omega^-1, then * 2^-k; batch polynomials of 2^k, in place */
-int trh_domain_lagrange_to_coeff(const trh_domain* d, void* a_dev, size_t batch, void* stream) {
+int trh_domain_lagrange_to_coeff(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
@@ -148,7 +148,7 @@ int trh_domain_lagrange_to_coeff(const trh_domain* d, void* a_dev, size_t batch,
 }
 /* EvaluationDomain::coeff_to_extended: zeta-coset shift + zero-pad (one kernel), FFT of size 2^extended_k.
  * coeff_dev: batch x 2^k, ext_dev: batch x 2^extended_k (output) */
-int trh_domain_coeff_to_extended(const trh_domain* d, const void* coeff_dev, void* ext_dev, size_t batch, void* stream) {
+int trh_domain_coeff_to_extended(trh_domain* d, const void* coeff_dev, void* ext_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, coeff_dev));
     if (!ext_dev) { set_error("domain: null pointer"); return TRH_EINVAL; }
     Ctx& c = ctx();
@@ -164,7 +164,7 @@ int trh_domain_coeff_to_extended(const trh_domain* d, const void* coeff_dev, voi
 }
 /* EvaluationDomain::extended_to_coeff: iFFT, * 2^-extended_k, inverse coset shift; in place on batch x 2^extended_k
  * (the caller truncates each polynomial to n * (j - 1) coefficients as the Rust code does) */
-int trh_domain_extended_to_coeff(const trh_domain* d, void* a_dev, size_t batch, void* stream) {
+int trh_domain_extended_to_coeff(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
@@ -174,7 +174,7 @@ int trh_domain_extended_to_coeff(const trh_domain* d, void* a_dev, size_t batch,
     return field_scale_periodic(d->field, a_dev, batch, N, N, tab(d, T_FROM), 3, (hipStream_t)stream);
 }
 /* EvaluationDomain::divide_by_vanishing_poly: a[i] *= t_inv[i % 2^(extended_k - k)] */
-int trh_domain_divide_by_vanishing_poly(const trh_domain* d, void* a_dev, size_t batch, void* stream) {
+int trh_domain_divide_by_vanishing_poly(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);

@@ -148,6 +148,117 @@ int bases_fold_t(void* g_lo, const void* g_hi, size_t half, const u64* u_mont, h
     return TRH_OK;
 }
 
+template <class F>
+int axpy_t(void* y, const void* x, size_t n, const FeMem& c_mont, hipStream_t s) {
+    if (!n) return TRH_OK;
+    void* d_c;
+    TRH_TRY(stage_constant(&c_mont, 32, s, &d_c));
+    hipLaunchKernelGGL((axpy_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)y, (const uint4*)x, n, (const uint4*)d_c);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole opening: poly::commitment::prover::create_proof with p', b and G' resident on the
+// device.  Host-side scalar arithmetic uses the shared field code; the transcript and the prover's
+// randomness are callbacks into the caller (BLAKE2b transcript and OsRng on the Rust side).
+// ---------------------------------------------------------------------------------------
+struct DevMem {  // frees on scope exit
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { set_error("ipa: hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); p = nullptr; return TRH_ENOMEM; }
+        return TRH_OK;
+    }
+};
+
+template <class SF, class BF>
+int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t k, const void* p_poly_dev, const u64* p_blind_m, const u64* x3_m,
+                       const void* s_poly_dev, const u64* s_blind_m, const trh_transcript_t* tr, trh_rng_scalar_fn rng, void* rng_ctx,
+                       hipStream_t s, u64* out_c, u64* out_f) {
+    const size_t n = (size_t)1 << k;
+    auto ld = [](const u64* p) { FeMem m; memcpy(&m, p, 32); return fe_load<SF>(m); };
+    auto stm = [](const Fe<SF>& v) { FeMem m; fe_store(v, m); return m; };
+    const Fe<SF> x3 = ld(x3_m), p_blind = ld(p_blind_m), s_blind = ld(s_blind_m);
+
+    DevMem b, sp, pp, gp, uw, sc2;
+    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(gp.alloc(n * 64)); TRH_TRY(uw.alloc(128)); TRH_TRY(sc2.alloc(64));
+    FeMem x3m = stm(x3);
+    TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
+    // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended
+    TRH_HIP_TRY(hipMemcpyAsync(sp.p, s_poly_dev, n * 32, hipMemcpyDeviceToDevice, s));
+    FeMem tmp;
+    TRH_TRY((inner_product_t<SF>(sp.p, b.p, n, s, (u64*)&tmp)));
+    const Fe<SF> s_at_x3 = fe_load<SF>(tmp);
+    TRH_HIP_TRY(hipMemcpy(&tmp, sp.p, 32, hipMemcpyDeviceToHost));
+    FeMem s0 = stm(fe_sub(fe_load<SF>(tmp), s_at_x3));
+    TRH_HIP_TRY(hipMemcpy(sp.p, &s0, 32, hipMemcpyHostToDevice));
+    FeMem sbm = stm(s_blind);
+    TRH_HIP_TRY(hipMemcpy((char*)sp.p + n * 32, &sbm, 32, hipMemcpyHostToDevice));
+    u64 pt[12], pt2[12], two[24];
+    TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
+    TRH_TRY(msm_finish(curve, s, pt, 1));
+    tr->write_point(tr->ctx, pt);
+    tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
+    const Fe<SF> xi = fe_load<SF>(tmp);
+    tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
+    const Fe<SF> z = fe_load<SF>(tmp);
+    // p'(X) = p(X) + xi s(X) - v
+    TRH_HIP_TRY(hipMemcpyAsync(pp.p, p_poly_dev, n * 32, hipMemcpyDeviceToDevice, s));
+    TRH_TRY((axpy_t<SF>(pp.p, sp.p, n, stm(xi), s)));
+    TRH_TRY((inner_product_t<SF>(pp.p, b.p, n, s, (u64*)&tmp)));
+    const Fe<SF> v = fe_load<SF>(tmp);
+    TRH_HIP_TRY(hipMemcpy(&tmp, pp.p, 32, hipMemcpyDeviceToHost));
+    FeMem p0 = stm(fe_sub(fe_load<SF>(tmp), v));
+    TRH_HIP_TRY(hipMemcpy(pp.p, &p0, 32, hipMemcpyHostToDevice));
+    Fe<SF> f = fe_add(fe_mul(s_blind, xi), p_blind);
+    // G' = private copy of g; (u, w) for the two-term MSMs
+    TRH_HIP_TRY(hipMemcpyAsync(gp.p, gw->d_xy, n * 64, hipMemcpyDeviceToDevice, s));
+    TRH_HIP_TRY(hipMemcpy(uw.p, u_xy, 64, hipMemcpyHostToDevice));
+    TRH_HIP_TRY(hipMemcpyAsync((char*)uw.p + 64, (const char*)gw->d_xy + n * 64, 64, hipMemcpyDeviceToDevice, s));
+
+    for (uint32_t j = 0; j < k; ++j) {
+        const size_t half = (size_t)1 << (k - j - 1);
+        char* pph = (char*)pp.p + half * 32;
+        char* bh = (char*)b.p + half * 32;
+        char* gph = (char*)gp.p + half * 64;
+        Fe<SF> val[2], rnd[2];
+        u64 lr[2][12];
+        for (int side = 0; side < 2; ++side) {  // 0: L_j = <p'[half..], G'[..half]>, 1: R_j = <p'[..half], G'[half..]>
+            TRH_TRY(msm_enqueue(curve, side == 0 ? gp.p : (void*)gph, nullptr, side == 0 ? (void*)pph : pp.p, half, 1, half, 1, s));
+            TRH_TRY(msm_finish(curve, s, pt, 1));
+            TRH_TRY((inner_product_t<SF>(side == 0 ? (void*)pph : pp.p, side == 0 ? b.p : (void*)bh, half, s, (u64*)&tmp)));
+            val[side] = fe_load<SF>(tmp);
+            rng(rng_ctx, (u64*)&tmp);
+            rnd[side] = fe_load<SF>(tmp);
+            FeMem two_sc[2] = {stm(fe_mul(val[side], z)), stm(rnd[side])};
+            TRH_HIP_TRY(hipMemcpy(sc2.p, two_sc, 64, hipMemcpyHostToDevice));
+            TRH_TRY(msm_enqueue(curve, uw.p, nullptr, sc2.p, 2, 1, 2, 1, s));
+            TRH_TRY(msm_finish(curve, s, pt2, 1));
+            memcpy(two, pt, 96); memcpy(two + 12, pt2, 96);
+            TRH_TRY(point_sum_host(curve, two, 2, lr[side]));
+        }
+        tr->write_point(tr->ctx, lr[0]);
+        tr->write_point(tr->ctx, lr[1]);
+        tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
+        const Fe<SF> u_j = fe_load<SF>(tmp), u_inv = fe_inv(u_j);
+        TRH_TRY((axpy_t<SF>(pp.p, pph, half, stm(u_inv), s)));
+        TRH_TRY((axpy_t<SF>(b.p, bh, half, stm(u_j), s)));
+        FeMem ujm = stm(u_j);
+        TRH_TRY((bases_fold_t<SF, BF>(gp.p, gph, half, (const u64*)&ujm, s)));
+        f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
+    }
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    TRH_HIP_TRY(hipMemcpy(&tmp, pp.p, 32, hipMemcpyDeviceToHost));
+    FeMem fm = stm(f);
+    tr->write_scalar(tr->ctx, (const u64*)&tmp);
+    tr->write_scalar(tr->ctx, (const u64*)&fm);
+    if (out_c) memcpy(out_c, &tmp, 32);
+    if (out_f) memcpy(out_f, &fm, 32);
+    return TRH_OK;
+}
+
 }  // namespace
 }  // namespace trh
 
@@ -172,13 +283,10 @@ int trh_field_axpy_dev(int field, void* y_dev, const void* x_dev, size_t n, cons
     if (!n) return TRH_OK;
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    void* d_c;
-    TRH_TRY(stage_constant(c_mont, 32, (hipStream_t)stream, &d_c));
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    if (field == TRH_FP) hipLaunchKernelGGL((axpy_kernel<FpParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, (uint4*)y_dev, (const uint4*)x_dev, n, (const uint4*)d_c);
-    else hipLaunchKernelGGL((axpy_kernel<FqParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, (uint4*)y_dev, (const uint4*)x_dev, n, (const uint4*)d_c);
-    TRH_HIP_TRY(hipGetLastError());
-    return TRH_OK;
+    FeMem cm;
+    memcpy(&cm, c_mont, 32);
+    if (field == TRH_FP) return axpy_t<FpParams>(y_dev, x_dev, n, cm, (hipStream_t)stream);
+    return axpy_t<FqParams>(y_dev, x_dev, n, cm, (hipStream_t)stream);
 }
 
 int trh_field_powers_dev(int field, void* out_dev, size_t n, const uint64_t x_mont[4], void* stream) {
@@ -202,6 +310,20 @@ int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t h
     // pallas: scalar field Fq, base field Fp
     if (curve == TRH_PALLAS) return bases_fold_t<FqParams, FpParams>(g_lo_dev, g_hi_dev, half, u_mont, (hipStream_t)stream);
     return bases_fold_t<FpParams, FqParams>(g_lo_dev, g_hi_dev, half, u_mont, (hipStream_t)stream);
+}
+
+int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, const void* p_poly_dev, const uint64_t p_blind[4], const uint64_t x3[4],
+                         const void* s_poly_dev, const uint64_t s_blind[4], const trh_transcript_t* transcript, trh_rng_scalar_fn rng, void* rng_ctx,
+                         void* stream, uint64_t out_c[4], uint64_t out_f[4]) {
+    TRH_TRY(require_init());
+    if (!g_w || !u_xy || !p_poly_dev || !p_blind || !x3 || !s_poly_dev || !s_blind || !transcript || !rng ||
+        !transcript->write_point || !transcript->write_scalar || !transcript->squeeze_challenge_scalar) { set_error("ipa_create_proof: null pointer"); return TRH_EINVAL; }
+    if (k > 26 || g_w->n != ((size_t)1 << k) + 1) { set_error("ipa_create_proof: bases must hold g (2^k points) followed by w"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (g_w->curve == TRH_PALLAS)
+        return ipa_create_proof_t<FqParams, FpParams>(TRH_PALLAS, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);
+    return ipa_create_proof_t<FpParams, FqParams>(TRH_VESTA, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);
 }
 
 }  // extern "C"

@@ -24,6 +24,37 @@ def _canon(field: str, limbs) -> int:
     return v * pow(1 << 256, -1, m) % m
 
 
+def create_proof_native(params, rng, transcript, p_poly, p_blind: int, x3: int, s_poly, s_blind: int):
+    """The same opening through the single C entry point `trh_ipa_create_proof` (csrc/ipa.hip): the round loop
+    and all host-side scalar arithmetic run in C++, the transcript and randomness are callbacks."""
+    import ctypes
+
+    import torch
+
+    curve, k, n = params.curve, params.k, params.n
+    sf = api.SCALAR_FIELD[curve]
+
+    def limbs_of(ptr, count):
+        return np.array([ptr[i] for i in range(count)], dtype=np.uint64)
+
+    def put(ptr, limbs):
+        for i in range(4):
+            ptr[i] = int(limbs[i])
+
+    wp = api.WRITE_POINT_FN(lambda ctx, p: transcript.write_point(limbs_of(p, 12)))
+    ws = api.WRITE_SCALAR_FN(lambda ctx, p: transcript.write_scalar(limbs_of(p, 4)))
+    sq = api.SQUEEZE_FN(lambda ctx, out: put(out, _mont(sf, transcript.squeeze_challenge_scalar())))
+    rn = api.RNG_FN(lambda ctx, out: put(out, _mont(sf, rng())))
+    tr = api.Transcript(None, wp, ws, sq)
+    s_dev = torch.from_numpy(np.ascontiguousarray(s_poly, dtype=np.uint64).view(np.int64).copy()).to(p_poly.device)
+    out_c, out_f = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+    u = np.ascontiguousarray(params.u, dtype=np.uint64).reshape(8)
+    api._check(api.lib().trh_ipa_create_proof(params._g.handle, api._p(u), k, api._devptr(p_poly), api._p(_mont(sf, p_blind)), api._p(_mont(sf, x3)),
+                                              api._devptr(s_dev), api._p(_mont(sf, s_blind)), ctypes.byref(tr), rn, None, _stream(p_poly),
+                                              api._p(out_c), api._p(out_f)))
+    return _canon(sf, out_c), _canon(sf, out_f)
+
+
 def create_proof(params, rng, transcript, p_poly, p_blind: int, x3: int, s_poly=None, s_blind: int | None = None):
     """p_poly: device tensor (n, 4) of coefficients (Montgomery limbs); p_blind, x3 canonical ints.
     s_poly (host numpy (n, 4), random with s(x3) = 0 enforced here) and s_blind default to rng draws."""

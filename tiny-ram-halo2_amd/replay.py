@@ -162,7 +162,7 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
     p_dev = torch.from_numpy(p_h.view(np.int64)).to(dev)
     draws = iter(range(7, 10 ** 9, 13))
     e0 = ev()
-    ipa.create_proof(params, lambda: next(draws), _FixedTranscript(m), p_dev, 0x1234, 0x77777, s_poly=synth.field_elements(0x5A, n), s_blind=0x99)
+    ipa.create_proof_native(params, lambda: next(draws), _FixedTranscript(m), p_dev, 0x1234, 0x77777, synth.field_elements(0x5A, n), 0x99)
     e1 = ev()
     torch.cuda.synchronize()
     times["ipa"] += e0.elapsed_time(e1)
