@@ -96,6 +96,31 @@ __global__ void __launch_bounds__(256) bases_fold_kernel(AffineMem* __restrict__
     aff_store(xyzz_to_affine(acc), g_lo[i]);
 }
 
+// ---- generator collapse without point arithmetic (native prover) ---------------------------
+// The folded generators are linear combinations of the original ones,
+//     G'_j[i] = sum over idx = i (mod n / 2^j) of wgt[idx] * G[idx],
+// and a collapse with challenge u multiplies wgt[idx] by u on every index whose bit log2(half) is set.
+// So L_j = <p'[half..], G'[..half]> and R_j = <p'[..half], G'[half..]> are MSMs over the ORIGINAL
+// resident bases with the scalars below (zero outside their half), and G' is never materialised.
+template <class F>
+__global__ void __launch_bounds__(256) ipa_weights_update_kernel(uint4* __restrict__ wgt, size_t n, u32 bit, const uint4* __restrict__ u) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n || !((idx >> bit) & 1u)) return;
+    st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), ld<F>(u)));
+}
+// out[0][idx] (scalars of L_j) and out[1][idx] (scalars of R_j)
+template <class F>
+__global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __restrict__ p, const uint4* __restrict__ wgt, uint4* __restrict__ out, size_t n, size_t half, u32 bit) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const size_t i = idx & (half - 1);
+    const bool hi = (idx >> bit) & 1u;
+    const Fe<F> v = fe_mul(ld<F>(wgt + 2 * idx), ld<F>(p + 2 * (hi ? i : half + i)));
+    const Fe<F> zero = fe_zero<F>();
+    st<F>(out + 2 * idx, hi ? zero : v);
+    st<F>(out + 2 * (n + idx), hi ? v : zero);
+}
+
 template <class F>
 int inner_product_t(const void* a, const void* b, size_t n, hipStream_t s, u64* out) {
     Ctx& c = ctx();
@@ -182,8 +207,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     auto stm = [](const Fe<SF>& v) { FeMem m; fe_store(v, m); return m; };
     const Fe<SF> x3 = ld(x3_m), p_blind = ld(p_blind_m), s_blind = ld(s_blind_m);
 
-    DevMem b, sp, pp, gp, uw, sc2;
-    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(gp.alloc(n * 64)); TRH_TRY(uw.alloc(128)); TRH_TRY(sc2.alloc(64));
+    DevMem b, sp, pp, wgt, lrsc, uw, sc2;
+    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(wgt.alloc(n * 32)); TRH_TRY(lrsc.alloc(2 * n * 32));
+    TRH_TRY(uw.alloc(128)); TRH_TRY(sc2.alloc(128));
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
     // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended
@@ -196,7 +222,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     TRH_HIP_TRY(hipMemcpy(sp.p, &s0, 32, hipMemcpyHostToDevice));
     FeMem sbm = stm(s_blind);
     TRH_HIP_TRY(hipMemcpy((char*)sp.p + n * 32, &sbm, 32, hipMemcpyHostToDevice));
-    u64 pt[12], pt2[12], two[24];
+    u64 pt[12], two[24];
     TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
     TRH_TRY(msm_finish(curve, s, pt, 1));
     tr->write_point(tr->ctx, pt);
@@ -213,30 +239,36 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     FeMem p0 = stm(fe_sub(fe_load<SF>(tmp), v));
     TRH_HIP_TRY(hipMemcpy(pp.p, &p0, 32, hipMemcpyHostToDevice));
     Fe<SF> f = fe_add(fe_mul(s_blind, xi), p_blind);
-    // G' = private copy of g; (u, w) for the two-term MSMs
-    TRH_HIP_TRY(hipMemcpyAsync(gp.p, gw->d_xy, n * 64, hipMemcpyDeviceToDevice, s));
+    // weights of the original generators inside the (virtual) folded ones; (u, w) for the two-term MSMs
+    FeMem one_m = stm(fe_one<SF>());
+    TRH_TRY((powers_t<SF>(wgt.p, n, (const u64*)&one_m, s)));  // all ones
     TRH_HIP_TRY(hipMemcpy(uw.p, u_xy, 64, hipMemcpyHostToDevice));
     TRH_HIP_TRY(hipMemcpyAsync((char*)uw.p + 64, (const char*)gw->d_xy + n * 64, 64, hipMemcpyDeviceToDevice, s));
 
     for (uint32_t j = 0; j < k; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
+        const u32 bit = k - j - 1;
         char* pph = (char*)pp.p + half * 32;
         char* bh = (char*)b.p + half * 32;
-        char* gph = (char*)gp.p + half * 64;
+        // L_j and R_j as one batch of two MSMs over the resident bases g[0..n)
+        hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit);
+        TRH_HIP_TRY(hipGetLastError());
+        u64 lr_main[24], lr_uw[24], lr[2][12];
+        TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, lrsc.p, n, 2, n, 1, s));
+        TRH_TRY(msm_finish(curve, s, lr_main, 2));
         Fe<SF> val[2], rnd[2];
-        u64 lr[2][12];
-        for (int side = 0; side < 2; ++side) {  // 0: L_j = <p'[half..], G'[..half]>, 1: R_j = <p'[..half], G'[half..]>
-            TRH_TRY(msm_enqueue(curve, side == 0 ? gp.p : (void*)gph, nullptr, side == 0 ? (void*)pph : pp.p, half, 1, half, 1, s));
-            TRH_TRY(msm_finish(curve, s, pt, 1));
-            TRH_TRY((inner_product_t<SF>(side == 0 ? (void*)pph : pp.p, side == 0 ? b.p : (void*)bh, half, s, (u64*)&tmp)));
-            val[side] = fe_load<SF>(tmp);
-            rng(rng_ctx, (u64*)&tmp);
-            rnd[side] = fe_load<SF>(tmp);
-            FeMem two_sc[2] = {stm(fe_mul(val[side], z)), stm(rnd[side])};
-            TRH_HIP_TRY(hipMemcpy(sc2.p, two_sc, 64, hipMemcpyHostToDevice));
-            TRH_TRY(msm_enqueue(curve, uw.p, nullptr, sc2.p, 2, 1, 2, 1, s));
-            TRH_TRY(msm_finish(curve, s, pt2, 1));
-            memcpy(two, pt, 96); memcpy(two + 12, pt2, 96);
+        TRH_TRY((inner_product_t<SF>(pph, b.p, half, s, (u64*)&tmp)));
+        val[0] = fe_load<SF>(tmp);
+        TRH_TRY((inner_product_t<SF>(pp.p, bh, half, s, (u64*)&tmp)));
+        val[1] = fe_load<SF>(tmp);
+        rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
+        rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
+        FeMem four_sc[4] = {stm(fe_mul(val[0], z)), stm(rnd[0]), stm(fe_mul(val[1], z)), stm(rnd[1])};
+        TRH_HIP_TRY(hipMemcpy(sc2.p, four_sc, 128, hipMemcpyHostToDevice));
+        TRH_TRY(msm_enqueue(curve, uw.p, nullptr, sc2.p, 2, 2, 2, 1, s));  // [value z] U + [rand] W for both sides
+        TRH_TRY(msm_finish(curve, s, lr_uw, 2));
+        for (int side = 0; side < 2; ++side) {
+            memcpy(two, lr_main + 12 * side, 96); memcpy(two + 12, lr_uw + 12 * side, 96);
             TRH_TRY(point_sum_host(curve, two, 2, lr[side]));
         }
         tr->write_point(tr->ctx, lr[0]);
@@ -245,8 +277,13 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const Fe<SF> u_j = fe_load<SF>(tmp), u_inv = fe_inv(u_j);
         TRH_TRY((axpy_t<SF>(pp.p, pph, half, stm(u_inv), s)));
         TRH_TRY((axpy_t<SF>(b.p, bh, half, stm(u_j), s)));
-        FeMem ujm = stm(u_j);
-        TRH_TRY((bases_fold_t<SF, BF>(gp.p, gph, half, (const u64*)&ujm, s)));
+        {
+            FeMem ujm = stm(u_j);
+            void* d_u;
+            TRH_TRY(stage_constant(&ujm, 32, s, &d_u));
+            hipLaunchKernelGGL((ipa_weights_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)wgt.p, n, bit, (const uint4*)d_u);
+            TRH_HIP_TRY(hipGetLastError());
+        }
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
     }
     TRH_HIP_TRY(hipStreamSynchronize(s));
