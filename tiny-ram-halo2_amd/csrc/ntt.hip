@@ -16,6 +16,7 @@
 // (omega^lo, omega^(hi << lo_bits)) built on the device per (field, log_n, omega).
 //
 // Integer work, no MFMA.  Algorithmic HBM bytes: 32 B read + 32 B write per element.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -163,15 +164,16 @@ __device__ __forceinline__ void bfly(Fe<F>& a, Fe<F>& b) {
     a = t;
 }
 
-// Same Stockham pass for full 2048-element tiles, with the stages grouped three at a time in
-// registers: a thread owns 8 rows of one column.  Round 0 takes its rows straight from HBM (rows
-// m + v R/8, i.e. the bit-reversed neighbours rr..rr+7), applies the inter-pass twiddle and runs
-// stages 0-2 whose twiddles are the constants 1, w4, w8, w8^3; later rounds exchange through LDS
-// (one read + one write per element per three stages, in place, one barrier per round); the
-// last round writes its results straight to HBM.
-template <class F>
-__global__ void __launch_bounds__(256) ntt_pass8_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
-                                                        const uint4* __restrict__ t_lo, const uint4* __restrict__ t_hi, int lo_bits) {
+// Same Stockham pass for full 2048-element tiles, with the stages grouped LG at a time in
+// registers: a thread owns G = 2^LG rows of one column (LG = 3: 256 threads, 8 rows).  Round 0 takes
+// its rows straight from HBM (rows m + v R/G, i.e. the bit-reversed neighbours rr..rr+G-1), applies the
+// inter-pass twiddle and runs stages 0..LG-1, whose twiddles are the constants 1, w4, w8, w8^3; later
+// rounds exchange through LDS (one read + one write per element per LG stages, in place, one barrier per
+// round); the last round writes its results straight to HBM.
+template <class F, int LG>
+__global__ void __launch_bounds__(TILE >> LG) ntt_passg_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
+                                                               const uint4* __restrict__ t_lo, const uint4* __restrict__ t_hi, int lo_bits) {
+    constexpr int G = 1 << LG, THREADS = TILE >> LG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
     const int log_c = TILE_LOG - s;
@@ -186,55 +188,49 @@ __global__ void __launch_bounds__(256) ntt_pass8_kernel(const uint4* __restrict_
     in += batch_off;
     out += batch_off;
     const int tid = threadIdx.x;
-    const u32 c = tid & (C - 1), m = tid >> log_c;  // m in [0, R/8)
+    const u32 c = tid & (C - 1), m = tid >> log_c;  // m in [0, R/G)
     const u32 j = (blockIdx.x << log_c) + c;
     const u32 k = j & ((1u << log_ns) - 1u);
     const size_t row_stride = N >> s;
 
-    for (int i = tid; i < (R >> 1); i += 256) lds_store<F>(tw_lo, tw_hi, i, twiddle<F>(t_lo, t_hi, (u32)i << (log_n - s), lo_bits));
+    for (int i = tid; i < (R >> 1); i += THREADS) lds_store<F>(tw_lo, tw_hi, i, twiddle<F>(t_lo, t_hi, (u32)i << (log_n - s), lo_bits));
 
-    Fe<F> x[8];
+    Fe<F> x[G];
     const int tw_shift = log_n - log_ns - s;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const u32 r = m + (u32)v * (u32)(R >> 3);
+    for (int v = 0; v < G; ++v) {
+        const u32 r = m + (u32)v * (u32)(R >> LG);
         Fe<F> val = load_fe<F>(in + 2 * ((size_t)j + (size_t)r * row_stride));
         if (log_ns > 0) {
             const u32 ex = (k * r) << tw_shift;
             if (ex) val = fe_mul(val, twiddle<F>(t_lo, t_hi, ex, lo_bits));
         }
-        x[((v & 1) << 2) | (v & 2) | (v >> 2)] = val;  // element v sits at bit-reversed slot u
+        x[(int)(__builtin_bitreverse32((u32)v) >> (32 - LG))] = val;  // element v sits at bit-reversed slot u (v is a compile-time constant)
     }
     __syncthreads();  // in-tile twiddle table complete
-    {   // round 0: stages 0..2 on rr = (brev(m) << 3) + u
-        const Fe<F> w4 = lds_load<F>(tw_lo, tw_hi, R >> 2);
-        const Fe<F> w8 = lds_load<F>(tw_lo, tw_hi, R >> 3);
-        const Fe<F> w83 = lds_load<F>(tw_lo, tw_hi, 3 * (R >> 3));
-        bfly(x[0], x[1]); bfly(x[2], x[3]); bfly(x[4], x[5]); bfly(x[6], x[7]);
-        x[3] = fe_mul(x[3], w4); x[7] = fe_mul(x[7], w4);
-        bfly(x[0], x[2]); bfly(x[1], x[3]); bfly(x[4], x[6]); bfly(x[5], x[7]);
-        x[5] = fe_mul(x[5], w8); x[6] = fe_mul(x[6], w4); x[7] = fe_mul(x[7], w83);
-        bfly(x[0], x[4]); bfly(x[1], x[5]); bfly(x[2], x[6]); bfly(x[3], x[7]);
-    }
-    u32 base = (s > 3) ? ((__brev(m) >> (32 - (s - 3))) << 3) : 0u;  // rows rr = base + (u << stl)
-    int stl = 0;
-    for (int st = 3; st < s; st += 3) {
-        // hand the finished rows over through LDS and pick up the next group of 8
+
+    u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;  // rows rr = base + (u << stl)
+    u32 L = 0;
+    int stl = 0, vb = 0;
+    for (int st = 0; st < s; st += LG) {
+        if (st > 0) {
+            // hand the finished rows over through LDS and pick up the next group of G
 #pragma unroll
-        for (int u = 0; u < 8; ++u) lds_store<F>(lds_lo, lds_hi, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
-        __syncthreads();
-        stl = st + 3 <= s ? st : s - 3;
-        const int vb = st - stl;  // stages below vb of this layout were done in the previous round
-        const u32 L = m & ((1u << stl) - 1u), H = m >> stl;
-        base = L | (H << (stl + 3));
+            for (int u = 0; u < G; ++u) lds_store<F>(lds_lo, lds_hi, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
+            __syncthreads();
+            stl = st + LG <= s ? st : s - LG;
+            vb = st - stl;  // stages below vb of this layout were done in the previous round
+            L = m & ((1u << stl) - 1u);
+            base = L | ((m >> stl) << (stl + LG));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = lds_load<F>(lds_lo, lds_hi, (int)(((base + ((u32)u << stl)) << log_c) | c));
+            for (int u = 0; u < G; ++u) x[u] = lds_load<F>(lds_lo, lds_hi, (int)(((base + ((u32)u << stl)) << log_c) | c));
+        }
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < LG; ++v) {
             if (v >= vb) {
                 const int sh = s - 1 - stl - v;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < G; ++u) {
                     if (u & (1 << v)) continue;
                     const u32 idx = (L + ((u32)(u & ((1 << v) - 1)) << stl)) << sh;
                     if (idx) x[u | (1 << v)] = fe_mul(x[u | (1 << v)], lds_load<F>(tw_lo, tw_hi, (int)idx));
@@ -244,7 +240,7 @@ __global__ void __launch_bounds__(256) ntt_pass8_kernel(const uint4* __restrict_
         }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < G; ++u) {
         const u32 rr = base + ((u32)u << stl);
         const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
         store_fe<F>(out + 2 * dst, x[u]);
@@ -345,8 +341,12 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const int tile_log = (int)log_n < TILE_LOG ? (int)log_n : TILE_LOG;
             const size_t tiles = N >> tile_log;
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
-            if ((int)log_n >= TILE_LOG && sp >= 3)
-                hipLaunchKernelGGL((ntt_pass8_kernel<F>), dim3((unsigned)tiles, (unsigned)nb), dim3(256), lds, s, src, o, (int)log_n, sp, log_ns,
+            static const int lg = getenv("TRH_NTT_LG") ? atoi(getenv("TRH_NTT_LG")) : 2;  // tuning knob: rows per thread = 2^lg
+            if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
+                hipLaunchKernelGGL((ntt_passg_kernel<F, 3>), dim3((unsigned)tiles, (unsigned)nb), dim3(TILE >> 3), lds, s, src, o, (int)log_n, sp, log_ns,
+                                   t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+            else if ((int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
+                hipLaunchKernelGGL((ntt_passg_kernel<F, 2>), dim3((unsigned)tiles, (unsigned)nb), dim3(TILE >> 2), lds, s, src, o, (int)log_n, sp, log_ns,
                                    t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else
                 hipLaunchKernelGGL((ntt_pass_kernel<F>), dim3((unsigned)tiles, (unsigned)nb), dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns,
@@ -368,8 +368,10 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass8_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass8_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         attr_set = true;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s);
