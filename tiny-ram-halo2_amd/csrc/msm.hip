@@ -588,10 +588,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const u32 nbins = 1u << k1;
     const size_t recode_lds = (size_t)W * nbins * 4;
     const int recode_use_lds = recode_lds <= 64 * 1024;
-    // reduce geometry
-    u32 tpw = nbk < 2048 ? nbk : 2048;  // threads per window
-    const u32 slice = nbk / tpw;
-    const u32 rblocks = (tpw + 255) / 256;
     // independent batch items (one MSM per column of create_proof, same bases) are processed
     // `chunk` at a time by the SAME launches (blockIdx.z = item), so the latency-bound sort and
     // reduction phases of one item are hidden behind the work of the others
@@ -602,6 +598,14 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (chunk > cap) chunk = cap ? cap : 1;
         if (chunk > 64) chunk = 64;
     }
+    // reduce geometry: each thread owns a slice of buckets and pays one short scalar multiplication for
+    // the slice offset, so long slices do less work per bucket but are a long serial chain: a lone MSM
+    // (latency-bound) gets 2048 threads per window, a batch (throughput-bound) as few as 256
+    u32 tpw = 2048;
+    while (tpw > 256 && (size_t)W * tpw * chunk > ((size_t)1 << 17)) tpw >>= 1;
+    if (tpw > nbk) tpw = nbk;
+    const u32 slice = nbk / tpw;
+    const u32 rblocks = (tpw + 255) / 256;
     // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 64 entries each
     u32 seg_len = 64;
     while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
