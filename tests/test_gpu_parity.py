@@ -311,3 +311,32 @@ def test_msm_heavy_buckets(curve):
     bases = cpu_ref.gen_bases(curve, 0xFEED, 0x35, n, threads=4)
     want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
     assert (api.best_multiexp(curve, sc, bases)[:8] == want).all()
+
+
+def test_concurrent_callers():
+    """entry points may be called from several host threads (rayon workers on the Rust side): results must not
+    depend on the interleaving"""
+    import threading
+    f = o.FIELDS["fp"]
+    log_n = 12
+    w = np.array(f.limbs(f.omega(log_n)), np.uint64)
+    inputs = [synth.field_elements(0x7EAD + t, 1 << log_n) for t in range(4)]
+    sc, bases = _edge_inputs("vesta", 2000, 0x7EAD)
+    want_fft = [cpu_ref.best_fft("fp", a, w, log_n, threads=2) for a in inputs]
+    want_msm = aff("vesta", cpu_ref.best_multiexp("vesta", sc, bases, threads=4))
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(5):
+                assert (api.best_fft("fp", inputs[t], w, log_n) == want_fft[t]).all()
+                assert (api.best_multiexp("vesta", sc, bases)[:8] == want_msm).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
