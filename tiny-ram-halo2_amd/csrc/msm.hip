@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
 //     entry = point index | low k2 bucket bits << idx_bits | sign << 31
 // ---------------------------------------------------------------------------------------
 constexpr int PART_TILE = 16384;
-constexpr int PART_THREADS = 512;
+constexpr int PART_THREADS = 1024;
 __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
                                                                      u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
     const size_t z = blockIdx.z;  // batch item
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
 //     (LDS histogram + scan + LDS cursors) and publishes the bucket ranges.
 // ---------------------------------------------------------------------------------------
 constexpr int BS_TILE = 8192;
-__global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
+__global__ void __launch_bounds__(1024) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
                                                               const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
                                                               u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
                                                               u32 nbins, int idx_bits, u32 nbk, u32* __restrict__ seg_bucket, u32 nseg, u32 seg_len) {
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) msm_bucket_sort_kernel(const u32* __restr
             stage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
         }
         __syncthreads();
-        for (u32 sub = wave; sub < nsub; sub += 4) {
+        for (u32 sub = wave; sub < nsub; sub += (blockDim.x >> 6)) {
             const u32 c = tcnt[sub], sb = tbase[sub], gb = lo + off[sub] + run[sub];
             for (u32 k = lane; k < c; k += 64) dst[gb + k] = stage[sb + k];
         }
@@ -588,6 +588,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const u32 nbins = 1u << k1;
     const size_t recode_lds = (size_t)W * nbins * 4;
     const int recode_use_lds = recode_lds <= 64 * 1024;
+    unsigned bs_threads = 256;  // bucket-sort workgroup: one per level-1 bin, wider when bins are large
+    if (const char* e = getenv("TRH_BS_THREADS")) bs_threads = (unsigned)atoi(e);
+    else if ((n >> k1) >= 16384) bs_threads = 1024; else if ((n >> k1) >= 4096) bs_threads = 512;
     // independent batch items (one MSM per column of create_proof, same bases) are processed
     // `chunk` at a time by the SAME launches (blockIdx.z = item), so the latency-bound sort and
     // reduction phases of one item are hidden behind the work of the others
@@ -665,7 +668,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), n, k2, nbins, idx_bits);
-        hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W, nb), dim3(256), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(),
+        hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W, nb), dim3(bs_threads), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(),
                            L.counts.as<u32>(), L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
                            L.seg_bucket.as<u32>(), nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
