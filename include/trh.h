@@ -166,6 +166,14 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
                          trh_rng_scalar_fn rng, void* rng_ctx, void* stream,
                          uint64_t out_c[4], uint64_t out_f[4]);
 
+/* ---- grand-product building blocks of the permutation / lookup arguments ----------------------
+ * (plonk/permutation/prover.rs, plonk/lookup/prover.rs: batch_invert of the denominators, then the
+ * running product z[0] = 1, z[i] = z[i-1] * numerator[i-1] / denominator[i-1])                    */
+/* ff::BatchInvert: a[i] <- a[i]^-1 in place, zeros stay zero */
+int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream);
+/* out[i] = prod_{j < i} a[j], out[0] = 1 (exclusive scan; out must not alias a) */
+int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
+
 /* ---- best_fft over curve points: Params::new's g -> g_lagrange -----------------------------
  * halo2_proofs::arithmetic::best_fft::<C::Curve>(a, omega, log_n): a'[i] = sum_j [omega^(i j)] a[j].
  * points_dev: 2^log_n affine PODs in device memory, transformed in place (natural order in and out)

@@ -137,3 +137,39 @@ def test_params_g_lagrange_point_fft(curve, k):
     c1 = params.commit(limbs(fs, coeffs), zero)
     c2 = params.commit_lagrange(limbs(fs, evals), zero)
     assert (c1 == c2).all()
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 4096, 4097, 100003])
+def test_batch_invert_and_prefix_product(field, n):
+    """grand-product primitives of the permutation / lookup arguments (SURVEY 8f-4): ff::BatchInvert semantics
+    (zeros stay zero) and z[i] = prod_{j<i} a[j], vs the CPU restatement / big-int oracle"""
+    f = o.FIELDS[field]
+    a = synth.field_elements(0x5CA0 + n, n)
+    if n >= 5:
+        a[3] = 0
+        a[n - 1] = 0
+    d = to_dev(a)
+    api.batch_invert_dev(field, d, n)
+    got = to_host(d)
+    nz = (a != 0).any(axis=1)
+    want = np.zeros_like(a)
+    want[nz] = cpu_ref.field_op(field, "inv", a[nz])
+    assert (got == want).all()
+    # inverse * original == 1 where non-zero (independent of the oracle's inversion)
+    one = np.array(f.limbs(1), np.uint64)
+    assert (cpu_ref.field_op(field, "mul", got[nz], a[nz]) == one).all()
+
+    b = synth.field_elements(0x5CB0 + n, n)
+    db, dout = to_dev(b), torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    api.prefix_product_dev(field, db, dout, n)
+    z = to_host(dout)
+    run = 1
+    vals = [f.from_limbs(r) for r in b]
+    for i in range(n):
+        if i < 200 or i % 997 == 0 or i == n - 1:
+            assert f.from_limbs(z[i]) == run, i
+        run = run * vals[i] % f.m
+    # z[i+1] == z[i] * b[i] everywhere (size-independent property)
+    if n > 1:
+        assert (cpu_ref.field_op(field, "mul", z[:-1], b[:-1]) == z[1:]).all()

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "trh_domain_extended_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_domain_divide_by_vanishing_poly": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_ipa_create_proof": ([_vp, _u64p, ctypes.c_uint32, _vp, _u64p, _u64p, _vp, _u64p, ctypes.POINTER(Transcript), RNG_FN, _vp, _vp, _u64p, _u64p], ctypes.c_int),
+    "trh_field_batch_invert_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_field_prefix_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
@@ -299,6 +301,16 @@ def point_fft_dev(curve: str, points_dev, log_n: int, omega, scale=None, stream=
     w = _c(omega).reshape(4)
     sc = None if scale is None else _c(scale).reshape(4)
     _check(lib().trh_point_fft_dev(CURVE_ID[curve], _devptr(points_dev), log_n, _p(w), None if sc is None else _p(sc), stream))
+
+
+def batch_invert_dev(field: str, a_dev, n: int, stream=None):
+    """ff::BatchInvert on a device vector, in place (zeros stay zero)"""
+    _check(lib().trh_field_batch_invert_dev(FIELD_ID[field], _devptr(a_dev), n, stream))
+
+
+def prefix_product_dev(field: str, a_dev, out_dev, n: int, stream=None):
+    """out[i] = prod_{j < i} a[j] (out[0] = 1): the running product of the permutation / lookup z columns"""
+    _check(lib().trh_field_prefix_product_dev(FIELD_ID[field], _devptr(a_dev), _devptr(out_dev), n, stream))
 
 
 def set_timing(on: bool):

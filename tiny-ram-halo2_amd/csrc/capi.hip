@@ -184,6 +184,7 @@ void trh_shutdown(void) {
     c.io.release();
     c.factors.release();
     c.pfft.release();
+    c.scan.release(); c.scan2.release();
     c.inited = false;
     c.device = -1;
 }

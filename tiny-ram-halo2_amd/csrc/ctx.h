@@ -97,6 +97,7 @@ struct Ctx {
     DevBuf ntt_tmp;
     DevBuf io;  // staging for host-pointer NTT entry points
     DevBuf pfft;  // curve-point FFT work array + twiddle scalars
+    DevBuf scan, scan2;  // prefix-product block totals / batch-inversion running products
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
     std::vector<TwiddleEntry*> twiddles;

@@ -1,0 +1,177 @@
+// Grand-product building blocks of the permutation / lookup arguments (halo2_proofs 0.2.0
+// plonk/permutation/prover.rs and plonk/lookup/prover.rs, reached from create_proof --
+// /root/reference/src/test_utils.rs:41-49): the product columns are
+//     z[0] = 1,   z[i] = prod_{j < i} numerator[j] / denominator[j],
+// computed in Rust as `batch_invert` of the denominators followed by a running product.  These are
+// the two device primitives: an in-place batch inversion (Montgomery's trick per thread chunk, zeros
+// left as zeros exactly like ff::BatchInvert) and an exclusive prefix product.
+#include <string.h>
+
+#include "ctx.h"
+
+namespace trh {
+namespace {
+
+template <class F>
+__device__ __forceinline__ Fe<F> ldf(const uint4* p) {
+    uint4 a = p[0], b = p[1];
+    return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+template <class F>
+__device__ __forceinline__ void stf(uint4* p, const Fe<F>& v) {
+    u32 w[8];
+    fe_store(v, w);
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+constexpr int INV_CHUNK = 64;  // elements per thread: one field inversion (~380 multiplies) per chunk
+
+// a[i] <- a[i]^-1 (0 stays 0); scratch holds the running products of the chunk
+template <class F>
+__global__ void __launch_bounds__(256) batch_invert_kernel(uint4* __restrict__ a, uint4* __restrict__ scratch, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lo = t * INV_CHUNK;
+    if (lo >= n) return;
+    const size_t hi = lo + INV_CHUNK < n ? lo + INV_CHUNK : n;
+    Fe<F> acc = fe_one<F>();
+    for (size_t i = lo; i < hi; ++i) {
+        stf<F>(scratch + 2 * i, acc);  // product of the non-zero elements before i
+        const Fe<F> v = ldf<F>(a + 2 * i);
+        if (!fe_is_zero(v)) acc = fe_mul(acc, v);
+    }
+    Fe<F> inv = fe_inv(acc);
+    for (size_t i = hi; i-- > lo;) {
+        const Fe<F> v = ldf<F>(a + 2 * i);
+        if (fe_is_zero(v)) continue;
+        stf<F>(a + 2 * i, fe_mul(inv, ldf<F>(scratch + 2 * i)));
+        inv = fe_mul(inv, v);
+    }
+}
+
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_BLOCK = 256 * SCAN_PER_THREAD;
+
+// exclusive scan of 256 values in LDS (Hillis-Steele); returns the exclusive prefix of this thread and the block total
+template <class F>
+__device__ __forceinline__ Fe<F> block_exclusive_scan(Fe<F>* sh, const Fe<F>& mine, Fe<F>& total) {
+    const int t = threadIdx.x;
+    sh[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        Fe<F> v = fe_one<F>();
+        const bool take = t >= off;
+        if (take) v = sh[t - off];
+        __syncthreads();
+        if (take) sh[t] = fe_mul(sh[t], v);
+        __syncthreads();
+    }
+    total = sh[255];
+    const Fe<F> incl_prev = t ? sh[t - 1] : fe_one<F>();
+    __syncthreads();
+    return incl_prev;
+}
+
+// phase 1: product of each block of SCAN_BLOCK elements
+template <class F>
+__global__ void __launch_bounds__(256) scan_block_totals_kernel(const uint4* __restrict__ a, size_t n, uint4* __restrict__ totals) {
+    __shared__ Fe<F> sh[256];
+    const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    Fe<F> p = fe_one<F>();
+    for (int k = 0; k < SCAN_PER_THREAD; ++k)
+        if (lo + k < n) p = fe_mul(p, ldf<F>(a + 2 * (lo + k)));
+    Fe<F> total;
+    block_exclusive_scan<F>(sh, p, total);
+    if (threadIdx.x == 0) stf<F>(totals + 2 * blockIdx.x, total);
+}
+// phase 2 (one workgroup): exclusive scan of the block totals, in place
+template <class F>
+__global__ void __launch_bounds__(256) scan_totals_kernel(uint4* __restrict__ totals, u32 count) {
+    __shared__ Fe<F> sh[256];
+    const u32 per = (count + 255u) / 256u;
+    const u32 lo = threadIdx.x * per;
+    Fe<F> p = fe_one<F>();
+    for (u32 k = 0; k < per; ++k)
+        if (lo + k < count) p = fe_mul(p, ldf<F>(totals + 2 * (lo + k)));
+    Fe<F> total;
+    Fe<F> run = block_exclusive_scan<F>(sh, p, total);
+    for (u32 k = 0; k < per; ++k) {
+        if (lo + k >= count) break;
+        const Fe<F> v = ldf<F>(totals + 2 * (lo + k));
+        stf<F>(totals + 2 * (lo + k), run);
+        run = fe_mul(run, v);
+    }
+}
+// phase 3: out[i] = prod_{j < i} a[j]
+template <class F>
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint4* __restrict__ a, uint4* __restrict__ out, size_t n, const uint4* __restrict__ totals) {
+    __shared__ Fe<F> sh[256];
+    const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    Fe<F> vals[SCAN_PER_THREAD];
+    Fe<F> p = fe_one<F>();
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        vals[k] = lo + k < n ? ldf<F>(a + 2 * (lo + k)) : fe_one<F>();
+        p = fe_mul(p, vals[k]);
+    }
+    Fe<F> total;
+    Fe<F> run = fe_mul(block_exclusive_scan<F>(sh, p, total), ldf<F>(totals + 2 * blockIdx.x));
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (lo + k < n) stf<F>(out + 2 * (lo + k), run);
+        run = fe_mul(run, vals[k]);
+    }
+}
+
+template <class F>
+int prefix_product_t(const void* a, void* out, size_t n, hipStream_t s) {
+    Ctx& c = ctx();
+    const unsigned blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    TRH_TRY(c.scan.ensure((size_t)blocks * 32 + 32));
+    hipLaunchKernelGGL((scan_block_totals_kernel<F>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, n, c.scan.as<uint4>());
+    hipLaunchKernelGGL((scan_totals_kernel<F>), dim3(1), dim3(256), 0, s, c.scan.as<uint4>(), blocks);
+    hipLaunchKernelGGL((scan_apply_kernel<F>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, (uint4*)out, n, c.scan.as<uint4>());
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+template <class F>
+int batch_invert_t(void* a, size_t n, hipStream_t s) {
+    Ctx& c = ctx();
+    TRH_TRY(c.scan2.ensure(n * 32 + 32));
+    const size_t threads = (n + INV_CHUNK - 1) / INV_CHUNK;
+    hipLaunchKernelGGL((batch_invert_kernel<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (uint4*)a, c.scan2.as<uint4>(), n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+}  // namespace
+}  // namespace trh
+
+using namespace trh;
+
+extern "C" {
+
+int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && !a_dev) { set_error("batch_invert: null pointer"); return TRH_EINVAL; }
+    if (!n) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return batch_invert_t<FpParams>(a_dev, n, (hipStream_t)stream);
+    return batch_invert_t<FqParams>(a_dev, n, (hipStream_t)stream);
+}
+
+int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && (!a_dev || !out_dev)) { set_error("prefix_product: null pointer"); return TRH_EINVAL; }
+    if (a_dev == out_dev) { set_error("prefix_product: in-place operation is not supported"); return TRH_EINVAL; }
+    if (!n) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return prefix_product_t<FpParams>(a_dev, out_dev, n, (hipStream_t)stream);
+    return prefix_product_t<FqParams>(a_dev, out_dev, n, (hipStream_t)stream);
+}
+
+}  // extern "C"
