@@ -170,17 +170,17 @@ __device__ __forceinline__ void bfly(Fe<F>& a, Fe<F>& b) {
 // inter-pass twiddle and runs stages 0..LG-1, whose twiddles are the constants 1, w4, w8, w8^3; later
 // rounds exchange through LDS (one read + one write per element per LG stages, in place, one barrier per
 // round); the last round writes its results straight to HBM.
-template <class F, int LG>
-__global__ void __launch_bounds__(TILE >> LG) ntt_passg_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
+template <class F, int LG, int TLOG>
+__global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passg_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
                                                                const uint4* __restrict__ t_lo, const uint4* __restrict__ t_hi, int lo_bits) {
-    constexpr int G = 1 << LG, THREADS = TILE >> LG;
+    constexpr int G = 1 << LG, T = 1 << TLOG, THREADS = T >> LG;  // T elements per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
-    const int log_c = TILE_LOG - s;
+    const int log_c = TLOG - s;
     const int C = 1 << log_c;
     uint4* lds_lo = (uint4*)smem;
-    uint4* lds_hi = lds_lo + TILE;
-    uint4* tw_lo = lds_hi + TILE;
+    uint4* lds_hi = lds_lo + T;
+    uint4* tw_lo = lds_hi + T;
     uint4* tw_hi = tw_lo + (R >> 1);
 
     const size_t N = (size_t)1 << log_n;
@@ -307,10 +307,16 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega);
     if (!t) TRH_TRY(build_tables<F>((int)log_n, omega, s, &t));
 
-    // pass plan
-    int sizes[8], P = 0;
+    // pass plan.  With TRH_NTT_TILE=12 sizes 2^19..2^22 run as TWO passes of <= 11 stages on 4096-element tiles (all 160 KiB of
+    // LDS, one workgroup of 1024 threads per CU): one inter-pass twiddle and one HBM round trip less than
+    // three passes on 2048-element tiles -- but only one workgroup per CU; measured equal at 2^22, so off by default.
+    static const int big_tile = getenv("TRH_NTT_TILE") ? atoi(getenv("TRH_NTT_TILE")) == 12 : 0;  // measured: no faster than three small-tile passes
+    int sizes[8], P = 0, tlog = TILE_LOG;
     if ((int)log_n <= TILE_LOG) { sizes[P++] = (int)log_n; }
-    else {
+    else if (big_tile && (int)log_n > 2 * MAX_PASS_LOG && (int)log_n <= 22) {
+        tlog = 12; P = 2;
+        sizes[0] = ((int)log_n + 1) / 2; sizes[1] = (int)log_n - sizes[0];
+    } else {
         P = ((int)log_n + MAX_PASS_LOG - 1) / MAX_PASS_LOG;
         if (P < 2) P = 2;
         int rem = (int)log_n;
@@ -338,19 +344,19 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const int sp = sizes[p];
             const bool in_place = (P == 1) || ((P & 1) && p == P - 1);
             uint4* o = in_place ? src : dst;
-            const int tile_log = (int)log_n < TILE_LOG ? (int)log_n : TILE_LOG;
+            const int tile_log = (int)log_n < tlog ? (int)log_n : tlog;
             const size_t tiles = N >> tile_log;
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
             static const int lg = getenv("TRH_NTT_LG") ? atoi(getenv("TRH_NTT_LG")) : 2;  // tuning knob: rows per thread = 2^lg
-            if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
-                hipLaunchKernelGGL((ntt_passg_kernel<F, 3>), dim3((unsigned)tiles, (unsigned)nb), dim3(TILE >> 3), lds, s, src, o, (int)log_n, sp, log_ns,
-                                   t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+            const dim3 grid((unsigned)tiles, (unsigned)nb);
+            if (tlog == 12)
+                hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+            else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
+                hipLaunchKernelGGL((ntt_passg_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else if ((int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
-                hipLaunchKernelGGL((ntt_passg_kernel<F, 2>), dim3((unsigned)tiles, (unsigned)nb), dim3(TILE >> 2), lds, s, src, o, (int)log_n, sp, log_ns,
-                                   t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+                hipLaunchKernelGGL((ntt_passg_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else
-                hipLaunchKernelGGL((ntt_pass_kernel<F>), dim3((unsigned)tiles, (unsigned)nb), dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns,
-                                   t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
+                hipLaunchKernelGGL((ntt_pass_kernel<F>), grid, dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             if (!in_place) { uint4* x = src; src = dst; dst = x; }
             log_ns += sp;
         }
@@ -368,10 +374,13 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        const int big_lds = (32 << 12) + (32 << 10);  // 160 KiB: the whole LDS of a CU
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         attr_set = true;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s);
