@@ -609,8 +609,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     if (tpw > nbk) tpw = nbk;
     const u32 slice = nbk / tpw;
     const u32 rblocks = (tpw + 255) / 256;
-    // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 64 entries each
-    u32 seg_len = 64;
+    // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 128 entries each
+    u32 seg_len = 128;
     while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
     if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len = (u32)v; }  // tuning knob
     const u32 nseg = (u32)((n + seg_len - 1) / seg_len);
