@@ -340,3 +340,29 @@ def test_concurrent_callers():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("kind", ["all_ones", "words16", "flags_quarter"])
+def test_msm_witness_like_scalars(kind):
+    """scalars shaped like TinyRAM witness columns (flags, small words, mostly-empty columns): millions of
+    entries share a handful of buckets / one level-1 bin; exercises the chunk-parallel bucket sort and the
+    workgroup-per-bucket combine at a size where they matter"""
+    curve, n = "vesta", 1 << 17
+    cv = o.CURVES[curve]
+    f = cv.scalar
+    rng = np.random.default_rng(7)
+    if kind == "all_ones":
+        vals = np.ones(n, np.int64)
+    elif kind == "words16":
+        vals = rng.integers(0, 1 << 16, n)
+    else:
+        vals = np.where(np.arange(n) < n // 4, rng.integers(0, 2, n), 0)
+    uniq = np.unique(vals)
+    lut = np.array([f.limbs(int(v)) for v in uniq], np.uint64)
+    sc = lut[np.searchsorted(uniq, vals)]
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+    got = bases.msm(sc)
+    total = (int(vals.sum()) * synth.BASE_S0 + int((vals * np.arange(n)).sum()) * synth.BASE_D) % f.m
+    g = np.array(cv.affine_limbs(cv.generator), np.uint64)
+    want = aff(curve, cpu_ref.scalar_mul(curve, g, np.array(o.int_to_limbs(total), np.uint64)))
+    assert (got[:8] == want).all()

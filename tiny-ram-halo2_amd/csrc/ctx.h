@@ -64,6 +64,7 @@ struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: bat
     DevBuf counts;       // W x nbins u32 level-1 histogram, then running cursor / bin end
     DevBuf bin_starts;   // W x nbins u32 level-1 bin start offsets
     DevBuf starts, ends; // W x (NB + 1) u32 bucket ranges in `sorted`
+    DevBuf bucket_cnt;   // W x (NB + 1) u32 bucket histogram, then write cursors of the scatter pass
     DevBuf seg_bucket;   // W x nseg u32: bucket holding the first entry of each segment
     DevBuf first, last;  // W x nseg raw lazy XYZZ: first run / unfinished last run of each segment
     DevBuf direct;       // W x (NB + 1) raw lazy XYZZ: buckets that lie inside one segment

@@ -204,82 +204,122 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
 }
 
 // ---------------------------------------------------------------------------------------
-// 3b. bucket sort: workgroup (bin, window) orders its bin's entries by the low k2 bucket bits
-//     (LDS histogram + scan + LDS cursors) and publishes the bucket ranges.
+// 3b. bucket sort, chunk-parallel: the bin-grouped list is cut into fixed chunks of BS_CHUNK entries
+//     whatever the bin sizes (witness-like scalars put millions of entries into one bin), and every
+//     (chunk, bin) piece is ordered by the low k2 bucket bits:
+//       count    LDS histogram per piece -> one global atomic per (piece, bucket)
+//       ranges   per window exclusive scan of the bucket counts -> bucket ranges, write cursors and the
+//                bucket of every segment start
+//       scatter  per piece: LDS histogram -> one global atomic per (piece, bucket) reserves a run in the
+//                bucket -> entries staged in LDS in bucket order -> coalesced copy-out (wave per bucket)
 // ---------------------------------------------------------------------------------------
-constexpr int BS_TILE = 8192;
-__global__ void __launch_bounds__(1024) msm_bucket_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
-                                                              const u32* __restrict__ bin_ends, u32* __restrict__ sorted,
-                                                              u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2,
-                                                              u32 nbins, int idx_bits, u32 nbk, u32* __restrict__ seg_bucket, u32 nseg, u32 seg_len) {
+constexpr int BS_CHUNK = 8192;
+constexpr int BS_THREADS = 512;
+
+// first bin whose end lies beyond position pos (empty bins are skipped)
+__device__ __forceinline__ u32 bin_of_position(const u32* __restrict__ bin_ends, u32 nbins, u32 pos) {
+    u32 lo = 0, hi = nbins;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (bin_ends[mid] > pos) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(BS_THREADS) msm_bucket_pass_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
+                                                                     const u32* __restrict__ bin_ends, u32* __restrict__ bucket_cnt /* count: histogram; scatter: cursor */,
+                                                                     u32* __restrict__ sorted, size_t n, int k2, u32 nbins, int idx_bits, u32 nbk) {
     const size_t z = blockIdx.z;  // batch item
     {
         const size_t Wz = gridDim.y;
         parted += z * Wz * n; sorted += z * Wz * n; bin_starts += z * Wz * nbins; bin_ends += z * Wz * nbins;
-        starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); seg_bucket += z * Wz * nseg;
+        bucket_cnt += z * Wz * (nbk + 1);
     }
-    __shared__ u32 cnt[128], off[128];
+    __shared__ u32 cnt[128], tbase[128], gbase[128];
+    __shared__ u32 stage[SCATTER ? BS_CHUNK : 1];
     const int j = blockIdx.y;
-    const u32 bin = blockIdx.x;
-    const u32 lo = bin_starts[(size_t)j * nbins + bin], hi = bin_ends[(size_t)j * nbins + bin];
-    const u32 nsub = 1u << k2, low_mask = nsub - 1u;
+    const u32* bs = bin_starts + (size_t)j * nbins;
+    const u32* be = bin_ends + (size_t)j * nbins;
+    const u32 total = be[nbins - 1];  // bins are contiguous from 0: the last end is the entry count
+    const u32 c0 = blockIdx.x * BS_CHUNK;
+    if (c0 >= total) return;
+    const u32 c1 = c0 + BS_CHUNK < total ? c0 + BS_CHUNK : total;
+    const u32 nsub = 1u << k2, low_mask = nsub - 1u, idx_mask = (1u << idx_bits) - 1u;
     const u32* src = parted + (size_t)j * n;
     u32* dst = sorted + (size_t)j * n;
-    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&cnt[(src[i] >> idx_bits) & low_mask], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = 0;
-        for (u32 k = 0; k < nsub; ++k) { off[k] = run; run += cnt[k]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < nsub) {
-        const u32 bucket = (bin << k2) + threadIdx.x + 1u;  // 1-based bucket id
-        if (bucket <= nbk) {
-            const u32 S = lo + off[threadIdx.x], E = S + cnt[threadIdx.x];
-            starts[(size_t)j * (nbk + 1) + bucket] = S;
-            ends[(size_t)j * (nbk + 1) + bucket] = E;
-            // segments whose first entry lies in this bucket
-            if (E > S)
-                for (u32 t = (S + seg_len - 1) / seg_len; t * seg_len < E; ++t) seg_bucket[(size_t)j * nseg + t] = bucket;
-        }
-    }
-    __syncthreads();
-    // second pass: tiles of BS_TILE entries are staged in LDS in sub-bucket order, so that every
-    // sub-bucket's piece leaves as a coalesced store (wave per sub-bucket) instead of scattered words
-    __shared__ u32 tcnt[128], tbase[128], run[128];
-    __shared__ u32 stage[BS_TILE];
-    if (threadIdx.x < 128) run[threadIdx.x] = 0;
-    const u32 idx_mask = (1u << idx_bits) - 1u;
+    u32* bc = bucket_cnt + (size_t)j * (nbk + 1);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (u32 t0 = lo; t0 < hi; t0 += BS_TILE) {
-        const u32 t1 = t0 + BS_TILE < hi ? t0 + BS_TILE : hi;
-        if (threadIdx.x < 128) tcnt[threadIdx.x] = 0;
+    for (u32 bin = bin_of_position(be, nbins, c0); bin < nbins; ++bin) {
+        const u32 lo = bs[bin] > c0 ? bs[bin] : c0;
+        if (lo >= c1) break;
+        const u32 hi = be[bin] < c1 ? be[bin] : c1;
+        if (hi <= lo) continue;  // empty bin
+        if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
         __syncthreads();
-        for (u32 i = t0 + threadIdx.x; i < t1; i += blockDim.x) atomicAdd(&tcnt[(src[i] >> idx_bits) & low_mask], 1u);
+        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&cnt[(src[i] >> idx_bits) & low_mask], 1u);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 r = 0;
-            for (u32 k = 0; k < nsub; ++k) { tbase[k] = r; r += tcnt[k]; }
+        if (!SCATTER) {
+            if (threadIdx.x < nsub && cnt[threadIdx.x]) atomicAdd(&bc[(bin << k2) + threadIdx.x + 1u], cnt[threadIdx.x]);
+        } else {
+            if (threadIdx.x == 0) {
+                u32 r = 0;
+                for (u32 k = 0; k < nsub; ++k) { tbase[k] = r; r += cnt[k]; }
+            }
+            if (threadIdx.x < nsub) {
+                const u32 v = cnt[threadIdx.x];
+                gbase[threadIdx.x] = v ? atomicAdd(&bc[(bin << k2) + threadIdx.x + 1u], v) : 0u;  // reserve the run
+            }
+            __syncthreads();
+            if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+            __syncthreads();
+            for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const u32 e = src[i];
+                const u32 sub = (e >> idx_bits) & low_mask;
+                const u32 r = atomicAdd(&cnt[sub], 1u);
+                stage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+            }
+            __syncthreads();
+            for (u32 sub = wave; sub < nsub; sub += BS_THREADS / 64) {
+                const u32 c = cnt[sub], sb = tbase[sub], gb = gbase[sub];
+                for (u32 k = lane; k < c; k += 64) dst[gb + k] = stage[sb + k];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 128) tcnt[threadIdx.x] = 0;
+    }
+}
+
+// per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts), seg_bucket
+__global__ void __launch_bounds__(1024) msm_bucket_ranges_kernel(u32* __restrict__ bucket_cnt, u32* __restrict__ starts, u32* __restrict__ ends,
+                                                                 u32* __restrict__ seg_bucket, u32 nbk, u32 nseg, u32 seg_len) {
+    __shared__ u32 part[1024];
+    const size_t z = blockIdx.z;
+    const size_t Wz = gridDim.x;
+    const int j = blockIdx.x, t = threadIdx.x;
+    const u32 nb1 = nbk + 1;
+    u32* cnt = bucket_cnt + (z * Wz + j) * nb1;
+    u32* st = starts + (z * Wz + j) * nb1;
+    u32* en = ends + (z * Wz + j) * nb1;
+    u32* sb = seg_bucket + (z * Wz + j) * nseg;
+    const u32 per = (nb1 + 1023u) / 1024u;
+    const u32 lo = t * per < nb1 ? t * per : nb1, hi = lo + per < nb1 ? lo + per : nb1;
+    u32 sum = 0;
+    for (u32 b = lo; b < hi; ++b) sum += cnt[b];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        u32 v = (t >= off) ? part[t - off] : 0;
         __syncthreads();
-        for (u32 i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
-            const u32 e = src[i];
-            const u32 sub = (e >> idx_bits) & low_mask;
-            const u32 r = atomicAdd(&tcnt[sub], 1u);
-            stage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
-        }
+        part[t] += v;
         __syncthreads();
-        for (u32 sub = wave; sub < nsub; sub += (blockDim.x >> 6)) {
-            const u32 c = tcnt[sub], sb = tbase[sub], gb = lo + off[sub] + run[sub];
-            for (u32 k = lane; k < c; k += 64) dst[gb + k] = stage[sb + k];
-        }
-        __syncthreads();
-        if (threadIdx.x < nsub) run[threadIdx.x] += tcnt[threadIdx.x];
-        __syncthreads();
+    }
+    u32 run = part[t] - sum;
+    for (u32 b = lo; b < hi; ++b) {
+        const u32 c = cnt[b], S = run, E = run + c;
+        st[b] = S; en[b] = E; cnt[b] = S;  // cursor starts at the bucket start
+        if (c)
+            for (u32 sg = (S + seg_len - 1) / seg_len; sg * seg_len < E; ++sg) sb[sg] = b;  // segments whose first entry lies in this bucket
+        run = E;
     }
 }
 
@@ -588,9 +628,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const u32 nbins = 1u << k1;
     const size_t recode_lds = (size_t)W * nbins * 4;
     const int recode_use_lds = recode_lds <= 64 * 1024;
-    unsigned bs_threads = 256;  // bucket-sort workgroup: one per level-1 bin, wider when bins are large
-    if (const char* e = getenv("TRH_BS_THREADS")) bs_threads = (unsigned)atoi(e);
-    else if ((n >> k1) >= 16384) bs_threads = 1024; else if ((n >> k1) >= 4096) bs_threads = 512;
     // independent batch items (one MSM per column of create_proof, same bases) are processed
     // `chunk` at a time by the SAME launches (blockIdx.z = item), so the latency-bound sort and
     // reduction phases of one item are hidden behind the work of the others
@@ -625,6 +662,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.counts.ensure(chunk * W * nbins * 4));
     TRH_TRY(L.bin_starts.ensure(chunk * W * nbins * 4));
     TRH_TRY(L.starts.ensure(chunk * W * nb1 * 4));
+    TRH_TRY(L.bucket_cnt.ensure(chunk * W * nb1 * 4));
     TRH_TRY(L.ends.ensure(chunk * W * nb1 * 4));
     TRH_TRY(L.seg_bucket.ensure(chunk * W * nseg * 4 + 16));
     TRH_TRY(L.first.ensure(chunk * W * nseg * sizeof(XYZZzMem)));
@@ -668,9 +706,16 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), n, k2, nbins, idx_bits);
-        hipLaunchKernelGGL(msm_bucket_sort_kernel, dim3(nbins, W, nb), dim3(bs_threads), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(),
-                           L.counts.as<u32>(), L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), n, k2, nbins, idx_bits, nbk,
-                           L.seg_bucket.as<u32>(), nseg, seg_len);
+        {
+            const dim3 cgrid((unsigned)((n + BS_CHUNK - 1) / BS_CHUNK), W, nb);
+            TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * W * nb1 * 4, s));
+            hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), n, k2, nbins, idx_bits, nbk);
+            hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.bucket_cnt.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(),
+                               L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
+            hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), n, k2, nbins, idx_bits, nbk);
+        }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
         if (b0 == 0 && !bases_z)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
@@ -780,7 +825,7 @@ void msm_release() {
     MsmScratch& m = ctx().msm;
     m.scalars.release(); m.bases_z.release(); m.window_sums.release();
     MsmLane& L = m.lane;
-    L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release();
+    L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release(); L.bucket_cnt.release();
     L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release();
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
