@@ -43,7 +43,7 @@ inline int choose_window_bits(size_t n) {
     // measured on MI355X (tools/window_sweep.py): below 2^15 pairs an MSM is latency-bound and the width
     // hardly matters; from 2^16 the wide windows win (fewer mixed adds, more level-1 sort bins)
     const int l = ilog2_floor(n ? n : 1);
-    return l < 9 ? 4 : l < 11 ? 5 : l < 13 ? 8 : l < 15 ? 9 : l < 16 ? 10 : l < 19 ? 15 : 16;
+    return l < 9 ? 4 : l < 15 ? 8 : l < 16 ? 9 : l < 17 ? 10 : l < 21 ? 15 : 16;
 }
 inline int num_windows(int c) { return 255 / c + 1; }
 
