@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) ipa_weights_update_kernel(uint4* __restri
 }
 // out[0][idx] (scalars of L_j) and out[1][idx] (scalars of R_j)
 template <class F>
-__global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __restrict__ p, const uint4* __restrict__ wgt, uint4* __restrict__ out, size_t n, size_t half, u32 bit) {
+__global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __restrict__ p, const uint4* __restrict__ wgt, uint4* __restrict__ out, size_t n, size_t half, u32 bit, size_t stride) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const size_t i = idx & (half - 1);
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __r
     const Fe<F> v = fe_mul(ld<F>(wgt + 2 * idx), ld<F>(p + 2 * (hi ? i : half + i)));
     const Fe<F> zero = fe_zero<F>();
     st<F>(out + 2 * idx, hi ? zero : v);
-    st<F>(out + 2 * (n + idx), hi ? v : zero);
+    st<F>(out + 2 * (stride + idx), hi ? v : zero);
 }
 
 template <class F>
@@ -207,9 +207,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     auto stm = [](const Fe<SF>& v) { FeMem m; fe_store(v, m); return m; };
     const Fe<SF> x3 = ld(x3_m), p_blind = ld(p_blind_m), s_blind = ld(s_blind_m);
 
-    DevMem b, sp, pp, wgt, lrsc, uw, sc2;
-    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(wgt.alloc(n * 32)); TRH_TRY(lrsc.alloc(2 * n * 32));
-    TRH_TRY(uw.alloc(128)); TRH_TRY(sc2.alloc(128));
+    DevMem b, sp, pp, wgt, lrsc, gwu, gwuz;
+    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(wgt.alloc(n * 32)); TRH_TRY(lrsc.alloc(2 * (n + 2) * 32));
+    TRH_TRY(gwu.alloc((n + 2) * 64)); TRH_TRY(gwuz.alloc((n + 2) * 64));
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
     // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended
@@ -222,7 +222,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     TRH_HIP_TRY(hipMemcpy(sp.p, &s0, 32, hipMemcpyHostToDevice));
     FeMem sbm = stm(s_blind);
     TRH_HIP_TRY(hipMemcpy((char*)sp.p + n * 32, &sbm, 32, hipMemcpyHostToDevice));
-    u64 pt[12], two[24];
+    u64 pt[12];
     TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
     TRH_TRY(msm_finish(curve, s, pt, 1));
     tr->write_point(tr->ctx, pt);
@@ -239,23 +239,23 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     FeMem p0 = stm(fe_sub(fe_load<SF>(tmp), v));
     TRH_HIP_TRY(hipMemcpy(pp.p, &p0, 32, hipMemcpyHostToDevice));
     Fe<SF> f = fe_add(fe_mul(s_blind, xi), p_blind);
-    // weights of the original generators inside the (virtual) folded ones; (u, w) for the two-term MSMs
+    // weights of the original generators inside the (virtual) folded ones; the bases of the round MSMs are
+    // g (n points) followed by w and u, so that [rand] W + [value z] U ride in the same MSM as the main sum
     FeMem one_m = stm(fe_one<SF>());
     TRH_TRY((powers_t<SF>(wgt.p, n, (const u64*)&one_m, s)));  // all ones
-    TRH_HIP_TRY(hipMemcpy(uw.p, u_xy, 64, hipMemcpyHostToDevice));
-    TRH_HIP_TRY(hipMemcpyAsync((char*)uw.p + 64, (const char*)gw->d_xy + n * 64, 64, hipMemcpyDeviceToDevice, s));
+    TRH_HIP_TRY(hipMemcpyAsync(gwu.p, gw->d_xy, (n + 1) * 64, hipMemcpyDeviceToDevice, s));
+    TRH_HIP_TRY(hipMemcpy((char*)gwu.p + (n + 1) * 64, u_xy, 64, hipMemcpyHostToDevice));
+    TRH_TRY(msm_convert_bases(curve, gwu.p, gwuz.p, n + 2, s));
+    const size_t stride = n + 2;
 
     for (uint32_t j = 0; j < k; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
         const u32 bit = k - j - 1;
         char* pph = (char*)pp.p + half * 32;
         char* bh = (char*)b.p + half * 32;
-        // L_j and R_j as one batch of two MSMs over the resident bases g[0..n)
-        hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit);
+        // scalars of L_j (row 0) and R_j (row 1) over the bases g ‖ w ‖ u
+        hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit, stride);
         TRH_HIP_TRY(hipGetLastError());
-        u64 lr_main[24], lr_uw[24], lr[2][12];
-        TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, lrsc.p, n, 2, n, 1, s));
-        TRH_TRY(msm_finish(curve, s, lr_main, 2));
         Fe<SF> val[2], rnd[2];
         TRH_TRY((inner_product_t<SF>(pph, b.p, half, s, (u64*)&tmp)));
         val[0] = fe_load<SF>(tmp);
@@ -263,14 +263,15 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         val[1] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
-        FeMem four_sc[4] = {stm(fe_mul(val[0], z)), stm(rnd[0]), stm(fe_mul(val[1], z)), stm(rnd[1])};
-        TRH_HIP_TRY(hipMemcpy(sc2.p, four_sc, 128, hipMemcpyHostToDevice));
-        TRH_TRY(msm_enqueue(curve, uw.p, nullptr, sc2.p, 2, 2, 2, 1, s));  // [value z] U + [rand] W for both sides
-        TRH_TRY(msm_finish(curve, s, lr_uw, 2));
         for (int side = 0; side < 2; ++side) {
-            memcpy(two, lr_main + 12 * side, 96); memcpy(two + 12, lr_uw + 12 * side, 96);
-            TRH_TRY(point_sum_host(curve, two, 2, lr[side]));
+            FeMem tail[2] = {stm(rnd[side]), stm(fe_mul(val[side], z))};  // [rand] W + [value z] U
+            TRH_HIP_TRY(hipMemcpyAsync((char*)lrsc.p + (side * stride + n) * 32, tail, 64, hipMemcpyHostToDevice, s));
+            TRH_HIP_TRY(hipStreamSynchronize(s));  // `tail` is a stack buffer
         }
+        u64 lrb[24], lr[2][12];
+        TRH_TRY(msm_enqueue(curve, gwu.p, gwuz.p, lrsc.p, n + 2, 2, stride, 1, s));
+        TRH_TRY(msm_finish(curve, s, lrb, 2));
+        memcpy(lr[0], lrb, 96); memcpy(lr[1], lrb + 12, 96);
         tr->write_point(tr->ctx, lr[0]);
         tr->write_point(tr->ctx, lr[1]);
         tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
