@@ -53,6 +53,7 @@ struct TwiddleEntry {
     int field, log_n;
     u64 omega[4];
     DevBuf lo, hi;  // lo[i] = omega^i (i < 2^lo_bits), hi[i] = omega^(i << lo_bits)
+    DevBuf zlo, zhi;  // the same in the lazy domain's Montgomery form (x 2^270, < 2 m)
     int lo_bits, hi_bits;
     u64 stamp;
 };

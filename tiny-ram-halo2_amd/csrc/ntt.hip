@@ -88,6 +88,17 @@ __global__ void __launch_bounds__(256) ntt_tables_kernel(const uint4* __restrict
         store_fe<F>(t_hi + 2 * (size_t)i, r);
     }
 }
+// the same tables in the lazy domain's Montgomery form (x 2^270), values < 2 m
+template <class F>
+__global__ void __launch_bounds__(256) ntt_tables_lazy_kernel(const uint4* __restrict__ t, uint4* __restrict__ z, u32 cnt) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const Fz<F> v = fz_from_fe(load_fe<F>(t + 2 * (size_t)i));
+    u32 w[8];
+    fz_store(v, w);
+    z[2 * (size_t)i] = make_uint4(w[0], w[1], w[2], w[3]);
+    z[2 * (size_t)i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
 
 // One Stockham pass: R = 2^s, Ns = 2^log_ns (size of the sub-transforms already done).
 template <class F>
@@ -247,6 +258,193 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passg_kernel(const uint
     }
 }
 
+// ---- lazy-domain pass (the default for full tiles) -------------------------------------------
+// Same schedule as ntt_passg_kernel, but the values stay unreduced nine-limb residues (Fz) for the
+// whole pass: the input words x R (canonical Montgomery, or < 2 m from a previous pass) are taken as
+// they are, every twiddle is held in the 2^270 Montgomery form so that fz_mul(v, W) = v w carries the
+// element's own 2^256 factor through, and a butterfly is one fz_mul + one carry chain each for
+// a + t and a + K m - t: no conditional subtraction, no 16-bit round, and the LDS exchange moves the
+// nine limbs as they are (two 16-byte planes + one 4-byte plane: no pack / unpack).
+// Bounds (in units of m, inputs < 2): round 0 does stages 0..LG-1 with the trivial twiddle left out,
+// so stage v sees operands < 2^(v+1) and leaves < 2^(v+2); every later stage multiplies (t < 2) and
+// adds 2.  After s <= 9 stages the values are < 2^(LG+1) + 2 (s - LG) <= 30 (LG = 3: 28), far below the 256 m
+// that fz_mul tolerates against a twiddle < 2 m, and nine limbs hold 2^16 m.  The pass ends with
+// v - max(floor(v / 2^254) - 1, 0) m in [0, 2 m) and, on the last pass, the conditional subtraction.
+template <class F>
+__device__ __forceinline__ Fz<F> load_fz(const uint4* __restrict__ p) {
+    uint4 a = p[0], b = p[1];
+    return fz_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+template <class F>
+__device__ __forceinline__ Fz<F> lds_load_words(const uint4* lo, const uint4* hi, int idx) {
+    uint4 a = lo[idx], b = hi[idx];
+    return fz_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+template <class F>
+__device__ __forceinline__ void lds_store_words(uint4* lo, uint4* hi, int idx, const Fz<F>& v) {
+    u32 w[8];
+    fz_store(v, w);
+    lo[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+    hi[idx] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+template <class F>
+__device__ __forceinline__ Fz<F> lds_load_limbs(const uint4* pa, const uint4* pb, const u32* pc, int idx) {
+    const uint4 a = pa[idx], b = pb[idx];
+    Fz<F> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = pc[idx];
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_store_limbs(uint4* pa, uint4* pb, u32* pc, int idx, const Fz<F>& v) {
+    pa[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    pb[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    pc[idx] = v.l[8];
+}
+template <class F>
+__device__ __forceinline__ Fz<F> twiddle_z(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, u32 e, int lo_bits) {
+    const u32 el = e & ((1u << lo_bits) - 1u), eh = e >> lo_bits;
+    Fz<F> w = load_fz<F>(z_lo + 2 * (size_t)el);
+    if (eh) w = fz_mul(w, load_fz<F>(z_hi + 2 * (size_t)eh));
+    return w;
+}
+// (a, b) -> (a + b, a + K m - b), bound(b) <= K m
+template <class F, u32 K>
+__device__ __forceinline__ void bfly_z(Fz<F>& a, Fz<F>& b) {
+    const Fz<F> t = fz_add(a, b);
+    b = fz_sub<F, K>(a, b);
+    a = t;
+}
+// v < 2^6 m  ->  [0, 2 m), then [0, m) when `canonical`
+template <class F>
+__device__ __forceinline__ void fz_finish(Fz<F>& v, bool canonical) {
+    const u32 q = v.l[8] >> 14;  // floor(v / 2^254) >= floor(v / m) >= q - 1
+    const u32 qq = q ? q - 1u : 0u;
+    u64 c = 0;
+    i32 br = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) {
+        c += (u64)qq * mod_limb<F>(i);
+        const i32 d = (i32)v.l[i] - (i32)((u32)c & LIMB_MASK) + br;
+        v.l[i] = (u32)d & LIMB_MASK;
+        br = d >> 30;
+        c >>= 30;
+    }
+    if (canonical) {
+        Fe<F> t;
+#pragma unroll
+        for (int i = 0; i < NLIMBS; ++i) t.l[i] = v.l[i];
+        fe_cond_sub(t);
+#pragma unroll
+        for (int i = 0; i < NLIMBS; ++i) v.l[i] = t.l[i];
+    }
+}
+
+// stage V of round 0 (rows u, u | 2^V of the thread's G = 2^LG registers)
+template <class F, int LG, int V>
+__device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const uint4* tw_lo, const uint4* tw_hi, int s) {
+    const int sh = s - 1 - V;
+#pragma unroll
+    for (int u = 0; u < (1 << LG); ++u) {
+        if (u & (1 << V)) continue;
+        const u32 ul = (u32)(u & ((1 << V) - 1));
+        if (ul) {
+            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], lds_load_words<F>(tw_lo, tw_hi, (int)(ul << sh)));
+            bfly_z<F, 2>(x[u], x[u | (1 << V)]);
+        } else {
+            bfly_z<F, (2u << V)>(x[u], x[u | (1 << V)]);
+        }
+    }
+}
+
+template <class F, int LG, int TLOG>
+__global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
+                                                               const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last) {
+    constexpr int G = 1 << LG, T = 1 << TLOG, THREADS = T >> LG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = 1 << s;
+    const int log_c = TLOG - s;
+    const int C = 1 << log_c;
+    uint4* pa = (uint4*)smem;
+    uint4* pb = pa + T;
+    uint4* tw_lo = pb + T;  // in-tile twiddles stay in word form (8 x u32): 80 KiB per workgroup at s = 9
+    uint4* tw_hi = tw_lo + (R >> 1);
+    u32* pc = (u32*)(tw_hi + (R >> 1));
+
+    const size_t N = (size_t)1 << log_n;
+    const size_t batch_off = (size_t)blockIdx.y * N * 2;
+    in += batch_off;
+    out += batch_off;
+    const int tid = threadIdx.x;
+    const u32 c = tid & (C - 1), m = tid >> log_c;
+    const u32 j = (blockIdx.x << log_c) + c;
+    const u32 k = j & ((1u << log_ns) - 1u);
+    const size_t row_stride = N >> s;
+
+    for (int i = tid; i < (R >> 1); i += THREADS) {
+        Fz<F> w = twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits);
+        fz_finish(w, false);  // < 2 m (already), normalised
+        lds_store_words<F>(tw_lo, tw_hi, i, w);
+    }
+
+    Fz<F> x[G];
+    const int tw_shift = log_n - log_ns - s;
+#pragma unroll
+    for (int v = 0; v < G; ++v) {
+        const u32 r = m + (u32)v * (u32)(R >> LG);
+        Fz<F> val = load_fz<F>(in + 2 * ((size_t)j + (size_t)r * row_stride));
+        if (log_ns > 0) {
+            const u32 ex = (k * r) << tw_shift;
+            if (ex) val = fz_mul(val, twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
+        }
+        x[(int)(__builtin_bitreverse32((u32)v) >> (32 - LG))] = val;
+    }
+    __syncthreads();
+
+    u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;
+    u32 L = 0;
+    int stl = 0, vb = 0;
+    // round 0: compile-time twiddles 1, w4, w8, w8^3 (index 0 is left out: operand bounds 2^(v+1))
+    round0_stage_z<F, LG, 0>(x, tw_lo, tw_hi, s);
+    if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw_lo, tw_hi, s);
+    if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw_lo, tw_hi, s);
+    for (int st = LG; st < s; st += LG) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) lds_store_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
+        __syncthreads();
+        stl = st + LG <= s ? st : s - LG;
+        vb = st - stl;
+        L = m & ((1u << stl) - 1u);
+        base = L | ((m >> stl) << (stl + LG));
+#pragma unroll
+        for (int u = 0; u < G; ++u) x[u] = lds_load_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
+#pragma unroll
+        for (int v = 0; v < LG; ++v) {
+            if (v >= vb) {
+                const int sh = s - 1 - stl - v;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    if (u & (1 << v)) continue;
+                    const u32 idx = (L + ((u32)(u & ((1 << v) - 1)) << stl)) << sh;
+                    x[u | (1 << v)] = fz_mul(x[u | (1 << v)], lds_load_words<F>(tw_lo, tw_hi, (int)idx));  // idx 0 holds the lazy one
+                    bfly_z<F, 2>(x[u], x[u | (1 << v)]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const u32 rr = base + ((u32)u << stl);
+        const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
+        fz_finish(x[u], last != 0);
+        u32 w[8];
+        fz_store(x[u], w);
+        out[2 * dst] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[2 * dst + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t rows, size_t row_len, size_t active_len,
                                                                    const uint4* __restrict__ factors, u32 period) {
@@ -273,7 +471,7 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
         for (size_t i = 1; i < c.twiddles.size(); ++i)
             if (c.twiddles[i]->stamp < c.twiddles[victim]->stamp) victim = i;
         TRH_HIP_TRY(hipDeviceSynchronize());
-        c.twiddles[victim]->lo.release(); c.twiddles[victim]->hi.release();
+        c.twiddles[victim]->lo.release(); c.twiddles[victim]->hi.release(); c.twiddles[victim]->zlo.release(); c.twiddles[victim]->zhi.release();
         delete c.twiddles[victim];
         c.twiddles.erase(c.twiddles.begin() + victim);
     }
@@ -284,6 +482,8 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     t->stamp = ++c.stamp;
     int rc = t->lo.ensure(((size_t)32 << t->lo_bits) + 32 * 64);
     if (rc == TRH_OK) rc = t->hi.ensure((size_t)32 << t->hi_bits);
+    if (rc == TRH_OK) rc = t->zlo.ensure((size_t)32 << t->lo_bits);
+    if (rc == TRH_OK) rc = t->zhi.ensure((size_t)32 << t->hi_bits);
     if (rc != TRH_OK) { delete t; return rc; }
     // omega^(2^b) on the host (shared field code), staged behind the lo table
     FeMem pw[32];
@@ -293,6 +493,8 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     TRH_HIP_TRY(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
     const u32 cnt = 1u << (t->lo_bits > t->hi_bits ? t->lo_bits : t->hi_bits);
     hipLaunchKernelGGL((ntt_tables_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, s, d_pw, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits, t->hi_bits);
+    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
+    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipStreamSynchronize(s));  // pw is a stack buffer
     c.twiddles.push_back(t);
@@ -349,7 +551,13 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
             static const int lg = getenv("TRH_NTT_LG") ? atoi(getenv("TRH_NTT_LG")) : 2;  // tuning knob: rows per thread = 2^lg
             const dim3 grid((unsigned)tiles, (unsigned)nb);
-            if (tlog == 12)
+            static const int lazy = getenv("TRH_NTT_LAZY") ? atoi(getenv("TRH_NTT_LAZY")) : 1;
+            const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
+            if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1));
+            else if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1));
+            else if (tlog == 12)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
@@ -378,6 +586,11 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
         const int big_lds = (32 << 12) + (32 << 10);  // 160 KiB: the whole LDS of a CU
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -399,7 +612,7 @@ int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, si
 
 void ntt_release_tables() {
     Ctx& c = ctx();
-    for (TwiddleEntry* t : c.twiddles) { t->lo.release(); t->hi.release(); delete t; }
+    for (TwiddleEntry* t : c.twiddles) { t->lo.release(); t->hi.release(); t->zlo.release(); t->zhi.release(); delete t; }
     c.twiddles.clear();
     c.ntt_tmp.release();
 }
