@@ -341,6 +341,20 @@ __device__ __forceinline__ void fz_finish(Fz<F>& v, bool canonical) {
     }
 }
 
+// inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), lazy form
+template <class F>
+__global__ void __launch_bounds__(256) ntt_direct_table_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
+                                                               int log_ns, int s, int tw_shift) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (log_ns + s))) return;
+    const u32 k = (u32)i & ((1u << log_ns) - 1u), r = (u32)(i >> log_ns);
+    Fz<F> w = twiddle_z<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits);
+    u32 o[8];
+    fz_store(w, o);
+    d[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    d[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // stage V of round 0 (rows u, u | 2^V of the thread's G = 2^LG registers)
 template <class F, int LG, int V>
 __device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const uint4* tw_lo, const uint4* tw_hi, int s) {
@@ -360,7 +374,8 @@ __device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const uint4*
 
 template <class F, int LG, int TLOG>
 __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
-                                                               const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last) {
+                                                               const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last,
+                                                               const uint4* __restrict__ direct) {
     constexpr int G = 1 << LG, T = 1 << TLOG, THREADS = T >> LG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
@@ -384,7 +399,6 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
 
     for (int i = tid; i < (R >> 1); i += THREADS) {
         Fz<F> w = twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits);
-        fz_finish(w, false);  // < 2 m (already), normalised
         lds_store_words<F>(tw_lo, tw_hi, i, w);
     }
 
@@ -396,7 +410,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
         Fz<F> val = load_fz<F>(in + 2 * ((size_t)j + (size_t)r * row_stride));
         if (log_ns > 0) {
             const u32 ex = (k * r) << tw_shift;
-            if (ex) val = fz_mul(val, twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
+            if (ex) val = fz_mul(val, direct ? load_fz<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
         }
         x[(int)(__builtin_bitreverse32((u32)v) >> (32 - LG))] = val;
     }
@@ -463,6 +477,30 @@ TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
     return nullptr;
 }
 
+// pass plan: log_n split into passes of <= MAX_PASS_LOG stages on 2^tlog-element tiles
+void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
+    // With TRH_NTT_TILE=12 sizes 2^19..2^22 run as TWO passes of <= 11 stages on 4096-element tiles (all 160 KiB of
+    // LDS, one workgroup of 1024 threads per CU): one inter-pass twiddle and one HBM round trip less than
+    // three passes on 2048-element tiles -- but only one workgroup per CU; measured equal at 2^22, so off by default.
+    static const int big_tile = getenv("TRH_NTT_TILE") ? atoi(getenv("TRH_NTT_TILE")) == 12 : 0;
+    int P = 0, tlog = TILE_LOG;
+    if (log_n <= TILE_LOG) { sizes[P++] = log_n; }
+    else if (big_tile && log_n > 2 * MAX_PASS_LOG && log_n <= 22) {
+        tlog = 12; P = 2;
+        sizes[0] = (log_n + 1) / 2; sizes[1] = log_n - sizes[0];
+    } else {
+        P = (log_n + MAX_PASS_LOG - 1) / MAX_PASS_LOG;
+        if (P < 2) P = 2;
+        int rem = log_n;
+        for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
+    }
+    *n_passes = P; *tile_log = tlog;
+}
+bool lazy_enabled() {
+    static const int lazy = getenv("TRH_NTT_LAZY") ? atoi(getenv("TRH_NTT_LAZY")) : 1;
+    return lazy != 0;
+}
+
 template <class F>
 int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** out) {
     Ctx& c = ctx();
@@ -471,7 +509,7 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
         for (size_t i = 1; i < c.twiddles.size(); ++i)
             if (c.twiddles[i]->stamp < c.twiddles[victim]->stamp) victim = i;
         TRH_HIP_TRY(hipDeviceSynchronize());
-        c.twiddles[victim]->lo.release(); c.twiddles[victim]->hi.release(); c.twiddles[victim]->zlo.release(); c.twiddles[victim]->zhi.release();
+        c.twiddles[victim]->release_all();
         delete c.twiddles[victim];
         c.twiddles.erase(c.twiddles.begin() + victim);
     }
@@ -495,8 +533,26 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     hipLaunchKernelGGL((ntt_tables_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, s, d_pw, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits, t->hi_bits);
     hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
     hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
+    // direct inter-pass tables for the lazy passes (pass p >= 1 reads Ns * R entries, coalesced): up to 1 GiB per pass
+    static const int direct_on = getenv("TRH_NTT_DIRECT") ? atoi(getenv("TRH_NTT_DIRECT")) : 1;
+    int sizes[8], P, tlog;
+    plan_passes(log_n, sizes, &P, &tlog);
+    if (direct_on && lazy_enabled() && tlog == TILE_LOG && log_n >= TILE_LOG) {
+        int log_ns = sizes[0];
+        for (int p = 1; p < P && rc == TRH_OK; ++p) {
+            const size_t entries = (size_t)1 << (log_ns + sizes[p]);
+            if (entries * 32 <= ((size_t)1 << 30)) {
+                rc = t->direct[p].ensure(entries * 32);
+                if (rc == TRH_OK)
+                    hipLaunchKernelGGL((ntt_direct_table_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
+                                       t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
+            }
+            log_ns += sizes[p];
+        }
+    }
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipStreamSynchronize(s));  // pw is a stack buffer
+    if (rc != TRH_OK) { t->release_all(); delete t; return rc; }
     c.twiddles.push_back(t);
     *out = t;
     return TRH_OK;
@@ -509,21 +565,8 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega);
     if (!t) TRH_TRY(build_tables<F>((int)log_n, omega, s, &t));
 
-    // pass plan.  With TRH_NTT_TILE=12 sizes 2^19..2^22 run as TWO passes of <= 11 stages on 4096-element tiles (all 160 KiB of
-    // LDS, one workgroup of 1024 threads per CU): one inter-pass twiddle and one HBM round trip less than
-    // three passes on 2048-element tiles -- but only one workgroup per CU; measured equal at 2^22, so off by default.
-    static const int big_tile = getenv("TRH_NTT_TILE") ? atoi(getenv("TRH_NTT_TILE")) == 12 : 0;  // measured: no faster than three small-tile passes
     int sizes[8], P = 0, tlog = TILE_LOG;
-    if ((int)log_n <= TILE_LOG) { sizes[P++] = (int)log_n; }
-    else if (big_tile && (int)log_n > 2 * MAX_PASS_LOG && (int)log_n <= 22) {
-        tlog = 12; P = 2;
-        sizes[0] = ((int)log_n + 1) / 2; sizes[1] = (int)log_n - sizes[0];
-    } else {
-        P = ((int)log_n + MAX_PASS_LOG - 1) / MAX_PASS_LOG;
-        if (P < 2) P = 2;
-        int rem = (int)log_n;
-        for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
-    }
+    plan_passes((int)log_n, sizes, &P, &tlog);
     const size_t N = (size_t)1 << log_n;
     uint4* a = (uint4*)a_dev;
     uint4* tmp = nullptr;
@@ -551,12 +594,13 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
             static const int lg = getenv("TRH_NTT_LG") ? atoi(getenv("TRH_NTT_LG")) : 2;  // tuning knob: rows per thread = 2^lg
             const dim3 grid((unsigned)tiles, (unsigned)nb);
-            static const int lazy = getenv("TRH_NTT_LAZY") ? atoi(getenv("TRH_NTT_LAZY")) : 1;
+            const bool lazy = lazy_enabled();
+            const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
             const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
             if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1));
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
             else if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1));
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
             else if (tlog == 12)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
@@ -612,7 +656,7 @@ int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, si
 
 void ntt_release_tables() {
     Ctx& c = ctx();
-    for (TwiddleEntry* t : c.twiddles) { t->lo.release(); t->hi.release(); t->zlo.release(); t->zhi.release(); delete t; }
+    for (TwiddleEntry* t : c.twiddles) { t->release_all(); delete t; }
     c.twiddles.clear();
     c.ntt_tmp.release();
 }
