@@ -356,15 +356,15 @@ __global__ void __launch_bounds__(256) ntt_direct_table_kernel(const uint4* __re
 }
 
 // stage V of round 0 (rows u, u | 2^V of the thread's G = 2^LG registers)
-template <class F, int LG, int V>
-__device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const uint4* tw_lo, const uint4* tw_hi, int s) {
+template <class F, int LG, int V, class TW>
+__device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const TW& tw, int s) {
     const int sh = s - 1 - V;
 #pragma unroll
     for (int u = 0; u < (1 << LG); ++u) {
         if (u & (1 << V)) continue;
         const u32 ul = (u32)(u & ((1 << V) - 1));
         if (ul) {
-            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], lds_load_words<F>(tw_lo, tw_hi, (int)(ul << sh)));
+            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], tw((int)(ul << sh)));
             bfly_z<F, 2>(x[u], x[u | (1 << V)]);
         } else {
             bfly_z<F, (2u << V)>(x[u], x[u | (1 << V)]);
@@ -372,7 +372,23 @@ __device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const uint4*
     }
 }
 
-template <class F, int LG, int TLOG>
+// in-tile twiddle table in LDS: nine limbs as they are (TWL, fits next to the data for s <= 8) or the eight memory words
+template <class F, bool TWL>
+struct TileTwiddles {
+    uint4* a;
+    uint4* b;
+    u32* c;
+    __device__ __forceinline__ Fz<F> operator()(int idx) const {
+        if constexpr (TWL) return lds_load_limbs<F>(a, b, c, idx);
+        else return lds_load_words<F>(a, b, idx);
+    }
+    __device__ __forceinline__ void put(int idx, const Fz<F>& v) const {
+        if constexpr (TWL) lds_store_limbs<F>(a, b, c, idx, v);
+        else lds_store_words<F>(a, b, idx, v);
+    }
+};
+
+template <class F, int LG, int TLOG, bool TWL>
 __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
                                                                const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last,
                                                                const uint4* __restrict__ direct) {
@@ -383,9 +399,10 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     const int C = 1 << log_c;
     uint4* pa = (uint4*)smem;
     uint4* pb = pa + T;
-    uint4* tw_lo = pb + T;  // in-tile twiddles stay in word form (8 x u32): 80 KiB per workgroup at s = 9
+    uint4* tw_lo = pb + T;
     uint4* tw_hi = tw_lo + (R >> 1);
     u32* pc = (u32*)(tw_hi + (R >> 1));
+    const TileTwiddles<F, TWL> tw{tw_lo, tw_hi, pc + T};  // word form at s = 9: exactly 80 KiB per workgroup, two per CU
 
     const size_t N = (size_t)1 << log_n;
     const size_t batch_off = (size_t)blockIdx.y * N * 2;
@@ -398,8 +415,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     const size_t row_stride = N >> s;
 
     for (int i = tid; i < (R >> 1); i += THREADS) {
-        Fz<F> w = twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits);
-        lds_store_words<F>(tw_lo, tw_hi, i, w);
+        tw.put(i, twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
     }
 
     Fz<F> x[G];
@@ -420,9 +436,9 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     u32 L = 0;
     int stl = 0, vb = 0;
     // round 0: compile-time twiddles 1, w4, w8, w8^3 (index 0 is left out: operand bounds 2^(v+1))
-    round0_stage_z<F, LG, 0>(x, tw_lo, tw_hi, s);
-    if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw_lo, tw_hi, s);
-    if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw_lo, tw_hi, s);
+    round0_stage_z<F, LG, 0>(x, tw, s);
+    if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw, s);
+    if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw, s);
     for (int st = LG; st < s; st += LG) {
 #pragma unroll
         for (int u = 0; u < G; ++u) lds_store_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
@@ -441,7 +457,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
                 for (int u = 0; u < G; ++u) {
                     if (u & (1 << v)) continue;
                     const u32 idx = (L + ((u32)(u & ((1 << v) - 1)) << stl)) << sh;
-                    x[u | (1 << v)] = fz_mul(x[u | (1 << v)], lds_load_words<F>(tw_lo, tw_hi, (int)idx));  // idx 0 holds the lazy one
+                    x[u | (1 << v)] = fz_mul(x[u | (1 << v)], tw((int)idx));  // idx 0 holds the lazy one
                     bfly_z<F, 2>(x[u], x[u | (1 << v)]);
                 }
             }
@@ -597,10 +613,12 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const bool lazy = lazy_enabled();
             const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
             const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
-            if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
-            else if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
+            if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= 8)
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, true>), grid, dim3(TILE >> 2), ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1)), s, src, o, (int)log_n, sp, log_ns,
+                                   t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
+            else if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp == 9)
+                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, false>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns,
+                                   t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
             else if (tlog == 12)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
@@ -631,10 +649,10 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
         const int big_lds = (32 << 12) + (32 << 10);  // 160 KiB: the whole LDS of a CU
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
