@@ -414,10 +414,6 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     const u32 k = j & ((1u << log_ns) - 1u);
     const size_t row_stride = N >> s;
 
-    for (int i = tid; i < (R >> 1); i += THREADS) {
-        tw.put(i, twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
-    }
-
     Fz<F> x[G];
     const int tw_shift = log_n - log_ns - s;
 #pragma unroll
@@ -430,6 +426,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
         }
         x[(int)(__builtin_bitreverse32((u32)v) >> (32 - LG))] = val;
     }
+    for (int i = tid; i < (R >> 1); i += THREADS) tw.put(i, twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
     __syncthreads();
 
     u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;
