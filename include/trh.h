@@ -79,6 +79,13 @@ int trh_bases_download(trh_bases_t b, size_t offset, size_t n, uint64_t* xy_host
 const void* trh_bases_device_ptr(trh_bases_t b);
 size_t trh_bases_len(trh_bases_t b);
 void trh_bases_destroy(trh_bases_t b);
+/* Fixed-base tables for an owned set (Params.g / g_lagrange serve ~500 commitments per proof): stores
+ * 2^(c j) * P_i for every window j (W x n x 64 B of HBM), after which a full-range MSM over the handle puts the
+ * digits of all windows into ONE bucket set -- one bucket reduction per MSM instead of W, wider windows, no
+ * Horner pass over windows.  window_bits 0 = automatic (<= 17); requires W * n <= 2^24.  Results are the same
+ * group elements; MSMs over a sub-range (offset != 0 or n < len) keep using the per-window path.           */
+int trh_bases_precompute(trh_bases_t b, int window_bits);
+int trh_bases_precomputed_window_bits(trh_bases_t b); /* 0 when no table is attached */
 
 /* MSM over bases[offset .. offset+n) with host scalars (Params::commit / commit_lagrange) */
 int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n,

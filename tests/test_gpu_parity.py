@@ -366,3 +366,51 @@ def test_msm_witness_like_scalars(kind):
     g = np.array(cv.affine_limbs(cv.generator), np.uint64)
     want = aff(curve, cpu_ref.scalar_mul(curve, g, np.array(o.int_to_limbs(total), np.uint64)))
     assert (got[:8] == want).all()
+
+
+# ---------------------------------------------------------------------------------------
+# fixed-base tables (trh_bases_precompute): same group elements as the per-window path and the oracle
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("cbits", [0, 6, 11, 16, 17, 18])
+def test_msm_fixed_base_tables(curve, cbits):
+    n = 3001
+    sc, bases = _edge_inputs(curve, n, 0xF1BA5E + cbits)
+    b = api.Bases.from_host(curve, bases)
+    plain = b.msm(sc)
+    used = b.precompute(cbits)
+    assert used == (cbits or 9)  # automatic: log2(n) - 2
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
+    got = b.msm(sc)
+    assert (got == plain).all() and (got[:8] == want).all()
+    # a sub-range keeps using the per-window path over the same handle
+    part = b.msm(sc[100:900], offset=100)
+    assert (part[:8] == aff(curve, cpu_ref.best_multiexp(curve, sc[100:900], bases[100:900], threads=8))).all()
+
+
+def test_msm_fixed_base_batch_and_skew():
+    curve, n, batch = "vesta", (1 << 12) + 1, 6
+    bases_h = cpu_ref.gen_bases(curve, 91, 5, n, threads=4)
+    b = api.Bases.from_host(curve, bases_h)
+    f = o.CURVES[curve].scalar
+    sc = synth.field_elements(0xF1BA7C, n * batch).reshape(batch, n, 4).copy()
+    sc[1, :] = np.array(f.limbs(1), np.uint64)          # all ones: one bucket of the lowest window holds everything
+    sc[2, :] = np.array(f.limbs(f.m - 1), np.uint64)    # -1: carries ripple through every window
+    sc[3, :] = 0
+    sc[4, : n // 2] = np.array(f.limbs(3), np.uint64)
+    d = api.DeviceBuffer.from_host(sc)
+    plain = b.msm_batch_dev(d, n, batch)
+    assert b.precompute(0) == 10
+    got = b.msm_batch_dev(d, n, batch)
+    assert (got == plain).all()
+    for k in range(batch):
+        assert (got[k, :8] == aff(curve, cpu_ref.best_multiexp(curve, sc[k], bases_h, threads=8))).all(), k
+
+
+def test_msm_fixed_base_limits():
+    b = api.Bases.generate("pallas", 5, 7, 1 << 10)
+    with pytest.raises(api.TrhError):
+        b.precompute(19)  # wider than the fixed-base sort supports
+    w = api.Bases.wrap_device("pallas", api.lib().trh_bases_device_ptr(b.handle), 1 << 10)
+    with pytest.raises(api.TrhError):
+        w.precompute(0)  # wrapped memory is not immutable

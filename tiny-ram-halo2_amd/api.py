@@ -77,6 +77,8 @@ _SIGNATURES = {
     "trh_bases_device_ptr": ([_vp], _vp),
     "trh_bases_len": ([_vp], ctypes.c_size_t),
     "trh_bases_destroy": ([_vp], None),
+    "trh_bases_precompute": ([_vp, ctypes.c_int], ctypes.c_int),
+    "trh_bases_precomputed_window_bits": ([_vp], ctypes.c_int),
     "trh_msm": ([_vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_int, _u64p], ctypes.c_int),
     "trh_msm_dev": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp, _u64p], ctypes.c_int),
     "trh_msm_dev_enqueue": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp], ctypes.c_int),
@@ -359,6 +361,11 @@ class Bases:
 
     def __len__(self):
         return int(lib().trh_bases_len(self.handle))
+
+    def precompute(self, window_bits: int = 0) -> int:
+        """Attach the fixed-base table (2^(c j) P_i for all windows j); returns the window width used."""
+        _check(lib().trh_bases_precompute(self.handle, window_bits))
+        return int(lib().trh_bases_precomputed_window_bits(self.handle))
 
     def download(self, offset: int = 0, n: int | None = None) -> np.ndarray:
         n = len(self) - offset if n is None else n

@@ -181,6 +181,7 @@ void trh_shutdown(void) {
     (void)hipDeviceSynchronize();
     msm_release();
     ntt_release_tables();
+    for (DevBuf& d : ctx().ipa) d.release();
     c.io.release();
     c.factors.release();
     c.pfft.release();
@@ -231,6 +232,7 @@ void trh_bases_destroy(trh_bases_t b) {
     if (!b) return;
     if (b->owned && b->d_xy) (void)hipFree(b->d_xy);
     if (b->d_z) (void)hipFree(b->d_z);
+    if (b->d_table) (void)hipFree(b->d_table);
     delete b;
 }
 
@@ -245,6 +247,39 @@ static const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
     }
     return (const char*)b->d_z + offset * 64;
 }
+
+// the fixed-base table covers the whole set: used for full-range MSMs unless a window width is forced
+static const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n) {
+    return (b->d_table && offset == 0 && n == b->n && ctx().window_override == 0) ? &b->fb : nullptr;
+}
+
+int trh_bases_precompute(trh_bases_t b, int window_bits) {
+    TRH_TRY(require_init());
+    if (!b) { set_error("bases_precompute: null handle"); return TRH_EINVAL; }
+    if (!b->owned) { set_error("bases_precompute: wrapped device memory may change under the table; create an owned set"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (b->d_table) { (void)hipFree(b->d_table); b->d_table = nullptr; b->fb = MsmFixedBase{nullptr, 0, 0}; }
+    if (b->n == 0) return TRH_OK;
+    int cb = window_bits;
+    if (cb == 0) {  // wide windows: the single reduction costs 2^(c-1) additions per MSM against n * ceil(255 / c) mixed adds
+        int l = 0;
+        while (((size_t)2 << l) <= b->n) ++l;
+        cb = l - 2 < 6 ? 6 : l - 2 > 17 ? 17 : l - 2;  // measured at 2^18 (batch 32): c = 16 beats 15 / 17
+    }
+    if (!msm_fixed_base_fits(b->n, cb)) { set_error("bases_precompute: window width %d with %zu bases is outside the fixed-base range (W * n <= 2^24, c <= 18)", cb, b->n); return TRH_EINVAL; }
+    const int W = msm_fixed_base_windows(cb);
+    void* t = nullptr;
+    hipError_t e = hipMalloc(&t, (size_t)W * b->n * 64 + 64);
+    if (e != hipSuccess) { set_error("bases_precompute: hipMalloc(%zu): %s", (size_t)W * b->n * 64, hipGetErrorString(e)); return TRH_ENOMEM; }
+    int rc = msm_build_table(b->curve, b->d_xy, b->n, cb, t, 0);
+    if (rc == TRH_OK && hipStreamSynchronize(0) != hipSuccess) { set_error("bases_precompute: table kernel failed"); rc = TRH_EHIP; }
+    if (rc != TRH_OK) { (void)hipFree(t); return rc; }
+    b->d_table = t;
+    b->fb = MsmFixedBase{t, cb, W};
+    return TRH_OK;
+}
+int trh_bases_precomputed_window_bits(trh_bases_t b) { return b && b->d_table ? b->fb.c : 0; }
 
 static int msm_args(trh_bases_t bases, size_t offset, const void* scalars, size_t n, size_t batch, void* out) {
     TRH_TRY(require_init());
@@ -261,7 +296,7 @@ int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size
     std::lock_guard<std::mutex> lk(c.mu);
     TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
     if (n) TRH_HIP_TRY(hipMemcpy(c.msm.scalars.p, scalars_host, n * 32, hipMemcpyHostToDevice));
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, 0), c.msm.scalars.p, n, 1, n, mont, 0));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, 0), c.msm.scalars.p, n, 1, n, mont, 0, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, 0, out, 1);
 }
 
@@ -270,7 +305,7 @@ int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_de
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, &dummy));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream);
+    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n));
 }
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out[12]) {
     TRH_TRY(require_init());
@@ -283,14 +318,14 @@ int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, out));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
 }
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch, int mont, void* stream, uint64_t* out) {
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, batch, out));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, batch, n, mont, (hipStream_t)stream));
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, batch, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
 }
 int trh_msm_set_window_bits(int cbits) {

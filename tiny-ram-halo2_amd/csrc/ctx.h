@@ -102,6 +102,7 @@ struct Ctx {
     DevBuf io;  // staging for host-pointer NTT entry points
     DevBuf pfft;  // curve-point FFT work array + twiddle scalars
     DevBuf scan, scan2;  // prefix-product block totals / batch-inversion running products
+    DevBuf ipa[7];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy), kept across proofs
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
     std::vector<TwiddleEntry*> twiddles;
@@ -115,8 +116,17 @@ int require_init();
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s);
 void ntt_release_tables();
 // msm.hip
+// fixed-base table of an owned base set: table[j * n + i] = 2^(c j) * P_i (lazy affine form), j < W.  With it the
+// digits of ALL windows go into one bucket set: one reduction per MSM instead of W, no Horner over windows.
+struct MsmFixedBase {
+    const void* table;
+    int c, W;
+};
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
-                size_t scalar_stride_elems, int mont, hipStream_t s);
+                size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr);
+int msm_fixed_base_windows(int c);
+bool msm_fixed_base_fits(size_t n, int c);
+int msm_build_table(int curve, const void* bases_dev, size_t n, int c, void* table_dev, hipStream_t s);
 int msm_convert_bases(int curve, const void* in_dev, void* out_dev, size_t n, hipStream_t s);
 int msm_finish(int curve, hipStream_t s, u64* out_xyz, size_t batch);
 int point_sum_host(int curve, const u64* pts, size_t count, u64* out);
@@ -131,4 +141,6 @@ struct trh_bases {
     size_t n;
     bool owned;
     void* d_z = nullptr;  // owned (immutable) sets: the bases converted once to the lazy Montgomery domain
+    void* d_table = nullptr;  // trh_bases_precompute: W x n shifted copies (see MsmFixedBase)
+    trh::MsmFixedBase fb{nullptr, 0, 0};
 };

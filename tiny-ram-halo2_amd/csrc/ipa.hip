@@ -188,16 +188,6 @@ int axpy_t(void* y, const void* x, size_t n, const FeMem& c_mont, hipStream_t s)
 // device.  Host-side scalar arithmetic uses the shared field code; the transcript and the prover's
 // randomness are callbacks into the caller (BLAKE2b transcript and OsRng on the Rust side).
 // ---------------------------------------------------------------------------------------
-struct DevMem {  // frees on scope exit
-    void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e != hipSuccess) { set_error("ipa: hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); p = nullptr; return TRH_ENOMEM; }
-        return TRH_OK;
-    }
-};
-
 template <class SF, class BF>
 int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t k, const void* p_poly_dev, const u64* p_blind_m, const u64* x3_m,
                        const void* s_poly_dev, const u64* s_blind_m, const trh_transcript_t* tr, trh_rng_scalar_fn rng, void* rng_ctx,
@@ -207,9 +197,11 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     auto stm = [](const Fe<SF>& v) { FeMem m; fe_store(v, m); return m; };
     const Fe<SF> x3 = ld(x3_m), p_blind = ld(p_blind_m), s_blind = ld(s_blind_m);
 
-    DevMem b, sp, pp, wgt, lrsc, gwu, gwuz;
-    TRH_TRY(b.alloc(n * 32)); TRH_TRY(sp.alloc((n + 1) * 32)); TRH_TRY(pp.alloc(n * 32)); TRH_TRY(wgt.alloc(n * 32)); TRH_TRY(lrsc.alloc(2 * (n + 2) * 32));
-    TRH_TRY(gwu.alloc((n + 2) * 64)); TRH_TRY(gwuz.alloc((n + 2) * 64));
+    // scratch kept in the context: a hipMalloc / hipFree pair per vector costs more than several rounds
+    DevBuf* sc = ctx().ipa;
+    DevBuf &b = sc[0], &sp = sc[1], &pp = sc[2], &wgt = sc[3], &lrsc = sc[4], &gwu = sc[5], &gwuz = sc[6];
+    TRH_TRY(b.ensure(n * 32)); TRH_TRY(sp.ensure((n + 1) * 32)); TRH_TRY(pp.ensure(n * 32)); TRH_TRY(wgt.ensure(n * 32)); TRH_TRY(lrsc.ensure(2 * (n + 2) * 32));
+    TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * 64));
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
     // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended

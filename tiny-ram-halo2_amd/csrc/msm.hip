@@ -29,6 +29,7 @@ namespace trh {
 namespace {
 
 constexpr int MAX_C = 16;
+constexpr int MAX_C_FIXED = 18;  // fixed-base tables: one bucket set per MSM, so wider windows pay
 constexpr u32 SIGN_BIT = 0x80000000u;
 
 inline int ilog2_floor(size_t n) {
@@ -54,11 +55,13 @@ inline int num_windows(int c) { return 255 / c + 1; }
 // ---------------------------------------------------------------------------------------
 template <class SF>
 __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W,
-                                                         u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds, size_t sstride) {
+                                                         u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds, size_t sstride,
+                                                         int one_row /* fixed-base mode: all windows share one histogram */) {
     const size_t z = blockIdx.z;  // batch item
-    scalars += z * sstride * 2; digits += z * (size_t)W * n; bin_counts += z * (size_t)W * nbins;
-    extern __shared__ u32 lhist[];  // W * nbins counters when use_lds
-    const u32 total = (u32)W * nbins;
+    const u32 rows = one_row ? 1u : (u32)W;
+    scalars += z * sstride * 2; digits += z * (size_t)W * n; bin_counts += z * (size_t)rows * nbins;
+    extern __shared__ u32 lhist[];  // rows * nbins counters when use_lds
+    const u32 total = rows * nbins;
     if (use_lds) {
         for (u32 k = threadIdx.x; k < total; k += blockDim.x) lhist[k] = 0;
         __syncthreads();
@@ -80,9 +83,9 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
             else { bucket = raw; carry = 0; }
             digits[(size_t)j * n + i] = bucket ? (bucket | sign) : 0u;
             if (bucket) {
-                const u32 bin = (bucket - 1u) >> k2;
-                if (use_lds) atomicAdd(&lhist[(u32)j * nbins + bin], 1u);
-                else atomicAdd(&bin_counts[(size_t)j * nbins + bin], 1u);
+                const u32 bin = (bucket - 1u) >> k2, row = one_row ? 0u : (u32)j;
+                if (use_lds) atomicAdd(&lhist[row * nbins + bin], 1u);
+                else atomicAdd(&bin_counts[(size_t)row * nbins + bin], 1u);
             }
         }
     }
@@ -611,22 +614,53 @@ __global__ void __launch_bounds__(256) bases_generate_kernel(u64 s0, u64 d, u64 
     store_fe4(p + 2, a.y);
 }
 
+// fixed-base table: out[j * n + i] = 2^(c j) * P_i in the lazy affine form (identity stays all-zero)
+template <class BF>
+__global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict__ bases, uint4* __restrict__ out, size_t n, int c, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<BF> a;
+    {
+        const uint4* p = bases + i * 4;
+        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        a.x = fe_load<BF>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w);
+        a.y = fe_load<BF>(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
+    }
+    for (int j = 0; j < W; ++j) {
+        if (j) {
+            XYZZ<BF> acc = xyzz_dbl_affine(a);
+            for (int k = 1; k < c; ++k) acc = xyzz_dbl(acc);
+            a = xyzz_to_affine(acc);
+        }
+        u32 wx[8], wy[8];
+        fz_store(fz_from_fe(a.x), wx);
+        fz_store(fz_from_fe(a.y), wy);
+        uint4* q = out + ((size_t)j * n + i) * 4;
+        q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
+        q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+    }
+}
+
 template <class SF, class BF>
-int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
+int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
     MsmLane& L = m.lane;
-    const int cb = choose_window_bits(n);
-    const int W = num_windows(cb);
+    if (fb && (n == 0 || !msm_fixed_base_fits(n, fb->c))) fb = nullptr;
+    const int cb = fb ? fb->c : choose_window_bits(n);
+    const int W = fb ? fb->W : num_windows(cb);  // windows of the recoding
+    // fixed-base mode: the W x n digits are one flat list over the W x n table entries -> ONE bucket set
+    const int Ws = fb ? 1 : W;
+    const size_t ns = fb ? (size_t)W * n : n;
     const u32 nbk = 1u << (cb - 1), nb1 = nbk + 1;
     // sort geometry: bucket - 1 = bin << k2 | sub; the partitioned entry packs sub above the index
     int idx_bits = 1;
-    while (((size_t)1 << idx_bits) < n) ++idx_bits;
+    while (((size_t)1 << idx_bits) < ns) ++idx_bits;
     int k2 = cb - 1 < 7 ? cb - 1 : 7;
     if (k2 > 31 - idx_bits) k2 = 31 - idx_bits;
     const int k1 = cb - 1 - k2;
     const u32 nbins = 1u << k1;
-    const size_t recode_lds = (size_t)W * nbins * 4;
+    const size_t recode_lds = (size_t)Ws * nbins * 4;
     const int recode_use_lds = recode_lds <= 64 * 1024;
     // independent batch items (one MSM per column of create_proof, same bases) are processed
     // `chunk` at a time by the SAME launches (blockIdx.z = item), so the latency-bound sort and
@@ -642,39 +676,39 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // the slice offset, so long slices do less work per bucket but are a long serial chain: a lone MSM
     // (latency-bound) gets 2048 threads per window, a batch (throughput-bound) as few as 256
     u32 tpw = 2048;
-    while (tpw > 256 && (size_t)W * tpw * chunk > ((size_t)1 << 17)) tpw >>= 1;
+    while (tpw > 256 && (size_t)Ws * tpw * chunk > ((size_t)1 << 17)) tpw >>= 1;
     if (tpw > nbk) tpw = nbk;
     const u32 slice = nbk / tpw;
     const u32 rblocks = (tpw + 255) / 256;
     // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 128 entries each
     u32 seg_len = 128;
-    while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+    while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;  // W * n == Ws * ns
     if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len = (u32)v; }  // tuning knob
-    const u32 nseg = (u32)((n + seg_len - 1) / seg_len);
+    const u32 nseg = (u32)((ns + seg_len - 1) / seg_len);
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
-    const size_t max_heavy = (size_t)W * nseg / HEAVY_PIECES + 1;
+    const size_t max_heavy = (size_t)Ws * nseg / HEAVY_PIECES + 1;
     const u32 heavy_stride = (u32)(max_heavy + 1);
     const unsigned heavy_blocks = (unsigned)(max_heavy < 256 ? max_heavy : 256);
 
     TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
-    TRH_TRY(L.counts.ensure(chunk * W * nbins * 4));
-    TRH_TRY(L.bin_starts.ensure(chunk * W * nbins * 4));
-    TRH_TRY(L.starts.ensure(chunk * W * nb1 * 4));
-    TRH_TRY(L.bucket_cnt.ensure(chunk * W * nb1 * 4));
-    TRH_TRY(L.ends.ensure(chunk * W * nb1 * 4));
-    TRH_TRY(L.seg_bucket.ensure(chunk * W * nseg * 4 + 16));
-    TRH_TRY(L.first.ensure(chunk * W * nseg * sizeof(XYZZzMem)));
-    TRH_TRY(L.last.ensure(chunk * W * nseg * sizeof(XYZZzMem)));
-    TRH_TRY(L.direct.ensure(chunk * W * nb1 * sizeof(XYZZzMem)));
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4));
+    TRH_TRY(L.bin_starts.ensure(chunk * Ws * nbins * 4));
+    TRH_TRY(L.starts.ensure(chunk * Ws * nb1 * 4));
+    TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4));
+    TRH_TRY(L.ends.ensure(chunk * Ws * nb1 * 4));
+    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * nseg * 4 + 16));
+    TRH_TRY(L.first.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
     TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
-    TRH_TRY(L.buckets.ensure(chunk * W * nbk * sizeof(XYZZMem)));
-    TRH_TRY(L.partials.ensure(chunk * W * rblocks * sizeof(XYZZMem)));
-    if (!bases_z) TRH_TRY(m.bases_z.ensure(n * 64 + 64));
-    const uint4* bz = bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
-    TRH_TRY(m.window_sums.ensure(batch * W * sizeof(XYZZMem)));
-    const size_t hs = batch * W * sizeof(XYZZMem);
+    TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZMem)));
+    TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZMem)));
+    if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * 64 + 64));
+    const uint4* bz = fb ? (const uint4*)fb->table : bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
+    TRH_TRY(m.window_sums.ensure(batch * Ws * sizeof(XYZZMem)));
+    const size_t hs = batch * Ws * sizeof(XYZZMem);
     if (hs > m.host_sums_cap) {
         if (m.host_sums) (void)hipHostFree(m.host_sums);
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
@@ -685,7 +719,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
         part_attr = true;
     }
-    const bool timing = c.timing && batch == 1;
+    const bool timing = c.timing && batch <= chunk;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
 
     if (!n) {
@@ -696,44 +730,44 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
-        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * W * nbins * 4, s));
+        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * Ws * nbins * 4, s));
         TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         unsigned gb = (unsigned)((n + 255) / 256);
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
-                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride);
+                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
-        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((n + PART_TILE - 1) / PART_TILE), W, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
-                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), n, k2, nbins, idx_bits);
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
+        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
+                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits);
         {
-            const dim3 cgrid((unsigned)((n + BS_CHUNK - 1) / BS_CHUNK), W, nb);
-            TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * W * nb1 * 4, s));
+            const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), Ws, nb);
+            TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), n, k2, nbins, idx_bits, nbk);
-            hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(W, 1, nb), dim3(1024), 0, s, L.bucket_cnt.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(),
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
+            hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.bucket_cnt.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(),
                                L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), n, k2, nbins, idx_bits, nbk);
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
-        if (b0 == 0 && !bases_z)
+        if (b0 == 0 && !bases_z && !fb)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, W, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
-                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), n, nbk, nseg, seg_len);
-        hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, W, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
+        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
+                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), ns, nbk, nseg, seg_len);
+        hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
                            L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
         hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
-                           L.last.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)W, heavy_stride);
+                           L.last.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
-        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, W, nb), dim3(256), 0, s, L.buckets.as<XYZZMem>(), L.partials.as<XYZZMem>(), nbk, slice, tpw);
-        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(W, 1, nb), dim3(256), 0, s, L.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + b0 * W, rblocks);
+        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZMem>(), L.partials.as<XYZZMem>(), nbk, slice, tpw);
+        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, rblocks);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
     }
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipMemcpyAsync(m.host_sums, m.window_sums.p, hs, hipMemcpyDeviceToHost, s));
     m.pending_curve = BF::ID;
-    m.pending_windows = W;
+    m.pending_windows = Ws;
     m.pending_c = cb;
     m.pending_batch = batch;
     m.ev_valid = timing;
@@ -792,10 +826,25 @@ int point_sum_host_t(const u64* pts, size_t count, u64* out) {
 
 }  // namespace
 
-int msm_enqueue(int curve, const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s) {
+int msm_fixed_base_windows(int c) { return num_windows(c); }
+// the partitioned entries pack 7 low bucket bits above the flat table index
+bool msm_fixed_base_fits(size_t n, int c) {
+    if (c < 2 || c > MAX_C_FIXED) return false;
+    return (size_t)num_windows(c) * n <= ((size_t)1 << 24);
+}
+int msm_build_table(int curve, const void* bases_dev, size_t n, int c, void* table_dev, hipStream_t s) {
+    if (!n) return TRH_OK;
+    const int W = num_windows(c);
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (curve == TRH_PALLAS) hipLaunchKernelGGL((msm_table_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)bases_dev, (uint4*)table_dev, n, c, W);
+    else hipLaunchKernelGGL((msm_table_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)bases_dev, (uint4*)table_dev, n, c, W);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+int msm_enqueue(int curve, const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb) {
     // pallas: base Fp, scalar Fq; vesta: base Fq, scalar Fp
-    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s);
-    return msm_enqueue_t<FpParams, FqParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s);
+    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb);
+    return msm_enqueue_t<FpParams, FqParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb);
 }
 int msm_convert_bases(int curve, const void* in_dev, void* out_dev, size_t n, hipStream_t s) {
     if (!n) return TRH_OK;

@@ -156,7 +156,9 @@ class EvaluationDomain:
 class Params:
     """commitment::Params with device-resident bases: g ‖ w and g_lagrange ‖ w (n + 1 points each)."""
 
-    def __init__(self, curve: str, k: int, g, g_lagrange, w, u=None):
+    def __init__(self, curve: str, k: int, g, g_lagrange, w, u=None, precompute: bool = True):
+        """precompute: attach libtrh's fixed-base tables (trh_bases_precompute) to both base sets -- Params are
+        fixed for the life of a proving key, and create_proof commits ~500 columns against them."""
         self.curve, self.k, self.n = curve, k, 1 << k
         g = np.ascontiguousarray(g, dtype=np.uint64).reshape(-1, 8)
         gl = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(-1, 8)
@@ -165,6 +167,17 @@ class Params:
         self.w, self.u = w, u
         self._g = api.Bases.from_host(curve, np.concatenate([g, w]))
         self._g_lagrange = api.Bases.from_host(curve, np.concatenate([gl, w]))
+        if precompute:
+            self.precompute()
+
+    def precompute(self):
+        """fixed-base tables for commit / commit_lagrange (full-range MSMs of n + 1 pairs); a no-op when the set is
+        outside the supported range (W (n + 1) <= 2^24, i.e. k <= 19)"""
+        for b in (self._g, self._g_lagrange):
+            try:
+                b.precompute(0)
+            except api.TrhError:
+                pass
 
     @staticmethod
     def g_lagrange_from_g(curve: str, k: int, g_dev):

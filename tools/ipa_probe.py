@@ -17,9 +17,10 @@ params.w = g.download(n, 1)
 params.u = api.Bases.generate(curve, 4242, 1, 1).download()
 m = poly._MODULUS["fp"]
 p_dev = torch.from_numpy(synth.field_elements(0x1FA, n).view(np.int64)).cuda()
+s_h = synth.field_elements(0x5A, n)
 for rep in range(2):
     draws = iter(range(7, 10 ** 9, 13))
     torch.cuda.synchronize(); t = time.perf_counter()
-    ipa.create_proof_native(params, lambda: next(draws), replay._FixedTranscript(m), p_dev, 0x1234, 0x77777, synth.field_elements(0x5A, n), 0x99)
+    ipa.create_proof_native(params, lambda: next(draws), replay._FixedTranscript(m), p_dev, 0x1234, 0x77777, s_h, 0x99)
     torch.cuda.synchronize()
     print(f"ipa k={k}: {(time.perf_counter() - t) * 1e3:.1f} ms")
