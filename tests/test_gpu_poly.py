@@ -173,3 +173,47 @@ def test_batch_invert_and_prefix_product(field, n):
     # z[i+1] == z[i] * b[i] everywhere (size-independent property)
     if n > 1:
         assert (cpu_ref.field_op(field, "mul", z[:-1], b[:-1]) == z[1:]).all()
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+@pytest.mark.parametrize("k,j", [(11, 2), (11, 3), (12, 5), (12, 6), (11, 17), (13, 9)])
+def test_domain_fused_passes_vs_unfused_primitives(field, k, j):
+    """From log_n = 11 the pointwise steps are fused into the NTT passes (zero-padding + coset shift on the loads of
+    pass 0 with the all-zero stages skipped, x 2^-k / inverse coset shift on the final store).  The same results must come
+    out of the separate primitives (scale kernels + plain NTT, themselves checked against the oracle) and of the CPU
+    restatement of best_fft."""
+    import cpu_ref
+    f = o.FIELDS[field]
+    dom = poly.EvaluationDomain(field, j, k)
+    n, N, batch = dom.n, dom.extended_len(), 2
+    a = synth.field_elements(0xF05E + 31 * k + j, batch * n).reshape(batch, n, 4)
+    # lagrange_to_coeff
+    got = to_host(dom.lagrange_to_coeff(to_dev(a)))
+    ref = to_dev(a)
+    api.ntt_dev(field, ref, k, dom._w["omega_inv"], batch=batch)
+    api.field_scale_dev(field, ref, batch * n, dom._w["ifft_divisor"])
+    coeff = to_host(ref)
+    assert (got == coeff).all()
+    assert (got[0] == cpu_ref.field_op(field, "mul", cpu_ref.best_fft(field, a[0], dom._w["omega_inv"], k, threads=4),
+                                       np.tile(dom._w["ifft_divisor"], (n, 1)))).all()
+    # coeff_to_extended
+    ext = dom.coeff_to_extended(to_dev(coeff))
+    padded = np.zeros((batch, N, 4), np.uint64)
+    padded[:, :n] = coeff
+    ref = to_dev(padded)
+    api.field_scale_rows_dev(field, ref, batch, N, n, dom._into_coset)
+    api.ntt_dev(field, ref, dom.extended_k, dom._w["extended_omega"], batch=batch)
+    want_ext = to_host(ref)
+    assert (to_host(ext) == want_ext).all()
+    shifted = cpu_ref.field_op(field, "mul", coeff[1], dom._into_coset[np.arange(n) % 3])
+    padded1 = np.zeros((N, 4), np.uint64)
+    padded1[:n] = shifted
+    assert (want_ext[1] == cpu_ref.best_fft(field, padded1, dom._w["extended_omega"], dom.extended_k, threads=4)).all()
+    # extended_to_coeff
+    back = to_host(dom.extended_to_coeff(ext.clone()))
+    assert (back[:, :n] == coeff).all() and (back[:, n:] == 0).all()
+    ref = to_dev(want_ext)
+    api.ntt_dev(field, ref, dom.extended_k, dom._w["extended_omega_inv"], batch=batch)
+    api.field_scale_dev(field, ref, batch * N, dom._w["extended_ifft_divisor"])
+    api.field_scale_rows_dev(field, ref, batch, N, N, dom._from_coset)
+    assert (back == to_host(ref)[:, : back.shape[1]]).all()  # the Rust code truncates to n * quotient_poly_degree coefficients

@@ -113,7 +113,18 @@ Ctx& ctx();
 int require_init();
 
 // ntt.hip
-int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s);
+// pointwise steps of EvaluationDomain fused into the first / last pass of a transform (lazy passes only:
+// ntt_can_fuse).  Factor tables hold `period` elements in the lazy Montgomery form (x 2^270, < 2 m), device memory.
+struct NttFusion {
+    const void* in_dev = nullptr;  // pass 0 reads rows of 2^in_log elements from here, zero beyond (zero-padding); null: a_dev
+    uint32_t in_log = 0;
+    const void* pre = nullptr;     // x[i] *= pre[i % pre_period] on load (i = index inside the row)
+    uint32_t pre_period = 0;
+    const void* post = nullptr;    // y[i] *= post[i % post_period] on the final store
+    uint32_t post_period = 0;
+};
+bool ntt_can_fuse(uint32_t log_n);
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr);
 void ntt_release_tables();
 // msm.hip
 // fixed-base table of an owned base set: table[j * n + i] = 2^(c j) * P_i (lazy affine form), j < W.  With it the

@@ -20,7 +20,8 @@ struct trh_domain {
     trh::FeMem omega, omega_inv, extended_omega, extended_omega_inv, ifft_divisor, extended_ifft_divisor;
     trh::FeMem into_coset[3], from_coset[3];  // 1, zeta, zeta^2  /  1, zeta^2, zeta
     std::vector<trh::FeMem> t_inv;            // (X^n - 1)^-1 on the coset, period 2^(extended_k - k)
-    void* d_tables = nullptr;                  // device copy: into_coset[3], from_coset[3], divisors[2], t_inv[...]
+    void* d_tables = nullptr;                  // device copy: into_coset[3], from_coset[3], divisors[2], t_inv[...], then the lazy-form block
+    trh::FeMem z_into[3], z_idiv, z_from_div[3];  // lazy Montgomery form (x 2^270) for the steps fused into the NTT passes
 };
 
 namespace trh {
@@ -46,6 +47,13 @@ void build_domain(trh_domain* d) {
     d->extended_ifft_divisor = mem(div);
     d->into_coset[0] = mem(one); d->into_coset[1] = mem(zeta); d->into_coset[2] = mem(zeta2);
     d->from_coset[0] = mem(one); d->from_coset[1] = mem(zeta2); d->from_coset[2] = mem(zeta);
+    // lazy form f * 2^270 = montmul(f * 2^256, 2^14 * 2^256)
+    Fe<F> two14 = one;
+    for (int i = 0; i < 14; ++i) two14 = fe_dbl(two14);
+    d->z_into[0] = mem(fe_mul(one, two14)); d->z_into[1] = mem(fe_mul(zeta, two14)); d->z_into[2] = mem(fe_mul(zeta2, two14));
+    d->z_idiv = mem(fe_mul(reg<F>(d->ifft_divisor), two14));
+    const Fe<F> ediv = reg<F>(d->extended_ifft_divisor);  // extended_to_coeff: 2^-extended_k and the inverse coset shift in one factor
+    d->z_from_div[0] = mem(fe_mul(ediv, two14)); d->z_from_div[1] = mem(fe_mul(fe_mul(ediv, zeta2), two14)); d->z_from_div[2] = mem(fe_mul(fe_mul(ediv, zeta), two14));
     // t(X) = X^n - 1 on zeta * extended_omega^i: zeta^n * (extended_omega^n)^i - 1, inverted
     Fe<F> orig = zeta, step = ext_omega;
     for (uint32_t i = 0; i < d->k; ++i) { orig = fe_sqr(orig); step = fe_sqr(step); }
@@ -81,12 +89,14 @@ __global__ void __launch_bounds__(256) pad_coset_kernel(const uint4* __restrict_
 }
 
 // device table layout (FeMem units)
-enum { T_INTO = 0, T_FROM = 3, T_IDIV = 6, T_EIDIV = 7, T_TINV = 8 };
+enum { T_INTO = 0, T_FROM = 3, T_IDIV = 6, T_EIDIV = 7, T_ZINTO = 8, T_ZIDIV = 11, T_ZFROMDIV = 12, T_TINV = 15 };
 
 int upload_tables(trh_domain* d) {
     std::vector<FeMem> t(T_TINV + d->t_inv.size());
     for (int i = 0; i < 3; ++i) { t[T_INTO + i] = d->into_coset[i]; t[T_FROM + i] = d->from_coset[i]; }
     t[T_IDIV] = d->ifft_divisor; t[T_EIDIV] = d->extended_ifft_divisor;
+    for (int i = 0; i < 3; ++i) { t[T_ZINTO + i] = d->z_into[i]; t[T_ZFROMDIV + i] = d->z_from_div[i]; }
+    t[T_ZIDIV] = d->z_idiv;
     for (size_t i = 0; i < d->t_inv.size(); ++i) t[T_TINV + i] = d->t_inv[i];
     TRH_HIP_TRY(hipMalloc(&d->d_tables, t.size() * sizeof(FeMem)));
     TRH_HIP_TRY(hipMemcpy(d->d_tables, t.data(), t.size() * sizeof(FeMem), hipMemcpyHostToDevice));
@@ -143,6 +153,11 @@ int trh_domain_lagrange_to_coeff(trh_domain* d, void* a_dev, size_t batch, void*
     TRH_TRY(check(d, a_dev));
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
+    if (ntt_can_fuse(d->k)) {  // x 2^-k on the final store of the last pass
+        NttFusion fu;
+        fu.post = tab(d, T_ZIDIV); fu.post_period = 1;
+        return ntt_device(d->field, a_dev, d->k, (const u64*)&d->omega_inv, batch, (hipStream_t)stream, &fu);
+    }
     TRH_TRY(ntt_device(d->field, a_dev, d->k, (const u64*)&d->omega_inv, batch, (hipStream_t)stream));
     return field_scale_periodic(d->field, a_dev, 1, batch << d->k, batch << d->k, tab(d, T_IDIV), 1, (hipStream_t)stream);
 }
@@ -154,6 +169,12 @@ int trh_domain_coeff_to_extended(trh_domain* d, const void* coeff_dev, void* ext
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     const size_t n = (size_t)1 << d->k, N = (size_t)1 << d->extended_k, total = batch * N;
+    if (ntt_can_fuse(d->extended_k)) {  // zero-padding and the zeta-coset shift happen on the loads of pass 0 (which also skips the stages that only see zeros)
+        NttFusion fu;
+        fu.in_dev = coeff_dev; fu.in_log = d->k;
+        fu.pre = tab(d, T_ZINTO); fu.pre_period = 3;
+        return ntt_device(d->field, ext_dev, d->extended_k, (const u64*)&d->extended_omega, batch, (hipStream_t)stream, &fu);
+    }
     if (total) {
         const unsigned gb = (unsigned)((total + 255) / 256);
         if (d->field == TRH_FP) hipLaunchKernelGGL((pad_coset_kernel<FpParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, (const uint4*)coeff_dev, (uint4*)ext_dev, batch, n, N, (const uint4*)tab(d, T_INTO));
@@ -169,6 +190,11 @@ int trh_domain_extended_to_coeff(trh_domain* d, void* a_dev, size_t batch, void*
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     const size_t N = (size_t)1 << d->extended_k;
+    if (ntt_can_fuse(d->extended_k)) {  // 2^-extended_k * zeta^-(i mod 3) on the final store
+        NttFusion fu;
+        fu.post = tab(d, T_ZFROMDIV); fu.post_period = 3;
+        return ntt_device(d->field, a_dev, d->extended_k, (const u64*)&d->extended_omega_inv, batch, (hipStream_t)stream, &fu);
+    }
     TRH_TRY(ntt_device(d->field, a_dev, d->extended_k, (const u64*)&d->extended_omega_inv, batch, (hipStream_t)stream));
     TRH_TRY(field_scale_periodic(d->field, a_dev, 1, batch * N, batch * N, tab(d, T_EIDIV), 1, (hipStream_t)stream));
     return field_scale_periodic(d->field, a_dev, batch, N, N, tab(d, T_FROM), 3, (hipStream_t)stream);

@@ -388,10 +388,27 @@ struct TileTwiddles {
     }
 };
 
-template <class F, int LG, int TLOG, bool TWL>
+// stage V of a later round: rows u, u | 2^V of the thread's registers, twiddle index (L + (u mod 2^V) << stl) << sh
+template <class F, int LG, int V, class TW>
+__device__ __forceinline__ void round_stage_z(Fz<F> (&x)[1 << LG], const TW& tw, u32 L, int stl, int s, bool partner_zero) {
+    const int sh = s - 1 - stl - V;
+#pragma unroll
+    for (int u = 0; u < (1 << LG); ++u) {
+        if (u & (1 << V)) continue;
+        if (partner_zero) {
+            x[u | (1 << V)] = x[u];  // a + w * 0 = a - w * 0
+        } else {
+            const u32 idx = (L + ((u32)(u & ((1 << V) - 1)) << stl)) << sh;
+            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], tw((int)idx));  // idx 0 holds the lazy one
+            bfly_z<F, 2>(x[u], x[u | (1 << V)]);
+        }
+    }
+}
+
+template <class F, int LG, int TLOG, bool TWL, bool FUSE>
 __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
                                                                const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last,
-                                                               const uint4* __restrict__ direct) {
+                                                               const uint4* __restrict__ direct, NttFusion fu) {
     constexpr int G = 1 << LG, T = 1 << TLOG, THREADS = T >> LG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
@@ -406,25 +423,43 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
 
     const size_t N = (size_t)1 << log_n;
     const size_t batch_off = (size_t)blockIdx.y * N * 2;
-    in += batch_off;
+    const bool padded = FUSE && fu.in_dev;
+    const size_t in_len = padded ? (size_t)1 << fu.in_log : N;  // pass 0 of a zero-padded transform reads a shorter row
+    in = padded ? (const uint4*)fu.in_dev + (size_t)blockIdx.y * in_len * 2 : in + batch_off;
     out += batch_off;
     const int tid = threadIdx.x;
     const u32 c = tid & (C - 1), m = tid >> log_c;
     const u32 j = (blockIdx.x << log_c) + c;
     const u32 k = j & ((1u << log_ns) - 1u);
     const size_t row_stride = N >> s;
+    // zero-padded input: rows r >= in_len / row_stride are zero.  With at most R/4 live rows a thread's rows 1..3 are
+    // zero and round 0 is a broadcast; with at most R/8 the third stage is one as well (uniform over the grid)
+    const u32 live_rows = (u32)(in_len / row_stride ? in_len / row_stride : 1);
+    const bool bcast0 = padded && LG == 2 && s > LG && live_rows <= (u32)(R >> 2);
+    const bool bcast2 = bcast0 && s >= 2 * LG && live_rows <= (u32)(R >> 3);
 
     Fz<F> x[G];
     const int tw_shift = log_n - log_ns - s;
-#pragma unroll
-    for (int v = 0; v < G; ++v) {
+    // element v of the thread (row m + v R/G) lands in the bit-reversed slot; one call per compile-time v keeps x[] in registers
+    auto load_row = [&](const int v) -> Fz<F> {
         const u32 r = m + (u32)v * (u32)(R >> LG);
-        Fz<F> val = load_fz<F>(in + 2 * ((size_t)j + (size_t)r * row_stride));
-        if (log_ns > 0) {
-            const u32 ex = (k * r) << tw_shift;
-            if (ex) val = fz_mul(val, direct ? load_fz<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
+        const size_t idx = (size_t)j + (size_t)r * row_stride;
+        Fz<F> val = fz_zero<F>();
+        if (!(bcast0 && v) && idx < in_len) {
+            val = load_fz<F>(in + 2 * idx);
+            if (FUSE && fu.pre) val = fz_mul(val, load_fz<F>((const uint4*)fu.pre + 2 * (idx % fu.pre_period)));
+            if (log_ns > 0) {
+                const u32 ex = (k * r) << tw_shift;
+                if (ex) val = fz_mul(val, direct ? load_fz<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
+            }
         }
-        x[(int)(__builtin_bitreverse32((u32)v) >> (32 - LG))] = val;
+        return val;
+    };
+    if constexpr (LG == 2) {
+        x[0] = load_row(0); x[2] = load_row(1); x[1] = load_row(2); x[3] = load_row(3);
+    } else {
+        x[0] = load_row(0); x[4] = load_row(1); x[2] = load_row(2); x[6] = load_row(3);
+        x[1] = load_row(4); x[5] = load_row(5); x[3] = load_row(6); x[7] = load_row(7);
     }
     for (int i = tid; i < (R >> 1); i += THREADS) tw.put(i, twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
     __syncthreads();
@@ -433,9 +468,14 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     u32 L = 0;
     int stl = 0, vb = 0;
     // round 0: compile-time twiddles 1, w4, w8, w8^3 (index 0 is left out: operand bounds 2^(v+1))
-    round0_stage_z<F, LG, 0>(x, tw, s);
-    if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw, s);
-    if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw, s);
+    if (bcast0) {
+#pragma unroll
+        for (int u = 1; u < G; ++u) x[u] = x[0];  // a + w * 0 = a - w * 0 = a in both stages
+    } else {
+        round0_stage_z<F, LG, 0>(x, tw, s);
+        if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw, s);
+        if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw, s);
+    }
     for (int st = LG; st < s; st += LG) {
 #pragma unroll
         for (int u = 0; u < G; ++u) lds_store_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
@@ -446,25 +486,26 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
         base = L | ((m >> stl) << (stl + LG));
 #pragma unroll
         for (int u = 0; u < G; ++u) x[u] = lds_load_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
-#pragma unroll
-        for (int v = 0; v < LG; ++v) {
-            if (v >= vb) {
-                const int sh = s - 1 - stl - v;
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    if (u & (1 << v)) continue;
-                    const u32 idx = (L + ((u32)(u & ((1 << v) - 1)) << stl)) << sh;
-                    x[u | (1 << v)] = fz_mul(x[u | (1 << v)], tw((int)idx));  // idx 0 holds the lazy one
-                    bfly_z<F, 2>(x[u], x[u | (1 << v)]);
-                }
-            }
-        }
+        const bool partner_zero = bcast2 && st == LG;  // third stage of a zero-padded input
+        if (0 >= vb) round_stage_z<F, LG, 0>(x, tw, L, stl, s, partner_zero);
+        if constexpr (LG > 1) { if (1 >= vb) round_stage_z<F, LG, 1>(x, tw, L, stl, s, false); }
+        if constexpr (LG > 2) { if (2 >= vb) round_stage_z<F, LG, 2>(x, tw, L, stl, s, false); }
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const u32 rr = base + ((u32)u << stl);
         const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
-        fz_finish(x[u], last != 0);
+        if (FUSE && fu.post && last) {
+            Fe<F> t;
+            const Fz<F> y = fz_mul(x[u], load_fz<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));  // < m (1 + 2^-8)
+#pragma unroll
+            for (int i = 0; i < NLIMBS; ++i) t.l[i] = y.l[i];
+            fe_cond_sub(t);
+#pragma unroll
+            for (int i = 0; i < NLIMBS; ++i) x[u].l[i] = t.l[i];
+        } else {
+            fz_finish(x[u], last != 0);
+        }
         u32 w[8];
         fz_store(x[u], w);
         out[2 * dst] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -572,7 +613,7 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
 }
 
 template <class F>
-int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s) {
+int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu) {
     if (log_n == 0 || batch == 0) return TRH_OK;
     Ctx& c = ctx();
     TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega);
@@ -609,13 +650,24 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const dim3 grid((unsigned)tiles, (unsigned)nb);
             const bool lazy = lazy_enabled();
             const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
+            NttFusion kf;  // what this pass fuses: input side on pass 0, output side on the last pass
+            if (fu && p == 0) {
+                kf.pre = fu->pre; kf.pre_period = fu->pre_period;
+                if (fu->in_dev) { kf.in_dev = (const char*)fu->in_dev + b0 * ((size_t)32 << fu->in_log); kf.in_log = fu->in_log; }
+            }
+            if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; }
             const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
-            if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= 8)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, true>), grid, dim3(TILE >> 2), ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1)), s, src, o, (int)log_n, sp, log_ns,
-                                   t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
-            else if (lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp == 9)
-                hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, false>), grid, dim3(TILE >> 2), ldz, s, src, o, (int)log_n, sp, log_ns,
-                                   t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct);
+            const bool fused = kf.in_dev || kf.pre || kf.post;
+            const bool lazy_pass = lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= MAX_PASS_LOG;
+            const size_t ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
+#define TRH_LAUNCH_PASSZ(TWL, FUSE, LDS)                                                                                                       \
+    hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
+                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct, kf)
+            if (lazy_pass && sp <= 8 && !fused) TRH_LAUNCH_PASSZ(true, false, ldl);
+            else if (lazy_pass && sp <= 8) TRH_LAUNCH_PASSZ(true, true, ldl);
+            else if (lazy_pass && !fused) TRH_LAUNCH_PASSZ(false, false, ldz);
+            else if (lazy_pass) TRH_LAUNCH_PASSZ(false, true, ldz);
+#undef TRH_LAUNCH_PASSZ
             else if (tlog == 12)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
@@ -634,8 +686,18 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
 
 }  // namespace
 
-int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s) {
+bool ntt_can_fuse(uint32_t log_n) {
+    int sizes[8], P, tlog;
+    plan_passes((int)log_n, sizes, &P, &tlog);
+    if (!lazy_enabled() || tlog != TILE_LOG || (int)log_n < TILE_LOG) return false;
+    for (int p = 0; p < P; ++p) if (sizes[p] < 2 || sizes[p] > MAX_PASS_LOG) return false;  // every pass must be a lazy one
+    static const int fuse = getenv("TRH_NTT_FUSE") ? atoi(getenv("TRH_NTT_FUSE")) : 1;
+    return fuse != 0;
+}
+
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu) {
     if (log_n > 27) { set_error("ntt: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    if (fu && !ntt_can_fuse(log_n)) { set_error("ntt: fused pointwise steps need the lazy passes (log_n >= %d)", TILE_LOG); return TRH_EINVAL; }
     static bool attr_set = false;
     if (!attr_set) {
         const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
@@ -646,17 +708,17 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FpParams, 2, TILE_LOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FqParams, 2, TILE_LOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds));
+#define TRH_PASSZ_ATTR(FIELD, TWL, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FIELD, 2, TILE_LOG, TWL, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
+        TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
+        TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
+#undef TRH_PASSZ_ATTR
         const int big_lds = (32 << 12) + (32 << 10);  // 160 KiB: the whole LDS of a CU
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         attr_set = true;
     }
-    if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s);
-    return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s);
+    if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu);
+    return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s, fu);
 }
 
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s) {
