@@ -103,7 +103,7 @@ int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch,
                       int scalars_are_montgomery, void* stream, uint64_t* out_xyz /* batch x 12 */);
 /* window width override for tuning (0 = automatic) */
-int trh_msm_set_window_bits(int c);
+int trh_msm_set_window_bits(int c); /* 0 or 2..18 */
 
 /* sum of `count` points (Jacobian 12 x u64 each) on the host: combines the per-GPU partial
  * results of a range-sharded MSM after the all-gather.                                       */

@@ -134,7 +134,7 @@ def test_msm_vs_cpu_ref(curve, n):
     assert (got[8:] == (one if want.any() else 0)).all()
 
 
-@pytest.mark.parametrize("cbits", [2, 3, 5, 8, 11, 13, 15, 16])
+@pytest.mark.parametrize("cbits", [2, 3, 5, 8, 11, 13, 15, 16, 17, 18])
 def test_msm_window_widths(cbits):
     """every window width must give the same group element (exercises the signed recoding,
     including widths that divide 255 and leave a carry-only top window)"""

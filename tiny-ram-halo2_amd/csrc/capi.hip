@@ -329,7 +329,7 @@ int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev,
     return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
 }
 int trh_msm_set_window_bits(int cbits) {
-    if (cbits != 0 && (cbits < 2 || cbits > 16)) { set_error("window bits must be 0 or in [2, 16]"); return TRH_EINVAL; }
+    if (cbits != 0 && (cbits < 2 || cbits > 18)) { set_error("window bits must be 0 or in [2, 18]"); return TRH_EINVAL; }
     ctx().window_override = cbits;
     return TRH_OK;
 }

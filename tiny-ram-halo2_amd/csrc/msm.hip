@@ -28,7 +28,7 @@ namespace trh {
 
 namespace {
 
-constexpr int MAX_C = 16;
+constexpr int MAX_C = 18;
 constexpr int MAX_C_FIXED = 18;  // fixed-base tables: one bucket set per MSM, so wider windows pay
 constexpr u32 SIGN_BIT = 0x80000000u;
 
@@ -44,7 +44,9 @@ inline int choose_window_bits(size_t n) {
     // measured on MI355X (tools/window_sweep.py): below 2^15 pairs an MSM is latency-bound and the width
     // hardly matters; from 2^16 the wide windows win (fewer mixed adds, more level-1 sort bins)
     const int l = ilog2_floor(n ? n : 1);
-    return l < 9 ? 4 : l < 15 ? 8 : l < 16 ? 9 : l < 17 ? 10 : l < 21 ? 15 : 16;
+    // 2^24 / 2^25: c = 17 (15 full windows + an almost always empty carry window) beats 16 by 3 %; from 2^26 the index
+    // takes 26 of the 31 entry bits, which leaves 5 low bucket bits for the second sort level, and 16 wins again
+    return l < 9 ? 4 : l < 15 ? 8 : l < 16 ? 9 : l < 17 ? 10 : l < 21 ? 15 : l < 24 ? 16 : l < 26 ? 17 : 16;
 }
 inline int num_windows(int c) { return 255 / c + 1; }
 
