@@ -181,6 +181,46 @@ int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream);
 /* out[i] = prod_{j < i} a[j], out[0] = 1 (exclusive scan; out must not alias a) */
 int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
 
+/* ---- gate expressions over resident columns: the h(X) numerator of plonk::create_proof ---------
+ * halo2's `Expression<F>` (Constant / Selector / Fixed / Advice / Instance query at a Rotation, Negated, Sum,
+ * Product, Scaled) compiled by the caller to a straight-line program for a stack machine that every row of the
+ * (extended) domain runs on its own: PUSH_* push a value, ADD / SUB / MUL replace the two top entries (next op top),
+ * NEG / SQR / MUL_CONST / ADD_CONST rewrite the top, FOLD does acc = acc * const[a] + top and pops (the challenge-y
+ * Horner over gates), STORE_TOP / STORE_ACC write output a.  Locals hold shared sub-expressions.
+ * A column query reads column[(row + rotation * rot_step) mod 2^log_n]: on the extended coset Rotation(r) is
+ * r * 2^(extended_k - k) rows.  Constants are Montgomery limbs.                                           */
+enum {
+    TRH_EXPR_PUSH_COLUMN = 0, /* a = column index, rotation */
+    TRH_EXPR_PUSH_CONST = 1,  /* a = constant index */
+    TRH_EXPR_PUSH_LOCAL = 2,  /* a = local index */
+    TRH_EXPR_ADD = 3,
+    TRH_EXPR_SUB = 4,         /* next - top */
+    TRH_EXPR_MUL = 5,
+    TRH_EXPR_NEG = 6,
+    TRH_EXPR_SQR = 7,
+    TRH_EXPR_MUL_CONST = 8,   /* a = constant index */
+    TRH_EXPR_ADD_CONST = 9,
+    TRH_EXPR_STORE_LOCAL = 10, /* local[a] = top (kept) */
+    TRH_EXPR_FOLD = 11,       /* acc = acc * const[a] + top; pop */
+    TRH_EXPR_STORE_TOP = 12,  /* output[a][row] = top; pop */
+    TRH_EXPR_STORE_ACC = 13   /* output[a][row] = acc */
+};
+typedef struct {
+    uint32_t op;
+    uint32_t a;
+    int32_t rotation;
+} trh_expr_insn_t;
+typedef struct trh_expr* trh_expr_t;
+/* validates the program (stack discipline, index ranges), fixes the LDS slot of every spill / refill and uploads it */
+int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, const uint64_t* consts /* n_consts x 4 */, size_t n_consts,
+                    size_t n_columns, size_t n_outputs, size_t n_locals, trh_expr_t* out);
+void trh_expr_destroy(trh_expr_t e);
+uint32_t trh_expr_lds_slots(trh_expr_t e); /* stack entries below the two register ones + locals */
+/* replace one constant: the per-proof challenges (y, beta, gamma, theta) of an otherwise fixed program */
+int trh_expr_set_const(trh_expr_t e, uint32_t index, const uint64_t value[4]);
+/* columns_dev / outputs_dev: host arrays of device pointers (2^log_n x 4 u64 each); synchronises the stream */
+int trh_expr_eval_dev(trh_expr_t e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, void* stream);
+
 /* ---- best_fft over curve points: Params::new's g -> g_lagrange -----------------------------
  * halo2_proofs::arithmetic::best_fft::<C::Curve>(a, omega, log_n): a'[i] = sum_j [omega^(i j)] a[j].
  * points_dev: 2^log_n affine PODs in device memory, transformed in place (natural order in and out)

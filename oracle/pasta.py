@@ -558,3 +558,37 @@ if __name__ == "__main__":
         assert c.is_on_curve(c.generator)
         assert c.mul(c.scalar.m, c.generator) is None
     print("oracle constants OK")
+
+
+# ---------------------------------------------------------------------------------------
+# Gate-expression evaluation (halo2_proofs 0.2.0 plonk/circuit.rs `Expression::evaluate`, as create_proof uses it
+# for the quotient numerator: /root/reference/src/test_utils.rs:41-49; gates of the reference:
+# src/circuits/tables/exe.rs:147-498).  Plain restatement over ints; nodes are tuples:
+#   ("const", v) | ("col", key, rotation) | ("neg", e) | ("sum", a, b) | ("prod", a, b) | ("scaled", e, v)
+# ---------------------------------------------------------------------------------------
+def evaluate_expression(f, node, columns, row, n, rot_step):
+    tag = node[0]
+    if tag == "const":
+        return node[1] % f.m
+    if tag == "col":
+        return columns[node[1]][(row + node[2] * rot_step) % n]
+    if tag == "neg":
+        return (-evaluate_expression(f, node[1], columns, row, n, rot_step)) % f.m
+    if tag == "sum":
+        return (evaluate_expression(f, node[1], columns, row, n, rot_step) + evaluate_expression(f, node[2], columns, row, n, rot_step)) % f.m
+    if tag == "prod":
+        return evaluate_expression(f, node[1], columns, row, n, rot_step) * evaluate_expression(f, node[2], columns, row, n, rot_step) % f.m
+    if tag == "scaled":
+        return evaluate_expression(f, node[1], columns, row, n, rot_step) * node[2] % f.m
+    raise ValueError(tag)
+
+
+def evaluate_gates(f, gates, columns, y, n, rot_step=1):
+    """h numerator as create_proof folds it: acc = acc * y + gate, gate by gate, for every row"""
+    out = []
+    for row in range(n):
+        acc = 0
+        for g in gates:
+            acc = (acc * y + evaluate_expression(f, g, columns, row, n, rot_step)) % f.m
+        out.append(acc)
+    return out

@@ -1,0 +1,149 @@
+"""GPU parity of the gate-expression evaluator (csrc/expr.hip through the C ABI) against the oracle's restatement of
+halo2's Expression::evaluate + y-folding (oracle/pasta.py::evaluate_gates).  Bit-exact."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import pasta as o
+from tiny_ram_halo2_amd import api, expr, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    api.init(0)
+    yield
+
+
+def to_tuple(e, key=lambda q: (q.kind, q.column)):
+    if isinstance(e, expr.Constant):
+        return ("const", e.value)
+    if isinstance(e, expr._Query):
+        return ("col", key(e), e.rotation)
+    if isinstance(e, expr.Negated):
+        return ("neg", to_tuple(e.e))
+    if isinstance(e, expr.Sum):
+        return ("sum", to_tuple(e.a), to_tuple(e.b))
+    if isinstance(e, expr.Product):
+        return ("prod", to_tuple(e.a), to_tuple(e.b))
+    if isinstance(e, expr.Scaled):
+        return ("scaled", to_tuple(e.e), e.value)
+    raise TypeError(e)
+
+
+def make_columns(f, keys, n, seed):
+    rng = random.Random(seed)
+    ints = {k: [rng.randrange(f.m) for _ in range(n)] for k in keys}
+    # selectors are 0/1 columns, some values are small as witness cells are
+    for k in keys:
+        if k[0] == "selector":
+            ints[k] = [rng.randrange(2) for _ in range(n)]
+    dev = {k: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda() for k, col in ints.items()}
+    return ints, dev
+
+
+def from_dev(f, t):
+    torch.cuda.synchronize()
+    return [f.from_limbs(r) for r in t.cpu().numpy().view(np.uint64)]
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+@pytest.mark.parametrize("log_n,rot_step", [(4, 1), (9, 8), (6, 2)])
+def test_synthetic_gates_vs_oracle(field, log_n, rot_step):
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    gates = expr.synthetic_gates(n_advice=12, n_fixed=3, n_gates=17, seed=log_n * 7 + rot_step)
+    y = 0x1234567890ABCDEF1234567890ABCDEF % f.m
+    prog = expr.compile_gates(field, gates, y)
+    assert prog.max_degree == 6
+    ints, dev = make_columns(f, prog.columns, n, seed=log_n)
+    ev = expr.GateEvaluator(prog)
+    got = from_dev(f, ev.eval(dev, log_n, rot_step))
+    want = o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n, rot_step)
+    assert got == want
+    # a new proof, a new challenge: only the constant changes
+    y2 = (y * y + 17) % f.m
+    ev.set_challenge(y2)
+    assert from_dev(f, ev.eval(dev, log_n, rot_step)) == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y2, n, rot_step)
+
+
+def test_deep_expression_spills_to_lds():
+    """a balanced tree of depth 6 over two-entry leaves needs 8 stack entries: six of them live in LDS"""
+    field, log_n = "fp", 5
+    f = o.FIELDS[field]
+    n = 1 << log_n
+
+    def tree(d, i=0):
+        if d == 0:
+            return expr.Advice(i % 9, (i % 3) - 1) + (i + 1)
+        return tree(d - 1, 2 * i) * tree(d - 1, 2 * i + 1) - expr.Fixed(i % 2, 0)
+
+    g = tree(6)
+    prog = expr.compile_gates(field, [g, -g * 3], 7)
+    ints, dev = make_columns(f, prog.columns, n, seed=99)
+    ev = expr.GateEvaluator(prog)
+    assert expr._need(g) == 8 and ev.lds_slots() == 6
+    assert from_dev(f, ev.eval(dev, log_n)) == o.evaluate_gates(f, [to_tuple(g), to_tuple(-g * 3)], ints, 7, n)
+
+
+def test_edge_values_and_operand_order():
+    """0, 1, m - 1 through every operator; SUB operand order; squaring of a shared node; rotation wrap-around"""
+    field, log_n = "fq", 3
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    a, b = expr.Advice(0, 0), expr.Advice(1, -3)
+    gates = [a - b, b - a, a * a, (a + b) * (a - b), -(a * 5) + b * (f.m - 1), expr.Constant(0) * a + 1, a * b * expr.Advice(1, 5)]
+    vals = [0, 1, f.m - 1, 2, f.m - 2, (f.m - 1) // 2, 12345, 1 << 200]
+    ints = {("advice", 0): vals, ("advice", 1): vals[::-1]}
+    dev = {k: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda() for k, col in ints.items()}
+    for y in (0, 1, f.m - 1):
+        prog = expr.compile_gates(field, gates, y)
+        got = from_dev(f, expr.GateEvaluator(prog).eval(dev, log_n))
+        assert got == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n)
+
+
+def test_program_validation():
+    I = expr._Insn
+    one = np.zeros((1, 4), np.uint64)
+
+    def create(insns, n_columns=1, n_consts=1, n_outputs=1, n_locals=0):
+        arr = (I * len(insns))(*[I(*t) for t in insns])
+        h = ctypes.c_void_p()
+        return api.lib().trh_expr_create(0, ctypes.cast(arr, ctypes.c_void_p), len(insns), api._p(one), n_consts, n_columns, n_outputs, n_locals, ctypes.byref(h))
+
+    OP = expr.OP
+    assert create([(OP["PUSH_COLUMN"], 0, 0), (OP["STORE_TOP"], 0, 0)]) == 0
+    assert create([(OP["ADD"], 0, 0)]) != 0                                  # stack underflow
+    assert create([(OP["PUSH_COLUMN"], 1, 0), (OP["STORE_TOP"], 0, 0)]) != 0  # column out of range
+    assert create([(OP["PUSH_CONST"], 3, 0), (OP["STORE_TOP"], 0, 0)]) != 0   # constant out of range
+    assert create([(OP["PUSH_COLUMN"], 0, 0), (OP["STORE_TOP"], 2, 0)]) != 0  # output out of range
+    assert create([(99, 0, 0)]) != 0                                         # unknown opcode
+    assert create([(OP["PUSH_LOCAL"], 0, 0), (OP["STORE_TOP"], 0, 0)]) != 0   # no locals declared
+    assert "instruction" in api.lib().trh_last_error().decode()
+
+
+def test_locals_share_a_subexpression():
+    field, log_n = "fp", 4
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    OP, I = expr.OP, expr._Insn
+    # t = a * b (kept in local 0); out0 = t + a; out1 = t * t
+    insns = [(OP["PUSH_COLUMN"], 0, 0), (OP["PUSH_COLUMN"], 1, 1), (OP["MUL"], 0, 0), (OP["STORE_LOCAL"], 0, 0), (OP["PUSH_COLUMN"], 0, 0), (OP["ADD"], 0, 0),
+             (OP["STORE_TOP"], 0, 0), (OP["PUSH_LOCAL"], 0, 0), (OP["SQR"], 0, 0), (OP["STORE_TOP"], 1, 0)]
+    arr = (I * len(insns))(*[I(*t) for t in insns])
+    h = ctypes.c_void_p()
+    api._check(api.lib().trh_expr_create(api.FIELD_ID[field], ctypes.cast(arr, ctypes.c_void_p), len(insns), None, 0, 2, 2, 1, ctypes.byref(h)))
+    ints, dev = make_columns(f, [("advice", 0), ("advice", 1)], n, seed=5)
+    cols = (ctypes.c_void_p * 2)(dev[("advice", 0)].data_ptr(), dev[("advice", 1)].data_ptr())
+    o0, o1 = torch.empty((n, 4), dtype=torch.int64, device="cuda"), torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    outs = (ctypes.c_void_p * 2)(o0.data_ptr(), o1.data_ptr())
+    api._check(api.lib().trh_expr_eval_dev(h, cols, outs, log_n, 1, None))
+    a, b = ints[("advice", 0)], ints[("advice", 1)]
+    t = [a[i] * b[(i + 1) % n] % f.m for i in range(n)]
+    assert from_dev(f, o0) == [(t[i] + a[i]) % f.m for i in range(n)]
+    assert from_dev(f, o1) == [t[i] * t[i] % f.m for i in range(n)]
+    api.lib().trh_expr_destroy(h)

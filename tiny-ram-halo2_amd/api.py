@@ -106,6 +106,12 @@ _SIGNATURES = {
     "trh_ipa_create_proof": ([_vp, _u64p, ctypes.c_uint32, _vp, _u64p, _u64p, _vp, _u64p, ctypes.POINTER(Transcript), RNG_FN, _vp, _vp, _u64p, _u64p], ctypes.c_int),
     "trh_field_batch_invert_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_prefix_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_expr_create": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                         ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
+    "trh_expr_destroy": ([_vp], None),
+    "trh_expr_lds_slots": ([_vp], ctypes.c_uint32),
+    "trh_expr_set_const": ([_vp, ctypes.c_uint32, _u64p], ctypes.c_int),
+    "trh_expr_eval_dev": ([_vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, _vp], ctypes.c_int),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),

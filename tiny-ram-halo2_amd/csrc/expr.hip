@@ -1,0 +1,294 @@
+// Pointwise evaluation of gate expressions over resident columns: the h(X) numerator of
+// halo2_proofs 0.2.0 `plonk::create_proof` (plonk/prover.rs builds, for every gate polynomial, an AST over the
+// extended-domain cosets of the advice / fixed / instance columns and folds the values with the challenge y:
+// h = h * y + gate; reached from /root/reference/src/test_utils.rs:41-49; the gates themselves are the
+// `Expression`s of /root/reference/src/circuits/tables/exe.rs:147-498, logic.rs:125-185, sprod.rs:65-92;
+// SURVEY.md section 8 row f-4).  After coeff_to_extended the ~500 extended columns (33 GB at k = 18) live in
+// HBM; evaluating the gates where the columns are avoids shipping them back to the host.
+//
+// A compiled expression is a straight-line program for a small stack machine, one thread per row:
+//   T, N      top / next of the evaluation stack, in registers
+//   M[...]    deeper stack entries and user locals, in LDS (nine limbs per thread in three conflict-free planes);
+//             which slot an instruction spills to / refills from is fixed when the program is created, because
+//             every thread runs the same program (no stack pointer at run time)
+//   ACC       accumulator of FOLD (acc = acc * const + T), the y-Horner over gates
+// Column reads are `column[(row + rotation * rot_step) mod 2^log_n]` (Rotation(r) on the extended coset moves by
+// r * 2^(extended_k - k) rows).  Integer work, HBM-bound for cheap gates: 32 B per column query.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ctx.h"
+
+struct trh_expr {
+    int field;
+    uint32_t n_insn, n_columns, n_outputs, n_consts, lds_slots;
+    void* d_prog = nullptr;    // DevInsn[n_insn]
+    void* d_consts = nullptr;  // n_consts x 32 B
+    void* d_ptrs = nullptr;    // n_columns + n_outputs device pointers, refreshed per evaluation
+    std::vector<const void*> h_ptrs;
+};
+
+namespace trh {
+namespace {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+
+struct DevInsn {
+    u8 op, slot;  // slot: LDS slot spilled to (pushes) / refilled from (pops), 0xFF = none
+    u16 a;
+    i32 rot;
+};
+static_assert(sizeof(DevInsn) == 8, "instruction encoding");
+// the kernel reads an instruction as two aligned dwords and unpacks the fields itself (hipcc 7.2 otherwise merges the
+// u16 / i32 reads into one s_load_dword at byte offset 2, whose low address bits the hardware ignores)
+struct RawInsn {
+    u32 w0;  // op | slot << 8 | a << 16
+    i32 rot;
+};
+constexpr u8 NO_SLOT = 0xFF;
+constexpr int THREADS = 256;
+
+template <class F>
+__device__ __forceinline__ void lds_put(unsigned char* smem, u32 slot, const Fe<F>& v) {
+    uint4* a = (uint4*)(smem + (size_t)slot * (THREADS * 36));
+    uint4* b = a + THREADS;
+    u32* c = (u32*)(b + THREADS);
+    a[threadIdx.x] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    b[threadIdx.x] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    c[threadIdx.x] = v.l[8];
+}
+template <class F>
+__device__ __forceinline__ Fe<F> lds_get(const unsigned char* smem, u32 slot) {
+    const uint4* a = (const uint4*)(smem + (size_t)slot * (THREADS * 36));
+    const uint4* b = a + THREADS;
+    const u32* c = (const u32*)(b + THREADS);
+    const uint4 x = a[threadIdx.x], y = b[threadIdx.x];
+    Fe<F> v;
+    v.l[0] = x.x; v.l[1] = x.y; v.l[2] = x.z; v.l[3] = x.w;
+    v.l[4] = y.x; v.l[5] = y.y; v.l[6] = y.z; v.l[7] = y.w;
+    v.l[8] = c[threadIdx.x];
+    return v;
+}
+template <class F>
+__device__ __forceinline__ Fe<F> ldg(const uint4* p) {
+    const uint4 a = p[0], b = p[1];
+    return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+
+template <class F>
+__global__ void __launch_bounds__(THREADS) expr_eval_kernel(const DevInsn* __restrict__ prog, u32 n_insn, const uint4* const* __restrict__ ptrs, u32 n_columns,
+                                                            const uint4* __restrict__ consts, u32 log_n, u32 rot_step) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t N = (size_t)1 << log_n;
+    const size_t row = ((size_t)blockIdx.x * THREADS + threadIdx.x) & (N - 1);  // N < 256: the surplus lanes repeat rows, their stores are masked
+    const bool live = (size_t)blockIdx.x * THREADS + threadIdx.x < N;
+    Fe<F> T = fe_zero<F>(), Nx = fe_zero<F>(), ACC = fe_zero<F>();
+    for (u32 pc = 0; pc < n_insn; ++pc) {
+        const RawInsn raw = ((const RawInsn*)prog)[pc];  // uniform: scalar loads
+        DevInsn in;
+        in.op = (u8)(raw.w0 & 0xffu); in.slot = (u8)((raw.w0 >> 8) & 0xffu); in.a = (u16)(raw.w0 >> 16); in.rot = raw.rot;
+        switch (in.op) {
+            case TRH_EXPR_PUSH_COLUMN: {
+                if (in.slot != NO_SLOT) lds_put<F>(smem, in.slot, Nx);
+                Nx = T;
+                const size_t r = (row + (size_t)((long long)in.rot * (long long)rot_step)) & (N - 1);
+                T = ldg<F>(ptrs[in.a] + 2 * r);
+                break;
+            }
+            case TRH_EXPR_PUSH_CONST:
+                if (in.slot != NO_SLOT) lds_put<F>(smem, in.slot, Nx);
+                Nx = T;
+                T = ldg<F>(consts + 2 * (size_t)in.a);
+                break;
+            case TRH_EXPR_PUSH_LOCAL:
+                if (in.slot != NO_SLOT) lds_put<F>(smem, in.slot, Nx);
+                Nx = T;
+                T = lds_get<F>(smem, in.a);
+                break;
+            case TRH_EXPR_ADD: T = fe_add(Nx, T); if (in.slot != NO_SLOT) Nx = lds_get<F>(smem, in.slot); break;
+            case TRH_EXPR_SUB: T = fe_sub(Nx, T); if (in.slot != NO_SLOT) Nx = lds_get<F>(smem, in.slot); break;
+            case TRH_EXPR_MUL: T = fe_mul(Nx, T); if (in.slot != NO_SLOT) Nx = lds_get<F>(smem, in.slot); break;
+            case TRH_EXPR_NEG: T = fe_neg(T); break;
+            case TRH_EXPR_SQR: T = fe_sqr(T); break;
+            case TRH_EXPR_MUL_CONST: T = fe_mul(T, ldg<F>(consts + 2 * (size_t)in.a)); break;
+            case TRH_EXPR_ADD_CONST: T = fe_add(T, ldg<F>(consts + 2 * (size_t)in.a)); break;
+            case TRH_EXPR_STORE_LOCAL: lds_put<F>(smem, in.a, T); break;  // keeps T
+            case TRH_EXPR_FOLD:  // acc = acc * const + T; pop
+                ACC = fe_add(fe_mul(ACC, ldg<F>(consts + 2 * (size_t)in.a)), T);
+                T = Nx;
+                if (in.slot != NO_SLOT) Nx = lds_get<F>(smem, in.slot);
+                break;
+            case TRH_EXPR_STORE_TOP:  // out[a][row] = T; pop
+            case TRH_EXPR_STORE_ACC: {
+                const Fe<F> v = in.op == TRH_EXPR_STORE_ACC ? ACC : T;
+                if (live) {
+                    u32 w[8];
+                    fe_store(v, w);
+                    uint4* o = (uint4*)ptrs[n_columns + in.a] + 2 * row;
+                    o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                    o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                }
+                if (in.op == TRH_EXPR_STORE_TOP) {
+                    T = Nx;
+                    if (in.slot != NO_SLOT) Nx = lds_get<F>(smem, in.slot);
+                }
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace trh
+
+using namespace trh;
+
+extern "C" {
+
+int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, const uint64_t* consts, size_t n_consts, size_t n_columns, size_t n_outputs,
+                    size_t n_locals, trh_expr** out) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (!out || !insns || !n_insn || (n_consts && !consts)) { set_error("expr_create: null pointer / empty program"); return TRH_EINVAL; }
+    if (n_columns > 65535 || n_outputs == 0 || n_outputs > 65535 || n_consts > 65535 || n_locals > 64) { set_error("expr_create: table sizes out of range"); return TRH_EINVAL; }
+    // pass 1: stack depth at every instruction, maximum depth (the two top entries live in registers)
+    std::vector<DevInsn> dev(n_insn);
+    int depth = 0, max_depth = 0;
+    for (size_t pc = 0; pc < n_insn; ++pc) {
+        const trh_expr_insn_t& u = insns[pc];
+        DevInsn d{(u8)u.op, NO_SLOT, (u16)u.a, u.rotation};
+        auto bad = [&](const char* what) { set_error("expr_create: instruction %zu: %s", pc, what); return TRH_EINVAL; };
+        switch (u.op) {
+            case TRH_EXPR_PUSH_COLUMN: if (u.a >= n_columns) return bad("column index out of range"); goto push;
+            case TRH_EXPR_PUSH_CONST: if (u.a >= n_consts) return bad("constant index out of range"); goto push;
+            case TRH_EXPR_PUSH_LOCAL: if (u.a >= n_locals) return bad("local index out of range");
+            push:
+                if (depth >= 2) d.slot = (u8)(depth - 2);  // the old next-of-stack is spilled below the two register entries
+                ++depth;
+                break;
+            case TRH_EXPR_ADD: case TRH_EXPR_SUB: case TRH_EXPR_MUL:
+                if (depth < 2) return bad("binary operator needs two stack entries");
+                --depth;
+                if (depth >= 2) d.slot = (u8)(depth - 2);
+                break;
+            case TRH_EXPR_NEG: case TRH_EXPR_SQR:
+                if (depth < 1) return bad("unary operator on an empty stack");
+                break;
+            case TRH_EXPR_MUL_CONST: case TRH_EXPR_ADD_CONST:
+                if (depth < 1) return bad("operator on an empty stack");
+                if (u.a >= n_consts) return bad("constant index out of range");
+                break;
+            case TRH_EXPR_STORE_LOCAL:
+                if (depth < 1) return bad("store of an empty stack");
+                if (u.a >= n_locals) return bad("local index out of range");
+                break;
+            case TRH_EXPR_FOLD:
+                if (u.a >= n_consts) return bad("constant index out of range");
+                goto pop;
+            case TRH_EXPR_STORE_TOP:
+                if (u.a >= n_outputs) return bad("output index out of range");
+            pop:
+                if (depth < 1) return bad("pop of an empty stack");
+                --depth;
+                if (depth >= 2) d.slot = (u8)(depth - 2);
+                break;
+            case TRH_EXPR_STORE_ACC:
+                if (u.a >= n_outputs) return bad("output index out of range");
+                break;
+            default: return bad("unknown opcode");
+        }
+        if (depth > max_depth) max_depth = depth;
+        if (max_depth - 2 > 120) return bad("evaluation stack deeper than 122 entries");
+        dev[pc] = d;
+    }
+    const uint32_t stack_slots = max_depth > 2 ? (uint32_t)(max_depth - 2) : 0;
+    // locals live behind the stack region
+    for (size_t pc = 0; pc < n_insn; ++pc)
+        if (dev[pc].op == TRH_EXPR_PUSH_LOCAL || dev[pc].op == TRH_EXPR_STORE_LOCAL) dev[pc].a = (u16)(dev[pc].a + stack_slots);
+    const uint32_t slots = stack_slots + (uint32_t)n_locals;
+    if ((size_t)slots * THREADS * 36 > 160 * 1024) { set_error("expr_create: %u LDS slots (stack %u + locals %zu) exceed the 160 KiB of a CU", slots, stack_slots, n_locals); return TRH_EINVAL; }
+
+    trh_expr* e = new trh_expr();
+    e->field = field; e->n_insn = (uint32_t)n_insn; e->n_columns = (uint32_t)n_columns; e->n_outputs = (uint32_t)n_outputs;
+    e->n_consts = (uint32_t)n_consts; e->lds_slots = slots;
+    e->h_ptrs.resize(n_columns + n_outputs);
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    hipError_t err = hipMalloc(&e->d_prog, n_insn * sizeof(DevInsn));
+    if (err == hipSuccess) err = hipMalloc(&e->d_consts, (n_consts ? n_consts : 1) * 32);
+    if (err == hipSuccess) err = hipMalloc(&e->d_ptrs, (n_columns + n_outputs) * sizeof(void*));
+    if (err == hipSuccess) err = hipMemcpy(e->d_prog, dev.data(), n_insn * sizeof(DevInsn), hipMemcpyHostToDevice);
+    if (err == hipSuccess && n_consts) err = hipMemcpy(e->d_consts, consts, n_consts * 32, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        set_error("expr_create: %s", hipGetErrorString(err));
+        if (e->d_prog) (void)hipFree(e->d_prog);
+        if (e->d_consts) (void)hipFree(e->d_consts);
+        if (e->d_ptrs) (void)hipFree(e->d_ptrs);
+        delete e;
+        return TRH_EHIP;
+    }
+    static bool attr = false;
+    if (!attr) {
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)expr_eval_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)expr_eval_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    *out = e;
+    return TRH_OK;
+}
+
+void trh_expr_destroy(trh_expr* e) {
+    if (!e) return;
+    if (e->d_prog) (void)hipFree(e->d_prog);
+    if (e->d_consts) (void)hipFree(e->d_consts);
+    if (e->d_ptrs) (void)hipFree(e->d_ptrs);
+    delete e;
+}
+
+uint32_t trh_expr_lds_slots(trh_expr* e) { return e ? e->lds_slots : 0; }
+
+/* replace one constant (the per-proof challenges y, beta, gamma, ... of an otherwise fixed program) */
+int trh_expr_set_const(trh_expr* e, uint32_t index, const uint64_t value[4]) {
+    TRH_TRY(require_init());
+    if (!e || !value || index >= e->n_consts) { set_error("expr_set_const: bad arguments"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_HIP_TRY(hipMemcpy((char*)e->d_consts + (size_t)index * 32, value, 32, hipMemcpyHostToDevice));
+    return TRH_OK;
+}
+
+int trh_expr_eval_dev(trh_expr* e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, void* stream) {
+    TRH_TRY(require_init());
+    if (!e || !outputs_dev || (e->n_columns && !columns_dev)) { set_error("expr_eval: null pointer"); return TRH_EINVAL; }
+    if (log_n > 30) { set_error("expr_eval: log_n %u too large", log_n); return TRH_EINVAL; }
+    for (uint32_t i = 0; i < e->n_columns; ++i) {
+        if (!columns_dev[i]) { set_error("expr_eval: column %u is null", i); return TRH_EINVAL; }
+        e->h_ptrs[i] = columns_dev[i];
+    }
+    for (uint32_t i = 0; i < e->n_outputs; ++i) {
+        if (!outputs_dev[i]) { set_error("expr_eval: output %u is null", i); return TRH_EINVAL; }
+        e->h_ptrs[e->n_columns + i] = outputs_dev[i];
+    }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    hipStream_t s = (hipStream_t)stream;
+    TRH_HIP_TRY(hipMemcpyAsync(e->d_ptrs, e->h_ptrs.data(), e->h_ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+    const size_t N = (size_t)1 << log_n;
+    const unsigned blocks = (unsigned)((N + THREADS - 1) / THREADS);
+    const size_t lds = (size_t)e->lds_slots * THREADS * 36;
+    if (e->field == TRH_FP)
+        hipLaunchKernelGGL((expr_eval_kernel<FpParams>), dim3(blocks), dim3(THREADS), lds, s, (const DevInsn*)e->d_prog, e->n_insn, (const uint4* const*)e->d_ptrs, e->n_columns,
+                           (const uint4*)e->d_consts, log_n, rot_step);
+    else
+        hipLaunchKernelGGL((expr_eval_kernel<FqParams>), dim3(blocks), dim3(THREADS), lds, s, (const DevInsn*)e->d_prog, e->n_insn, (const uint4* const*)e->d_ptrs, e->n_columns,
+                           (const uint4*)e->d_consts, log_n, rot_step);
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // h_ptrs is reused by the next call
+    return TRH_OK;
+}
+
+}  // extern "C"
