@@ -5,9 +5,23 @@ import pytest
 
 import cpu_ref
 import pasta as o
-from tiny_ram_halo2_amd import replay
+from tiny_ram_halo2_amd import expr, replay
 
 pytestmark = pytest.mark.gpu
+
+
+def to_tuple(e):
+    if isinstance(e, expr.Constant):
+        return ("const", e.value)
+    if isinstance(e, expr._Query):
+        return ("col", (e.kind, e.column), e.rotation)
+    if isinstance(e, expr.Negated):
+        return ("neg", to_tuple(e.e))
+    if isinstance(e, expr.Sum):
+        return ("sum", to_tuple(e.a), to_tuple(e.b))
+    if isinstance(e, expr.Product):
+        return ("prod", to_tuple(e.a), to_tuple(e.b))
+    return ("scaled", to_tuple(e.e), e.value)
 
 
 def test_replay_k10_matches_oracle():
@@ -19,6 +33,18 @@ def test_replay_k10_matches_oracle():
             bases = inp["bases"].download()
             want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], bases, threads=8))
             assert (np.asarray(out)[:8] == want).all(), kind
+            return
+        if kind == "h_eval":  # sampled rows of the gate evaluation against the oracle's Expression::evaluate restatement
+            f = o.FIELDS[inp["field"]]
+            n = 1 << inp["log_n"]
+            cols = {key: [f.from_limbs(r) for r in t.cpu().numpy().view(np.uint64)] for key, t in inp["resident"].items()}
+            got = out.cpu().numpy().view(np.uint64)
+            gates = [to_tuple(g) for g in inp["gates"]]
+            for row in (0, 1, n - 1, 4097 % n, n // 2 + 3):
+                acc = 0
+                for g in gates:
+                    acc = (acc * inp["y"] + o.evaluate_expression(f, g, cols, row, n, inp["rot_step"])) % f.m
+                assert f.from_limbs(got[row]) == acc, row
             return
         field, j, k = inp["domain"]
         f = o.FIELDS[field]
@@ -35,4 +61,4 @@ def test_replay_k10_matches_oracle():
     res = replay.run(16, batch=32, hook=hook, verbose=False)
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}

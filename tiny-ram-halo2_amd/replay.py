@@ -8,8 +8,10 @@ pairs over the resident Lagrange bases), `lagrange_to_coeff` (iNTT n) and `coeff
 8n); the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
 and one IPA opening (k rounds).  Column / lookup / permutation counts are derived from the reference's
 `configure` code (Appendix B): 94 instance + 263 advice columns, 31 lookups, 47 permutation products,
-quotient degree 5 => extended_k = k + 3.  Witness generation, the quotient evaluation h(X) itself and
-the transcript stay on the host in the real prover and are not part of the replay.
+quotient degree 5 => extended_k = k + 3.  The h(X) numerator runs on the device as well (`expr.GateEvaluator`
+over the resident extended cosets) -- with a SYNTHETIC gate set of the reference's shape (selector-gated
+constraints up to degree 6), because the real one is the circuit definition and needs the Rust toolchain to
+extract.  Witness generation and the transcript stay on the host and are not part of the replay.
 
     python -m tiny_ram_halo2_amd.replay --word-bits 32           # k = 18, the 2^14-cycle configuration
     python -m tiny_ram_halo2_amd.replay --word-bits 16           # k = 10 (BASELINE config 1's circuit size)
@@ -25,10 +27,11 @@ import time
 
 import numpy as np
 
-from . import api, ipa, poly, synth
+from . import api, expr, ipa, poly, synth
 
 # Appendix B counts for TinyRamCircuit<WB, 8>
 N_INSTANCE, N_ADVICE, N_LOOKUPS, N_PERM_PRODUCTS, N_H_PIECES = 94, 263, 31, 47, 5
+N_SYNTH_GATES = 300  # gate polynomials of the synthetic h(X) step (the real count is a property of the circuit definition)
 QUOTIENT_J = 6  # cs.degree() = 6 => EvaluationDomain::new(6, k): quotient_poly_degree 5, extended_k = k + 3
 
 
@@ -93,7 +96,7 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
         e.record()
         return e
 
-    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "commit": 0.0,
+    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "h_eval": 0.0, "commit": 0.0,
              "extended_to_coeff": 0.0, "ipa": 0.0}
     counts = {kk: 0 for kk in times}
     checked = 0
@@ -130,8 +133,31 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
                 hook("lagrange_to_coeff", dict(a=cols_h[i], domain=(field, QUOTIENT_J, k)), coeff[i].cpu().numpy().view(np.uint64))
                 hook("coeff_to_extended", dict(a=coeff[i].cpu().numpy().view(np.uint64), domain=(field, QUOTIENT_J, k)), ext[i].cpu().numpy().view(np.uint64))
                 checked += 3
+        if done + b >= lag_total:
+            ext_keep = ext  # the last batch of extended cosets stays resident for the h(X) step below
         del ext, coeff, cols
         done += b
+
+    # --- h(X) numerator: gate expressions over the extended cosets, folded with the challenge y.  The real gate set is the
+    # reference's circuit definition (src/circuits/tables/exe.rs:147-498 etc.), which cannot be extracted without the Rust
+    # toolchain: a synthetic set with the same shape (selector-gated constraints up to degree 6) over the resident columns ---
+    nres = ext_keep.shape[0]
+    gates = expr.synthetic_gates(n_advice=max(1, nres - 4), n_fixed=min(4, nres), n_gates=N_SYNTH_GATES)
+    prog = expr.compile_gates(field, gates, y=0x5EED)
+    res = {}
+    for i, key in enumerate(sorted(prog.columns)):
+        res[key] = ext_keep[i % nres]
+    gev = expr.GateEvaluator(prog)
+    e0 = ev()
+    h_num = gev.eval(res, ek, 1 << (ek - k))
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["h_eval"] += e0.elapsed_time(e1)
+    counts["h_eval"] += 1
+    if hook is not None:
+        hook("h_eval", dict(gates=gates, resident=res, log_n=ek, rot_step=1 << (ek - k), y=0x5EED, field=field), h_num)
+        checked += 1
+    del ext_keep, res, h_num
 
     # --- coefficient-basis commits: vanishing random poly, h pieces ---
     ncoef = 1 + N_H_PIECES
