@@ -169,7 +169,7 @@ def main():
     for _ in range(args.steps):
         result = step()
         tm = api.last_timing()
-        acc_ms.append(tm["accumulate_ms"])
+        acc_ms.append(tm["accumulate_kernel_ms"])
         for k in phase:
             phase[k] += tm[k] / args.steps
     fence()
@@ -231,6 +231,8 @@ def main():
 
     if rank == 0:
         acc = float(np.mean(acc_ms))
+        # scalars are uniform below 2^254, so the carry window above ceil(254 / c) full windows is (almost surely) empty
+        madds = n * min(int(tm["windows"]), -(-254 // int(tm["window_bits"])))
         ach = 96.0 * n / (acc * 1e-3) / 1e9
         out = {
             "metric": METRIC,
@@ -252,6 +254,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_seg_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(f"msm_accumulate_2^{log_n}"),
                          "kernel_ms": acc, "algorithmic_bytes": 96 * n},
+            # what actually bounds the kernel: VALU issue.  Per mixed add 8 fz_mul (126 v_mad_u64_u32 each) + 2 fz_sqr (90) =
+            # 1188 half-rate multiply-adds and ~900 full-rate ALU instructions (static counts of the gfx950 ISA); peaks are the
+            # measured issue rates of tools/microbench.hip (profiles/microbench_r01.txt)
+            "valu": {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc * 1e-3),
+                     "mad_u64_u32_per_s": 1188 * madds / (acc * 1e-3), "mad_peak_per_s": 32.7e12,
+                     "other_valu_per_s": 900 * madds / (acc * 1e-3), "other_peak_per_s": 65e12,
+                     "issue_frac": (1188 * madds / 32.7e12 + 900 * madds / 65e12) / (acc * 1e-3)},
             "phases_ms": phase,
             "check": check,
             "secondary": ntt,

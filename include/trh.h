@@ -252,6 +252,7 @@ typedef struct trh_timing {
     float reduce_ms;       /* MSM: bucket reduction + window sums */
     int window_bits;
     int windows;
+    float accumulate_kernel_ms; /* msm_accumulate_seg_kernel alone (accumulate_ms also covers the per-bucket combine) */
 } trh_timing_t;
 int trh_set_timing(int enabled);
 int trh_last_timing(trh_timing_t* out);

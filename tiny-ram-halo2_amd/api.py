@@ -56,7 +56,7 @@ class Transcript(ctypes.Structure):
 class Timing(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("digits_ms", ctypes.c_float), ("sort_ms", ctypes.c_float),
                 ("accumulate_ms", ctypes.c_float), ("reduce_ms", ctypes.c_float),
-                ("window_bits", ctypes.c_int), ("windows", ctypes.c_int)]
+                ("window_bits", ctypes.c_int), ("windows", ctypes.c_int), ("accumulate_kernel_ms", ctypes.c_float)]
 
 
 _SIGNATURES = {

@@ -726,7 +726,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
 
     if (!n) {
         TRH_HIP_TRY(hipMemsetAsync(m.window_sums.p, 0, hs, s));
-        if (timing) for (int k = 0; k <= 4; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
+        if (timing) for (int k = 0; k <= 5; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
     }
     for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
         const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
@@ -757,6 +757,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
         hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), ns, nbk, nseg, seg_len);
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
                            L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
         hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
@@ -798,7 +799,9 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     for (size_t bi = 0; bi < batch; ++bi) combine_windows_host<BF>(ws + bi * m.pending_windows, m.pending_windows, m.pending_c, out_xyz + 12 * bi);
     if (m.ev_valid) {
-        float t01, t12, t23, t34, tt;
+        float t01, t12, t23, t34, tt, t25;
+        TRH_HIP_TRY(hipEventElapsedTime(&t25, m.ev[2], m.ev[5]));
+        c.last.accumulate_kernel_ms = t25;
         TRH_HIP_TRY(hipEventElapsedTime(&t01, m.ev[0], m.ev[1]));
         TRH_HIP_TRY(hipEventElapsedTime(&t12, m.ev[1], m.ev[2]));
         TRH_HIP_TRY(hipEventElapsedTime(&t23, m.ev[2], m.ev[3]));
