@@ -147,3 +147,36 @@ def test_locals_share_a_subexpression():
     assert from_dev(f, o0) == [(t[i] + a[i]) % f.m for i in range(n)]
     assert from_dev(f, o1) == [t[i] * t[i] % f.m for i in range(n)]
     api.lib().trh_expr_destroy(h)
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_permutation_product_column(field):
+    """plonk/permutation/prover.rs: z[i+1] = z[i] * prod_j (v_j + beta delta^j omega^i + gamma) / (v_j + beta sigma_j + gamma)"""
+    from tiny_ram_halo2_amd import permutation
+    f = o.FIELDS[field]
+    k, ncol, first = 7, 4, 8  # the third chunk of a 4-columns-per-product permutation
+    n = 1 << k
+    rng = random.Random(0xBEE)
+    vals = [[rng.randrange(f.m) for _ in range(n)] for _ in range(ncol)]
+    sigs = [[rng.randrange(f.m) for _ in range(n)] for _ in range(ncol)]
+    vals[1][5] = 0; sigs[2][9] = 0
+    beta, gamma, z0 = rng.randrange(f.m), rng.randrange(f.m), rng.randrange(1, f.m)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    pc = permutation.ProductColumn(field, k, ncol, first_column=first)
+    z = from_dev(f, pc.compute([dev(c) for c in vals], [dev(c) for c in sigs], beta, gamma, z0))
+    delta = pow(5, 1 << 32, f.m)
+    assert delta == permutation.delta(field) and pow(delta, (f.m - 1) >> 32, f.m) == 1  # order divides t = (m - 1) / 2^32
+    w = f.omega(k)
+    want, acc = [], z0
+    for i in range(n):
+        want.append(acc)
+        num = den = 1
+        for j in range(ncol):
+            num = num * (vals[j][i] + beta * pow(delta, first + j, f.m) * pow(w, i, f.m) + gamma) % f.m
+            den = den * (vals[j][i] + beta * sigs[j][i] + gamma) % f.m
+        acc = acc * num * pow(den, -1, f.m) % f.m
+    assert z == want
+    # a permutation that fixes every cell (sigma_j = delta^j omega^i): the product telescopes to z0 everywhere
+    ident = [[pow(delta, first + j, f.m) * pow(w, i, f.m) % f.m for i in range(n)] for j in range(ncol)]
+    z = from_dev(f, pc.compute([dev(c) for c in vals], [dev(c) for c in ident], beta, gamma, z0))
+    assert z == [z0] * n

@@ -146,38 +146,39 @@ class Program:
     max_degree: int
 
 
-def compile_gates(field: str, gates, y: int = 1) -> Program:
-    """gates: iterable of Expression.  Constant 0 of the program is y (GateEvaluator.set_challenge replaces it)."""
-    m = _MODULUS[field]
-    consts, const_ix = [y % m], {}
-    columns, col_ix = [], {}
-    insns = []
+class _Lowering:
+    def __init__(self, field: str, first_const: int | None = None):
+        self.m = _MODULUS[field]
+        self.consts, self.const_ix = ([first_const % self.m] if first_const is not None else []), {}
+        self.columns, self.col_ix = [], {}
+        self.insns = []
 
-    def const(v):
-        v %= m
-        if v not in const_ix:
-            const_ix[v] = len(consts)
-            consts.append(v)
-        return const_ix[v]
+    def const(self, v):
+        v %= self.m
+        if v not in self.const_ix:
+            self.const_ix[v] = len(self.consts)
+            self.consts.append(v)
+        return self.const_ix[v]
 
-    def column(q):
+    def column(self, q):
         key = (q.kind, q.column)
-        if key not in col_ix:
-            col_ix[key] = len(columns)
-            columns.append(key)
-        return col_ix[key]
+        if key not in self.col_ix:
+            self.col_ix[key] = len(self.columns)
+            self.columns.append(key)
+        return self.col_ix[key]
 
-    def emit(e):
+    def emit(self, e):
+        insns, emit = self.insns, self.emit
         if isinstance(e, Constant):
-            insns.append((OP["PUSH_CONST"], const(e.value), 0))
+            insns.append((OP["PUSH_CONST"], self.const(e.value), 0))
         elif isinstance(e, _Query):
-            insns.append((OP["PUSH_COLUMN"], column(e), e.rotation))
+            insns.append((OP["PUSH_COLUMN"], self.column(e), e.rotation))
         elif isinstance(e, Negated):
             emit(e.e)
             insns.append((OP["NEG"], 0, 0))
         elif isinstance(e, Scaled):
             emit(e.e)
-            insns.append((OP["MUL_CONST"], const(e.value), 0))
+            insns.append((OP["MUL_CONST"], self.const(e.value), 0))
         elif isinstance(e, Sum):
             if isinstance(e.b, Negated):  # a + (-b): one SUB instead of NEG + ADD
                 a, b = e.a, e.b.e
@@ -202,13 +203,32 @@ def compile_gates(field: str, gates, y: int = 1) -> Program:
         else:
             raise TypeError(f"not an Expression: {e!r}")
 
+    def program(self, field, max_degree):
+        return Program(field, np.array(self.insns, dtype=np.int64).reshape(-1, 3), self.consts, self.columns, max_degree)
+
+
+def compile_gates(field: str, gates, y: int = 1) -> Program:
+    """gates: iterable of Expression, folded into ONE output with the challenge y (h = h * y + gate).
+    Constant 0 of the program is y (GateEvaluator.set_challenge replaces it)."""
+    lo = _Lowering(field, first_const=y)
     max_degree = 0
     for g in gates:
         max_degree = max(max_degree, g.degree())
-        emit(g)
-        insns.append((OP["FOLD"], 0, 0))  # acc = acc * y + gate
-    insns.append((OP["STORE_ACC"], 0, 0))
-    return Program(field, np.array(insns, dtype=np.int64).reshape(-1, 3), consts, columns, max_degree)
+        lo.emit(g)
+        lo.insns.append((OP["FOLD"], 0, 0))  # acc = acc * y + gate
+    lo.insns.append((OP["STORE_ACC"], 0, 0))
+    return lo.program(field, max_degree)
+
+
+def compile_outputs(field: str, exprs) -> Program:
+    """one output column per expression (e.g. the numerator and denominator of a grand-product argument)"""
+    lo = _Lowering(field)
+    max_degree = 0
+    for i, e in enumerate(exprs):
+        max_degree = max(max_degree, e.degree())
+        lo.emit(e)
+        lo.insns.append((OP["STORE_TOP"], i, 0))
+    return lo.program(field, max_degree)
 
 
 def _limbs(field: str, v: int) -> np.ndarray:
@@ -229,7 +249,7 @@ class GateEvaluator:
         arr = (_Insn * len(program.insns))()
         for i, (op, a, rot) in enumerate(program.insns):
             arr[i] = _Insn(int(op), int(a), int(rot))
-        consts = np.stack([_limbs(program.field, v) for v in program.consts])
+        consts = np.stack([_limbs(program.field, v) for v in program.consts]) if program.consts else np.zeros((1, 4), np.uint64)
         h = ctypes.c_void_p()
         api._check(api.lib().trh_expr_create(api.FIELD_ID[program.field], ctypes.cast(arr, ctypes.c_void_p), len(program.insns), api._p(consts), len(program.consts),
                                             len(program.columns), n_outputs, n_locals, ctypes.byref(h)))
@@ -253,12 +273,13 @@ class GateEvaluator:
             assert t.shape[-2] == n and t.is_contiguous(), key
             ptrs[i] = t.data_ptr()
         if out is None:
-            out = torch.empty((n, 4), dtype=first.dtype, device=first.device)
-        outs = (ctypes.c_void_p * 1)(out.data_ptr())
+            out = torch.empty((self.n_outputs, n, 4), dtype=first.dtype, device=first.device)
+        o3 = out.reshape(self.n_outputs, n, 4)
+        outs = (ctypes.c_void_p * self.n_outputs)(*[o3[i].data_ptr() for i in range(self.n_outputs)])
         if stream is None:
             stream = torch.cuda.current_stream(first.device).cuda_stream
         api._check(api.lib().trh_expr_eval_dev(self.handle, ptrs, outs, log_n, rot_step, stream))
-        return out
+        return o3[0] if self.n_outputs == 1 else o3
 
     def __del__(self):
         try:

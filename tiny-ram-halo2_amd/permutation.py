@@ -1,0 +1,77 @@
+"""The grand-product column of halo2_proofs 0.2.0's permutation argument (plonk/permutation/prover.rs `Argument::commit`,
+reached from create_proof: /root/reference/src/test_utils.rs:41-49; the reference enables equality on 188 columns,
+src/circuits/tables/prog.rs:151-152, i.e. 47 product columns of 4 columns each -- SURVEY.md Appendix B) on device columns:
+
+    z[0] = z0,   z[i + 1] = z[i] * prod_j (v_j[i] + beta * delta^(j0 + j) * omega^i + gamma) / (v_j[i] + beta * sigma_j[i] + gamma)
+
+built from libtrh primitives: the numerator and denominator products are one two-output expression program
+(expr.compile_outputs), the division is ff::BatchInvert (trh_field_batch_invert_dev) + an element-wise multiply, the
+running product is trh_field_prefix_product_dev.  Blinding rows and the commitment of z are the caller's (the replay
+commits product columns as ordinary Lagrange columns)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import api, expr
+from .poly import _MODULUS, _ROOT_OF_UNITY, S
+
+
+def delta(field: str) -> int:
+    """pasta_curves `DELTA` = GENERATOR^(2^S), GENERATOR = 5: generator of the odd-order part of the multiplicative group"""
+    return pow(5, 1 << S, _MODULUS[field])
+
+
+def omega(field: str, k: int) -> int:
+    w = _ROOT_OF_UNITY[field]
+    for _ in range(k, S):
+        w = w * w % _MODULUS[field]
+    return w
+
+
+class ProductColumn:
+    """compiled once per (field, k, number of columns in the chunk, index of the chunk's first column)"""
+
+    def __init__(self, field: str, k: int, n_columns: int, first_column: int = 0):
+        self.field, self.k, self.n, self.n_columns = field, k, 1 << k, n_columns
+        m = _MODULUS[field]
+        self.d = [pow(delta(field), first_column + j, m) for j in range(n_columns)]
+        self._ev = None
+        self._key = None
+
+    def _evaluator(self, beta: int, gamma: int):
+        if self._key != (beta, gamma):
+            m = _MODULUS[self.field]
+            x = expr.Fixed(0, 0)  # the column of omega^i
+            num = den = None
+            for j in range(self.n_columns):
+                v, sg = expr.Advice(j, 0), expr.Advice(self.n_columns + j, 0)
+                tn = v + x * (beta * self.d[j] % m) + gamma
+                td = v + sg * beta + gamma
+                num = tn if num is None else num * tn
+                den = td if den is None else den * td
+            self._ev = expr.GateEvaluator(expr.compile_outputs(self.field, [num, den]), n_outputs=2)
+            self._key = (beta, gamma)
+        return self._ev
+
+    def compute(self, values, sigmas, beta: int, gamma: int, z0: int = 1):
+        """values, sigmas: lists of n_columns device tensors (n, 4); returns z as a device tensor (n, 4)"""
+        import torch
+        assert len(values) == self.n_columns and len(sigmas) == self.n_columns
+        dev = values[0].device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        xs = torch.empty((self.n, 4), dtype=torch.int64, device=dev)
+        api.powers_dev(self.field, xs, self.n, expr._limbs(self.field, omega(self.field, self.k)), stream=st)
+        cols = {("fixed", 0): xs}
+        for j in range(self.n_columns):
+            cols[("advice", j)] = values[j]
+            cols[("advice", self.n_columns + j)] = sigmas[j]
+        nd = self._evaluator(beta, gamma).eval(cols, self.k, 1, stream=st)
+        num, den = nd[0], nd[1]
+        api.batch_invert_dev(self.field, den, self.n, stream=st)
+        ratio = torch.empty_like(num)
+        api._check(api.lib().trh_field_op_dev(api.FIELD_ID[self.field], api.FIELD_OPS["mul"], api._devptr(num), api._devptr(den), api._devptr(ratio), self.n, st))
+        z = torch.empty_like(num)
+        api.prefix_product_dev(self.field, ratio, z, self.n, stream=st)
+        if z0 % _MODULUS[self.field] != 1:
+            api.field_scale_dev(self.field, z, self.n, expr._limbs(self.field, z0), stream=st)
+        return z
