@@ -305,7 +305,6 @@ __global__ void __launch_bounds__(1024) msm_bucket_ranges_kernel(u32* __restrict
     u32* cnt = bucket_cnt + (z * Wz + j) * nb1;
     u32* st = starts + (z * Wz + j) * nb1;
     u32* en = ends + (z * Wz + j) * nb1;
-    u32* sb = seg_bucket + (z * Wz + j) * nseg;
     const u32 per = (nb1 + 1023u) / 1024u;
     const u32 lo = t * per < nb1 ? t * per : nb1, hi = lo + per < nb1 ? lo + per : nb1;
     u32 sum = 0;
@@ -322,10 +321,30 @@ __global__ void __launch_bounds__(1024) msm_bucket_ranges_kernel(u32* __restrict
     for (u32 b = lo; b < hi; ++b) {
         const u32 c = cnt[b], S = run, E = run + c;
         st[b] = S; en[b] = E; cnt[b] = S;  // cursor starts at the bucket start
-        if (c)
-            for (u32 sg = (S + seg_len - 1) / seg_len; sg * seg_len < E; ++sg) sb[sg] = b;  // segments whose first entry lies in this bucket
         run = E;
     }
+}
+
+// seg_bucket[sg] = the bucket that holds entry sg * seg_len (first bucket whose end lies beyond it); one thread per
+// segment, binary search over the (L2-resident) bucket ends -- a single workgroup filling 10^5 segments was the
+// latency floor of small MSMs
+__global__ void __launch_bounds__(256) msm_seg_bucket_kernel(const u32* __restrict__ ends, u32* __restrict__ seg_bucket, u32 nbk, u32 nseg, u32 seg_len) {
+    const size_t z = blockIdx.z;
+    const size_t Wz = gridDim.y;
+    const int j = blockIdx.y;
+    const u32 nb1 = nbk + 1;
+    const u32* en = ends + (z * Wz + j) * nb1;
+    u32* sb = seg_bucket + (z * Wz + j) * nseg;
+    const u32 sg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg >= nseg) return;
+    const u32 pos = sg * seg_len;
+    if (pos >= en[nbk]) return;  // beyond the last entry: never read
+    u32 lo = 0, hi = nbk;        // smallest b with en[b] > pos (en is non-decreasing, en[0] = 0)
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (en[mid] > pos) hi = mid; else lo = mid + 1;
+    }
+    sb[sg] = lo;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -749,6 +768,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
             hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.bucket_cnt.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(),
                                L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
+            hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, L.ends.as<u32>(), L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
         }
