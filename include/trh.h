@@ -145,6 +145,9 @@ int trh_domain_divide_by_vanishing_poly(trh_domain_t d, void* a_dev, size_t batc
  * (trh_bases_wrap_device + offset); these are the remaining per-round primitives.            */
 /* halo2_proofs::arithmetic::compute_inner_product(a, b): sum a[i] * b[i] -> out (Montgomery) */
 int trh_field_inner_product_dev(int field, const void* a_dev, const void* b_dev, size_t n, void* stream, uint64_t out[4]);
+/* halo2_proofs::arithmetic::eval_polynomial for `batch` polynomials (n coefficients each, back to back in device memory)
+ * at one point -- the evaluations create_proof sends before the multiopen argument; out: batch x 4 u64 on the host */
+int trh_poly_eval_batch_dev(int field, const void* polys_dev, size_t n, size_t batch, const uint64_t point[4], void* stream, uint64_t* out);
 /* y[i] += c * x[i]: the folds p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] */
 int trh_field_axpy_dev(int field, void* y_dev, const void* x_dev, size_t n, const uint64_t c_mont[4], void* stream);
 /* out[i] = x^i for i < n: the evaluation vector b = (1, x3, x3^2, ...) */

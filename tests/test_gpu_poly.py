@@ -217,3 +217,35 @@ def test_domain_fused_passes_vs_unfused_primitives(field, k, j):
     api.field_scale_dev(field, ref, batch * N, dom._w["extended_ifft_divisor"])
     api.field_scale_rows_dev(field, ref, batch, N, N, dom._from_coset)
     assert (back == to_host(ref)[:, : back.shape[1]]).all()  # the Rust code truncates to n * quotient_poly_degree coefficients
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_poly_eval_batch(field):
+    """arithmetic::eval_polynomial (Horner) for a batch of device polynomials; at x = omega^i it must agree with the NTT"""
+    f = o.FIELDS[field]
+    rng = random.Random(0xE7A1)
+    for n, batch in ((1, 2), (5, 3), (257, 4), (3000, 2)):
+        polys = [[rng.randrange(f.m) for _ in range(n)] for _ in range(batch)]
+        x = rng.randrange(f.m)
+        d = to_dev(np.stack([limbs(f, p) for p in polys]))
+        got = api.poly_eval_batch_dev(field, d, n, batch, np.array(f.limbs(x), np.uint64))
+        for b in range(batch):
+            acc = 0
+            for cf in reversed(polys[b]):
+                acc = (acc * x + cf) % f.m
+            assert f.from_limbs(got[b]) == acc, (n, b)
+    # x = 0 and x = 1
+    d = to_dev(limbs(f, [7, 8, 9])[None])
+    assert f.from_limbs(api.poly_eval_batch_dev(field, d, 3, 1, np.array(f.limbs(0), np.uint64))[0]) == 7
+    assert f.from_limbs(api.poly_eval_batch_dev(field, d, 3, 1, np.array(f.limbs(1), np.uint64))[0]) == 24
+    # size-independent property at 2^16: evaluations at omega^i are entries of the forward transform
+    k, batch = 16, 3
+    n = 1 << k
+    a = synth.field_elements(0xE7A2, batch * n).reshape(batch, n, 4)
+    w = f.omega(k)
+    fwd = to_dev(a)
+    api.ntt_dev(field, fwd, k, np.array(f.limbs(w), np.uint64), batch=batch)
+    fwd = to_host(fwd)
+    for i in (0, 1, 12345, n - 1):
+        got = api.poly_eval_batch_dev(field, to_dev(a), n, batch, np.array(f.limbs(pow(w, i, f.m)), np.uint64))
+        assert (got == fwd[:, i]).all(), i

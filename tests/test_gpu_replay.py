@@ -34,6 +34,13 @@ def test_replay_k10_matches_oracle():
             want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], bases, threads=8))
             assert (np.asarray(out)[:8] == want).all(), kind
             return
+        if kind == "evals":  # arithmetic::eval_polynomial: Horner at the challenge
+            f = o.FIELDS[inp["field"]]
+            x, acc = f.from_limbs(inp["x"]), 0
+            for r in np.asarray(inp["a"]).reshape(-1, 4)[::-1]:
+                acc = (acc * x + f.from_limbs(r)) % f.m
+            assert f.from_limbs(out) == acc
+            return
         if kind == "h_eval":  # sampled rows of the gate evaluation against the oracle's Expression::evaluate restatement
             f = o.FIELDS[inp["field"]]
             n = 1 << inp["log_n"]
@@ -61,4 +68,4 @@ def test_replay_k10_matches_oracle():
     res = replay.run(16, batch=32, hook=hook, verbose=False)
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}

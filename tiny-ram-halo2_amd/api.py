@@ -104,6 +104,7 @@ _SIGNATURES = {
     "trh_domain_extended_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_domain_divide_by_vanishing_poly": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_ipa_create_proof": ([_vp, _u64p, ctypes.c_uint32, _vp, _u64p, _u64p, _vp, _u64p, ctypes.POINTER(Transcript), RNG_FN, _vp, _vp, _u64p, _u64p], ctypes.c_int),
+    "trh_poly_eval_batch_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp, _u64p], ctypes.c_int),
     "trh_field_batch_invert_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_prefix_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_expr_create": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
@@ -286,6 +287,14 @@ def inner_product_dev(field: str, a_dev, b_dev, n: int, stream=None) -> np.ndarr
     """halo2_proofs::arithmetic::compute_inner_product on device vectors -> (4,) Montgomery limbs"""
     out = np.zeros(4, dtype=np.uint64)
     _check(lib().trh_field_inner_product_dev(FIELD_ID[field], _devptr(a_dev), _devptr(b_dev), n, stream, _p(out)))
+    return out
+
+
+def poly_eval_batch_dev(field: str, polys_dev, n: int, batch: int, point, stream=None) -> np.ndarray:
+    """arithmetic::eval_polynomial of `batch` device polynomials at one point -> (batch, 4) limbs"""
+    out = np.zeros((batch, 4), dtype=np.uint64)
+    x = _c(point).reshape(4)
+    _check(lib().trh_poly_eval_batch_dev(FIELD_ID[field], _devptr(polys_dev), n, batch, _p(x), stream, _p(out)))
     return out
 
 

@@ -58,6 +58,37 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const uint4* __restri
     if (threadIdx.x == 0) st<F>(out, sh[0]);
 }
 
+// evaluation of a batch of polynomials at one point: partial[poly][block] = sum over the block's share of a[poly][i] * pw[i]
+template <class F>
+__global__ void __launch_bounds__(256) eval_batch_kernel(const uint4* __restrict__ polys, const uint4* __restrict__ pw, size_t n, uint4* __restrict__ partial) {
+    __shared__ Fe<F> sh[256];
+    const uint4* a = polys + (size_t)blockIdx.y * n * 2;
+    Fe<F> acc = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc = fe_add(acc, fe_mul(ld<F>(a + 2 * i), ld<F>(pw + 2 * i)));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st<F>(partial + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), sh[0]);
+}
+template <class F>
+__global__ void __launch_bounds__(256) sum_partials_batch_kernel(const uint4* __restrict__ partial, u32 count, uint4* __restrict__ out) {
+    __shared__ Fe<F> sh[256];
+    const uint4* p = partial + 2 * (size_t)blockIdx.x * count;
+    Fe<F> acc = fe_zero<F>();
+    for (u32 i = threadIdx.x; i < count; i += 256) acc = fe_add(acc, ld<F>(p + 2 * i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st<F>(out + 2 * (size_t)blockIdx.x, sh[0]);
+}
+
 // y[i] += c * x[i]
 template <class F>
 __global__ void __launch_bounds__(256) axpy_kernel(uint4* __restrict__ y, const uint4* __restrict__ x, size_t n, const uint4* __restrict__ c) {
@@ -158,6 +189,29 @@ int powers_t(void* out, size_t n, const u64* x, hipStream_t s) {
     TRH_TRY(stage_constant(pw, sizeof(pw), s, &d_pw));
     hipLaunchKernelGGL((powers_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)out, n, (const uint4*)d_pw);
     TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+// poly::eval_polynomial for `batch` polynomials of n coefficients at one point: the powers x^i are built once
+template <class F>
+int eval_batch_t(const void* polys, size_t n, size_t batch, const u64* x, hipStream_t s, u64* out) {
+    Ctx& c = ctx();
+    unsigned blocks = (unsigned)((n + 2047) / 2048);  // eight elements per thread
+    if (blocks > 64) blocks = 64;
+    if (blocks == 0) blocks = 1;
+    TRH_TRY(c.scan.ensure(n * 32 + 32));
+    TRH_TRY(c.io.ensure((size_t)batch * (blocks + 1) * 32));
+    TRH_TRY((powers_t<F>(c.scan.p, n, x, s)));
+    uint4* partial = c.io.as<uint4>();
+    uint4* result = partial + 2 * (size_t)batch * blocks;
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        const unsigned nb = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
+        hipLaunchKernelGGL((eval_batch_kernel<F>), dim3(blocks, nb), dim3(256), 0, s, (const uint4*)polys + b0 * n * 2, c.scan.as<uint4>(), n, partial + 2 * b0 * blocks);
+        hipLaunchKernelGGL((sum_partials_batch_kernel<F>), dim3(nb), dim3(256), 0, s, partial + 2 * b0 * blocks, blocks, result + 2 * b0);
+    }
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipMemcpyAsync(out, result, batch * 32, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
     return TRH_OK;
 }
 
@@ -295,6 +349,18 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
 using namespace trh;
 
 extern "C" {
+
+int trh_poly_eval_batch_dev(int field, const void* polys_dev, size_t n, size_t batch, const uint64_t point[4], void* stream, uint64_t* out) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (!out || !point || (n && batch && !polys_dev)) { set_error("poly_eval: null pointer"); return TRH_EINVAL; }
+    if (!batch) return TRH_OK;
+    if (!n) { memset(out, 0, batch * 32); return TRH_OK; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return eval_batch_t<FpParams>(polys_dev, n, batch, point, (hipStream_t)stream, out);
+    return eval_batch_t<FqParams>(polys_dev, n, batch, point, (hipStream_t)stream, out);
+}
 
 int trh_field_inner_product_dev(int field, const void* a_dev, const void* b_dev, size_t n, void* stream, uint64_t out[4]) {
     TRH_TRY(require_init());

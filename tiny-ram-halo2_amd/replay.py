@@ -96,13 +96,14 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
         e.record()
         return e
 
-    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "h_eval": 0.0, "commit": 0.0,
+    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
              "extended_to_coeff": 0.0, "ipa": 0.0}
     counts = {kk: 0 for kk in times}
     checked = 0
     torch.cuda.synchronize()
     t_wall = time.perf_counter()
 
+    x_eval = synth.field_elements(0xE7A, 1)[0]
     # --- Lagrange-basis columns: instance, advice, lookup permuted x2 + z, permutation z ---
     lag_total = sch["intt_n"]
     done = 0
@@ -119,7 +120,13 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
         e2 = ev()
         ext = dom.coeff_to_extended(coeff)
         e3 = ev()
+        # the evaluations at the challenge x that precede the multiopen argument (eval_polynomial per queried column;
+        # the real prover does them after x is squeezed, with the coefficient forms kept resident: same work)
+        evals = api.poly_eval_batch_dev(field, coeff, n, b, x_eval, stream=torch.cuda.current_stream().cuda_stream)
+        e4 = ev()
         torch.cuda.synchronize()
+        times["evals"] += e3.elapsed_time(e4)
+        counts["evals"] += b
         times["commit_lagrange"] += e0.elapsed_time(e1)
         times["lagrange_to_coeff"] += e1.elapsed_time(e2)
         times["coeff_to_extended"] += e2.elapsed_time(e3)
@@ -132,7 +139,8 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
                 hook("commit_lagrange", dict(scalars=np.concatenate([cols_h[i], blinds[i][None]]), bases=gl), pts[i])
                 hook("lagrange_to_coeff", dict(a=cols_h[i], domain=(field, QUOTIENT_J, k)), coeff[i].cpu().numpy().view(np.uint64))
                 hook("coeff_to_extended", dict(a=coeff[i].cpu().numpy().view(np.uint64), domain=(field, QUOTIENT_J, k)), ext[i].cpu().numpy().view(np.uint64))
-                checked += 3
+                hook("evals", dict(a=coeff[i].cpu().numpy().view(np.uint64), x=x_eval, field=field), evals[i])
+                checked += 4
         if done + b >= lag_total:
             ext_keep = ext  # the last batch of extended cosets stays resident for the h(X) step below
         del ext, coeff, cols
