@@ -180,3 +180,26 @@ def test_permutation_product_column(field):
     ident = [[pow(delta, first + j, f.m) * pow(w, i, f.m) % f.m for i in range(n)] for j in range(ncol)]
     z = from_dev(f, pc.compute([dev(c) for c in vals], [dev(c) for c in ident], beta, gamma, z0))
     assert z == [z0] * n
+
+
+def test_lookup_product_column():
+    """plonk/lookup/prover.rs commit_product: z[i+1] = z[i] (a_i + beta)(s_i + gamma) / ((a'_i + beta)(s'_i + gamma)); with
+    a' a permutation of a and s' of s the product returns to 1 after the last row"""
+    from tiny_ram_halo2_amd import permutation
+    field, k = "fp", 8
+    f = o.FIELDS[field]
+    n = 1 << k
+    rng = random.Random(0x100C)
+    table = [rng.randrange(f.m) for _ in range(n)]
+    a = [table[rng.randrange(n)] for _ in range(n)]
+    ap, sp = sorted(a), list(table)
+    rng.shuffle(sp)
+    beta, gamma = rng.randrange(f.m), rng.randrange(f.m)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    cols = {("advice", i): dev(c) for i, c in enumerate((a, table, ap, sp))}
+    z = from_dev(f, permutation.lookup_product(field, k, beta, gamma).compute(cols))
+    want, acc = [], 1
+    for i in range(n):
+        want.append(acc)
+        acc = acc * (a[i] + beta) * (table[i] + gamma) % f.m * pow((ap[i] + beta) * (sp[i] + gamma), -1, f.m) % f.m
+    assert z == want and acc == 1

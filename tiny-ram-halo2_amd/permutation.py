@@ -28,6 +28,37 @@ def omega(field: str, k: int) -> int:
     return w
 
 
+class GrandProduct:
+    """z[0] = z0, z[i + 1] = z[i] * num(row i) / den(row i) for two Expressions over device columns -- the common core of the
+    permutation product above and of the lookup argument's product (plonk/lookup/prover.rs `commit_product`:
+    num = (a + beta)(s + gamma) over the compressed input / table, den = (a' + beta)(s' + gamma) over the permuted ones)."""
+
+    def __init__(self, field: str, k: int, num: expr.Expression, den: expr.Expression):
+        self.field, self.k, self.n = field, k, 1 << k
+        self.ev = expr.GateEvaluator(expr.compile_outputs(field, [num, den]), n_outputs=2)
+
+    def compute(self, columns: dict, z0: int = 1, rot_step: int = 1):
+        import torch
+        first = next(iter(columns.values()))
+        st = torch.cuda.current_stream(first.device).cuda_stream
+        nd = self.ev.eval(columns, self.k, rot_step, stream=st)
+        num, den = nd[0], nd[1]
+        api.batch_invert_dev(self.field, den, self.n, stream=st)
+        ratio = torch.empty_like(num)
+        api._check(api.lib().trh_field_op_dev(api.FIELD_ID[self.field], api.FIELD_OPS["mul"], api._devptr(num), api._devptr(den), api._devptr(ratio), self.n, st))
+        z = torch.empty_like(num)
+        api.prefix_product_dev(self.field, ratio, z, self.n, stream=st)
+        if z0 % _MODULUS[self.field] != 1:
+            api.field_scale_dev(self.field, z, self.n, expr._limbs(self.field, z0), stream=st)
+        return z
+
+
+def lookup_product(field: str, k: int, beta: int, gamma: int) -> GrandProduct:
+    """columns: ("advice", 0) = compressed input A, 1 = compressed table S, 2 = permuted input A', 3 = permuted table S'"""
+    a, s_, ap, sp = (expr.Advice(i, 0) for i in range(4))
+    return GrandProduct(field, k, (a + beta) * (s_ + gamma), (ap + beta) * (sp + gamma))
+
+
 class ProductColumn:
     """compiled once per (field, k, number of columns in the chunk, index of the chunk's first column)"""
 
