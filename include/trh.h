@@ -183,6 +183,17 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
 int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream);
 /* out[i] = prod_{j < i} a[j], out[0] = 1 (exclusive scan; out must not alias a) */
 int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
+/* out[i] = sum_{j < i} a[j], out[0] = 0 */
+int trh_field_prefix_sum_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
+
+/* ---- multiopen building blocks (poly/multiopen/prover.rs: the x1 / x4 linear combinations of the queried polynomials
+ *      and the division of (q(X) - r(X)) by the (X - point) factors) ------------------------------------------------- */
+/* out[i] = sum_b coeffs[b] * polys[b][i]; polys: batch x n back to back in device memory, coeffs: batch x 4 u64 on the host */
+int trh_poly_lincomb_dev(int field, const void* polys_dev, size_t n, size_t batch, const uint64_t* coeffs_host, void* out_dev, void* stream);
+/* arithmetic::kate_division(a, z): quotient of a(X) (n coefficients) by (X - z), n - 1 coefficients, remainder a(z) dropped.
+ * pz_dev / pzinv_dev: z^i and z^-i for i < n (trh_field_powers_dev; shared by every polynomial divided at this point, z != 0),
+ * scratch_dev: 2 n elements.                                                                                          */
+int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const void* pz_dev, const void* pzinv_dev, void* scratch_dev, void* q_dev, void* stream);
 
 /* ---- gate expressions over resident columns: the h(X) numerator of plonk::create_proof ---------
  * halo2's `Expression<F>` (Constant / Selector / Fixed / Advice / Instance query at a Rotation, Negated, Sum,

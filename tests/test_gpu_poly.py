@@ -249,3 +249,39 @@ def test_poly_eval_batch(field):
     for i in (0, 1, 12345, n - 1):
         got = api.poly_eval_batch_dev(field, to_dev(a), n, batch, np.array(f.limbs(pow(w, i, f.m)), np.uint64))
         assert (got == fwd[:, i]).all(), i
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_multiopen_lincomb_and_kate_division(field):
+    """poly/multiopen/prover.rs building blocks: sum_b x1^b p_b and arithmetic::kate_division (synthetic division by X - z)"""
+    from tiny_ram_halo2_amd import multiopen
+    f = o.FIELDS[field]
+    rng = random.Random(0x0FE7)
+    for n, batch in ((2, 1), (7, 3), (300, 5), (4097, 2), (70000, 2)):
+        polys = [[rng.randrange(f.m) for _ in range(n)] for _ in range(batch)]
+        if n > 4:
+            polys[0][n - 1] = 0; polys[0][2] = f.m - 1
+        x1 = rng.randrange(f.m)
+        coeffs = [pow(x1, b, f.m) for b in range(batch)]
+        d = to_dev(np.stack([limbs(f, p) for p in polys]))
+        comb = multiopen.lincomb(field, d, coeffs)
+        want = [sum(coeffs[b] * polys[b][i] for b in range(batch)) % f.m for i in range(n)]
+        got = [f.from_limbs(r) for r in to_host(comb)]
+        assert got == want
+        for z in (rng.randrange(f.m), 1, f.m - 1, 0):
+            q = [f.from_limbs(r) for r in to_host(multiopen.KateDivider(field, n, z, comb.device).divide(comb))]
+            # the Rust loop: q[n-2] = a[n-1]; q[i-1] = a[i] + z q[i]
+            ref, tmp = [0] * (n - 1), 0
+            for i in range(n - 1, 0, -1):
+                tmp = (want[i] + z * tmp) % f.m
+                ref[i - 1] = tmp
+            assert q == ref, (n, z)
+    # prefix sums on their own
+    a = [rng.randrange(f.m) for _ in range(5000)]
+    d, out = to_dev(limbs(f, a)), to_dev(limbs(f, [0] * 5000))
+    api._check(api.lib().trh_field_prefix_sum_dev(api.FIELD_ID[field], api._devptr(d), api._devptr(out), 5000, None))
+    acc, want = 0, []
+    for v in a:
+        want.append(acc)
+        acc = (acc + v) % f.m
+    assert [f.from_limbs(r) for r in to_host(out)] == want

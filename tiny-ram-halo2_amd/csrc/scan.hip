@@ -53,87 +53,122 @@ constexpr int SCAN_PER_THREAD = 16;
 constexpr int SCAN_BLOCK = 256 * SCAN_PER_THREAD;
 
 // exclusive scan of 256 values in LDS (Hillis-Steele); returns the exclusive prefix of this thread and the block total
-template <class F>
+// the scanned operation: running product (grand products) or running sum (kate_division, see multiopen.py)
+template <class F> struct OpMul {
+    static __device__ __forceinline__ Fe<F> id() { return fe_one<F>(); }
+    static __device__ __forceinline__ Fe<F> op(const Fe<F>& a, const Fe<F>& b) { return fe_mul(a, b); }
+};
+template <class F> struct OpAdd {
+    static __device__ __forceinline__ Fe<F> id() { return fe_zero<F>(); }
+    static __device__ __forceinline__ Fe<F> op(const Fe<F>& a, const Fe<F>& b) { return fe_add(a, b); }
+};
+
+template <class F, class OP>
 __device__ __forceinline__ Fe<F> block_exclusive_scan(Fe<F>* sh, const Fe<F>& mine, Fe<F>& total) {
     const int t = threadIdx.x;
     sh[t] = mine;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-        Fe<F> v = fe_one<F>();
+        Fe<F> v = OP::id();
         const bool take = t >= off;
         if (take) v = sh[t - off];
         __syncthreads();
-        if (take) sh[t] = fe_mul(sh[t], v);
+        if (take) sh[t] = OP::op(sh[t], v);
         __syncthreads();
     }
     total = sh[255];
-    const Fe<F> incl_prev = t ? sh[t - 1] : fe_one<F>();
+    const Fe<F> incl_prev = t ? sh[t - 1] : OP::id();
     __syncthreads();
     return incl_prev;
 }
 
 // phase 1: product of each block of SCAN_BLOCK elements
-template <class F>
+template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_block_totals_kernel(const uint4* __restrict__ a, size_t n, uint4* __restrict__ totals) {
     __shared__ Fe<F> sh[256];
     const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
-    Fe<F> p = fe_one<F>();
+    Fe<F> p = OP::id();
     for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (lo + k < n) p = fe_mul(p, ldf<F>(a + 2 * (lo + k)));
+        if (lo + k < n) p = OP::op(p, ldf<F>(a + 2 * (lo + k)));
     Fe<F> total;
-    block_exclusive_scan<F>(sh, p, total);
+    block_exclusive_scan<F, OP>(sh, p, total);
     if (threadIdx.x == 0) stf<F>(totals + 2 * blockIdx.x, total);
 }
 // phase 2 (one workgroup): exclusive scan of the block totals, in place
-template <class F>
+template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_totals_kernel(uint4* __restrict__ totals, u32 count) {
     __shared__ Fe<F> sh[256];
     const u32 per = (count + 255u) / 256u;
     const u32 lo = threadIdx.x * per;
-    Fe<F> p = fe_one<F>();
+    Fe<F> p = OP::id();
     for (u32 k = 0; k < per; ++k)
-        if (lo + k < count) p = fe_mul(p, ldf<F>(totals + 2 * (lo + k)));
+        if (lo + k < count) p = OP::op(p, ldf<F>(totals + 2 * (lo + k)));
     Fe<F> total;
-    Fe<F> run = block_exclusive_scan<F>(sh, p, total);
+    Fe<F> run = block_exclusive_scan<F, OP>(sh, p, total);
     for (u32 k = 0; k < per; ++k) {
         if (lo + k >= count) break;
         const Fe<F> v = ldf<F>(totals + 2 * (lo + k));
         stf<F>(totals + 2 * (lo + k), run);
-        run = fe_mul(run, v);
+        run = OP::op(run, v);
     }
 }
 // phase 3: out[i] = prod_{j < i} a[j]
-template <class F>
+template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_apply_kernel(const uint4* __restrict__ a, uint4* __restrict__ out, size_t n, const uint4* __restrict__ totals) {
     __shared__ Fe<F> sh[256];
     const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     Fe<F> vals[SCAN_PER_THREAD];
-    Fe<F> p = fe_one<F>();
+    Fe<F> p = OP::id();
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        vals[k] = lo + k < n ? ldf<F>(a + 2 * (lo + k)) : fe_one<F>();
-        p = fe_mul(p, vals[k]);
+        vals[k] = lo + k < n ? ldf<F>(a + 2 * (lo + k)) : OP::id();
+        p = OP::op(p, vals[k]);
     }
     Fe<F> total;
-    Fe<F> run = fe_mul(block_exclusive_scan<F>(sh, p, total), ldf<F>(totals + 2 * blockIdx.x));
+    Fe<F> run = OP::op(block_exclusive_scan<F, OP>(sh, p, total), ldf<F>(totals + 2 * blockIdx.x));
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
         if (lo + k < n) stf<F>(out + 2 * (lo + k), run);
-        run = fe_mul(run, vals[k]);
+        run = OP::op(run, vals[k]);
     }
 }
 
-template <class F>
-int prefix_product_t(const void* a, void* out, size_t n, hipStream_t s) {
+template <class F, class OP>
+int prefix_scan_t(const void* a, void* out, size_t n, hipStream_t s) {
     Ctx& c = ctx();
     const unsigned blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     TRH_TRY(c.scan.ensure((size_t)blocks * 32 + 32));
-    hipLaunchKernelGGL((scan_block_totals_kernel<F>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, n, c.scan.as<uint4>());
-    hipLaunchKernelGGL((scan_totals_kernel<F>), dim3(1), dim3(256), 0, s, c.scan.as<uint4>(), blocks);
-    hipLaunchKernelGGL((scan_apply_kernel<F>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, (uint4*)out, n, c.scan.as<uint4>());
+    hipLaunchKernelGGL((scan_block_totals_kernel<F, OP>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, n, c.scan.as<uint4>());
+    hipLaunchKernelGGL((scan_totals_kernel<F, OP>), dim3(1), dim3(256), 0, s, c.scan.as<uint4>(), blocks);
+    hipLaunchKernelGGL((scan_apply_kernel<F, OP>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, (uint4*)out, n, c.scan.as<uint4>());
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
+// ---- multiopen building blocks (halo2_proofs 0.2.0 poly/multiopen/prover.rs) -----------------------------
+// out[i] = sum_b coeff[b] * polys[b][i]: the x1 / x4 linear combinations of the queried polynomials
+template <class F>
+__global__ void __launch_bounds__(256) lincomb_kernel(const uint4* __restrict__ polys, size_t n, u32 batch, const uint4* __restrict__ coeffs, uint4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> acc = fe_zero<F>();
+    for (u32 b = 0; b < batch; ++b) acc = fe_add(acc, fe_mul(ldf<F>(polys + 2 * ((size_t)b * n + i)), ldf<F>(coeffs + 2 * b)));
+    stf<F>(out + 2 * i, acc);
+}
+// kate_division, step 1: t[m] = a[m] * z^m (pz = the powers of z)
+template <class F>
+__global__ void __launch_bounds__(256) mul_pointwise_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stf<F>(out + 2 * i, fe_mul(ldf<F>(a + 2 * i), ldf<F>(b + 2 * i)));
+}
+// step 3: q[i - 1] = (total - P[i]) * zinv^i for i = 1..n-1, P = exclusive prefix sums of t, total = P[n-1] + t[n-1]
+template <class F>
+__global__ void __launch_bounds__(256) kate_finish_kernel(const uint4* __restrict__ t, const uint4* __restrict__ P, const uint4* __restrict__ pzinv, uint4* __restrict__ q, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i >= n) return;
+    const Fe<F> total = fe_add(ldf<F>(P + 2 * (n - 1)), ldf<F>(t + 2 * (n - 1)));
+    stf<F>(q + 2 * (i - 1), fe_mul(fe_sub(total, ldf<F>(P + 2 * i)), ldf<F>(pzinv + 2 * i)));
+}
+
 template <class F>
 int batch_invert_t(void* a, size_t n, hipStream_t s) {
     Ctx& c = ctx();
@@ -170,8 +205,66 @@ int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, si
     if (!n) return TRH_OK;
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
-    if (field == TRH_FP) return prefix_product_t<FpParams>(a_dev, out_dev, n, (hipStream_t)stream);
-    return prefix_product_t<FqParams>(a_dev, out_dev, n, (hipStream_t)stream);
+    if (field == TRH_FP) return prefix_scan_t<FpParams, OpMul<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream);
+    return prefix_scan_t<FqParams, OpMul<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream);
+}
+
+int trh_poly_lincomb_dev(int field, const void* polys_dev, size_t n, size_t batch, const uint64_t* coeffs_host, void* out_dev, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && (!out_dev || (batch && (!polys_dev || !coeffs_host)))) { set_error("poly_lincomb: null pointer"); return TRH_EINVAL; }
+    if (batch > ((size_t)1 << 20)) { set_error("poly_lincomb: batch too large"); return TRH_EINVAL; }
+    if (!n) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    hipStream_t s = (hipStream_t)stream;
+    TRH_TRY(c.scan.ensure((batch ? batch : 1) * 32));
+    if (batch) TRH_HIP_TRY(hipMemcpyAsync(c.scan.p, coeffs_host, batch * 32, hipMemcpyHostToDevice, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // the caller's coefficient buffer may be reused
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (field == TRH_FP) hipLaunchKernelGGL((lincomb_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)polys_dev, n, (u32)batch, c.scan.as<uint4>(), (uint4*)out_dev);
+    else hipLaunchKernelGGL((lincomb_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)polys_dev, n, (u32)batch, c.scan.as<uint4>(), (uint4*)out_dev);
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // c.scan is shared scratch
+    return TRH_OK;
+}
+
+/* poly::kate_division(a, z): the quotient of a(X) by (X - z), remainder dropped; pz / pzinv: the powers of z and of z^-1
+ * (n elements each, device; trh_field_powers_dev), scratch: 2 n elements of device memory */
+int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const void* pz_dev, const void* pzinv_dev, void* scratch_dev, void* q_dev, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n < 2) return TRH_OK;  // a constant has an empty quotient
+    if (!a_dev || !pz_dev || !pzinv_dev || !scratch_dev || !q_dev) { set_error("kate_division: null pointer"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    hipStream_t s = (hipStream_t)stream;
+    uint4* t = (uint4*)scratch_dev;
+    uint4* P = t + 2 * n;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (field == TRH_FP) {
+        hipLaunchKernelGGL((mul_pointwise_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)a_dev, (const uint4*)pz_dev, t, n);
+        TRH_TRY((prefix_scan_t<FpParams, OpAdd<FpParams>>(t, P, n, s)));
+        hipLaunchKernelGGL((kate_finish_kernel<FpParams>), dim3(gb), dim3(256), 0, s, t, P, (const uint4*)pzinv_dev, (uint4*)q_dev, n);
+    } else {
+        hipLaunchKernelGGL((mul_pointwise_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)a_dev, (const uint4*)pz_dev, t, n);
+        TRH_TRY((prefix_scan_t<FqParams, OpAdd<FqParams>>(t, P, n, s)));
+        hipLaunchKernelGGL((kate_finish_kernel<FqParams>), dim3(gb), dim3(256), 0, s, t, P, (const uint4*)pzinv_dev, (uint4*)q_dev, n);
+    }
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+int trh_field_prefix_sum_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && (!a_dev || !out_dev)) { set_error("prefix_sum: null pointer"); return TRH_EINVAL; }
+    if (a_dev == out_dev) { set_error("prefix_sum: in-place operation is not supported"); return TRH_EINVAL; }
+    if (!n) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return prefix_scan_t<FpParams, OpAdd<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream);
+    return prefix_scan_t<FqParams, OpAdd<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream);
 }
 
 }  // extern "C"
