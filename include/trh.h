@@ -102,6 +102,11 @@ int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
 /* batch of MSMs over the same bases (one per column): scalars_dev holds batch x n x 4 u64 */
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch,
                       int scalars_are_montgomery, void* stream, uint64_t* out_xyz /* batch x 12 */);
+/* Params::commit / commit_lagrange for `batch` polynomials already in device memory (batch x n x 4 u64, back to back):
+ * item b is the MSM of polys[b] || blinds[b] over the handle's n + 1 bases (g or g_lagrange followed by w) -- the blind
+ * is read from its own small array, so the polynomials are not copied to make room for it.  blinds: batch x 4 u64, host. */
+int trh_commit_batch_dev(trh_bases_t bases, const void* polys_dev, size_t n, size_t batch, const uint64_t* blinds_host,
+                         void* stream, uint64_t* out_xyz /* batch x 12 */);
 /* window width override for tuning (0 = automatic) */
 int trh_msm_set_window_bits(int c); /* 0 or 2..18 */
 

@@ -109,6 +109,12 @@ def test_params_commit(curve):
     for i in range(batch):
         wl = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([ps[i], rs[i][None]]), np.concatenate([gl, w]), threads=4))
         assert (got[i, :8] == wl).all()
+    got_c = params.commit_batch(to_dev(ps), rs)  # coefficient-form counterpart, also without the fixed-base tables
+    plain = poly.Params(curve, k, g, gl, w, precompute=False)
+    assert (plain.commit_batch(to_dev(ps), rs) == got_c).all() and (plain.commit_lagrange_batch(to_dev(ps), rs) == got).all()
+    for i in range(batch):
+        wc = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([ps[i], rs[i][None]]), np.concatenate([g, w]), threads=4))
+        assert (got_c[i, :8] == wc).all()
     # commit(a) == commit_lagrange(lagrange form of a) when g_lagrange is the Lagrange basis of g is a
     # property of Params::new (a "next" row); here the two base sets are independent.
     del sf

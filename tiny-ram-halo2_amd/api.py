@@ -84,6 +84,7 @@ _SIGNATURES = {
     "trh_msm_dev_enqueue": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp], ctypes.c_int),
     "trh_msm_dev_finish": ([_vp, _vp, _u64p], ctypes.c_int),
     "trh_msm_batch_dev": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _vp, _u64p], ctypes.c_int),
+    "trh_commit_batch_dev": ([_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp, _u64p], ctypes.c_int),
     "trh_msm_set_window_bits": ([ctypes.c_int], ctypes.c_int),
     "trh_point_sum": ([ctypes.c_int, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_ntt_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, ctypes.c_size_t, _vp], ctypes.c_int),
@@ -413,6 +414,14 @@ class Bases:
     def msm_batch_dev(self, scalars_dev, n: int, batch: int, offset: int = 0, montgomery: bool = True, stream=None) -> np.ndarray:
         out = np.zeros((batch, 12), dtype=np.uint64)
         _check(lib().trh_msm_batch_dev(self.handle, offset, _devptr(scalars_dev), n, batch, 1 if montgomery else 0, stream, _p(out)))
+        return out
+
+    def commit_batch_dev(self, polys_dev, n: int, batch: int, blinds, stream=None) -> np.ndarray:
+        """Params::commit(_lagrange) of `batch` device polynomials: MSM of polys[b] || blinds[b] over the n + 1 bases"""
+        out = np.zeros((batch, 12), dtype=np.uint64)
+        bl = _c(blinds, 4)
+        assert bl.shape[0] == batch
+        _check(lib().trh_commit_batch_dev(self.handle, _devptr(polys_dev), n, batch, _p(bl), stream, _p(out)))
         return out
 
     def destroy(self):

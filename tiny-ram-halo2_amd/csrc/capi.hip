@@ -328,6 +328,22 @@ int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev,
     TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, batch, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
 }
+/* Params::commit / commit_lagrange for `batch` polynomials resident on the device: item b is the MSM of
+ * polys[b] (n scalars) || blinds[b] over the n + 1 bases of the handle (g or g_lagrange followed by w) */
+int trh_commit_batch_dev(trh_bases_t bases, const void* polys_dev, size_t n, size_t batch, const uint64_t* blinds_host, void* stream, uint64_t* out) {
+    TRH_TRY(msm_args(bases, 0, polys_dev, n + 1, batch, out));
+    if (!blinds_host) { set_error("commit_batch: null blinds"); return TRH_EINVAL; }
+    if (bases->n != n + 1) { set_error("commit_batch: the handle must hold n + 1 = %zu bases (g or g_lagrange followed by w), it holds %zu", n + 1, bases->n); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    hipStream_t s = (hipStream_t)stream;
+    TRH_TRY(c.msm.tails.ensure(batch * 32));
+    TRH_HIP_TRY(hipMemcpyAsync(c.msm.tails.p, blinds_host, batch * 32, hipMemcpyHostToDevice, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // the caller's blinds may be reused
+    TRH_TRY(msm_enqueue(bases->curve, bases->d_xy, lazy_bases(bases, 0, s), polys_dev, n + 1, batch, n, 1, s, fixed_base(bases, 0, n + 1), c.msm.tails.p));
+    return msm_finish(bases->curve, s, out, batch);
+}
+
 int trh_msm_set_window_bits(int cbits) {
     if (cbits != 0 && (cbits < 2 || cbits > 18)) { set_error("window bits must be 0 or in [2, 18]"); return TRH_EINVAL; }
     ctx().window_override = cbits;

@@ -78,6 +78,7 @@ struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: bat
 
 struct MsmScratch {
     DevBuf scalars;      // host-scalar entry points stage here
+    DevBuf tails;        // blinds of a commit batch (scalar n of every item)
     DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
@@ -134,7 +135,7 @@ struct MsmFixedBase {
     int c, W;
 };
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
-                size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr);
+                size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr, const void* tails_dev = nullptr);
 int msm_fixed_base_windows(int c);
 bool msm_fixed_base_fits(size_t n, int c);
 int msm_build_table(int curve, const void* bases_dev, size_t n, int c, void* table_dev, hipStream_t s);

@@ -58,7 +58,8 @@ inline int num_windows(int c) { return 255 / c + 1; }
 template <class SF>
 __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                          u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds, size_t sstride,
-                                                         int one_row /* fixed-base mode: all windows share one histogram */) {
+                                                         int one_row /* fixed-base mode: all windows share one histogram */,
+                                                         const uint4* __restrict__ tails /* or null: scalar n - 1 of item z is tails[z] (the commitment blind) */) {
     const size_t z = blockIdx.z;  // batch item
     const u32 rows = one_row ? 1u : (u32)W;
     scalars += z * sstride * 2; digits += z * (size_t)W * n; bin_counts += z * (size_t)rows * nbins;
@@ -70,7 +71,8 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
     }
     const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
+        const uint4* src = (tails && i == n - 1) ? tails + 2 * z : scalars + 2 * i;
+        uint4 lo = src[0], hi = src[1];
         u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (mont) fe_store(fe_from_mont(fe_load<SF>(w)), w);
         u32 carry = 0;
@@ -663,7 +665,8 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
 }
 
 template <class SF, class BF>
-int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb) {
+int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb,
+                  const void* tails_dev) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
     MsmLane& L = m.lane;
@@ -756,7 +759,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         unsigned gb = (unsigned)((n + 255) / 256);
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
-                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0);
+                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
+                           tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
@@ -866,10 +870,11 @@ int msm_build_table(int curve, const void* bases_dev, size_t n, int c, void* tab
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
-int msm_enqueue(int curve, const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb) {
+int msm_enqueue(int curve, const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb,
+                const void* tails_dev) {
     // pallas: base Fp, scalar Fq; vesta: base Fq, scalar Fp
-    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb);
-    return msm_enqueue_t<FpParams, FqParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb);
+    if (curve == TRH_PALLAS) return msm_enqueue_t<FqParams, FpParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb, tails_dev);
+    return msm_enqueue_t<FpParams, FqParams>(bases_dev, bases_z, scalars_dev, n, batch, stride, mont, s, fb, tails_dev);
 }
 int msm_convert_bases(int curve, const void* in_dev, void* out_dev, size_t n, hipStream_t s) {
     if (!n) return TRH_OK;
@@ -897,7 +902,7 @@ int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* o
 }
 void msm_release() {
     MsmScratch& m = ctx().msm;
-    m.scalars.release(); m.bases_z.release(); m.window_sums.release();
+    m.scalars.release(); m.tails.release(); m.bases_z.release(); m.window_sums.release();
     MsmLane& L = m.lane;
     L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release(); L.bucket_cnt.release();
     L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release();

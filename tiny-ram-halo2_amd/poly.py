@@ -213,9 +213,12 @@ class Params:
 
     def commit_lagrange_batch(self, polys, blinds):
         """polys: device tensor (batch, n, 4); blinds: (batch, 4) host limbs -> (batch, 12) points"""
-        import torch
         batch = polys.shape[0]
-        assert polys.shape[1] == self.n
-        bl = torch.from_numpy(np.ascontiguousarray(blinds, dtype=np.uint64).reshape(batch, 1, 4).view(np.int64)).to(polys.device)
-        sc = torch.cat([polys, bl], dim=1).contiguous()
-        return self._g_lagrange.msm_batch_dev(sc, self.n + 1, batch, stream=_stream(sc))
+        assert polys.shape[1] == self.n and polys.is_contiguous()
+        return self._g_lagrange.commit_batch_dev(polys, self.n, batch, np.ascontiguousarray(blinds, dtype=np.uint64).reshape(batch, 4), stream=_stream(polys))
+
+    def commit_batch(self, polys, blinds):
+        """coefficient-form counterpart of commit_lagrange_batch"""
+        batch = polys.shape[0]
+        assert polys.shape[1] == self.n and polys.is_contiguous()
+        return self._g.commit_batch_dev(polys, self.n, batch, np.ascontiguousarray(blinds, dtype=np.uint64).reshape(batch, 4), stream=_stream(polys))

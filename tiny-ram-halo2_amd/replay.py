@@ -62,7 +62,7 @@ class _FixedTranscript:
         return (w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192) % self.m
 
 
-def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True) -> dict:
+def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True) -> dict:
     import torch
 
     k = 2 + word_bits // 2
@@ -173,8 +173,7 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
     blinds = synth.field_elements(0xABD, ncoef)
     cols = torch.from_numpy(cols_h.view(np.int64)).to(dev)
     e0 = ev()
-    sc = torch.cat([cols, torch.from_numpy(blinds.reshape(ncoef, 1, 4).view(np.int64)).to(dev)], dim=1).contiguous()
-    pts = g.msm_batch_dev(sc, n + 1, ncoef, stream=torch.cuda.current_stream().cuda_stream)
+    pts = params.commit_batch(cols, blinds)
     e1 = ev()
     torch.cuda.synchronize()
     times["commit"] += e0.elapsed_time(e1)
@@ -223,7 +222,7 @@ def run(word_bits: int, batch: int = 32, hook=None, device: int = 0, verbose: bo
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--word-bits", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-precompute", action="store_true", help="commit over the plain per-window path (no fixed-base tables)")
     a = ap.parse_args()
     run(a.word_bits, a.batch, precompute=not a.no_precompute)
