@@ -131,12 +131,17 @@ class EvaluationDomain:
         api.ntt_dev(self.field, a, self.k, self._w["omega"], batch=self._batch(a), stream=_stream(a))
         return a
 
-    def coeff_to_extended(self, a):
-        """(..., n, 4) coefficients -> new (..., 2^extended_k, 4) tensor of coset evaluations"""
+    def coeff_to_extended(self, a, out=None):
+        """(..., n, 4) coefficients -> (..., 2^extended_k, 4) tensor of coset evaluations (a new one unless `out` is given)"""
         import torch
         assert a.shape[-2] == self.n
         a = a.contiguous()
-        ext = torch.empty(a.shape[:-2] + (self.extended_len(), 4), dtype=a.dtype, device=a.device)
+        shape = a.shape[:-2] + (self.extended_len(), 4)
+        if out is not None:
+            assert out.is_contiguous() and out.numel() >= int(np.prod(shape))
+            ext = out.reshape(-1)[: int(np.prod(shape))].reshape(shape)
+        else:
+            ext = torch.empty(shape, dtype=a.dtype, device=a.device)
         api._check(api.lib().trh_domain_coeff_to_extended(self.handle(), api._devptr(a), api._devptr(ext), self._batch(a), _stream(a)))
         return ext
 

@@ -104,6 +104,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     t_wall = time.perf_counter()
 
     x_eval = synth.field_elements(0xE7A, 1)[0]
+    ext_buf = torch.empty((min(batch, sch["intt_n"]), 1 << ek, 4), dtype=torch.int64, device=dev)  # the batch's extended cosets, reused
     # --- Lagrange-basis columns: instance, advice, lookup permuted x2 + z, permutation z ---
     lag_total = sch["intt_n"]
     done = 0
@@ -118,7 +119,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         e1 = ev()
         coeff = dom.lagrange_to_coeff(cols)
         e2 = ev()
-        ext = dom.coeff_to_extended(coeff)
+        ext = dom.coeff_to_extended(coeff, out=ext_buf)
         e3 = ev()
         # the evaluations at the challenge x that precede the multiopen argument (eval_polynomial per queried column;
         # the real prover does them after x is squeezed, with the coefficient forms kept resident: same work)
@@ -143,7 +144,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
                 checked += 4
         if done + b >= lag_total:
             ext_keep = ext  # the last batch of extended cosets stays resident for the h(X) step below
-        del ext, coeff, cols
+        del coeff, cols
         done += b
 
     # --- h(X) numerator: gate expressions over the extended cosets, folded with the challenge y.  The real gate set is the
@@ -165,7 +166,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     if hook is not None:
         hook("h_eval", dict(gates=gates, resident=res, log_n=ek, rot_step=1 << (ek - k), y=0x5EED, field=field), h_num)
         checked += 1
-    del ext_keep, res, h_num
+    del ext_keep, ext_buf, res, h_num
 
     # --- coefficient-basis commits: vanishing random poly, h pieces ---
     ncoef = 1 + N_H_PIECES
