@@ -203,3 +203,38 @@ def test_lookup_product_column():
         want.append(acc)
         acc = acc * (a[i] + beta) * (table[i] + gamma) % f.m * pow((ap[i] + beta) * (sp[i] + gamma), -1, f.m) % f.m
     assert z == want and acc == 1
+
+
+def test_random_expression_trees():
+    """every node type of halo2's Expression in random shapes (unbalanced trees exercise both operand orders of the lowering)"""
+    field, log_n = "fp", 5
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    rng = random.Random(0x7EE5)
+
+    def tree(depth):
+        if depth == 0 or rng.random() < 0.15:
+            kind = rng.randrange(5)
+            if kind == 0:
+                return expr.Constant(rng.choice([0, 1, f.m - 1, rng.randrange(f.m)]))
+            cls = (expr.Advice, expr.Fixed, expr.Instance, expr.Selector)[kind - 1]
+            return cls(rng.randrange(3), 0 if cls is expr.Selector else rng.randrange(-2, 3))
+        kind = rng.randrange(5)
+        if kind == 0:
+            return expr.Negated(tree(depth - 1))
+        if kind == 1:
+            return expr.Scaled(tree(depth - 1), rng.randrange(f.m))
+        a, b = tree(depth - 1), tree(rng.randrange(depth))
+        if rng.random() < 0.5:
+            a, b = b, a
+        return expr.Sum(a, b) if kind in (2, 3) else expr.Product(a, b)
+
+    for trial in range(12):
+        gates = [tree(rng.randrange(1, 7)) for _ in range(rng.randrange(1, 6))]
+        y = rng.randrange(f.m)
+        prog = expr.compile_gates(field, gates, y)
+        ints, dev = make_columns(f, prog.columns or [("advice", 0)], n, seed=trial)
+        if not prog.columns:  # constant-only gates still need one column to size the launch
+            continue
+        got = from_dev(f, expr.GateEvaluator(prog).eval(dev, log_n, 2))
+        assert got == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n, 2), trial

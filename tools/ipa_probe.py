@@ -1,4 +1,4 @@
-"""IPA opening alone at size k: tools/ipa_probe.py [k]"""
+"""IPA opening alone at size k: tools/ipa_probe.py [k] [window bits override]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +8,8 @@ from tiny_ram_halo2_amd import api, ipa, poly, replay, synth
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 n = 1 << k
 api.init(0)
+if len(sys.argv) > 2:
+    api.set_window_bits(int(sys.argv[2]))
 curve = "vesta"
 g = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n + 1)
 params = poly.Params.__new__(poly.Params)
