@@ -414,3 +414,24 @@ def test_msm_fixed_base_limits():
     w = api.Bases.wrap_device("pallas", api.lib().trh_bases_device_ptr(b.handle), 1 << 10)
     with pytest.raises(api.TrhError):
         w.precompute(0)  # wrapped memory is not immutable
+
+
+def test_best_multiexp_host_cache():
+    """the host-pointer entry point keeps recently seen base sets resident (pointer + length + fingerprint); results must not
+    change over repeated calls (the fourth switches to fixed-base tables), and a different set at the same address is noticed"""
+    curve, n = "vesta", 5000
+    sc, bases = _edge_inputs(curve, n, 0xCAC4E)
+    bases = np.ascontiguousarray(bases)
+    want = aff(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=8))
+    for rep in range(6):
+        sc_r = np.ascontiguousarray(np.roll(sc, rep, axis=0))
+        got = api.best_multiexp(curve, sc_r, bases)
+        if rep == 0:
+            assert (got[:8] == want).all()
+        else:
+            assert (got[:8] == aff(curve, cpu_ref.best_multiexp(curve, sc_r, bases, threads=8))).all(), rep
+    # overwrite the SAME buffer with another set: the fingerprint must miss
+    other = cpu_ref.gen_bases(curve, 0x5151, 7, n, threads=4)
+    bases[:] = other
+    got = api.best_multiexp(curve, sc, bases)
+    assert (got[:8] == aff(curve, cpu_ref.best_multiexp(curve, sc, other, threads=8))).all()

@@ -1,4 +1,5 @@
 // C ABI of libtrh.so (include/trh.h): argument checking, staging of host buffers, context.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -85,10 +86,68 @@ int check_field(int field) {
     return TRH_OK;
 }
 
+// ---- cache of base sets seen by the host-pointer entry points ---------------------------------------------------
+// `best_multiexp(coeffs, bases)` is called ~500 times per proof with the SAME `Params.g_lagrange` / `Params.g` slices.
+// The plain two-function shim passes host pointers every time; re-uploading 64 B per base
+// would cost as much as the MSM.  A set is recognised by (curve, pointer, length, fingerprint of 256 sampled points)
+// and kept resident (8 sets, LRU); from its fourth use it also gets the fixed-base tables.  TRH_BASES_CACHE=0 turns
+// the cache off (every call then uploads, as before).
+struct BasesCacheEntry {
+    int curve;
+    const void* host;
+    size_t n;
+    uint64_t fp;
+    trh_bases* h;
+    uint64_t stamp;
+    unsigned uses;
+};
+std::mutex g_cache_mu;
+std::vector<BasesCacheEntry> g_cache;
+uint64_t g_cache_stamp = 0;
+
+uint64_t bases_fingerprint(const uint64_t* bases, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+    const size_t samples = n < 256 ? n : 256;
+    for (size_t k = 0; k < samples; ++k) {
+        const size_t i = samples == n ? k : (k * (n - 1)) / (samples - 1);  // includes the first and the last point
+        for (int w = 0; w < 8; ++w) { h ^= bases[8 * i + w]; h *= 0x100000001b3ull; }
+    }
+    return h;
+}
+
+void bases_cache_clear() {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (BasesCacheEntry& e : g_cache) trh_bases_destroy(e.h);
+    g_cache.clear();
+}
+
 int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t* out) {
     TRH_TRY(require_init());
     if (!out || (n && (!coeffs || !bases))) { set_error("best_multiexp: null pointer"); return TRH_EINVAL; }
     if (n >= ((size_t)1 << 31)) { set_error("best_multiexp: n too large"); return TRH_EINVAL; }
+    static const int cache_on = getenv("TRH_BASES_CACHE") ? atoi(getenv("TRH_BASES_CACHE")) : 1;
+    if (cache_on && n >= 1024) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        const uint64_t fp = bases_fingerprint(bases, n);
+        BasesCacheEntry* hit = nullptr;
+        for (BasesCacheEntry& e : g_cache)
+            if (e.curve == curve && e.host == (const void*)bases && e.n == n && e.fp == fp) { hit = &e; break; }
+        if (!hit) {
+            if (g_cache.size() >= 8) {
+                size_t victim = 0;
+                for (size_t i = 1; i < g_cache.size(); ++i) if (g_cache[i].stamp < g_cache[victim].stamp) victim = i;
+                trh_bases_destroy(g_cache[victim].h);
+                g_cache.erase(g_cache.begin() + victim);
+            }
+            trh_bases* h = nullptr;
+            TRH_TRY(curve == TRH_PALLAS ? trh_bases_create_pallas(bases, n, &h) : trh_bases_create_vesta(bases, n, &h));
+            g_cache.push_back(BasesCacheEntry{curve, bases, n, fp, h, 0, 0});
+            hit = &g_cache.back();
+        }
+        hit->stamp = ++g_cache_stamp;
+        if (++hit->uses == 4) (void)trh_bases_precompute(hit->h, 0);  // outside the supported range: stays on the per-window path
+        return trh_msm(hit->h, 0, coeffs, n, 1, out);
+    }
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     DevBuf bbuf;
@@ -175,6 +234,7 @@ int trh_init(int device) {
 }
 
 void trh_shutdown(void) {
+    bases_cache_clear();  // before the context lock: the cache lock is always taken first
     Ctx& c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     if (!c.inited) return;
