@@ -7,7 +7,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functi
 OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h include/trh.h
 
-all: $(PKG)/libtrh.so oracle
+all: $(PKG)/libtrh.so oracle examples/replay
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -15,11 +15,15 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 $(PKG)/libtrh.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
+# native (C++17, no Python) driver over include/trh.hpp
+examples/replay: examples/replay.cpp include/trh.hpp include/trh.h $(PKG)/libtrh.so
+	g++ -O2 -std=c++17 -Wall -Iinclude $< -o $@ -L$(PKG) -ltrh -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
 oracle:
 	$(MAKE) -s -C oracle libtrh_oracle.so
 
 clean:
-	rm -f $(OBJS) $(PKG)/libtrh.so
+	rm -f $(OBJS) $(PKG)/libtrh.so examples/replay
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

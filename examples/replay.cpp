@@ -1,0 +1,224 @@
+// Native driver over include/trh.hpp: the arithmetic schedule `halo2_proofs::plonk::create_proof` issues for the
+// reference's TinyRamCircuit<WORD_BITS, 8> (reference call site
+// /root/reference/src/test_utils.rs:41-49, k = 2 + WORD_BITS / 2 from :20), from a compiled host with no Python in the
+// process -- what the Rust prover's side of the boundary looks like.  Synthetic column data; the same primitive kinds,
+// sizes and counts as tiny-ram-halo2_amd/replay.py, each kind self-checked once with the host arithmetic of trh.hpp
+// or against a second libtrh path (the bit-exact parity against the oracle lives in tests/).
+//
+//   ./examples/replay [--word-bits 16|32] [--batch 64]      -> one JSON line, exit code 0 iff every check passed
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "trh.hpp"
+
+using namespace trh;
+
+namespace {
+
+constexpr int N_INSTANCE = 94, N_ADVICE = 263, N_LOOKUPS = 31, N_PERM_PRODUCTS = 47, N_H_PIECES = 5, QUOTIENT_J = 6, N_SYNTH_GATES = 300;
+
+struct SplitMix {
+    uint64_t s;
+    uint64_t next() { uint64_t z = (s += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+    Limbs element() { Limbs v{next(), next(), next(), next() >> 2}; return v; }  // < 2^254 < m: a valid residue
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Timer {
+    double t0;
+    Timer() { check(trh_stream_synchronize(nullptr), "sync"); t0 = now_ms(); }
+    double stop() { check(trh_stream_synchronize(nullptr), "sync"); return now_ms() - t0; }
+};
+
+int failures = 0;
+void expect(bool ok, const char* what) { if (!ok) { ++failures; std::fprintf(stderr, "CHECK FAILED: %s\n", what); } }
+
+// a stand-in for the BLAKE2b transcript: challenges from a counter
+struct Transcript { SplitMix rng{0x7e57}; int points = 0, scalars = 0; };
+void tr_write_point(void* c, const uint64_t*) { ++((Transcript*)c)->points; }
+void tr_write_scalar(void* c, const uint64_t*) { ++((Transcript*)c)->scalars; }
+void tr_squeeze(void* c, uint64_t* out) { const Limbs v = ((Transcript*)c)->rng.element(); std::memcpy(out, v.data(), 32); }
+void rng_scalar(void* c, uint64_t* out) { const Limbs v = ((SplitMix*)c)->element(); std::memcpy(out, v.data(), 32); }
+
+// synthetic gate set with the shape of the reference's (selector-gated constraints up to degree 6)
+std::vector<Expr> synthetic_gates(Field f, uint32_t n_advice, uint32_t n_fixed, int n_gates) {
+    SplitMix r{0x6a7e};
+    auto adv = [&]() { const uint32_t c = (uint32_t)(r.next() % n_advice); const int rot[5] = {0, 0, 0, 1, -1}; return advice(c, rot[r.next() % 5]); };
+    const Expr one = constant(host::one(f)), two = constant(host::from_u64(f, 2));
+    std::vector<Expr> gates;
+    for (int g = 0; g < n_gates; ++g) {
+        const Expr sel = selector((uint32_t)(r.next() % n_fixed));
+        Expr body;
+        switch (g % 4) {
+            case 0: body = adv() + scaled(adv(), host::from_u64(f, 1u << 16)) - adv(); break;
+            case 1: body = adv() * adv() - adv(); break;
+            case 2: { const Expr v = adv(); body = v * (one - v) * (two - v); break; }
+            default: { const Expr a = adv(), b = adv(); body = (a * a - adv()) * (b * b - adv()) * (adv() - one); }
+        }
+        gates.push_back(sel * body);
+    }
+    return gates;
+}
+
+// host evaluation of one row (the check of the device evaluator)
+Limbs eval_host(Field f, const Expr& e, const std::vector<std::vector<Limbs>>& cols, const Program& p, size_t row, size_t n, size_t rot_step) {
+    switch (e->kind) {
+        case Expression::Constant: return e->value;
+        case Expression::Negated: return host::neg(f, eval_host(f, e->a, cols, p, row, n, rot_step));
+        case Expression::Scaled: return host::mul(f, eval_host(f, e->a, cols, p, row, n, rot_step), e->value);
+        case Expression::Sum: return host::add(f, eval_host(f, e->a, cols, p, row, n, rot_step), eval_host(f, e->b, cols, p, row, n, rot_step));
+        case Expression::Product: return host::mul(f, eval_host(f, e->a, cols, p, row, n, rot_step), eval_host(f, e->b, cols, p, row, n, rot_step));
+        default: {
+            size_t slot = 0;
+            while (!(p.columns[slot].first == e->kind && p.columns[slot].second == e->column)) ++slot;
+            const size_t r = (row + (size_t)((long long)e->rotation * (long long)rot_step)) & (n - 1);
+            return cols[slot][r];
+        }
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int word_bits = 32;
+    size_t batch = 64;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
+        else if (std::string(argv[i]) == "--batch") batch = (size_t)std::atol(argv[i + 1]);
+    }
+    try {
+        init(0);
+        const uint32_t k = 2 + word_bits / 2;
+        const size_t n = (size_t)1 << k;
+        const Curve curve = Curve::Vesta;  // the reference proves over Fp with Params<EqAffine> (test_utils.rs:8, 21)
+        const Field field = scalar_field(curve);
+        EvaluationDomain dom(field, QUOTIENT_J, k);
+        const uint32_t ek = dom.extended_k;
+        const size_t N = dom.extended_len();
+        require(ek == k + 3, "extended_k == k + 3");
+
+        Timer t_setup;
+        Params params(curve, k, 0x1234567, 0x89abcdef, true);
+        const double setup_ms = t_setup.stop();
+
+        const int lag_total = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS;
+        if (batch > (size_t)lag_total) batch = lag_total;
+        DeviceBuffer cols(batch * n * 32), ext(batch * N * 32), h_num(N * 32);
+        std::vector<Limbs> host_cols(batch * n), blinds(batch);
+        SplitMix rng{0xc01};
+        const Limbs x_eval = rng.element();
+        double ms_commit = 0, ms_intt = 0, ms_ext = 0, ms_evals = 0, ms_h = 0, ms_commit_coeff = 0, ms_ext_inv = 0, ms_ipa = 0;
+        size_t last_b = 0;
+        std::vector<Limbs> first_col, first_coeff;
+
+        for (int done = 0; done < lag_total; done += (int)batch) {
+            const size_t b = std::min(batch, (size_t)(lag_total - done));
+            for (size_t i = 0; i < b * n; ++i) host_cols[i] = rng.element();
+            for (size_t i = 0; i < b; ++i) blinds[i] = rng.element();
+            cols.upload(host_cols.data(), b * n * 32);
+            Timer t1;
+            const std::vector<Point> pts = params.commit_lagrange_batch(cols, b, std::vector<Limbs>(blinds.begin(), blinds.begin() + b));
+            { const double dt = t1.stop(); ms_commit += dt; if (std::getenv("TRH_REPLAY_VERBOSE")) std::fprintf(stderr, "batch at %d: commit %.2f ms\n", done, dt); }
+            if (done == 0) {  // Params::commit_lagrange of column 0 through the host-scalar path must give the same point
+                first_col.assign(host_cols.begin(), host_cols.begin() + n);
+                const Point single = params.commit_lagrange(first_col, blinds[0]);
+                expect(std::memcmp(&single, &pts[0], sizeof(Point)) == 0, "commit_lagrange_batch[0] == commit_lagrange");
+            }
+            Timer t2;
+            dom.lagrange_to_coeff(cols.data(), b);
+            ms_intt += t2.stop();
+            if (done == 0) { first_coeff.resize(n); cols.download(first_coeff.data(), n * 32); }
+            Timer t3;
+            dom.coeff_to_extended(cols.data(), ext.data(), b);
+            ms_ext += t3.stop();
+            Timer t4;
+            std::vector<Limbs> evals(b);
+            check(trh_poly_eval_batch_dev((int)field, cols.data(), n, b, x_eval.data(), nullptr, (uint64_t*)evals.data()), "poly_eval_batch");
+            ms_evals += t4.stop();
+            if (done == 0) {  // eval_polynomial: Horner on the host
+                Limbs acc{0, 0, 0, 0};
+                for (size_t i = n; i-- > 0;) acc = host::add(field, host::mul(field, acc, x_eval), first_coeff[i]);
+                expect(acc == evals[0], "eval_polynomial(column 0, x)");
+            }
+            last_b = b;
+        }
+
+        // h(X) numerator over the last batch of extended cosets (synthetic gate set, see replay.py)
+        const uint32_t nres = (uint32_t)last_b;
+        const std::vector<Expr> gates = synthetic_gates(field, nres > 4 ? nres - 4 : 1, nres < 4 ? nres : 4, N_SYNTH_GATES);
+        const Limbs y = host::from_u64(field, 0x5eed);
+        GateEvaluator gev(compile_gates(field, gates, y));
+        std::vector<const void*> res(gev.program.columns.size());
+        for (size_t i = 0; i < res.size(); ++i) res[i] = ext.at((i % nres) * N * 32);
+        Timer t5;
+        gev.eval(res, h_num.data(), ek, 1u << (ek - k));
+        ms_h = t5.stop();
+        {   // three rows against the host evaluation
+            std::vector<std::vector<Limbs>> hc(res.size(), std::vector<Limbs>(N));
+            for (size_t i = 0; i < res.size(); ++i) check(trh_memcpy_d2h(hc[i].data(), res[i], N * 32), "d2h");
+            std::vector<Limbs> got(N);
+            h_num.download(got.data(), N * 32);
+            for (size_t row : {(size_t)0, N - 1, (size_t)4097 % N}) {
+                Limbs acc{0, 0, 0, 0};
+                for (const Expr& g : gates) acc = host::add(field, host::mul(field, acc, y), eval_host(field, g, hc, gev.program, row, N, (size_t)1 << (ek - k)));
+                expect(acc == got[row], "h(X) numerator row");
+            }
+        }
+
+        // coefficient-basis commits: the random vanishing polynomial and the h pieces
+        const size_t ncoef = 1 + N_H_PIECES;
+        DeviceBuffer cf(ncoef * n * 32);
+        for (size_t i = 0; i < ncoef * n; ++i) host_cols[i % host_cols.size()] = rng.element();
+        cf.upload(host_cols.data(), ncoef * n * 32);
+        std::vector<Limbs> bl(ncoef);
+        for (auto& v : bl) v = rng.element();
+        Timer t6;
+        params.commit_batch(cf, ncoef, bl);
+        ms_commit_coeff = t6.stop();
+
+        // extended iNTT of h(X): divide_by_vanishing_poly + extended_to_coeff; round trip check on one column
+        Timer t7;
+        dom.divide_by_vanishing_poly(h_num.data(), 1);
+        dom.extended_to_coeff(h_num.data(), 1);
+        ms_ext_inv = t7.stop();
+        {
+            DeviceBuffer one_col(n * 32), one_ext(N * 32);
+            one_col.upload(first_coeff.data(), n * 32);
+            dom.coeff_to_extended(one_col.data(), one_ext.data(), 1);
+            dom.extended_to_coeff(one_ext.data(), 1);
+            std::vector<Limbs> back(N);
+            one_ext.download(back.data(), N * 32);
+            bool ok = true;
+            for (size_t i = 0; i < N; ++i) ok = ok && (i < n ? back[i] == first_coeff[i] : back[i] == Limbs{0, 0, 0, 0});
+            expect(ok, "extended_to_coeff(coeff_to_extended(a)) == a || 0");
+        }
+
+        // IPA opening of the final polynomial
+        DeviceBuffer p_poly(n * 32), s_poly(n * 32);
+        p_poly.upload(first_coeff.data(), n * 32);
+        for (size_t i = 0; i < n; ++i) host_cols[i] = rng.element();
+        s_poly.upload(host_cols.data(), n * 32);
+        Transcript tr;
+        trh_transcript_t tcb{&tr, tr_write_point, tr_write_scalar, tr_squeeze};
+        SplitMix prng{0x99};
+        Timer t8;
+        const auto cfp = ipa_create_proof(params, p_poly, rng.element(), x_eval, s_poly, rng.element(), tcb, rng_scalar, &prng);
+        ms_ipa = t8.stop();
+        (void)cfp;
+        expect(tr.points == 1 + 2 * (int)k && tr.scalars == 2, "IPA transcript: S, L_j / R_j per round, then c and f");
+
+        const double total = ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_ipa;
+        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"checks_failed\": %d, \"setup_ms\": %.3f, "
+                    "\"ms\": {\"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
+                    "\"extended_to_coeff\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f}\n",
+                    word_bits, k, batch, failures, setup_ms, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_ipa, total);
+        trh_shutdown();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,21 @@
+"""GPU test (-m gpu): the native C++ driver (examples/replay.cpp over include/trh.hpp) -- the host side of the boundary as a
+compiled caller, no Python in the process.  It runs the create_proof schedule at k = 10 and checks one item of every
+primitive kind itself (host-side field arithmetic of trh.hpp / a second libtrh path); a non-zero exit code is a failed check."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_native_replay_k10():
+    exe = os.path.join(ROOT, "examples", "replay")
+    assert os.path.exists(exe), "examples/replay is built by `make` (g++ over include/trh.hpp)"
+    r = subprocess.run([exe, "--word-bits", "16", "--batch", "32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["k"] == 10 and out["checks_failed"] == 0
+    assert set(out["ms"]) == {"commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "ipa"}
