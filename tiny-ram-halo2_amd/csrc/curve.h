@@ -198,17 +198,28 @@ template <class F> TRH_HD XYZZz<F> xyzzz_from_canonical(const XYZZ<F>& p) {
     return r;
 }
 
+// 2 p for an affine point of the lazy domain (x, y < 1.01m, not the identity; y != 0: no points of order two):
+// dbl-2008-s-1 with Z = 1.  Result within the XYZZz invariants (x < 4.01m, y < 3.01m, zz, zzz < 1.01m).
+template <class F> TRH_HD XYZZz<F> xyzzz_dbl_affine(const AffineZ<F>& p) {
+    XYZZz<F> r;
+    const Fz<F> U = fz_add(p.y, p.y);                                  // < 2.02m
+    const Fz<F> V = fz_sqr(U), W = fz_mul(U, V), S = fz_mul(p.x, V);
+    const Fz<F> xx = fz_sqr(p.x), M = fz_add(fz_add(xx, xx), xx);       // < 3.02m
+    r.x = fz_sub<F, 3>(fz_sqr(M), fz_add(S, S));                        // < 4.01m
+    r.y = fz_sub<F, 2>(fz_mul(M, fz_sub<F, 5>(S, r.x)), fz_mul(W, p.y));  // < 3.01m
+    r.zz = V; r.zzz = W;
+    return r;
+}
+
 // acc += p, p affine in the lazy domain
 template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
     if (fz_is_exact_zero(p.x) && fz_is_exact_zero(p.y)) return;
     if (xyzzz_is_identity(acc)) { acc.x = p.x; acc.y = p.y; acc.zz = fz_one<F>(); acc.zzz = fz_one<F>(); return; }
     const Fz<F> U2 = fz_mul(p.x, acc.zz), S2 = fz_mul(p.y, acc.zzz);
     const Fz<F> P = fz_sub<F, 8>(U2, acc.x), R = fz_sub<F, 8>(S2, acc.y);  // < 9.01m
-    if (fz_is_zero_mod(P)) {  // same x: doubling or cancellation, through the canonical formulas
-        XYZZ<F> c = xyzzz_to_canonical(acc);
-        Affine<F> q; q.x = fz_to_fe(p.x); q.y = fz_to_fe(p.y);
-        xyzz_madd(c, q);
-        acc = xyzzz_from_canonical(c);
+    if (fz_is_zero_mod(P)) {  // same x: acc is p (the sum is 2 p, which only needs p) or -p (the sum is the identity)
+        if (fz_is_zero_mod(R)) acc = xyzzz_dbl_affine(p);
+        else acc = xyzzz_identity<F>();
         return;
     }
     const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(acc.x, PP);
