@@ -547,6 +547,11 @@ void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
         if (P < 2) P = 2;
         int rem = log_n;
         for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
+        if (const char* e = getenv("TRH_NTT_PLAN")) {  // tuning knob: explicit pass sizes "8,8,6"
+            int v[8], cnt = 0, sum = 0;
+            for (const char* q = e; *q && cnt < 8;) { v[cnt] = atoi(q); sum += v[cnt++]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            if (sum == log_n) { P = cnt; for (int p = 0; p < P; ++p) sizes[p] = v[p]; }
+        }
     }
     *n_passes = P; *tile_log = tlog;
 }
