@@ -211,6 +211,20 @@ template <class F> TRH_HD XYZZz<F> xyzzz_dbl_affine(const AffineZ<F>& p) {
     return r;
 }
 
+// 2 p for a lazy XYZZ point (dbl-2008-s-1, a = 0); inputs and result within the XYZZz invariants
+template <class F> TRH_HD XYZZz<F> xyzzz_dbl(const XYZZz<F>& p) {
+    if (xyzzz_is_identity(p)) return p;
+    XYZZz<F> r;
+    const Fz<F> U = fz_add(p.y, p.y);                                  // < 16m
+    const Fz<F> V = fz_sqr(U), W = fz_mul(U, V), S = fz_mul(p.x, V);
+    const Fz<F> xx = fz_sqr(p.x), M = fz_add(fz_add(xx, xx), xx);       // < 3.02m
+    r.x = fz_sub<F, 3>(fz_sqr(M), fz_add(S, S));                        // < 4.01m
+    r.y = fz_sub<F, 2>(fz_mul(M, fz_sub<F, 5>(S, r.x)), fz_mul(W, p.y));  // < 3.01m
+    r.zz = fz_mul(V, p.zz);
+    r.zzz = fz_mul(W, p.zzz);
+    return r;
+}
+
 // acc += p, p affine in the lazy domain
 template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
     if (fz_is_exact_zero(p.x) && fz_is_exact_zero(p.y)) return;

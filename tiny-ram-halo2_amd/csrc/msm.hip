@@ -492,7 +492,7 @@ constexpr u32 HEAVY_PIECES = 64;
 template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                                 const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
-                                                                XYZZMem* __restrict__ buckets, u32 nbk, u32 nseg, u32 seg_len,
+                                                                XYZZzMem* __restrict__ buckets, u32 nbk, u32 nseg, u32 seg_len,
                                                                 const u32* __restrict__ heavy, u32 W, u32 heavy_stride) {
     const size_t z = blockIdx.z;  // batch item
     {
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __res
             if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
             __syncthreads();
         }
-        if (threadIdx.x == 0) store_xyzz(&buckets[(size_t)j * nbk + (b - 1)], xyzzz_to_canonical(sh[0]));
+        if (threadIdx.x == 0) store_raw(&buckets[(size_t)j * nbk + (b - 1)], sh[0]);
         __syncthreads();
     }
 }
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __res
 template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                           const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
-                                                          const XYZZzMem* __restrict__ direct, XYZZMem* __restrict__ buckets,
+                                                          const XYZZzMem* __restrict__ direct, XYZZzMem* __restrict__ buckets,
                                                           u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride) {
     const size_t z = blockIdx.z;  // batch item
     {
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
         else acc = load_raw<BF>(last + (size_t)j * nseg + t_lo);
         for (u32 t = t_lo + 1; t <= t_hi; ++t) acc = xyzzz_add(acc, load_raw<BF>(fj + t));
     }
-    store_xyzz(&buckets[(size_t)j * nbk + (b - 1)], xyzzz_to_canonical(acc));
+    store_raw(&buckets[(size_t)j * nbk + (b - 1)], acc);  // stays in the lazy domain for the reduction
 }
 
 // ---------------------------------------------------------------------------------------
@@ -559,60 +559,60 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
 //    thread t of a window owns buckets t*m+1 .. (t+1)*m; blocks of 256 threads tree-add in LDS.
 // ---------------------------------------------------------------------------------------
 template <class BF>
-__global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZMem* __restrict__ buckets, XYZZMem* __restrict__ partials,
+__global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZzMem* __restrict__ buckets, XYZZzMem* __restrict__ partials,
                                                          u32 nbk, u32 m, u32 threads_per_window) {
     const size_t z = blockIdx.z;  // batch item
     buckets += z * (size_t)gridDim.y * nbk; partials += z * (size_t)gridDim.y * gridDim.x;
-    __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
+    __shared__ XYZZz<BF> sh[256];  // register form (9 limbs per element), lazy domain throughout
     const int j = blockIdx.y;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    XYZZ<BF> total = xyzz_identity<BF>();
+    XYZZz<BF> total = xyzzz_identity<BF>();
     if (t < threads_per_window) {
-        const XYZZMem* bk = buckets + (size_t)j * nbk + (size_t)t * m;
-        XYZZ<BF> run = xyzz_identity<BF>(), acc = xyzz_identity<BF>();
+        const XYZZzMem* bk = buckets + (size_t)j * nbk + (size_t)t * m;
+        XYZZz<BF> run = xyzzz_identity<BF>(), acc = xyzzz_identity<BF>();
         for (int k = (int)m - 1; k >= 0; --k) {
-            XYZZ<BF> v = load_xyzz<BF>(&bk[k]);
-            run = xyzz_add(run, v);
-            acc = xyzz_add(acc, run);
+            const XYZZz<BF> v = load_raw<BF>(&bk[k]);
+            run = xyzzz_add(run, v);
+            acc = xyzzz_add(acc, run);
         }
         // acc = sum (k+1) * B[k]; the slice starts at global bucket id t*m + 1 -> add (t*m) * run
         const u32 off = t * m;
         if (off) {
-            XYZZ<BF> sc = xyzz_identity<BF>();
+            XYZZz<BF> sc = xyzzz_identity<BF>();
             int top = 31 - __clz(off);
             for (int i = top; i >= 0; --i) {
-                sc = xyzz_dbl(sc);
-                if ((off >> i) & 1u) sc = xyzz_add(sc, run);
+                sc = xyzzz_dbl(sc);
+                if ((off >> i) & 1u) sc = xyzzz_add(sc, run);
             }
-            acc = xyzz_add(acc, sc);
+            acc = xyzzz_add(acc, sc);
         }
         total = acc;
     }
     sh[threadIdx.x] = total;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz(&partials[(size_t)j * gridDim.x + blockIdx.x], sh[0]);
+    if (threadIdx.x == 0) store_raw(&partials[(size_t)j * gridDim.x + blockIdx.x], sh[0]);
 }
 
-// one block per window: sum `count` partials
+// one block per window: sum `count` partials, hand the window sum over in the canonical form
 template <class BF>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
     const size_t z = blockIdx.z;  // batch item
     partials += z * (size_t)gridDim.x * count; window_sums += z * (size_t)gridDim.x;
-    __shared__ XYZZ<BF> sh[256];  // register form (9 limbs per element)
+    __shared__ XYZZz<BF> sh[256];
     const int j = blockIdx.x;
-    XYZZ<BF> v = xyzz_identity<BF>();
-    for (u32 k = threadIdx.x; k < count; k += 256) v = xyzz_add(v, load_xyzz<BF>(&partials[(size_t)j * count + k]));
+    XYZZz<BF> v = xyzzz_identity<BF>();
+    for (u32 k = threadIdx.x; k < count; k += 256) v = xyzzz_add(v, load_raw<BF>(&partials[(size_t)j * count + k]));
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz(&window_sums[j], sh[0]);
+    if (threadIdx.x == 0) store_xyzz(&window_sums[j], xyzzz_to_canonical(sh[0]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -727,8 +727,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
     TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
     TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
-    TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZMem)));
-    TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZMem)));
+    TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZzMem)));
+    TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZzMem)));
     if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * 64 + 64));
     const uint4* bz = fb ? (const uint4*)fb->table : bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
     TRH_TRY(m.window_sums.ensure(batch * Ws * sizeof(XYZZMem)));
@@ -783,12 +783,12 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), ns, nbk, nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
-                           L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
+                           L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
         hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
-                           L.last.as<XYZZzMem>(), L.buckets.as<XYZZMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
+                           L.last.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
-        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZMem>(), L.partials.as<XYZZMem>(), nbk, slice, tpw);
-        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, rblocks);
+        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, slice, tpw);
+        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, rblocks);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
     }
     TRH_HIP_TRY(hipGetLastError());
