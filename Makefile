@@ -4,7 +4,7 @@ ARCH ?= gfx950
 PKG := tiny-ram-halo2_amd
 CSRC := $(PKG)/csrc
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-result
-OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o
+OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h $(CSRC)/hostcombine.h include/trh.h
 
 all: $(PKG)/libtrh.so oracle examples/replay

@@ -200,6 +200,15 @@ int trh_poly_lincomb_dev(int field, const void* polys_dev, size_t n, size_t batc
  * scratch_dev: 2 n elements.                                                                                          */
 int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const void* pz_dev, const void* pzinv_dev, void* scratch_dev, void* q_dev, void* stream);
 
+/* ---- lookup argument: plonk/lookup/prover.rs `permute_expression_pair` ------------------------------------------
+ * out_input = the first usable_rows input values sorted (field Ord = canonical integer order); out_table[row] = out_input[row]
+ * where that row starts a run of equal values (one instance of the value leaves the table multiset), the remaining rows take
+ * the left-over table values in ascending order starting from the LAST repeated row, exactly as the Rust code fills them.
+ * Returns TRH_EINVAL when an input value does not occur in the table (halo2: Error::ConstraintSystemFailure).  The blinding
+ * rows behind usable_rows are the caller's.  Synchronises the stream.                                                       */
+int trh_lookup_permute_dev(int field, const void* input_dev, const void* table_dev, size_t usable_rows, void* out_input_dev,
+                           void* out_table_dev, void* stream);
+
 /* ---- gate expressions over resident columns: the h(X) numerator of plonk::create_proof ---------
  * halo2's `Expression<F>` (Constant / Selector / Fixed / Advice / Instance query at a Rotation, Negated, Sum,
  * Product, Scaled) compiled by the caller to a straight-line program for a stack machine that every row of the

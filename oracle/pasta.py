@@ -592,3 +592,31 @@ def evaluate_gates(f, gates, columns, y, n, rot_step=1):
             acc = (acc * y + evaluate_expression(f, g, columns, row, n, rot_step)) % f.m
         out.append(acc)
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# Lookup argument: halo2_proofs 0.2.0 plonk/lookup/prover.rs `permute_expression_pair` (reached from create_proof,
+# /root/reference/src/test_utils.rs:41-49), restated step by step: sort the input, walk it, first occurrences take
+# their own value and consume one instance from the table's BTreeMap<value, count>, repeated rows are remembered;
+# then the map is walked in ascending order and every left-over instance goes to `repeated_input_rows.pop()`.
+# ---------------------------------------------------------------------------------------
+def permute_expression_pair(input_values, table_values, usable_rows):
+    permuted_input = sorted(input_values[:usable_rows])
+    leftover = {}
+    for v in table_values[:usable_rows]:
+        leftover[v] = leftover.get(v, 0) + 1
+    permuted_table = [0] * usable_rows
+    repeated_input_rows = []
+    for row, v in enumerate(permuted_input):
+        if row == 0 or v != permuted_input[row - 1]:
+            permuted_table[row] = v
+            if leftover.get(v, 0) == 0:
+                raise ValueError("ConstraintSystemFailure: input value not in the table")
+            leftover[v] -= 1
+        else:
+            repeated_input_rows.append(row)
+    for v in sorted(leftover):
+        for _ in range(leftover[v]):
+            permuted_table[repeated_input_rows.pop()] = v
+    assert not repeated_input_rows
+    return permuted_input, permuted_table

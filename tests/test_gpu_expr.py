@@ -238,3 +238,40 @@ def test_random_expression_trees():
             continue
         got = from_dev(f, expr.GateEvaluator(prog).eval(dev, log_n, 2))
         assert got == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n, 2), trial
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_lookup_permuted_columns(field):
+    """plonk/lookup/prover.rs permute_expression_pair: bit-exact against the step-by-step restatement (oracle), incl. the order in
+    which the left-over table values fill the repeated rows; small values (high limbs zero), wide values, duplicates in the table"""
+    from tiny_ram_halo2_amd import permutation
+    f = o.FIELDS[field]
+    rng = random.Random(0x100CA)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    cases = []
+    for n, tsize, wide in ((1, 1, False), (7, 3, False), (64, 16, True), (1000, 256, False), (5000, 700, True), (1 << 14, 1 << 12, True)):
+        distinct = [rng.randrange(f.m) if wide else rng.randrange(1 << 16) for _ in range(tsize)]
+        if wide and tsize > 4:
+            distinct[0] = 0; distinct[1] = f.m - 1; distinct[2] = 1 << 64; distinct[3] = (1 << 64) - 1  # limb boundaries
+        table = [distinct[i % tsize] for i in range(n)]          # duplicates in the table when tsize < n
+        rng.shuffle(table)
+        inp = [rng.choice(distinct) for _ in range(n)]
+        cases.append((inp, table))
+    inp = [5] * 300
+    cases.append((inp, [5] + [9] * 299))   # one run only: every other row takes a left-over value
+    for inp, table in cases:
+        n = len(inp)
+        want_a, want_s = o.permute_expression_pair(inp, table, n)
+        a, s = permutation.lookup_permute(field, dev(inp), dev(table))
+        assert from_dev(f, a) == want_a and from_dev(f, s) == want_s, n
+        # the defining constraints of the argument
+        for row in range(n):
+            assert want_a[row] == want_s[row] or (row > 0 and want_a[row] == want_a[row - 1])
+    # usable_rows < n: only the first rows take part
+    inp, table = cases[3]
+    want_a, want_s = o.permute_expression_pair(inp, table, 900)
+    a, s = permutation.lookup_permute(field, dev(inp), dev(table), 900)
+    assert from_dev(f, a) == want_a and from_dev(f, s) == want_s
+    # an input value that is not in the table
+    with pytest.raises(api.TrhError):
+        permutation.lookup_permute(field, dev([1, 2, 3, 4]), dev([1, 2, 3, 3]))

@@ -34,6 +34,13 @@ def test_replay_k10_matches_oracle():
             want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], bases, threads=8))
             assert (np.asarray(out)[:8] == want).all(), kind
             return
+        if kind == "lookup_permute":
+            f = o.FIELDS[inp["field"]]
+            a = [f.from_limbs(r) for r in inp["input"]]
+            t = [f.from_limbs(r) for r in inp["table"]]
+            want_a, want_s = o.permute_expression_pair(a, t, len(a))
+            assert [f.from_limbs(r) for r in out[0]] == want_a and [f.from_limbs(r) for r in out[1]] == want_s
+            return
         if kind == "evals":  # arithmetic::eval_polynomial: Horner at the challenge
             f = o.FIELDS[inp["field"]]
             x, acc = f.from_limbs(inp["x"]), 0
@@ -68,4 +75,4 @@ def test_replay_k10_matches_oracle():
     res = replay.run(16, batch=32, hook=hook, verbose=False)
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"lookup_permute": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}

@@ -240,6 +240,7 @@ void trh_shutdown(void) {
     if (!c.inited) return;
     (void)hipDeviceSynchronize();
     msm_release();
+    lookup_release();
     ntt_release_tables();
     for (DevBuf& d : ctx().ipa) d.release();
     c.io.release();

@@ -144,6 +144,7 @@ int msm_finish(int curve, hipStream_t s, u64* out_xyz, size_t batch);
 int point_sum_host(int curve, const u64* pts, size_t count, u64* out);
 int bases_generate_device(int curve, u64 s0, u64 d, u64 first, size_t n, void* out_dev, hipStream_t s);
 void msm_release();
+void lookup_release();
 
 }  // namespace trh
 

@@ -1,0 +1,198 @@
+// The permuted columns of halo2_proofs 0.2.0's lookup argument (plonk/lookup/prover.rs `permute_expression_pair`, reached
+// from create_proof -- /root/reference/src/test_utils.rs:41-49; the reference's circuit has 31 lookups,
+// src/circuits/even_bits.rs:158-170, aux/out_table.rs:33-74, shift.rs:142-165, tables/prog.rs:170-192):
+//
+//   A' = the first `usable_rows` input values sorted (Ord of the field = order of the canonical integers)
+//   S'[row] = A'[row] where A'[row] is the first of its run; one instance of that value leaves the table multiset;
+//   the other rows receive the left-over table values in ascending order, the LAST repeated row first
+//   (the Rust code pops the rows of a Vec and walks a BTreeMap);  an input value missing from the table is an error.
+//
+// A sort of 256-bit keys, not a hot kernel of this path: the 64-bit limb sorts are rocPRIM's radix sort (four stable
+// least-significant-limb-first passes over (limb, index) pairs), everything else (canonical form, run flags, membership
+// by binary search, compaction by prefix sums, the final placement) is a handful of small kernels here.
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "ctx.h"
+
+namespace trh {
+namespace {
+
+template <class F>
+__device__ __forceinline__ Fe<F> ldf(const uint4* p) {
+    uint4 a = p[0], b = p[1];
+    return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+
+// canonical limbs of a[i] (Montgomery -> integer), one u64 plane per limb; perm = identity
+template <class F>
+__global__ void __launch_bounds__(256) canon_planes_kernel(const uint4* __restrict__ a, size_t n, u64* __restrict__ planes /* 4 x n */, u32* __restrict__ perm) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    fe_store(fe_from_mont(ldf<F>(a + 2 * i)), w);
+    for (int k = 0; k < 4; ++k) planes[(size_t)k * n + i] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+    perm[i] = (u32)i;
+}
+__global__ void __launch_bounds__(256) gather_u64_kernel(const u64* __restrict__ src, const u32* __restrict__ perm, u64* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+__global__ void __launch_bounds__(256) gather_elems_kernel(const uint4* __restrict__ src, const u32* __restrict__ perm, uint4* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* p = src + 2 * (size_t)perm[i];
+    dst[2 * i] = p[0]; dst[2 * i + 1] = p[1];
+}
+// sorted canonical keys as 4 planes gathered through perm: cmp(i, j) on the planes
+__device__ __forceinline__ int cmp_keys(const u64* __restrict__ pa, size_t na, const u32* __restrict__ perma, size_t i, const u64* __restrict__ pb, size_t nb, const u32* __restrict__ permb, size_t j) {
+    const u32 ia = perma[i], ib = permb[j];
+    for (int k = 3; k >= 0; --k) {
+        const u64 x = pa[(size_t)k * na + ia], y = pb[(size_t)k * nb + ib];
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+// first[i] = 1 when sorted element i starts a run of equal values
+__global__ void __launch_bounds__(256) run_flags_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, u32* __restrict__ first) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    first[i] = (i == 0 || cmp_keys(planes, n, perm, i, planes, n, perm, i - 1) != 0) ? 1u : 0u;
+}
+// every run start of the sorted input removes the first table instance of its value: removed[pos] = 1; missing -> *err = 1
+__global__ void __launch_bounds__(256) remove_from_table_kernel(const u64* __restrict__ pa, const u32* __restrict__ perma, const u32* __restrict__ first, size_t n,
+                                                                const u64* __restrict__ ps, const u32* __restrict__ perms, u32* __restrict__ removed, u32* __restrict__ err) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !first[i]) return;
+    size_t lo = 0, hi = n;  // lower bound of the value in the sorted table
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (cmp_keys(ps, n, perms, mid, pa, n, perma, i) < 0) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && cmp_keys(ps, n, perms, lo, pa, n, perma, i) == 0) removed[lo] = 1u;  // distinct run starts hit distinct positions
+    else *err = 1u;
+}
+__global__ void __launch_bounds__(256) invert_flags_kernel(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] ? 0u : 1u;
+}
+// rows[] of the flagged positions in ascending order (pos = exclusive prefix sum of the flags)
+__global__ void __launch_bounds__(256) compact_kernel(const u32* __restrict__ flags, const u32* __restrict__ pos, u32* __restrict__ rows, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) rows[pos[i]] = (u32)i;
+}
+// S'[row] = A'[row] at run starts; left-over table element k (ascending) goes to the (count - 1 - k)-th repeated row
+__global__ void __launch_bounds__(256) place_table_kernel(const uint4* __restrict__ a_sorted, const u32* __restrict__ first, const uint4* __restrict__ table, const u32* __restrict__ perms,
+                                                          const u32* __restrict__ left_rows /* positions in the sorted table */, const u32* __restrict__ rep_rows, u32 n_rep,
+                                                          uint4* __restrict__ out_table, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (first[i]) { out_table[2 * i] = a_sorted[2 * i]; out_table[2 * i + 1] = a_sorted[2 * i + 1]; }
+    if (i < n_rep) {
+        const uint4* src = table + 2 * (size_t)perms[left_rows[i]];
+        const size_t dst = rep_rows[n_rep - 1 - i];
+        out_table[2 * dst] = src[0]; out_table[2 * dst + 1] = src[1];
+    }
+}
+
+struct Scratch {
+    DevBuf planes_a, planes_s, keys_in, keys_out, perm_a, perm_s, perm_tmp, first, removed, flags, pos, rows_rep, rows_left, tmp, err;
+};
+Scratch& scratch() { static Scratch s; return s; }
+
+// stable sort of the permutation by the 256-bit keys: least significant limb first
+int sort_perm(const u64* planes, size_t n, u32* perm, hipStream_t s) {
+    Scratch& sc = scratch();
+    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(n * 4));
+    size_t tmp_bytes = 0;
+    TRH_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm, sc.perm_tmp.as<u32>(), n, 0, 64, s));
+    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    u32* cur = perm;
+    u32* nxt = sc.perm_tmp.as<u32>();
+    for (int k = 0; k < 4; ++k) {
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)k * n, cur, sc.keys_in.as<u64>(), n);
+        TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), cur, nxt, n, 0, 64, s));
+        u32* t = cur; cur = nxt; nxt = t;
+    }
+    // four passes: the result is back in `perm`
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+int exclusive_scan_u32(const u32* in, u32* out, size_t n, hipStream_t s) {
+    Scratch& sc = scratch();
+    size_t tmp_bytes = 0;
+    TRH_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0u, n, rocprim::plus<u32>(), s));
+    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
+    TRH_HIP_TRY(rocprim::exclusive_scan(sc.tmp.p, tmp_bytes, in, out, 0u, n, rocprim::plus<u32>(), s));
+    return TRH_OK;
+}
+
+template <class F>
+int lookup_permute_t(const void* input, const void* table, size_t n, void* out_input, void* out_table, hipStream_t s) {
+    Scratch& sc = scratch();
+    TRH_TRY(sc.planes_a.ensure(n * 32)); TRH_TRY(sc.planes_s.ensure(n * 32)); TRH_TRY(sc.perm_a.ensure(n * 4)); TRH_TRY(sc.perm_s.ensure(n * 4));
+    TRH_TRY(sc.first.ensure(n * 4)); TRH_TRY(sc.removed.ensure(n * 4)); TRH_TRY(sc.flags.ensure(n * 4)); TRH_TRY(sc.pos.ensure(n * 4 + 4));
+    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(16));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)input, n, sc.planes_a.as<u64>(), sc.perm_a.as<u32>());
+    hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)table, n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>());
+    TRH_TRY(sort_perm(sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), s));
+    TRH_TRY(sort_perm(sc.planes_s.as<u64>(), n, sc.perm_s.as<u32>(), s));
+    hipLaunchKernelGGL(gather_elems_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)input, sc.perm_a.as<u32>(), (uint4*)out_input, n);
+    hipLaunchKernelGGL(run_flags_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), sc.first.as<u32>());
+    TRH_HIP_TRY(hipMemsetAsync(sc.removed.p, 0, n * 4, s));
+    TRH_HIP_TRY(hipMemsetAsync(sc.err.p, 0, 16, s));
+    hipLaunchKernelGGL(remove_from_table_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), sc.perm_a.as<u32>(), sc.first.as<u32>(), n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>(),
+                       sc.removed.as<u32>(), sc.err.as<u32>());
+    // repeated input rows (ascending) and left-over table positions (ascending)
+    hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.first.as<u32>(), sc.flags.as<u32>(), n);
+    TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
+    hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_rep.as<u32>(), n);
+    u32 tail[2], last_flag;
+    TRH_HIP_TRY(hipMemcpyAsync(&tail[0], sc.pos.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipMemcpyAsync(&last_flag, sc.flags.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.removed.as<u32>(), sc.flags.as<u32>(), n);
+    TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
+    hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_left.as<u32>(), n);
+    u32 err = 0;
+    TRH_HIP_TRY(hipMemcpyAsync(&err, sc.err.p, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    if (err) { set_error("lookup_permute: an input value does not occur in the table (halo2: Error::ConstraintSystemFailure)"); return TRH_EINVAL; }
+    const u32 n_rep = tail[0] + last_flag;  // repeated rows == left-over table elements (both n - #distinct inputs)
+    hipLaunchKernelGGL(place_table_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)out_input, sc.first.as<u32>(), (const uint4*)table, sc.perm_s.as<u32>(), sc.rows_left.as<u32>(),
+                       sc.rows_rep.as<u32>(), n_rep, (uint4*)out_table, n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+}  // namespace
+
+void lookup_release() {
+    Scratch& sc = scratch();
+    for (DevBuf* b : {&sc.planes_a, &sc.planes_s, &sc.keys_in, &sc.keys_out, &sc.perm_a, &sc.perm_s, &sc.perm_tmp, &sc.first, &sc.removed, &sc.flags, &sc.pos, &sc.rows_rep, &sc.rows_left, &sc.tmp,
+                      &sc.err})
+        b->release();
+}
+
+}  // namespace trh
+
+using namespace trh;
+
+extern "C" int trh_lookup_permute_dev(int field, const void* input_dev, const void* table_dev, size_t usable_rows, void* out_input_dev, void* out_table_dev, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (usable_rows && (!input_dev || !table_dev || !out_input_dev || !out_table_dev)) { set_error("lookup_permute: null pointer"); return TRH_EINVAL; }
+    if (out_input_dev == input_dev || out_table_dev == table_dev || out_input_dev == out_table_dev) { set_error("lookup_permute: outputs must not alias the inputs"); return TRH_EINVAL; }
+    if (usable_rows >= ((size_t)1 << 31)) { set_error("lookup_permute: too many rows"); return TRH_EINVAL; }
+    if (!usable_rows) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return lookup_permute_t<FpParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
+    return lookup_permute_t<FqParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
+}

@@ -106,3 +106,16 @@ class ProductColumn:
         if z0 % _MODULUS[self.field] != 1:
             api.field_scale_dev(self.field, z, self.n, expr._limbs(self.field, z0), stream=st)
         return z
+
+
+def lookup_permute(field: str, input_col, table_col, usable_rows: int | None = None):
+    """plonk/lookup/prover.rs permute_expression_pair on device columns (n, 4): returns (permuted_input, permuted_table) of
+    usable_rows rows each; raises api.TrhError when an input value is missing from the table"""
+    import torch
+    n = input_col.shape[0] if usable_rows is None else usable_rows
+    assert table_col.shape[0] >= n and input_col.shape[0] >= n and input_col.is_contiguous() and table_col.is_contiguous()
+    a = torch.empty((n, 4), dtype=input_col.dtype, device=input_col.device)
+    s = torch.empty_like(a)
+    api._check(api.lib().trh_lookup_permute_dev(api.FIELD_ID[field], api._devptr(input_col), api._devptr(table_col), n, api._devptr(a), api._devptr(s),
+                                               torch.cuda.current_stream(input_col.device).cuda_stream))
+    return a, s

@@ -5,7 +5,7 @@ site is /root/reference/src/test_utils.rs:41-49 with k = 2 + WORD_BITS / 2 from 
 The Rust prover cannot run here (no toolchain), so this driver issues the same primitive kinds, sizes
 and counts against libtrh with synthetic column data: per column a `commit_lagrange` (MSM of n + 1
 pairs over the resident Lagrange bases), `lagrange_to_coeff` (iNTT n) and `coeff_to_extended` (coset NTT
-8n); the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
+8n); the permuted input / table columns of the 31 lookups; the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
 and one IPA opening (k rounds).  Column / lookup / permutation counts are derived from the reference's
 `configure` code (Appendix B): 94 instance + 263 advice columns, 31 lookups, 47 permutation products,
 quotient degree 5 => extended_k = k + 3.  The h(X) numerator runs on the device as well (`expr.GateEvaluator`
@@ -27,7 +27,7 @@ import time
 
 import numpy as np
 
-from . import api, expr, ipa, poly, synth
+from . import api, expr, ipa, permutation, poly, synth
 
 # Appendix B counts for TinyRamCircuit<WB, 8>
 N_INSTANCE, N_ADVICE, N_LOOKUPS, N_PERM_PRODUCTS, N_H_PIECES = 94, 263, 31, 47, 5
@@ -96,12 +96,31 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         e.record()
         return e
 
-    times = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
+    times = {"lookup_permute": 0.0, "commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
              "extended_to_coeff": 0.0, "ipa": 0.0}
     counts = {kk: 0 for kk in times}
     checked = 0
     torch.cuda.synchronize()
     t_wall = time.perf_counter()
+
+    # --- lookup argument: permuted input / table columns of the 31 lookups (permute_expression_pair) ---
+    distinct = torch.from_numpy(synth.field_elements(0x7AB1E, min(n, 1 << 16)).view(np.int64)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x100C)
+    for li in range(N_LOOKUPS):
+        table = distinct[torch.arange(n, device=dev) % distinct.shape[0]].contiguous()
+        inp = distinct[torch.randint(0, distinct.shape[0], (n,), device=dev, generator=gen)].contiguous()
+        e0 = ev()
+        pa, ps = permutation.lookup_permute(field, inp, table)
+        e1 = ev()
+        torch.cuda.synchronize()
+        times["lookup_permute"] += e0.elapsed_time(e1)
+        counts["lookup_permute"] += 1
+        if hook is not None and li == 0:
+            hook("lookup_permute", dict(input=inp.cpu().numpy().view(np.uint64), table=table.cpu().numpy().view(np.uint64), field=field),
+                 (pa.cpu().numpy().view(np.uint64), ps.cpu().numpy().view(np.uint64)))
+            checked += 1
+    del distinct
 
     x_eval = synth.field_elements(0xE7A, 1)[0]
     ext_buf = torch.empty((min(batch, sch["intt_n"]), 1 << ek, 4), dtype=torch.int64, device=dev)  # the batch's extended cosets, reused
