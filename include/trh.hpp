@@ -357,6 +357,23 @@ inline std::pair<Limbs, Limbs> ipa_create_proof(const Params& params, const Devi
     return {c, f};
 }
 
+// ---- the remaining polynomial steps of create_proof on resident data -------------------------------------------------
+// arithmetic::eval_polynomial for `batch` coefficient forms (n each, back to back) at one point
+inline std::vector<Limbs> eval_polynomials(Field f, const void* polys_dev, size_t n, size_t batch, const Limbs& point, void* stream = nullptr) {
+    std::vector<Limbs> out(batch);
+    check(trh_poly_eval_batch_dev((int)f, polys_dev, n, batch, point.data(), stream, (uint64_t*)out.data()), "eval_polynomial");
+    return out;
+}
+// poly/multiopen/prover.rs: sum_b coeffs[b] * polys[b]
+inline void lincomb(Field f, const void* polys_dev, size_t n, const std::vector<Limbs>& coeffs, void* out_dev, void* stream = nullptr) {
+    check(trh_poly_lincomb_dev((int)f, polys_dev, n, coeffs.size(), (const uint64_t*)coeffs.data(), out_dev, stream), "lincomb");
+}
+// plonk/lookup/prover.rs permute_expression_pair over the first usable_rows rows; throws where the Rust code returns
+// Error::ConstraintSystemFailure (an input value that is not in the table)
+inline void lookup_permute(Field f, const void* input_dev, const void* table_dev, size_t usable_rows, void* permuted_input_dev, void* permuted_table_dev, void* stream = nullptr) {
+    check(trh_lookup_permute_dev((int)f, input_dev, table_dev, usable_rows, permuted_input_dev, permuted_table_dev, stream), "permute_expression_pair");
+}
+
 inline void init(int device = 0) { check(trh_init(device), "trh_init"); }
 
 }  // namespace trh

@@ -19,4 +19,4 @@ def test_native_replay_k10():
     assert r.returncode == 0, r.stderr + r.stdout
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["k"] == 10 and out["checks_failed"] == 0
-    assert set(out["ms"]) == {"commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "ipa"}
+    assert set(out["ms"]) == {"lookup_permute", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "ipa"}
