@@ -99,27 +99,67 @@ __global__ void __launch_bounds__(256) place_table_kernel(const uint4* __restric
     }
 }
 
+// varies[k] = 1 when limb plane k is not constant over the column
+__global__ void __launch_bounds__(256) plane_varies_kernel(const u64* __restrict__ planes, size_t n, u32* __restrict__ varies) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 4; ++k)
+        if (planes[(size_t)k * n + i] != planes[(size_t)k * n] && !varies[k]) varies[k] = 1u;  // benign race: every writer stores 1
+}
+// after a sort by ONE limb: *bad = 1 when two neighbours agree in that limb but are different values (the order inside the tie is then unknown)
+__global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, int primary, u32* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    const u32 a = perm[i - 1], b = perm[i];
+    if (planes[(size_t)primary * n + a] != planes[(size_t)primary * n + b]) return;
+    for (int k = 0; k < 4; ++k)
+        if (planes[(size_t)k * n + a] != planes[(size_t)k * n + b]) { *bad = 1u; return; }
+}
+
 struct Scratch {
     DevBuf planes_a, planes_s, keys_in, keys_out, perm_a, perm_s, perm_tmp, first, removed, flags, pos, rows_rep, rows_left, tmp, err;
 };
 Scratch& scratch() { static Scratch s; return s; }
 
-// stable sort of the permutation by the 256-bit keys: least significant limb first
+// sort of the permutation by the 256-bit keys.  Field elements are either small (range tables: only the low limb varies) or
+// spread over the whole field (compressed expressions: two different values practically never share their top limb), so ONE
+// radix sort by the most significant limb that varies is almost always the complete order -- checked, with the four stable
+// least-significant-limb-first passes as the fallback.
 int sort_perm(const u64* planes, size_t n, u32* perm, hipStream_t s) {
     Scratch& sc = scratch();
-    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(n * 4));
+    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(n * 4)); TRH_TRY(sc.err.ensure(32));
     size_t tmp_bytes = 0;
     TRH_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm, sc.perm_tmp.as<u32>(), n, 0, 64, s));
     TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
     const unsigned gb = (unsigned)((n + 255) / 256);
+    u32* flags = sc.err.as<u32>() + 1;  // [0] is the caller's error word: varies[4], bad
+    TRH_HIP_TRY(hipMemsetAsync(flags, 0, 20, s));
+    hipLaunchKernelGGL(plane_varies_kernel, dim3(gb), dim3(256), 0, s, planes, n, flags);
+    u32 h[5];
+    TRH_HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    int primary = -1;
+    for (int k = 3; k >= 0; --k) if (h[k]) { primary = k; break; }
+    if (primary < 0) return TRH_OK;  // a constant column: any order
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)primary * n, perm, sc.keys_in.as<u64>(), n);
+    TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm, sc.perm_tmp.as<u32>(), n, 0, 64, s));
+    hipLaunchKernelGGL(tie_check_kernel, dim3(gb), dim3(256), 0, s, planes, n, sc.perm_tmp.as<u32>(), primary, flags + 4);
+    TRH_HIP_TRY(hipMemcpyAsync(&h[4], flags + 4, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    if (!h[4]) {
+        TRH_HIP_TRY(hipMemcpyAsync(perm, sc.perm_tmp.p, n * 4, hipMemcpyDeviceToDevice, s));
+        return TRH_OK;
+    }
+    // stable least-significant-limb-first passes over the limbs that vary (perm still holds the identity order)
     u32* cur = perm;
     u32* nxt = sc.perm_tmp.as<u32>();
     for (int k = 0; k < 4; ++k) {
+        if (!h[k]) continue;
         hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)k * n, cur, sc.keys_in.as<u64>(), n);
         TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), cur, nxt, n, 0, 64, s));
         u32* t = cur; cur = nxt; nxt = t;
     }
-    // four passes: the result is back in `perm`
+    if (cur != perm) TRH_HIP_TRY(hipMemcpyAsync(perm, cur, n * 4, hipMemcpyDeviceToDevice, s));
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -138,7 +178,7 @@ int lookup_permute_t(const void* input, const void* table, size_t n, void* out_i
     Scratch& sc = scratch();
     TRH_TRY(sc.planes_a.ensure(n * 32)); TRH_TRY(sc.planes_s.ensure(n * 32)); TRH_TRY(sc.perm_a.ensure(n * 4)); TRH_TRY(sc.perm_s.ensure(n * 4));
     TRH_TRY(sc.first.ensure(n * 4)); TRH_TRY(sc.removed.ensure(n * 4)); TRH_TRY(sc.flags.ensure(n * 4)); TRH_TRY(sc.pos.ensure(n * 4 + 4));
-    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(16));
+    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(32));
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)input, n, sc.planes_a.as<u64>(), sc.perm_a.as<u32>());
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)table, n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>());
@@ -147,7 +187,7 @@ int lookup_permute_t(const void* input, const void* table, size_t n, void* out_i
     hipLaunchKernelGGL(gather_elems_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)input, sc.perm_a.as<u32>(), (uint4*)out_input, n);
     hipLaunchKernelGGL(run_flags_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), sc.first.as<u32>());
     TRH_HIP_TRY(hipMemsetAsync(sc.removed.p, 0, n * 4, s));
-    TRH_HIP_TRY(hipMemsetAsync(sc.err.p, 0, 16, s));
+    TRH_HIP_TRY(hipMemsetAsync(sc.err.p, 0, 4, s));
     hipLaunchKernelGGL(remove_from_table_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), sc.perm_a.as<u32>(), sc.first.as<u32>(), n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>(),
                        sc.removed.as<u32>(), sc.err.as<u32>());
     // repeated input rows (ascending) and left-over table positions (ascending)
