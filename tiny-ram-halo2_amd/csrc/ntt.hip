@@ -176,7 +176,7 @@ __device__ __forceinline__ void bfly(Fe<F>& a, Fe<F>& b) {
 }
 
 // Same Stockham pass for full 2048-element tiles, with the stages grouped LG at a time in
-// registers: a thread owns G = 2^LG rows of one column (LG = 3: 256 threads, 8 rows).  Round 0 takes
+// registers: a thread owns G = 2^LG rows of one column (LG = 2: 512 threads, 4 rows; 8 rows spill).  Round 0 takes
 // its rows straight from HBM (rows m + v R/G, i.e. the bit-reversed neighbours rr..rr+G-1), applies the
 // inter-pass twiddle and runs stages 0..LG-1, whose twiddles are the constants 1, w4, w8, w8^3; later
 // rounds exchange through LDS (one read + one write per element per LG stages, in place, one barrier per
@@ -533,16 +533,10 @@ TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
 
 // pass plan: log_n split into passes of <= MAX_PASS_LOG stages on 2^tlog-element tiles
 void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
-    // With TRH_NTT_TILE=12 sizes 2^19..2^22 run as TWO passes of <= 11 stages on 4096-element tiles (all 160 KiB of
-    // LDS, one workgroup of 1024 threads per CU): one inter-pass twiddle and one HBM round trip less than
-    // three passes on 2048-element tiles -- but only one workgroup per CU; measured equal at 2^22, so off by default.
-    static const int big_tile = getenv("TRH_NTT_TILE") ? atoi(getenv("TRH_NTT_TILE")) == 12 : 0;
+    // (a 4096-element tile -- two passes for 2^19..2^22, all 160 KiB of LDS, one workgroup per CU -- measured equal: removed)
     int P = 0, tlog = TILE_LOG;
     if (log_n <= TILE_LOG) { sizes[P++] = log_n; }
-    else if (big_tile && log_n > 2 * MAX_PASS_LOG && log_n <= 22) {
-        tlog = 12; P = 2;
-        sizes[0] = (log_n + 1) / 2; sizes[1] = log_n - sizes[0];
-    } else {
+    else {
         P = (log_n + MAX_PASS_LOG - 1) / MAX_PASS_LOG;
         if (P < 2) P = 2;
         int rem = log_n;
@@ -651,7 +645,6 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const int tile_log = (int)log_n < tlog ? (int)log_n : tlog;
             const size_t tiles = N >> tile_log;
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
-            static const int lg = getenv("TRH_NTT_LG") ? atoi(getenv("TRH_NTT_LG")) : 2;  // tuning knob: rows per thread = 2^lg
             const dim3 grid((unsigned)tiles, (unsigned)nb);
             const bool lazy = lazy_enabled();
             const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
@@ -673,11 +666,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             else if (lazy_pass && !fused) TRH_LAUNCH_PASSZ(false, false, ldz);
             else if (lazy_pass) TRH_LAUNCH_PASSZ(false, true, ldz);
 #undef TRH_LAUNCH_PASSZ
-            else if (tlog == 12)
-                hipLaunchKernelGGL((ntt_passg_kernel<F, 2, 12>), grid, dim3(1024), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
-            else if ((int)log_n >= TILE_LOG && sp >= 3 && lg == 3)
-                hipLaunchKernelGGL((ntt_passg_kernel<F, 3, TILE_LOG>), grid, dim3(TILE >> 3), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
-            else if ((int)log_n >= TILE_LOG && sp >= 2 && lg == 2)
+            else if ((int)log_n >= TILE_LOG && sp >= 2)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else
                 hipLaunchKernelGGL((ntt_pass_kernel<F>), grid, dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
@@ -708,8 +697,6 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 3, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
@@ -717,9 +704,6 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
         TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
 #undef TRH_PASSZ_ATTR
-        const int big_lds = (32 << 12) + (32 << 10);  // 160 KiB: the whole LDS of a CU
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-        TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
         attr_set = true;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu);
