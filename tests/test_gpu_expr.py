@@ -275,3 +275,50 @@ def test_lookup_permuted_columns(field):
     # an input value that is not in the table
     with pytest.raises(api.TrhError):
         permutation.lookup_permute(field, dev([1, 2, 3, 4]), dev([1, 2, 3, 3]))
+
+
+@pytest.mark.parametrize("k", [9, 14])
+def test_quotient_identity_end_to_end(k):
+    """The chain create_proof runs for h(X), on a satisfied toy circuit, checked through an identity no single kernel can fake:
+    columns a, b random and c = a * b on every row, gates s (a b - c) and s (c(X omega) - a(X omega) b(X omega)) folded with y.  Lagrange -> coefficients
+    -> extended coset -> gate evaluation -> divide_by_vanishing_poly -> extended_to_coeff must give an h(X) with
+        (1) zero coefficients from degree n on (the numerator has degree < 3n and is divisible by X^n - 1), and
+        (2) h(x) (x^n - 1) == folded gates evaluated from the column polynomials at a random point x."""
+    from tiny_ram_halo2_amd import poly
+    field, j = "fp", 4   # degree-3 gates (selector x product): EvaluationDomain::new(4, k), extended_k = k + 2
+    f = o.FIELDS[field]
+    n = 1 << k
+    dom = poly.EvaluationDomain(field, j, k)
+    a_l = synth.field_elements(0xA0 + k, n)
+    b_l = synth.field_elements(0xB0 + k, n)
+    d_a, d_b = torch.from_numpy(a_l.view(np.int64)).cuda(), torch.from_numpy(b_l.view(np.int64)).cuda()
+    d_c = torch.empty_like(d_a)
+    api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["mul"], api._devptr(d_a), api._devptr(d_b), api._devptr(d_c), n, None))
+    one = np.array(f.limbs(1), np.uint64)
+    d_s = torch.from_numpy(np.tile(one, (n, 1)).view(np.int64)).cuda()   # selector enabled on every row
+    cols = torch.stack([d_a, d_b, d_c, d_s]).contiguous()                # Lagrange form, (4, n, 4)
+    coeff = dom.lagrange_to_coeff(cols.clone())
+    ext = dom.coeff_to_extended(coeff)
+    A, B, C, S = expr.Advice(0), expr.Advice(1), expr.Advice(2), expr.Selector(0)
+    An, Bn, Cn = expr.Advice(0, 1), expr.Advice(1, 1), expr.Advice(2, 1)
+    gates = [S * (A * B - C), S * (Cn - An * Bn)]
+    y = 0x1F2E3D4C5B6A7988 % f.m
+    prog = expr.compile_gates(field, gates, y)
+    res = {("advice", 0): ext[0], ("advice", 1): ext[1], ("advice", 2): ext[2], ("selector", 0): ext[3]}
+    h = expr.GateEvaluator(prog).eval(res, dom.extended_k, 1 << (dom.extended_k - k)).reshape(1, -1, 4).contiguous()
+    dom.divide_by_vanishing_poly(h)
+    hc = dom.extended_to_coeff(h)[0]
+    torch.cuda.synchronize()
+    hc_host = hc.cpu().numpy().view(np.uint64)
+    assert hc_host[: 2 * n].any() and not hc_host[2 * n:].any()     # (1): degree of h < 2n
+    # (2) at a random point, from the coefficient forms
+    x = 0x0123456789ABCDEF0FEDCBA987654321 % f.m
+    w = f.omega(k)
+    ev = lambda t, pt: [f.from_limbs(r) for r in api.poly_eval_batch_dev(field, t.contiguous(), t.shape[-2], t.shape[0], np.array(f.limbs(pt), np.uint64))]
+    a_x, b_x, c_x, s_x = ev(coeff, x)
+    a_wx, b_wx, c_wx, _ = ev(coeff, x * w % f.m)
+    g0 = s_x * (a_x * b_x - c_x) % f.m
+    g1 = s_x * (c_wx - a_wx * b_wx) % f.m
+    folded = (g0 * y + g1) % f.m
+    h_x = ev(hc.reshape(1, -1, 4), x)[0]
+    assert h_x * (pow(x, n, f.m) - 1) % f.m == folded
