@@ -322,3 +322,45 @@ def test_quotient_identity_end_to_end(k):
     folded = (g0 * y + g1) % f.m
     h_x = ev(hc.reshape(1, -1, 4), x)[0]
     assert h_x * (pow(x, n, f.m) - 1) % f.m == folded
+
+
+def test_permutation_argument_closes_on_a_real_permutation():
+    """copy constraints honoured by the witness: values constant on the cycles of a random permutation pi of all cells, sigma the
+    encoding of pi (delta^j' omega^i' for pi(j, i) = (j', i')): the grand product over all rows is 1, i.e. z returns to z0"""
+    from tiny_ram_halo2_amd import permutation
+    field, k, ncol = "fq", 7, 4
+    f = o.FIELDS[field]
+    n = 1 << k
+    rng = random.Random(0xC0B7)
+    cells = [(j, i) for j in range(ncol) for i in range(n)]
+    image = cells[:]
+    rng.shuffle(image)
+    pi = dict(zip(cells, image))
+    vals = {}
+    for c in cells:                      # one value per cycle
+        if c in vals:
+            continue
+        v, cur = rng.randrange(f.m), c
+        while cur not in vals:
+            vals[cur] = v
+            cur = pi[cur]
+    delta, w = pow(5, 1 << 32, f.m), f.omega(k)
+    label = lambda j, i: pow(delta, j, f.m) * pow(w, i, f.m) % f.m
+    v_cols = [[vals[(j, i)] for i in range(n)] for j in range(ncol)]
+    s_cols = [[label(*pi[(j, i)]) for i in range(n)] for j in range(ncol)]
+    beta, gamma = rng.randrange(f.m), rng.randrange(f.m)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    z = from_dev(f, permutation.ProductColumn(field, k, ncol).compute([dev(c) for c in v_cols], [dev(c) for c in s_cols], beta, gamma))
+    num = den = 1
+    for j in range(ncol):
+        num = num * (v_cols[j][n - 1] + beta * label(j, n - 1) + gamma) % f.m
+        den = den * (v_cols[j][n - 1] + beta * s_cols[j][n - 1] + gamma) % f.m
+    assert z[0] == 1 and z[n - 1] * num % f.m == den      # z[n] = z[n-1] num / den = 1
+    # and it does NOT close when one copy constraint is violated
+    v_cols[2][5] = (v_cols[2][5] + 1) % f.m
+    z = from_dev(f, permutation.ProductColumn(field, k, ncol).compute([dev(c) for c in v_cols], [dev(c) for c in s_cols], beta, gamma))
+    num = den = 1
+    for j in range(ncol):
+        num = num * (v_cols[j][n - 1] + beta * label(j, n - 1) + gamma) % f.m
+        den = den * (v_cols[j][n - 1] + beta * s_cols[j][n - 1] + gamma) % f.m
+    assert z[n - 1] * num % f.m != den
