@@ -552,6 +552,37 @@ def ipa_create_proof(curve: Curve, k: int, g: List[Affine], w: Affine, u: Affine
     return c, f
 
 
+def ipa_verify_proof(curve: Curve, k: int, g: List[Affine], w: Affine, u: Affine, commitment: Affine, x3: int, v: int,
+                     s_commitment: Affine, xi: int, z: int, rounds, challenges: List[int], c: int, f: int) -> bool:
+    """halo2_proofs 0.2.0 poly/commitment/verifier.rs `verify_proof`, the equation the reference's own prove -> verify tests
+    exercise (/root/reference/src/test_utils.rs:52-68, 106-118):
+
+        P - [v] G_0 + [xi] S + sum_j [u_j^-1] L_j + sum_j [u_j] R_j  ==  [c] G'_0 + [c b z] U + [f] W
+
+    with G'_0 = sum_i s_i G_i and b = sum_i s_i x3^i, s_i = prod over the rounds j whose fold put index i in the upper half
+    of u_j (`compute_s` / `compute_b`).  Independent of the prover restatement above: it only uses the group law."""
+    f_, m, n = curve.scalar, curve.scalar.m, 1 << k
+    assert len(g) == n and len(rounds) == k and len(challenges) == k
+    s = [1] * n
+    for j, u_j in enumerate(challenges):
+        bit = k - 1 - j  # round j folds index i + half (half = 2^(k-j-1)) onto i with weight u_j
+        for i in range(n):
+            if (i >> bit) & 1:
+                s[i] = s[i] * u_j % m
+    b = 0
+    for i in range(n):
+        b = (b + s[i] * pow(x3, i, m)) % m
+    lhs = curve.add(commitment, curve.mul((-v) % m, g[0]))
+    lhs = curve.add(lhs, curve.mul(xi, s_commitment))
+    for (l_j, r_j), u_j in zip(rounds, challenges):
+        lhs = curve.add(lhs, curve.mul(f_.inv(u_j), l_j))
+        lhs = curve.add(lhs, curve.mul(u_j, r_j))
+    g0 = best_multiexp(curve, s, list(g))
+    rhs = curve.add(curve.mul(c, g0), curve.mul(c * b % m * z % m, u))
+    rhs = curve.add(rhs, curve.mul(f, w))
+    return lhs == rhs
+
+
 if __name__ == "__main__":
     check_published_constants()
     for c in CURVES.values():

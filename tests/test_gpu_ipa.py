@@ -145,3 +145,58 @@ def test_ipa_create_proof_vs_oracle(curve, k):
     assert (c_nat, f_nat) == (c_ref, f_ref)
     assert t_nat.log == t_ref.log
     del sfn
+
+
+class RecordingTranscript(DeviceTranscript):
+    """keeps the points / scalars and the challenges in the order the prover produced them"""
+
+    def __init__(self, modulus):
+        super().__init__(modulus)
+        self.points, self.scalars, self.challenges = [], [], []
+
+    def write_point(self, jac):
+        self.points.append(np.ascontiguousarray(jac, dtype=np.uint64)[:8].copy())
+        super().write_point(jac)
+
+    def write_scalar(self, limbs):
+        self.scalars.append(np.ascontiguousarray(limbs, dtype=np.uint64).copy())
+        super().write_scalar(limbs)
+
+    def squeeze_challenge_scalar(self):
+        c = super().squeeze_challenge_scalar()
+        self.challenges.append(c)
+        return c
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 4), ("pallas", 6)])
+def test_ipa_proof_verifies(curve, k):
+    """what the reference's own tests pin: the verifier accepts.  The opening produced on the GPU (single-call prover, device
+    commitments) is checked with the oracle's restatement of commitment::verify_proof, which shares nothing with the prover
+    restatement but the group law; a tampered evaluation must be rejected."""
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0xFEF1 + k)
+    g_l = cpu_ref.gen_bases(curve, 17, 5, n, threads=4)
+    w_l = cpu_ref.gen_bases(curve, 515151, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 626262, 1, 1, threads=1)
+    params = poly.Params(curve, k, g_l, g_l, w_l, u=u_l)
+    p_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    s_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    draws = iter([rnd.randrange(fs.m) for _ in range(2 * k)])
+    p_l = np.array([fs.limbs(v) for v in p_poly], np.uint64)
+    commitment = params.commit(p_l, np.array(fs.limbs(p_blind), np.uint64))           # P, on the device
+    tr = RecordingTranscript(fs.m)
+    c, f = ipa.create_proof_native(params, lambda: next(draws), tr, to_dev(p_l), p_blind, x3, np.array([fs.limbs(v) for v in s_poly], np.uint64), s_blind)
+    assert len(tr.points) == 1 + 2 * k and len(tr.challenges) == 2 + k
+    pts = [cv.affine_from_limbs(p) for p in tr.points]
+    xi, z, ch = tr.challenges[0], tr.challenges[1], tr.challenges[2:]
+    rounds = [(pts[1 + 2 * j], pts[2 + 2 * j]) for j in range(k)]
+    v = 0
+    for cf in reversed(p_poly):
+        v = (v * x3 + cf) % fs.m
+    args = (cv, k, [cv.affine_from_limbs(r) for r in g_l], cv.affine_from_limbs(w_l[0]), cv.affine_from_limbs(u_l[0]), cv.affine_from_limbs(commitment[:8]))
+    assert o.ipa_verify_proof(*args, x3, v, pts[0], xi, z, rounds, ch, c, f)
+    assert not o.ipa_verify_proof(*args, x3, (v + 1) % fs.m, pts[0], xi, z, rounds, ch, c, f)
+    assert not o.ipa_verify_proof(*args, x3, v, pts[0], xi, z, rounds, ch, c, (f + 1) % fs.m)

@@ -122,3 +122,43 @@ def test_ntt_roundtrip_and_horner_2_16(field):
     inv = cpu_ref.best_fft(field, fwd, np.array(f.limbs(f.inv(w)), np.uint64), log_n, threads=8)
     ninv = np.tile(np.array(f.limbs(f.inv(1 << log_n)), np.uint64), (1 << log_n, 1))
     assert (cpu_ref.field_op(field, "mul", inv, ninv) == a).all()
+
+
+def test_ipa_prover_restatement_satisfies_the_verifier_equation():
+    """the two oracle restatements (commitment::create_proof and commitment::verify_proof) agree: what the reference's own
+    tests pin for this path is exactly `verifier accepts` (src/test_utils.rs:52-68)"""
+    import random
+    cv = o.CURVES["vesta"]
+    fs = cv.scalar
+    k, n = 3, 8
+    rnd = random.Random(5)
+    g = [cv.mul(rnd.randrange(1, fs.m), cv.generator) for _ in range(n)]
+    w, u = cv.mul(12345, cv.generator), cv.mul(6789, cv.generator)
+
+    class T:
+        def __init__(self):
+            self.pts, self.ch, self.sc, self.r = [], [], [], random.Random(9)
+
+        def write_point(self, p):
+            self.pts.append(p)
+
+        def write_scalar(self, v):
+            self.sc.append(v)
+
+        def squeeze_challenge_scalar(self):
+            c = self.r.randrange(1, fs.m)
+            self.ch.append(c)
+            return c
+
+    p = [rnd.randrange(fs.m) for _ in range(n)]
+    sp = [rnd.randrange(fs.m) for _ in range(n)]
+    pb, sb, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    t = T()
+    c, f = o.ipa_create_proof(cv, k, g, w, u, lambda: rnd.randrange(fs.m), t, p, pb, x3, sp, sb)
+    P = o.best_multiexp(cv, p + [pb], g + [w])
+    v = 0
+    for cf in reversed(p):
+        v = (v * x3 + cf) % fs.m
+    rounds = [(t.pts[1 + 2 * j], t.pts[2 + 2 * j]) for j in range(k)]
+    assert o.ipa_verify_proof(cv, k, g, w, u, P, x3, v, t.pts[0], t.ch[0], t.ch[1], rounds, t.ch[2:], c, f)
+    assert not o.ipa_verify_proof(cv, k, g, w, u, P, x3, (v + 1) % fs.m, t.pts[0], t.ch[0], t.ch[1], rounds, t.ch[2:], c, f)
