@@ -245,6 +245,7 @@ void trh_shutdown(void) {
     for (DevBuf& d : ctx().ipa) d.release();
     c.io.release();
     c.factors.release();
+    if (c.pinned_ring) { (void)hipHostFree(c.pinned_ring); c.pinned_ring = nullptr; c.pinned_slot = 0; }
     c.pfft.release();
     c.scan.release(); c.scan2.release();
     c.inited = false;

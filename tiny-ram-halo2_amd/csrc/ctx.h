@@ -106,6 +106,8 @@ struct Ctx {
     DevBuf ipa[7];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy), kept across proofs
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
+    void* pinned_ring = nullptr;  // 64 x 2 KiB of pinned host memory mirroring the factor ring: constants are copied here first, so the
+    unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;
 };

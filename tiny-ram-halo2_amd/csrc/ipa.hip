@@ -152,6 +152,25 @@ __global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __r
     st<F>(out + 2 * (stride + idx), hi ? v : zero);
 }
 
+// both inner products of an IPA round in one launch: partial[pair][block]
+template <class F>
+__global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __restrict__ a0, const uint4* __restrict__ b0, const uint4* __restrict__ a1, const uint4* __restrict__ b1, size_t n,
+                                                             uint4* __restrict__ partial) {
+    __shared__ Fe<F> sh[256];
+    const uint4* a = blockIdx.y ? a1 : a0;
+    const uint4* b = blockIdx.y ? b1 : b0;
+    Fe<F> acc = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc = fe_add(acc, fe_mul(ld<F>(a + 2 * i), ld<F>(b + 2 * i)));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st<F>(partial + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), sh[0]);
+}
+
 template <class F>
 int inner_product_t(const void* a, const void* b, size_t n, hipStream_t s, u64* out) {
     Ctx& c = ctx();
@@ -169,14 +188,37 @@ int inner_product_t(const void* a, const void* b, size_t n, hipStream_t s, u64* 
     return TRH_OK;
 }
 
+template <class F>
+int inner_product2_t(const void* a0, const void* b0, const void* a1, const void* b1, size_t n, hipStream_t s, u64* out /* 2 x 4 */) {
+    Ctx& c = ctx();
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    if (blocks == 0) blocks = 1;
+    TRH_TRY(c.io.ensure((size_t)(2 * blocks + 2) * 32));
+    uint4* partial = c.io.as<uint4>();
+    uint4* result = partial + 4 * blocks;
+    hipLaunchKernelGGL((inner_product2_kernel<F>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)a0, (const uint4*)b0, (const uint4*)a1, (const uint4*)b1, n, partial);
+    hipLaunchKernelGGL((sum_partials_batch_kernel<F>), dim3(2), dim3(256), 0, s, partial, blocks, result);
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipMemcpyAsync(out, result, 64, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    return TRH_OK;
+}
+
 // small per-call constant staged in the factor ring (see trh_field_scale_rows_dev)
 int stage_constant(const void* host, size_t bytes, hipStream_t s, void** dev) {
     Ctx& c = ctx();
-    TRH_TRY(c.factors.ensure(16 * 64 * 32));
-    char* slot = (char*)c.factors.p + (size_t)(c.factor_slot++ & 15) * 64 * 32;
-    TRH_HIP_TRY(hipMemcpyAsync(slot, host, bytes, hipMemcpyHostToDevice, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    *dev = slot;
+    constexpr unsigned SLOTS = 64, SLOT_BYTES = 2048;
+    if (bytes > SLOT_BYTES) { set_error("stage_constant: %zu bytes", bytes); return TRH_EINVAL; }
+    TRH_TRY(c.factors.ensure(16 * 64 * 32 + SLOTS * SLOT_BYTES));  // the first 32 KiB belong to the scale kernels' ring
+    if (!c.pinned_ring) TRH_HIP_TRY(hipHostMalloc(&c.pinned_ring, SLOTS * SLOT_BYTES, hipHostMallocDefault));
+    const unsigned k = c.pinned_slot++ % SLOTS;
+    if (k == 0 && c.pinned_slot > 1) TRH_HIP_TRY(hipDeviceSynchronize());  // wrap-around: every earlier upload (on whatever stream) has left the pinned slots
+    char* hslot = (char*)c.pinned_ring + (size_t)k * SLOT_BYTES;
+    char* dslot = (char*)c.factors.p + 16 * 64 * 32 + (size_t)k * SLOT_BYTES;
+    memcpy(hslot, host, bytes);
+    TRH_HIP_TRY(hipMemcpyAsync(dslot, hslot, bytes, hipMemcpyHostToDevice, s));
+    *dev = dslot;
     return TRH_OK;
 }
 
@@ -303,16 +345,17 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit, stride);
         TRH_HIP_TRY(hipGetLastError());
         Fe<SF> val[2], rnd[2];
-        TRH_TRY((inner_product_t<SF>(pph, b.p, half, s, (u64*)&tmp)));
-        val[0] = fe_load<SF>(tmp);
-        TRH_TRY((inner_product_t<SF>(pp.p, bh, half, s, (u64*)&tmp)));
-        val[1] = fe_load<SF>(tmp);
+        FeMem ips[2];
+        TRH_TRY((inner_product2_t<SF>(pph, b.p, pp.p, bh, half, s, (u64*)ips)));
+        val[0] = fe_load<SF>(ips[0]);
+        val[1] = fe_load<SF>(ips[1]);
         rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
         for (int side = 0; side < 2; ++side) {
             FeMem tail[2] = {stm(rnd[side]), stm(fe_mul(val[side], z))};  // [rand] W + [value z] U
-            TRH_HIP_TRY(hipMemcpyAsync((char*)lrsc.p + (side * stride + n) * 32, tail, 64, hipMemcpyHostToDevice, s));
-            TRH_HIP_TRY(hipStreamSynchronize(s));  // `tail` is a stack buffer
+            void* d_tail;
+            TRH_TRY(stage_constant(tail, 64, s, &d_tail));  // through the pinned ring: no synchronisation
+            TRH_HIP_TRY(hipMemcpyAsync((char*)lrsc.p + (side * stride + n) * 32, d_tail, 64, hipMemcpyDeviceToDevice, s));
         }
         u64 lrb[24], lr[2][12];
         TRH_TRY(msm_enqueue(curve, gwu.p, gwuz.p, lrsc.p, n + 2, 2, stride, 1, s));
