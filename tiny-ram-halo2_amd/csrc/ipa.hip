@@ -336,6 +336,14 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     TRH_TRY(msm_convert_bases(curve, gwu.p, gwuz.p, n + 2, s));
     const size_t stride = n + 2;
 
+    // the round MSMs are batches of two with half of the scalars zero: their time is the latency of the sort / reduction chain,
+    // which narrow windows shorten (measured: k = 18 -> c = 10 gives 24.4 ms against 26.7 at the table's 15; k = 14 -> 8)
+    struct WindowGuard {
+        int& slot; int saved;
+        WindowGuard(int& s_, int v) : slot(s_), saved(s_) { if (!saved) slot = v; }
+        ~WindowGuard() { slot = saved; }
+    } window_guard(ctx().window_override, (k >= 16 && k <= 18) ? (int)k - 8 : 0);  // k = 20: the table's 15 is better again (60 vs 68 ms)
+
     for (uint32_t j = 0; j < k; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
         const u32 bit = k - j - 1;
