@@ -47,7 +47,7 @@ inline int choose_window_bits(size_t n) {
     const int l = ilog2_floor(n ? n : 1);
     // 2^24 / 2^25: c = 17 (15 full windows + an almost always empty carry window) beats 16 by 3 %; from 2^26 the index
     // takes 26 of the 31 entry bits, which leaves 5 low bucket bits for the second sort level, and 16 wins again
-    return l < 9 ? 4 : l < 15 ? 8 : l < 16 ? 9 : l < 17 ? 10 : l < 21 ? 15 : l < 24 ? 16 : l < 26 ? 17 : 16;
+    return l < 9 ? 4 : l < 15 ? 8 : l == 15 ? 11 : l == 16 ? 10 : l == 17 ? 12 : l < 20 ? 15 : l < 24 ? 16 : l < 26 ? 17 : 16;
 }
 inline int num_windows(int c) { return 255 / c + 1; }
 

@@ -12,7 +12,7 @@ for log_n in [int(x) for x in sys.argv[1].split(",")]:
     bases = api.Bases.generate("vesta", synth.BASE_S0, synth.BASE_D, n)
     sc = torch.from_numpy(synth.field_elements(0x79, n).view(np.int64)).cuda()
     row = []
-    for c in range(max(3, log_n - 8), min(16, log_n + 1) + 1):
+    for c in range(max(3, log_n - 9), min(18, log_n + 1) + 1):
         api.set_window_bits(c)
         bases.msm_dev(sc, n, stream=st)
         torch.cuda.synchronize(); t = time.perf_counter()
