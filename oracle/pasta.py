@@ -651,3 +651,65 @@ def permute_expression_pair(input_values, table_values, usable_rows):
             permuted_table[repeated_input_rows.pop()] = v
     assert not repeated_input_rows
     return permuted_input, permuted_table
+
+
+# ---------------------------------------------------------------------------------------
+# poly::multiopen::create_proof (halo2_proofs 0.2.0 poly/multiopen/prover.rs + multiopen.rs construct_intermediate_sets,
+# reached from create_proof: /root/reference/src/test_utils.rs:41-49), restated over integer coefficient lists.
+# ---------------------------------------------------------------------------------------
+def kate_division(f, a, z):
+    q, tmp = [0] * (len(a) - 1), 0
+    for i in range(len(a) - 1, 0, -1):
+        tmp = (a[i] + z * tmp) % f.m
+        q[i - 1] = tmp
+    return q
+
+
+def multiopen_create_proof(curve: Curve, k: int, g, w, u, rng, transcript, queries, polys, blinds):
+    """queries: [(point, key)], polys[key]: n coefficients, blinds[key]: int.  Written to `transcript`: the commitment of q',
+    the evaluations of the q_i at x3, then everything the IPA writes."""
+    f_, m, n = curve.scalar, curve.scalar.m, 1 << k
+    x1 = transcript.squeeze_challenge_scalar()
+    x2 = transcript.squeeze_challenge_scalar()
+    point_index, commitment_points, order = {}, {}, []
+    for point, key in queries:
+        idx = point_index.setdefault(point, len(point_index))
+        if key not in commitment_points:
+            commitment_points[key] = []
+            order.append(key)
+        commitment_points[key].append(idx)
+    inverse = {i: p for p, i in point_index.items()}
+    set_index, set_of = {}, {}
+    for key in order:
+        s_ = tuple(sorted(set(commitment_points[key])))
+        set_of[key] = set_index.setdefault(s_, len(set_index))
+    point_sets = [None] * len(set_index)
+    for s_, i in set_index.items():
+        point_sets[i] = [inverse[j] for j in s_]
+    q_polys, q_blinds = [None] * len(point_sets), [0] * len(point_sets)
+    for key in order:  # accumulate(set_idx, poly, blind): q = q * x1 + poly
+        i = set_of[key]
+        q_polys[i] = list(polys[key]) if q_polys[i] is None else [(a * x1 + b) % m for a, b in zip(q_polys[i], polys[key])]
+        q_blinds[i] = (q_blinds[i] * x1 + blinds[key]) % m
+    q_prime = None
+    for pts, q in zip(point_sets, q_polys):
+        cur = q
+        for z in pts:
+            cur = kate_division(f_, cur, z)
+        cur = cur + [0] * (n - len(cur))
+        q_prime = cur if q_prime is None else [(a * x2 + b) % m for a, b in zip(q_prime, cur)]
+    q_prime_blind = rng()
+    transcript.write_point(best_multiexp(curve, q_prime + [q_prime_blind], list(g) + [w]))
+    x3 = transcript.squeeze_challenge_scalar()
+    for q in q_polys:
+        acc = 0
+        for cf in reversed(q):
+            acc = (acc * x3 + cf) % m
+        transcript.write_scalar(acc)
+    x4 = transcript.squeeze_challenge_scalar()
+    p_poly, p_blind = q_prime, q_prime_blind
+    for q, b in zip(q_polys, q_blinds):
+        p_poly = [(a * x4 + c) % m for a, c in zip(p_poly, q)]
+        p_blind = (p_blind * x4 + b) % m
+    s_poly = [rng() for _ in range(n)]
+    return ipa_create_proof(curve, k, g, w, u, rng, transcript, p_poly, p_blind, x3, s_poly, rng())

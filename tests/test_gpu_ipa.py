@@ -200,3 +200,36 @@ def test_ipa_proof_verifies(curve, k):
     assert o.ipa_verify_proof(*args, x3, v, pts[0], xi, z, rounds, ch, c, f)
     assert not o.ipa_verify_proof(*args, x3, (v + 1) % fs.m, pts[0], xi, z, rounds, ch, c, f)
     assert not o.ipa_verify_proof(*args, x3, v, pts[0], xi, z, rounds, ch, c, (f + 1) % fs.m)
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 5)])
+def test_multiopen_create_proof_vs_oracle(curve, k):
+    """poly::multiopen::create_proof on resident polynomials (x1 folds per point set, kate_division, x2 fold, commitment, evaluations,
+    x4 fold, IPA) against the oracle's restatement: identical transcripts"""
+    from tiny_ram_halo2_amd import multiopen
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0x0BE1)
+    g_l = cpu_ref.gen_bases(curve, 23, 9, n, threads=4)
+    w_l = cpu_ref.gen_bases(curve, 818181, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 929292, 1, 1, threads=1)
+    params = poly.Params(curve, k, g_l, g_l, w_l, u=u_l)
+    keys = ["a", "b", "c", "z", "h"]
+    polys = {key: [rnd.randrange(fs.m) for _ in range(n)] for key in keys}
+    blinds = {key: rnd.randrange(fs.m) for key in keys}
+    x = rnd.randrange(fs.m)
+    wgen = fs.omega(k)
+    xw, xwinv = x * wgen % fs.m, x * pow(wgen, -1, fs.m) % fs.m
+    # advice at x; one column also at the next and previous rows; the product column at x and x omega; h at x: three point sets
+    queries = [(x, "a"), (x, "b"), (xw, "b"), (xwinv, "b"), (x, "c"), (x, "z"), (xw, "z"), (x, "h"), (xw, "b")]
+    draws = [rnd.randrange(fs.m) for _ in range(2 + n + 1 + 2 * k)]
+    it1, it2 = iter(draws), iter(draws)
+    t_dev, t_ref = DeviceTranscript(fs.m), OracleTranscript(cv)
+    dev_polys = {key: to_dev(np.array([fs.limbs(v) for v in polys[key]], np.uint64)) for key in keys}
+    got = multiopen.create_proof(params, lambda: next(it1), t_dev, queries, dev_polys, blinds)
+    want = o.multiopen_create_proof(cv, k, [cv.affine_from_limbs(r) for r in g_l], cv.affine_from_limbs(w_l[0]), cv.affine_from_limbs(u_l[0]),
+                                    lambda: next(it2), t_ref, queries, polys, blinds)
+    assert got == want
+    assert len(t_dev.log) == len(t_ref.log) == 1 + 3 + (1 + 2 * k + 2)   # q' commitment, three set evaluations, then the IPA
+    assert t_dev.log == t_ref.log

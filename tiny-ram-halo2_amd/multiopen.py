@@ -55,3 +55,74 @@ class KateDivider:
         api._check(api.lib().trh_poly_kate_division_dev(api.FIELD_ID[self.field], api._devptr(a), self.n, api._devptr(self.pz), api._devptr(self.pzinv),
                                                        api._devptr(self.scratch), api._devptr(q), torch.cuda.current_stream(a.device).cuda_stream))
         return q
+
+
+# ---------------------------------------------------------------------------------------
+# poly::multiopen::create_proof -- the whole opening phase on resident polynomials
+# ---------------------------------------------------------------------------------------
+def construct_intermediate_sets(queries):
+    """poly/multiopen.rs `construct_intermediate_sets` on (point, key) pairs (key identifies the polynomial):
+    polynomials in order of first appearance, point indices in order of first appearance, point-index sets numbered in order
+    of first appearance among the polynomials, the points of a set ordered by point index.
+    Returns (commitments: list of (key, set_index), point_sets: list of lists of points)."""
+    point_index, commitment_points, order = {}, {}, []
+    for point, key in queries:
+        idx = point_index.setdefault(point, len(point_index))
+        if key not in commitment_points:
+            commitment_points[key] = []
+            order.append(key)
+        commitment_points[key].append(idx)
+    inverse = {i: p for p, i in point_index.items()}
+    set_index, commitments = {}, []
+    for key in order:
+        s = tuple(sorted(set(commitment_points[key])))
+        commitments.append((key, set_index.setdefault(s, len(set_index))))
+    point_sets = [None] * len(set_index)
+    for s, i in set_index.items():
+        point_sets[i] = [inverse[j] for j in s]
+    return commitments, point_sets
+
+
+def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict):
+    """queries: list of (point, key) in the prover's order; polys[key]: device tensor (n, 4) of coefficients; blinds[key]: int.
+    Mirrors poly/multiopen/prover.rs: x1 / x2 squeezes, per-set Horner fold in x1, kate_division by every point of the set,
+    x2 fold, commitment of q'(X), x3, the evaluations of the q_i at x3, x4 fold and the IPA opening at x3.  Returns what the
+    IPA returns; everything the Rust prover writes goes to `transcript` in the same order."""
+    import torch
+    from . import ipa
+    curve, n = params.curve, params.n
+    sf = api.SCALAR_FIELD[curve]
+    m = _MODULUS[sf]
+    x1 = transcript.squeeze_challenge_scalar()
+    x2 = transcript.squeeze_challenge_scalar()
+    commitments, point_sets = construct_intermediate_sets(queries)
+    nsets = len(point_sets)
+    members = [[key for key, s in commitments if s == i] for i in range(nsets)]
+    q_polys, q_blinds = [], []
+    for keys in members:  # q = (((p_0 x1 + p_1) x1 + p_2) ...): coefficient of p_j is x1^(len - 1 - j)
+        coeffs = [pow(x1, len(keys) - 1 - j, m) for j in range(len(keys))]
+        stack = torch.stack([polys[k] for k in keys]).contiguous()
+        q_polys.append(lincomb(sf, stack, coeffs))
+        q_blinds.append(sum(c * blinds[k] for c, k in zip(coeffs, keys)) % m)
+    dev = q_polys[0].device
+    divided = []
+    for pts, q in zip(point_sets, q_polys):
+        cur = q
+        for z in pts:
+            cur = KateDivider(sf, cur.shape[0], z, dev).divide(cur)
+        pad = torch.zeros((n, 4), dtype=q.dtype, device=dev)   # poly.resize(params.n, 0)
+        pad[: cur.shape[0]] = cur
+        divided.append(pad)
+    q_prime = lincomb(sf, torch.stack(divided).contiguous(), [pow(x2, nsets - 1 - i, m) for i in range(nsets)])
+    q_prime_blind = rng()
+    transcript.write_point(params.commit(q_prime, _limbs(sf, q_prime_blind)))
+    x3 = transcript.squeeze_challenge_scalar()
+    evals = api.poly_eval_batch_dev(sf, torch.stack(q_polys).contiguous(), n, nsets, _limbs(sf, x3))
+    for e in evals:
+        transcript.write_scalar(e)
+    x4 = transcript.squeeze_challenge_scalar()
+    # p = ((q' x4 + q_0) x4 + q_1) ...: q' gets x4^nsets, q_i gets x4^(nsets - 1 - i)
+    p_poly = lincomb(sf, torch.stack([q_prime] + q_polys).contiguous(), [pow(x4, nsets - i, m) for i in range(nsets + 1)])
+    p_blind = (q_prime_blind * pow(x4, nsets, m) + sum(pow(x4, nsets - 1 - i, m) * b for i, b in enumerate(q_blinds))) % m
+    s_poly = np.stack([_limbs(sf, rng()) for _ in range(n)])
+    return ipa.create_proof_native(params, rng, transcript, p_poly, p_blind, x3, s_poly, rng())
