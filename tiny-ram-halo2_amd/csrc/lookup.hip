@@ -121,45 +121,61 @@ struct Scratch {
 };
 Scratch& scratch() { static Scratch s; return s; }
 
-// sort of the permutation by the 256-bit keys.  Field elements are either small (range tables: only the low limb varies) or
-// spread over the whole field (compressed expressions: two different values practically never share their top limb), so ONE
-// radix sort by the most significant limb that varies is almost always the complete order -- checked, with the four stable
-// least-significant-limb-first passes as the fallback.
-int sort_perm(const u64* planes, size_t n, u32* perm, hipStream_t s) {
+// sort of the permutations of BOTH columns by their 256-bit keys.  Field elements are either small (range tables: only the low
+// limb varies) or spread over the whole field (compressed expressions: two different values practically never share their top
+// limb), so ONE radix sort by the most significant limb that varies is almost always the complete order -- checked, with the
+// stable least-significant-limb-first passes as the fallback.  The two columns go through the phases together so that the
+// host reads the flags of both with one synchronisation per phase.
+int sort_perm_fallback(const u64* planes, size_t n, u32* perm, const u32* varies, size_t tmp_bytes, hipStream_t s) {
     Scratch& sc = scratch();
-    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(n * 4)); TRH_TRY(sc.err.ensure(32));
-    size_t tmp_bytes = 0;
-    TRH_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm, sc.perm_tmp.as<u32>(), n, 0, 64, s));
-    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
     const unsigned gb = (unsigned)((n + 255) / 256);
-    u32* flags = sc.err.as<u32>() + 1;  // [0] is the caller's error word: varies[4], bad
-    TRH_HIP_TRY(hipMemsetAsync(flags, 0, 20, s));
-    hipLaunchKernelGGL(plane_varies_kernel, dim3(gb), dim3(256), 0, s, planes, n, flags);
-    u32 h[5];
-    TRH_HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    int primary = -1;
-    for (int k = 3; k >= 0; --k) if (h[k]) { primary = k; break; }
-    if (primary < 0) return TRH_OK;  // a constant column: any order
-    hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)primary * n, perm, sc.keys_in.as<u64>(), n);
-    TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm, sc.perm_tmp.as<u32>(), n, 0, 64, s));
-    hipLaunchKernelGGL(tie_check_kernel, dim3(gb), dim3(256), 0, s, planes, n, sc.perm_tmp.as<u32>(), primary, flags + 4);
-    TRH_HIP_TRY(hipMemcpyAsync(&h[4], flags + 4, 4, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    if (!h[4]) {
-        TRH_HIP_TRY(hipMemcpyAsync(perm, sc.perm_tmp.p, n * 4, hipMemcpyDeviceToDevice, s));
-        return TRH_OK;
-    }
-    // stable least-significant-limb-first passes over the limbs that vary (perm still holds the identity order)
-    u32* cur = perm;
+    u32* cur = perm;  // still the identity order
     u32* nxt = sc.perm_tmp.as<u32>();
     for (int k = 0; k < 4; ++k) {
-        if (!h[k]) continue;
+        if (!varies[k]) continue;
         hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)k * n, cur, sc.keys_in.as<u64>(), n);
         TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), cur, nxt, n, 0, 64, s));
         u32* t = cur; cur = nxt; nxt = t;
     }
     if (cur != perm) TRH_HIP_TRY(hipMemcpyAsync(perm, cur, n * 4, hipMemcpyDeviceToDevice, s));
+    return TRH_OK;
+}
+
+int sort_perm_pair(const u64* planes_a, u32* perm_a, const u64* planes_s, u32* perm_s, size_t n, hipStream_t s) {
+    Scratch& sc = scratch();
+    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(2 * n * 4)); TRH_TRY(sc.err.ensure(64));
+    size_t tmp_bytes = 0;
+    TRH_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm_a, sc.perm_tmp.as<u32>(), n, 0, 64, s));
+    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    const u64* planes[2] = {planes_a, planes_s};
+    u32* perms[2] = {perm_a, perm_s};
+    u32* flags = sc.err.as<u32>() + 1;  // [0] is the caller's error word; per column: varies[4], bad
+    TRH_HIP_TRY(hipMemsetAsync(flags, 0, 40, s));
+    for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(plane_varies_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, flags + 5 * c);
+    u32 h[10];
+    TRH_HIP_TRY(hipMemcpyAsync(h, flags, 40, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    int primary[2];
+    for (int c = 0; c < 2; ++c) {
+        primary[c] = -1;
+        for (int k = 3; k >= 0; --k) if (h[5 * c + k]) { primary[c] = k; break; }
+        if (primary[c] < 0) continue;  // a constant column: any order
+        u32* out = sc.perm_tmp.as<u32>() + (size_t)c * n;
+        hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes[c] + (size_t)primary[c] * n, perms[c], sc.keys_in.as<u64>(), n);
+        TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perms[c], out, n, 0, 64, s));
+        hipLaunchKernelGGL(tie_check_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, out, primary[c], flags + 5 * c + 4);
+    }
+    u32 bad[2] = {0, 0};
+    TRH_HIP_TRY(hipMemcpyAsync(&bad[0], flags + 4, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipMemcpyAsync(&bad[1], flags + 9, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    for (int c = 0; c < 2; ++c) {
+        if (primary[c] < 0) continue;
+        if (!bad[c]) TRH_HIP_TRY(hipMemcpyAsync(perms[c], sc.perm_tmp.as<u32>() + (size_t)c * n, n * 4, hipMemcpyDeviceToDevice, s));
+    }
+    for (int c = 0; c < 2; ++c)  // after the copies: the fallback reuses perm_tmp
+        if (primary[c] >= 0 && bad[c]) TRH_TRY(sort_perm_fallback(planes[c], n, perms[c], h + 5 * c, tmp_bytes, s));
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -178,12 +194,11 @@ int lookup_permute_t(const void* input, const void* table, size_t n, void* out_i
     Scratch& sc = scratch();
     TRH_TRY(sc.planes_a.ensure(n * 32)); TRH_TRY(sc.planes_s.ensure(n * 32)); TRH_TRY(sc.perm_a.ensure(n * 4)); TRH_TRY(sc.perm_s.ensure(n * 4));
     TRH_TRY(sc.first.ensure(n * 4)); TRH_TRY(sc.removed.ensure(n * 4)); TRH_TRY(sc.flags.ensure(n * 4)); TRH_TRY(sc.pos.ensure(n * 4 + 4));
-    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(32));
+    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(64));
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)input, n, sc.planes_a.as<u64>(), sc.perm_a.as<u32>());
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)table, n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>());
-    TRH_TRY(sort_perm(sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), s));
-    TRH_TRY(sort_perm(sc.planes_s.as<u64>(), n, sc.perm_s.as<u32>(), s));
+    TRH_TRY(sort_perm_pair(sc.planes_a.as<u64>(), sc.perm_a.as<u32>(), sc.planes_s.as<u64>(), sc.perm_s.as<u32>(), n, s));
     hipLaunchKernelGGL(gather_elems_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)input, sc.perm_a.as<u32>(), (uint4*)out_input, n);
     hipLaunchKernelGGL(run_flags_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), sc.first.as<u32>());
     TRH_HIP_TRY(hipMemsetAsync(sc.removed.p, 0, n * 4, s));
