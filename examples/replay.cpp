@@ -194,6 +194,46 @@ int main(int argc, char** argv) {
             }
         }
 
+        {   // permutation argument: the 47 product columns of 4 columns each; here one, over the identity permutation
+            // (sigma_j = delta^j omega^i), for which every factor is 1 and z must stay at z[0] = 1 on every row
+            const Limbs delta = [&] { Limbs d = host::from_u64(field, 5); for (int i = 0; i < 32; ++i) d = host::mul(field, d, d); return d; }();  // 5^(2^32)
+            const Limbs beta = rng.element(), gamma = rng.element();
+            const Expr x = fixed(0);
+            Expr num, den;
+            Limbs dj = host::one(field);
+            for (uint32_t j = 0; j < 4; ++j) {
+                const Expr tn = advice(j) + scaled(x, host::mul(field, beta, dj)) + constant(gamma);
+                const Expr td = advice(j) + scaled(advice(4 + j), beta) + constant(gamma);
+                num = num ? num * tn : tn;
+                den = den ? den * td : td;
+                dj = host::mul(field, dj, delta);
+            }
+            GrandProduct gp(field, k, num, den);
+            DeviceBuffer omegas(n * 32), sig(4 * n * 32), zcol(n * 32);
+            check(trh_field_powers_dev((int)field, omegas.data(), n, dom.get_omega().data(), nullptr), "powers");
+            Limbs dpow = host::one(field);
+            for (uint32_t j = 0; j < 4; ++j) {  // sigma_j = delta^j * omega^i
+                check(trh_memcpy_d2h(host_cols.data(), omegas.data(), n * 32), "d2h");
+                for (size_t i = 0; i < n; ++i) host_cols[i] = host::mul(field, host_cols[i], dpow);
+                sig.upload(host_cols.data(), n * 32, j * n * 32);
+                dpow = host::mul(field, dpow, delta);
+            }
+            std::vector<const void*> pc;
+            for (const auto& c : gp.columns()) {
+                if (c.first == Expression::Fixed) pc.push_back(omegas.data());
+                else pc.push_back(c.second < 4 ? ext.at(c.second * N * 32) /* any n values serve as the witness */ : sig.at((c.second - 4) * n * 32));
+            }
+            Timer tp;
+            gp.compute(pc, zcol.data());
+            const double ms_perm = tp.stop();
+            std::vector<Limbs> zh(n);
+            zcol.download(zh.data(), n * 32);
+            bool ok = true;
+            for (size_t i = 0; i < n; ++i) ok = ok && zh[i] == host::one(field);
+            expect(ok, "permutation product over the identity permutation stays at 1");
+            if (std::getenv("TRH_REPLAY_VERBOSE")) std::fprintf(stderr, "permutation product column: %.3f ms\n", ms_perm);
+        }
+
         // coefficient-basis commits: the random vanishing polynomial and the h pieces
         const size_t ncoef = 1 + N_H_PIECES;
         DeviceBuffer cf(ncoef * n * 32);

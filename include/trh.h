@@ -188,6 +188,8 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
 int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream);
 /* out[i] = prod_{j < i} a[j], out[0] = 1 (exclusive scan; out must not alias a) */
 int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
+/* the same for `rows` independent vectors of n elements stored back to back (all product columns of a proof at once) */
+int trh_field_prefix_product_rows_dev(int field, const void* a_dev, void* out_dev, size_t n, size_t rows, void* stream);
 /* out[i] = sum_{j < i} a[j], out[0] = 0 */
 int trh_field_prefix_sum_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
 

@@ -325,11 +325,21 @@ inline Program compile_gates(Field f, const std::vector<Expr>& gates, const Limb
     return p;
 }
 
+// one output column per expression (numerator / denominator of a grand-product argument)
+inline Program compile_outputs(Field f, const std::vector<Expr>& exprs) {
+    Program p; p.field = f;
+    p.consts.push_back(Limbs{0, 0, 0, 0});  // slot 0 is reserved for a challenge in compile_gates; unused here
+    detail::Lowering lo{p};
+    uint32_t i = 0;
+    for (const Expr& e : exprs) { p.max_degree = std::max(p.max_degree, e->degree()); lo.emit(e); lo.op(TRH_EXPR_STORE_TOP, i++); }
+    return p;
+}
+
 class GateEvaluator {
 public:
-    explicit GateEvaluator(Program p) : program(std::move(p)) {
+    explicit GateEvaluator(Program p, size_t n_outputs = 1) : program(std::move(p)), n_outputs(n_outputs) {
         check(trh_expr_create((int)program.field, program.insns.data(), program.insns.size(), (const uint64_t*)program.consts.data(), program.consts.size(),
-                              program.columns.size(), 1, 0, &e_), "expr_create");
+                              program.columns.size(), n_outputs, 0, &e_), "expr_create");
     }
     GateEvaluator(const GateEvaluator&) = delete;
     GateEvaluator& operator=(const GateEvaluator&) = delete;
@@ -341,7 +351,12 @@ public:
         void* outs[1] = {out_dev};
         check(trh_expr_eval_dev(e_, columns.data(), outs, log_n, rot_step, stream), "expr_eval");
     }
+    void eval_outputs(const std::vector<const void*>& columns, const std::vector<void*>& outs, uint32_t log_n, uint32_t rot_step, void* stream = nullptr) const {
+        require(columns.size() == program.columns.size() && outs.size() == n_outputs, "one device pointer per program column / output");
+        check(trh_expr_eval_dev(e_, columns.data(), outs.data(), log_n, rot_step, stream), "expr_eval");
+    }
     Program program;
+    size_t n_outputs;
 private:
     trh_expr_t e_ = nullptr;
 };
@@ -373,6 +388,43 @@ inline void lincomb(Field f, const void* polys_dev, size_t n, const std::vector<
 inline void lookup_permute(Field f, const void* input_dev, const void* table_dev, size_t usable_rows, void* permuted_input_dev, void* permuted_table_dev, void* stream = nullptr) {
     check(trh_lookup_permute_dev((int)f, input_dev, table_dev, usable_rows, permuted_input_dev, permuted_table_dev, stream), "permute_expression_pair");
 }
+
+// z[0] = z0, z[i + 1] = z[i] * num(row i) / den(row i): the product columns of the permutation argument
+// (plonk/permutation/prover.rs) and of the lookup argument (plonk/lookup/prover.rs commit_product)
+class GrandProduct {
+public:
+    GrandProduct(Field f, uint32_t k, const Expr& num, const Expr& den) : field(f), k(k), n((size_t)1 << k), ev_(compile_outputs(f, {num, den}), 2), num_(n * 32), den_(n * 32), ratio_(n * 32) {}
+    const std::vector<std::pair<Expression::Kind, uint32_t>>& columns() const { return ev_.program.columns; }
+    // columns[i]: device pointer of columns()[i]; z_dev: 2^k elements
+    void compute(const std::vector<const void*>& cols, void* z_dev, uint32_t rot_step = 1, void* stream = nullptr) {
+        ev_.eval_outputs(cols, {num_.data(), den_.data()}, k, rot_step, stream);
+        check(trh_field_batch_invert_dev((int)field, den_.data(), n, stream), "batch_invert");
+        check(trh_field_op_dev((int)field, 2 /* mul */, num_.data(), den_.data(), ratio_.data(), n, stream), "ratio");
+        check(trh_field_prefix_product_dev((int)field, ratio_.data(), z_dev, n, stream), "prefix_product");
+    }
+    Field field;
+    uint32_t k;
+    size_t n;
+private:
+    GateEvaluator ev_;
+    DeviceBuffer num_, den_, ratio_;
+};
+
+// arithmetic::kate_division by (X - z) for polynomials of n coefficients (z != 0; the powers of z and 1/z are built once)
+class KateDivider {
+public:
+    KateDivider(Field f, size_t n, const Limbs& z, const Limbs& z_inv) : field(f), n(n), pz_(n * 32), pzinv_(n * 32), scratch_(2 * n * 32) {
+        check(trh_field_powers_dev((int)f, pz_.data(), n, z.data(), nullptr), "powers");
+        check(trh_field_powers_dev((int)f, pzinv_.data(), n, z_inv.data(), nullptr), "powers");
+    }
+    void divide(const void* a_dev, void* q_dev /* n - 1 coefficients */, void* stream = nullptr) {
+        check(trh_poly_kate_division_dev((int)field, a_dev, n, pz_.data(), pzinv_.data(), scratch_.data(), q_dev, stream), "kate_division");
+    }
+    Field field;
+    size_t n;
+private:
+    DeviceBuffer pz_, pzinv_, scratch_;
+};
 
 inline void init(int device = 0) { check(trh_init(device), "trh_init"); }
 

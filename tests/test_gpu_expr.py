@@ -364,3 +364,23 @@ def test_permutation_argument_closes_on_a_real_permutation():
         num = num * (v_cols[j][n - 1] + beta * label(j, n - 1) + gamma) % f.m
         den = den * (v_cols[j][n - 1] + beta * s_cols[j][n - 1] + gamma) % f.m
     assert z[n - 1] * num % f.m != den
+
+
+def test_grand_products_batch_equals_single_columns():
+    """the batched path (one inversion over every denominator, batched prefix product) gives the same z columns"""
+    from tiny_ram_halo2_amd import permutation
+    field, k, ncol, chunks = "fp", 9, 4, 5
+    f = o.FIELDS[field]
+    n = 1 << k
+    rng = random.Random(0xBA7C)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    beta, gamma = rng.randrange(f.m), rng.randrange(f.m)
+    pcs, vals, sigs = [], [], []
+    for c in range(chunks):
+        pcs.append(permutation.ProductColumn(field, k, ncol, first_column=c * ncol))
+        vals.append([dev([rng.randrange(f.m) for _ in range(n)]) for _ in range(ncol)])
+        sigs.append([dev([rng.randrange(f.m) for _ in range(n)]) for _ in range(ncol)])
+    singles = [from_dev(f, pcs[c].compute(vals[c], sigs[c], beta, gamma)) for c in range(chunks)]
+    z = permutation.grand_products_batch(field, k, [pc.evaluator(beta, gamma) for pc in pcs], [pcs[c].columns(vals[c], sigs[c]) for c in range(chunks)])
+    for c in range(chunks):
+        assert from_dev(f, z[c]) == singles[c], c

@@ -41,6 +41,22 @@ def test_replay_k10_matches_oracle():
             want_a, want_s = o.permute_expression_pair(a, t, len(a))
             assert [f.from_limbs(r) for r in out[0]] == want_a and [f.from_limbs(r) for r in out[1]] == want_s
             return
+        if kind == "product_column":  # plonk/permutation/prover.rs: the second chunk's z column against big ints
+            f = o.FIELDS[inp["field"]]
+            n = 1 << inp["k"]
+            vals = [[f.from_limbs(r) for r in c] for c in inp["values"]]
+            sigs = [[f.from_limbs(r) for r in c] for c in inp["sigmas"]]
+            delta, w, beta, gamma = pow(5, 1 << 32, f.m), f.omega(inp["k"]), inp["beta"], inp["gamma"]
+            acc, want = 1, []
+            for i in range(n):
+                want.append(acc)
+                num = den = 1
+                for j in range(4):
+                    num = num * (vals[j][i] + beta * pow(delta, inp["first_column"] + j, f.m) * pow(w, i, f.m) + gamma) % f.m
+                    den = den * (vals[j][i] + beta * sigs[j][i] + gamma) % f.m
+                acc = acc * num * pow(den, -1, f.m) % f.m
+            assert [f.from_limbs(r) for r in out] == want
+            return
         if kind == "evals":  # arithmetic::eval_polynomial: Horner at the challenge
             f = o.FIELDS[inp["field"]]
             x, acc = f.from_limbs(inp["x"]), 0
@@ -75,4 +91,4 @@ def test_replay_k10_matches_oracle():
     res = replay.run(16, batch=32, hook=hook, verbose=False)
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"lookup_permute": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "trh_expr_lds_slots": ([_vp], ctypes.c_uint32),
     "trh_expr_set_const": ([_vp, ctypes.c_uint32, _u64p], ctypes.c_int),
     "trh_expr_eval_dev": ([_vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, _vp], ctypes.c_int),
+    "trh_field_prefix_product_rows_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_prefix_sum_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_poly_lincomb_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp, _vp], ctypes.c_int),
     "trh_poly_kate_division_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp], ctypes.c_int),

@@ -86,6 +86,7 @@ __device__ __forceinline__ Fe<F> block_exclusive_scan(Fe<F>* sh, const Fe<F>& mi
 template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_block_totals_kernel(const uint4* __restrict__ a, size_t n, uint4* __restrict__ totals) {
     __shared__ Fe<F> sh[256];
+    a += (size_t)blockIdx.y * n * 2; totals += (size_t)blockIdx.y * gridDim.x * 2;  // independent rows of n elements
     const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     Fe<F> p = OP::id();
     for (int k = 0; k < SCAN_PER_THREAD; ++k)
@@ -98,6 +99,7 @@ __global__ void __launch_bounds__(256) scan_block_totals_kernel(const uint4* __r
 template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_totals_kernel(uint4* __restrict__ totals, u32 count) {
     __shared__ Fe<F> sh[256];
+    totals += (size_t)blockIdx.x * count * 2;  // one workgroup per row
     const u32 per = (count + 255u) / 256u;
     const u32 lo = threadIdx.x * per;
     Fe<F> p = OP::id();
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(256) scan_totals_kernel(uint4* __restrict__ to
 template <class F, class OP>
 __global__ void __launch_bounds__(256) scan_apply_kernel(const uint4* __restrict__ a, uint4* __restrict__ out, size_t n, const uint4* __restrict__ totals) {
     __shared__ Fe<F> sh[256];
+    a += (size_t)blockIdx.y * n * 2; out += (size_t)blockIdx.y * n * 2; totals += (size_t)blockIdx.y * gridDim.x * 2;
     const size_t lo = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     Fe<F> vals[SCAN_PER_THREAD];
     Fe<F> p = OP::id();
@@ -134,13 +137,18 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint4* __restrict
 }
 
 template <class F, class OP>
-int prefix_scan_t(const void* a, void* out, size_t n, hipStream_t s) {
+int prefix_scan_t(const void* a, void* out, size_t n, hipStream_t s, size_t rows = 1) {
     Ctx& c = ctx();
     const unsigned blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    TRH_TRY(c.scan.ensure((size_t)blocks * 32 + 32));
-    hipLaunchKernelGGL((scan_block_totals_kernel<F, OP>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, n, c.scan.as<uint4>());
-    hipLaunchKernelGGL((scan_totals_kernel<F, OP>), dim3(1), dim3(256), 0, s, c.scan.as<uint4>(), blocks);
-    hipLaunchKernelGGL((scan_apply_kernel<F, OP>), dim3(blocks), dim3(256), 0, s, (const uint4*)a, (uint4*)out, n, c.scan.as<uint4>());
+    for (size_t r0 = 0; r0 < rows; r0 += 32768) {  // grid.y limit
+        const unsigned nr = (unsigned)(rows - r0 < 32768 ? rows - r0 : 32768);
+        TRH_TRY(c.scan.ensure((size_t)nr * blocks * 32 + 32));
+        const uint4* ar = (const uint4*)a + r0 * n * 2;
+        uint4* outr = (uint4*)out + r0 * n * 2;
+        hipLaunchKernelGGL((scan_block_totals_kernel<F, OP>), dim3(blocks, nr), dim3(256), 0, s, ar, n, c.scan.as<uint4>());
+        hipLaunchKernelGGL((scan_totals_kernel<F, OP>), dim3(nr), dim3(256), 0, s, c.scan.as<uint4>(), blocks);
+        hipLaunchKernelGGL((scan_apply_kernel<F, OP>), dim3(blocks, nr), dim3(256), 0, s, ar, outr, n, c.scan.as<uint4>());
+    }
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -253,6 +261,18 @@ int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const voi
     }
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
+}
+
+int trh_field_prefix_product_rows_dev(int field, const void* a_dev, void* out_dev, size_t n, size_t rows, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && rows && (!a_dev || !out_dev)) { set_error("prefix_product_rows: null pointer"); return TRH_EINVAL; }
+    if (a_dev == out_dev) { set_error("prefix_product_rows: in-place operation is not supported"); return TRH_EINVAL; }
+    if (!n || !rows) return TRH_OK;
+    Ctx& c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (field == TRH_FP) return prefix_scan_t<FpParams, OpMul<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream, rows);
+    return prefix_scan_t<FqParams, OpMul<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream, rows);
 }
 
 int trh_field_prefix_sum_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream) {

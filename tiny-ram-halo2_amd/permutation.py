@@ -53,6 +53,26 @@ class GrandProduct:
         return z
 
 
+def grand_products_batch(field: str, k: int, evaluators, column_sets, rot_step: int = 1):
+    """All product columns of a proof at once: evaluators[i] (a two-output GateEvaluator: numerator, denominator) over
+    column_sets[i]; ONE batch inversion over every denominator (a 255-step exponentiation per 64 elements is latency-bound
+    for a single column and free across 78), one multiply, one batched prefix product.  Returns z as (len, n, 4)."""
+    import torch
+    n, rows = 1 << k, len(evaluators)
+    first = next(iter(column_sets[0].values()))
+    st = torch.cuda.current_stream(first.device).cuda_stream
+    num = torch.empty((rows, n, 4), dtype=first.dtype, device=first.device)
+    den = torch.empty_like(num)
+    for i, (ev, cols) in enumerate(zip(evaluators, column_sets)):
+        nd = ev.eval(cols, k, rot_step, stream=st)
+        num[i].copy_(nd[0]); den[i].copy_(nd[1])
+    api.batch_invert_dev(field, den, rows * n, stream=st)
+    api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["mul"], api._devptr(num), api._devptr(den), api._devptr(den), rows * n, st))
+    z = torch.empty_like(num)
+    api._check(api.lib().trh_field_prefix_product_rows_dev(api.FIELD_ID[field], api._devptr(den), api._devptr(z), n, rows, st))
+    return z
+
+
 def lookup_product(field: str, k: int, beta: int, gamma: int) -> GrandProduct:
     """columns: ("advice", 0) = compressed input A, 1 = compressed table S, 2 = permuted input A', 3 = permuted table S'"""
     a, s_, ap, sp = (expr.Advice(i, 0) for i in range(4))
@@ -84,18 +104,29 @@ class ProductColumn:
             self._key = (beta, gamma)
         return self._ev
 
-    def compute(self, values, sigmas, beta: int, gamma: int, z0: int = 1):
-        """values, sigmas: lists of n_columns device tensors (n, 4); returns z as a device tensor (n, 4)"""
+    def columns(self, values, sigmas, omega_powers=None):
+        """the column dictionary of this chunk's expression program; omega_powers: the shared column of omega^i"""
         import torch
         assert len(values) == self.n_columns and len(sigmas) == self.n_columns
         dev = values[0].device
-        st = torch.cuda.current_stream(dev).cuda_stream
-        xs = torch.empty((self.n, 4), dtype=torch.int64, device=dev)
-        api.powers_dev(self.field, xs, self.n, expr._limbs(self.field, omega(self.field, self.k)), stream=st)
-        cols = {("fixed", 0): xs}
+        if omega_powers is None:
+            omega_powers = torch.empty((self.n, 4), dtype=torch.int64, device=dev)
+            api.powers_dev(self.field, omega_powers, self.n, expr._limbs(self.field, omega(self.field, self.k)), stream=torch.cuda.current_stream(dev).cuda_stream)
+        cols = {("fixed", 0): omega_powers}
         for j in range(self.n_columns):
             cols[("advice", j)] = values[j]
             cols[("advice", self.n_columns + j)] = sigmas[j]
+        return cols
+
+    def evaluator(self, beta: int, gamma: int):
+        return self._evaluator(beta, gamma)
+
+    def compute(self, values, sigmas, beta: int, gamma: int, z0: int = 1):
+        """values, sigmas: lists of n_columns device tensors (n, 4); returns z as a device tensor (n, 4)"""
+        import torch
+        dev = values[0].device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        cols = self.columns(values, sigmas)
         nd = self._evaluator(beta, gamma).eval(cols, self.k, 1, stream=st)
         num, den = nd[0], nd[1]
         api.batch_invert_dev(self.field, den, self.n, stream=st)

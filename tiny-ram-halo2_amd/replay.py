@@ -5,7 +5,7 @@ site is /root/reference/src/test_utils.rs:41-49 with k = 2 + WORD_BITS / 2 from 
 The Rust prover cannot run here (no toolchain), so this driver issues the same primitive kinds, sizes
 and counts against libtrh with synthetic column data: per column a `commit_lagrange` (MSM of n + 1
 pairs over the resident Lagrange bases), `lagrange_to_coeff` (iNTT n) and `coeff_to_extended` (coset NTT
-8n); the permuted input / table columns of the 31 lookups; the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
+8n); the permuted input / table columns of the 31 lookups and the 47 + 31 grand-product columns; the lookup / permutation / vanishing commitments; the extended iNTT of h(X); five h-piece commits;
 and one IPA opening (k rounds).  Column / lookup / permutation counts are derived from the reference's
 `configure` code (Appendix B): 94 instance + 263 advice columns, 31 lookups, 47 permutation products,
 quotient degree 5 => extended_k = k + 3.  The h(X) numerator runs on the device as well (`expr.GateEvaluator`
@@ -96,7 +96,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         e.record()
         return e
 
-    times = {"lookup_permute": 0.0, "commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
+    times = {"lookup_permute": 0.0, "product_columns": 0.0, "commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
              "extended_to_coeff": 0.0, "ipa": 0.0}
     counts = {kk: 0 for kk in times}
     checked = 0
@@ -121,6 +121,30 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
                  (pa.cpu().numpy().view(np.uint64), ps.cpu().numpy().view(np.uint64)))
             checked += 1
     del distinct
+
+    # --- grand products: the 47 permutation product columns (4 columns each) and the 31 lookup products, all at once ---
+    m_ = poly._MODULUS[field]
+    beta, gamma = 0xBE7A % m_, 0x6A33A % m_
+    wit = [torch.from_numpy(synth.field_elements(0x9E0 + j, n).view(np.int64)).to(dev) for j in range(8)]
+    om = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    api.powers_dev(field, om, n, expr._limbs(field, permutation.omega(field, k)))
+    pcs = [permutation.ProductColumn(field, k, 4, first_column=4 * c) for c in range(N_PERM_PRODUCTS)]
+    evs = [pc.evaluator(beta, gamma) for pc in pcs]
+    sets = [pc.columns(wit[:4], wit[4:], om) for pc in pcs]
+    lk = permutation.lookup_product(field, k, beta, gamma)
+    evs += [lk.ev] * N_LOOKUPS
+    sets += [{("advice", i): wit[(i + li) % 8] for i in range(4)} for li in range(N_LOOKUPS)]
+    e0 = ev()
+    zs = permutation.grand_products_batch(field, k, evs, sets)
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["product_columns"] += e0.elapsed_time(e1)
+    counts["product_columns"] += len(evs)
+    if hook is not None:
+        hook("product_column", dict(values=[w.cpu().numpy().view(np.uint64) for w in wit[:4]], sigmas=[w.cpu().numpy().view(np.uint64) for w in wit[4:]],
+                                    beta=beta, gamma=gamma, first_column=4, field=field, k=k), zs[1].cpu().numpy().view(np.uint64))
+        checked += 1
+    del zs, evs, sets, pcs, wit, om
 
     x_eval = synth.field_elements(0xE7A, 1)[0]
     ext_buf = torch.empty((min(batch, sch["intt_n"]), 1 << ek, 4), dtype=torch.int64, device=dev)  # the batch's extended cosets, reused
