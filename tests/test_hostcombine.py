@@ -14,3 +14,14 @@ def test_hostcombine_matches_generic_implementation():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", src, "-o", exe])
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "hostcombine: ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_trh_hpp_host_side():
+    """include/trh.hpp without a device: its host field arithmetic against hostcombine.h, and the Expression lowering against
+    an interpreter of the stack program (random trees, every node type, shared sub-expressions)"""
+    src = os.path.join(ROOT, "tests", "native", "trh_hpp_host_test.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "trh_hpp_host_test")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "trh.hpp host side: ok" in r.stdout, r.stdout + r.stderr
