@@ -162,3 +162,18 @@ def test_ipa_prover_restatement_satisfies_the_verifier_equation():
     rounds = [(t.pts[1 + 2 * j], t.pts[2 + 2 * j]) for j in range(k)]
     assert o.ipa_verify_proof(cv, k, g, w, u, P, x3, v, t.pts[0], t.ch[0], t.ch[1], rounds, t.ch[2:], c, f)
     assert not o.ipa_verify_proof(cv, k, g, w, u, P, x3, (v + 1) % fs.m, t.pts[0], t.ch[0], t.ch[1], rounds, t.ch[2:], c, f)
+
+
+def test_permutation_delta_is_the_published_constant():
+    """pasta_curves 0.4.1 `DELTA` (fields/fp.rs, fields/fq.rs; crate pinned at /root/reference/Cargo.lock:847-858) = GENERATOR^(2^S)
+    with GENERATOR = 5, S = 32: the constant the permutation argument's column labels delta^j omega^i are built from"""
+    from tiny_ram_halo2_amd import permutation
+    published = {
+        "fp": [0x6A6CCD20DD7B9BA2, 0xF5E4F3F13EEE5636, 0xBD455B7112A5049D, 0x0A757D0F0006AB6C],
+        "fq": [0x8494392472D1683C, 0xE3AC3376541D1140, 0x06F0A88E7F7949F8, 0x2237D54423724166],
+    }
+    for field, limbs in published.items():
+        v = sum(w << (64 * i) for i, w in enumerate(limbs))
+        assert permutation.delta(field) == v
+        f = o.FIELDS[field]
+        assert pow(v, (f.m - 1) >> 32, f.m) == 1 and pow(v, (f.m - 1) >> 33, f.m) != 1 or ((f.m - 1) >> 32) % 2 == 1
