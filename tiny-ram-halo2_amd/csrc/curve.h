@@ -237,7 +237,7 @@ template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
         return;
     }
     const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(acc.x, PP);
-    const Fz<F> x3 = fz_sub<F, 4>(fz_sqr(R), fz_add(PPP, fz_add(Q, Q)));             // < 5.01m
+    const Fz<F> x3 = fz_sub<F, 4>(fz_sqr(R), fz_add_dbl(PPP, Q));             // < 5.01m
     acc.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, x3)), fz_mul(acc.y, PPP));         // < 3.01m
     acc.x = x3;
     acc.zz = fz_mul(acc.zz, PP);
@@ -254,7 +254,7 @@ template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& 
     if (fz_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
     const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(U1, PP);
     XYZZz<F> r;
-    r.x = fz_sub<F, 4>(fz_sqr(R), fz_add(PPP, fz_add(Q, Q)));
+    r.x = fz_sub<F, 4>(fz_sqr(R), fz_add_dbl(PPP, Q));
     r.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, r.x)), fz_mul(S1, PPP));
     r.zz = fz_mul(fz_mul(a.zz, b.zz), PP);
     r.zzz = fz_mul(fz_mul(a.zzz, b.zzz), PPP);

@@ -415,6 +415,18 @@ template <class F> TRH_HD Fz<F> fz_add(const Fz<F>& a, const Fz<F>& b) {
     }
     return r;
 }
+// a + 2 b in one carry chain, no reduction (bound(a) + 2 bound(b) must stay < 16 m)
+template <class F> TRH_HD Fz<F> fz_add_dbl(const Fz<F>& a, const Fz<F>& b) {
+    Fz<F> r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) {
+        const u32 v = a.l[i] + (b.l[i] << 1) + c;  // < 2^30 + 2^31 + 3
+        r.l[i] = v & LIMB_MASK;
+        c = v >> 30;
+    }
+    return r;
+}
 // a + KM * m - b  (KM * m must be >= bound(b)); result < bound(a) + KM m
 template <class F, u32 KM> TRH_HD Fz<F> fz_sub(const Fz<F>& a, const Fz<F>& b) {
     Fz<F> r;
