@@ -459,27 +459,40 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     XYZZzMem* my_first = first + (size_t)j * nseg + t;
     XYZZz<BF> acc = xyzzz_identity<BF>();
     bool is_first = true;
-    u32 e = lst[pos];
-    const uint4* bp = bases_z + (size_t)(e & ~SIGN_BIT) * 4;
-    uint4 na = bp[0], nb = bp[1], nc = bp[2], nd = bp[3];
-    for (; pos < stop; ++pos) {
+    // two bases in flight: the gather for entry pos + 2 is issued while entry pos is added (its index was read one step earlier),
+    // so neither the index read nor the 64-byte gather sits on the dependency chain of an iteration
+    struct Slot { u32 e; uint4 a, b, c, d; };
+    auto issue = [&](Slot& sl, u32 entry) {
+        sl.e = entry;
+        const uint4* bp = bases_z + (size_t)(entry & ~SIGN_BIT) * 4;
+        sl.a = bp[0]; sl.b = bp[1]; sl.c = bp[2]; sl.d = bp[3];
+    };
+    Slot s0, s1;
+    issue(s0, lst[pos]);
+    if (pos + 1 < stop) issue(s1, lst[pos + 1]);
+    u32 e_ahead = pos + 2 < stop ? lst[pos + 2] : 0u;  // index of the entry two steps ahead
+    auto step = [&](Slot& sl) {
         if (pos == cur_end) {  // bucket finished: publish its run and start the next bucket
             store_raw(is_first ? my_first : direct + (size_t)j * nb1 + B, acc);
             is_first = false;
             acc = xyzzz_identity<BF>();
             do { ++B; cur_end = en[B]; } while (cur_end <= pos);
         }
-        const u32 ce = e;
+        const u32 ce = sl.e;
         AffineZ<BF> cur;
-        cur.x = fz_load<BF>(na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w);
-        cur.y = fz_load<BF>(nc.x, nc.y, nc.z, nc.w, nd.x, nd.y, nd.z, nd.w);
-        if (pos + 1 < stop) {  // prefetch the next base while this add runs
-            e = lst[pos + 1];
-            bp = bases_z + (size_t)(e & ~SIGN_BIT) * 4;
-            na = bp[0]; nb = bp[1]; nc = bp[2]; nd = bp[3];
+        cur.x = fz_load<BF>(sl.a.x, sl.a.y, sl.a.z, sl.a.w, sl.b.x, sl.b.y, sl.b.z, sl.b.w);
+        cur.y = fz_load<BF>(sl.c.x, sl.c.y, sl.c.z, sl.c.w, sl.d.x, sl.d.y, sl.d.z, sl.d.w);
+        if (pos + 2 < stop) {
+            issue(sl, e_ahead);
+            if (pos + 3 < stop) e_ahead = lst[pos + 3];
         }
         if ((ce & SIGN_BIT) && !(fz_is_exact_zero(cur.x) && fz_is_exact_zero(cur.y))) cur.y = fz_sub<BF, 2>(fz_zero<BF>(), cur.y);
         xyzzz_madd(acc, cur);
+        ++pos;
+    };
+    while (pos < stop) {
+        step(s0);
+        if (pos < stop) step(s1);
     }
     if (is_first) store_raw(my_first, acc);
     else if (cur_end == stop) store_raw(direct + (size_t)j * nb1 + B, acc);
