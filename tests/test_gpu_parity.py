@@ -174,9 +174,9 @@ def test_msm_all_same_base_skewed():
     assert o.CURVES[curve].affine_from_limbs(got[:8]) == want
 
 
-@pytest.mark.parametrize("log_n", [16, 20])
+@pytest.mark.parametrize("log_n", [16, 20, 24])
 def test_msm_closed_form(log_n):
-    """BASELINE config 2 (2^20 Pallas MSM): bases P_i = (s0 + i d) G so the expected result is
+    """BASELINE config 2 (2^20 Pallas MSM) and the headline size 2^24: bases P_i = (s0 + i d) G so the expected result is
     (sum_i s_i (s0 + i d) mod q) G -- a size-independent check; at 2^16 also vs the CPU restatement."""
     curve = "pallas"
     n = 1 << log_n
@@ -192,6 +192,28 @@ def test_msm_closed_form(log_n):
     if log_n <= 16:
         want2 = aff(curve, cpu_ref.best_multiexp(curve, sc, bases.download(), threads=8))
         assert (got[:8] == want2).all()
+
+
+def test_msm_tiled_beyond_2_25():
+    """above 2^25 pairs an MSM runs as range tiles whose points are added on the host (msm.hip MSM_TILE): closed form over a
+    repeated 2^20 scalar block, ragged last tile, canonical scalars"""
+    curve, BL, reps, extra = "vesta", 20, 32, 3
+    q = o.CURVES[curve].scalar.m
+    n = (reps << BL) + extra
+    block = synth.field_elements(0x711ED, 1 << BL)  # < 2^254: canonical scalars
+    T0 = synth.weighted_scalar_sum(block, 1, 0)
+    T1 = synth.weighted_scalar_sum(block, 0, 1)
+    total = reps * (synth.BASE_S0 * T0 + synth.BASE_D * T1) + synth.BASE_D * (1 << BL) * T0 * (reps * (reps - 1) // 2)
+    total = (total + synth.weighted_scalar_sum(block[:extra], synth.BASE_S0, synth.BASE_D, start=reps << BL)) % q
+    g = np.array(o.CURVES[curve].affine_limbs(o.CURVES[curve].generator), np.uint64)
+    want = aff(curve, cpu_ref.scalar_mul(curve, g, np.array(o.int_to_limbs(total), np.uint64)))
+    import torch
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+    d = torch.from_numpy(block.view(np.int64)).cuda().repeat(reps + 1, 1)[:n].contiguous()
+    got = bases.msm_dev(d, n, montgomery=False)
+    assert (got[:8] == want).all()
+    del d, bases
+    torch.cuda.empty_cache()
 
 
 def test_msm_batch_dev():

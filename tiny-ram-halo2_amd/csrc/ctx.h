@@ -87,6 +87,9 @@ struct MsmScratch {
     // state of the enqueued-but-not-finished MSM
     int pending_curve = -1, pending_windows = 0, pending_c = 0;
     size_t pending_batch = 0;
+    // an MSM beyond MSM_TILE pairs runs as range tiles: the sum of the finished tiles (normalised Jacobian), added by msm_finish
+    bool tile_sum_valid = false, in_tile = false;
+    u64 tile_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };

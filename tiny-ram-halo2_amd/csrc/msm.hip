@@ -678,6 +678,14 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
     }
 }
 
+template <class BF> int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch);
+template <class BF> int point_sum_host_t(const u64* pts, size_t count, u64* out);
+
+// Above 2^25 pairs the entry index squeezes the second sort level (31 bits = index + low bucket bits) and the rate drops
+// (2^25: 815 M pairs/s, 2^26: 740, 2^27: 490, 2^28: 410): larger MSMs run as equal range tiles of at most 2^25 pairs, each
+// at the full rate; the tiles' points are added on the host (the same sum the range-sharded multi-GPU path forms).
+constexpr size_t MSM_TILE = (size_t)1 << 25;
+
 template <class SF, class BF>
 int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalars_dev, size_t n, size_t batch, size_t stride, int mont, hipStream_t s, const MsmFixedBase* fb,
                   const void* tails_dev) {
@@ -685,7 +693,37 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     MsmScratch& m = c.msm;
     MsmLane& L = m.lane;
     if (fb && (n == 0 || !msm_fixed_base_fits(n, fb->c))) fb = nullptr;
-    const int cb = fb ? fb->c : choose_window_bits(n);
+    if (!m.in_tile) m.tile_sum_valid = false;
+    if (!fb && batch == 1 && n > MSM_TILE && !m.in_tile && c.window_override == 0) {
+        const size_t tiles = (n + MSM_TILE - 1) / MSM_TILE, len = (n + tiles - 1) / tiles;
+        u64 acc[24];
+        memset(acc, 0, sizeof(acc));
+        m.in_tile = true;
+        int rc = TRH_OK;
+        for (size_t off = 0; off < n && rc == TRH_OK; off += len) {
+            const size_t cur = off + len < n ? len : n - off;
+            const bool last = off + cur == n;
+            rc = msm_enqueue_t<SF, BF>((const char*)bases_dev + off * 64, bases_z ? (const char*)bases_z + off * 64 : nullptr, (const char*)scalars_dev + off * 32, cur, 1, cur,
+                                       mont, s, nullptr, last ? tails_dev : nullptr);
+            if (rc != TRH_OK || last) break;
+            rc = msm_finish_t<BF>(s, acc + 12, 1);  // blocks: the next tile reuses the sort scratch anyway
+            if (rc == TRH_OK) rc = point_sum_host_t<BF>(acc, 2, acc);
+        }
+        m.in_tile = false;
+        if (rc != TRH_OK) return rc;
+        memcpy(m.tile_sum, acc, 96);
+        m.tile_sum_valid = true;
+        return TRH_OK;
+    }
+    int cb = fb ? fb->c : choose_window_bits(n);
+    if (!fb) {
+        // beyond 2^27 pairs the index leaves fewer than 4 entry bits for the second sort level; the first level has at most
+        // 2^11 bins (LDS of the partition), so the window narrows with n (15 bits up to 2^28 pairs ... 12 up to 2^31)
+        int ib = 1;
+        while (((size_t)1 << ib) < n) ++ib;
+        const int k2max = 31 - ib < 7 ? 31 - ib : 7;
+        if (cb - 1 - k2max > 11) cb = 12 + k2max;
+    }
     const int W = fb ? fb->W : num_windows(cb);  // windows of the recoding
     // fixed-base mode: the W x n digits are one flat list over the W x n table entries -> ONE bucket set
     const int Ws = fb ? 1 : W;
@@ -844,6 +882,13 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     c.last.window_bits = m.pending_c;
     c.last.windows = m.pending_windows;
     m.pending_curve = -1;
+    if (m.tile_sum_valid && !m.in_tile) {  // last tile of a tiled MSM: add the earlier tiles
+        u64 two[24];
+        memcpy(two, m.tile_sum, 96);
+        memcpy(two + 12, out_xyz, 96);
+        m.tile_sum_valid = false;
+        return point_sum_host_t<BF>(two, 2, out_xyz);
+    }
     return TRH_OK;
 }
 
