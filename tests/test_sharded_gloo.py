@@ -66,3 +66,34 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _col_worker(rank, world, port, ncol, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tiny_ram_halo2_amd import sharded
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    calls = []
+
+    def local(lo, hi):   # stands for commit_lagrange_batch over columns [lo, hi): a recognisable 12-word result per column
+        calls.append((lo, hi))
+        return np.array([[c * 1000 + w for w in range(12)] for c in range(lo, hi)], dtype=np.uint64).reshape(hi - lo, 12)
+
+    res = sharded.sharded_columns(ncol, local)
+    assert calls == [sharded.shard_range(ncol, rank, world)]
+    np.save(os.path.join(out_dir, f"cols{rank}.npy"), res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncol", [1, 5, 64])
+def test_sharded_columns_world2(tmp_path, ncol):
+    """column-sharded commitments: every rank ends with all results in column order, ragged split included"""
+    world = 2
+    port = 31500 + (os.getpid() % 2000) + ncol % 11
+    mp.spawn(_col_worker, args=(world, port, ncol, str(tmp_path)), nprocs=world, join=True)
+    want = np.array([[c * 1000 + w for w in range(12)] for c in range(ncol)], dtype=np.uint64)
+    for r in range(world):
+        assert (np.load(tmp_path / f"cols{r}.npy") == want).all()
