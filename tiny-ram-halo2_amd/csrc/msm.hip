@@ -162,8 +162,17 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
     const u32* dg = digits + (size_t)j * n;
     for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
-    for (size_t i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
-        const u32 b = dg[i] & ~SIGN_BIT;
+    // the thread's PART_TILE / PART_THREADS digits stay in registers between the histogram and the scatter (one HBM read)
+    constexpr int PER = PART_TILE / PART_THREADS;
+    u32 mine[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const size_t i = t0 + threadIdx.x + (size_t)q * PART_THREADS;
+        mine[q] = i < t1 ? dg[i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 b = mine[q] & ~SIGN_BIT;
         if (b) atomicAdd(&cnt[(b - 1u) >> k2], 1u);
     }
     __syncthreads();
@@ -192,13 +201,14 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
     for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
     const u32 low_mask = (1u << k2) - 1u;
-    for (size_t i = t0 + threadIdx.x; i < t1; i += blockDim.x) {
-        const u32 e = dg[i];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 e = mine[q];
         const u32 b = e & ~SIGN_BIT;
         if (b) {
             const u32 bm = b - 1u, bin = bm >> k2;
             const u32 r = atomicAdd(&cnt[bin], 1u);
-            stage[lbase[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
+            stage[lbase[bin] + r] = (u32)(t0 + threadIdx.x + (size_t)q * PART_THREADS) | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
         }
     }
     __syncthreads();
@@ -297,34 +307,56 @@ __global__ void __launch_bounds__(BS_THREADS) msm_bucket_pass_kernel(const u32* 
     }
 }
 
-// per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts), seg_bucket
-__global__ void __launch_bounds__(1024) msm_bucket_ranges_kernel(u32* __restrict__ bucket_cnt, u32* __restrict__ starts, u32* __restrict__ ends,
-                                                                 u32* __restrict__ seg_bucket, u32 nbk, u32 nseg, u32 seg_len) {
-    __shared__ u32 part[1024];
-    const size_t z = blockIdx.z;
-    const size_t Wz = gridDim.x;
-    const int j = blockIdx.x, t = threadIdx.x;
-    const u32 nb1 = nbk + 1;
-    u32* cnt = bucket_cnt + (z * Wz + j) * nb1;
-    u32* st = starts + (z * Wz + j) * nb1;
-    u32* en = ends + (z * Wz + j) * nb1;
-    const u32 per = (nb1 + 1023u) / 1024u;
-    const u32 lo = t * per < nb1 ? t * per : nb1, hi = lo + per < nb1 ? lo + per : nb1;
-    u32 sum = 0;
-    for (u32 b = lo; b < hi; ++b) sum += cnt[b];
-    part[t] = sum;
+// per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts).  Two launches over
+// 1024-bucket blocks (coalesced): block totals, then every block adds the totals before it to its own LDS scan -- one
+// workgroup per window walking 64 buckets per thread was a 0.18 ms latency chain at 2^16 buckets.
+constexpr int RANGE_BLOCK = 1024;
+__global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ block_sums, u32 nbk) {
+    __shared__ u32 part[RANGE_BLOCK / 64];
+    const size_t z = blockIdx.z, Wz = gridDim.y;
+    const u32 nb1 = nbk + 1, b = blockIdx.x * RANGE_BLOCK + threadIdx.x;
+    u32 v = b < nb1 ? bucket_cnt[(z * Wz + blockIdx.y) * nb1 + b] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        u32 v = (t >= off) ? part[t - off] : 0;
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int k = 0; k < RANGE_BLOCK / 64; ++k) t += part[k];
+        block_sums[(z * Wz + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_ranges_kernel(u32* __restrict__ bucket_cnt, const u32* __restrict__ block_sums, u32* __restrict__ starts,
+                                                                        u32* __restrict__ ends, u32 nbk) {
+    __shared__ u32 part[RANGE_BLOCK];
+    __shared__ u32 before;
+    const size_t z = blockIdx.z, Wz = gridDim.y;
+    const int t = threadIdx.x;
+    const u32 nb1 = nbk + 1, b = blockIdx.x * RANGE_BLOCK + t;
+    const size_t row = (z * Wz + blockIdx.y) * nb1;
+    const u32 c = b < nb1 ? bucket_cnt[row + b] : 0u;
+    {   // total of the blocks before this one (at most 2^18 / 1024 = 256 of them)
+        u32 v = (u32)t < blockIdx.x ? block_sums[(z * Wz + blockIdx.y) * gridDim.x + t] : 0u;
+        part[t] = v;
+        __syncthreads();
+        for (int s = RANGE_BLOCK / 2; s > 0; s >>= 1) {
+            if (t < s) part[t] += part[t + s];
+            __syncthreads();
+        }
+        if (t == 0) before = part[0];
+        __syncthreads();
+    }
+    part[t] = c;
+    __syncthreads();
+    for (int off = 1; off < RANGE_BLOCK; off <<= 1) {  // Hillis-Steele inclusive scan
+        const u32 v = (t >= off) ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    u32 run = part[t] - sum;
-    for (u32 b = lo; b < hi; ++b) {
-        const u32 c = cnt[b], S = run, E = run + c;
-        st[b] = S; en[b] = E; cnt[b] = S;  // cursor starts at the bucket start
-        run = E;
+    if (b < nb1) {
+        const u32 E = before + part[t], S = E - c;
+        starts[row + b] = S; ends[row + b] = E; bucket_cnt[row + b] = S;  // cursor starts at the bucket start
     }
 }
 
@@ -775,7 +807,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.starts.ensure(chunk * Ws * nb1 * 4));
     TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4));
     TRH_TRY(L.ends.ensure(chunk * Ws * nb1 * 4));
-    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * nseg * 4 + 16));
+    const unsigned range_blocks = (nb1 + RANGE_BLOCK - 1) / RANGE_BLOCK;  // <= 2^17 / 1024 + 1 = 129 < RANGE_BLOCK threads
+    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg > range_blocks ? nseg : range_blocks) * 4 + 16));
     TRH_TRY(L.first.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
     TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
     TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
@@ -823,8 +856,10 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
-            hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.bucket_cnt.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(),
-                               L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
+            // block totals live in seg_bucket, which is only filled afterwards
+            hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), nbk);
+            hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), L.starts.as<u32>(),
+                               L.ends.as<u32>(), nbk);
             hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, L.ends.as<u32>(), L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
