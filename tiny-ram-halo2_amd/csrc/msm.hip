@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
 // ---------------------------------------------------------------------------------------
 // 2. exclusive scan per window of cnt[0..len) -> starts; cnt becomes the running cursor
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1) {
+__global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1, u32* __restrict__ oversize, u32 bin_cap) {
     const size_t z = blockIdx.z;  // batch item
     counts += z * (size_t)gridDim.x * nb1; starts += z * (size_t)gridDim.x * nb1;
     __shared__ u32 part[1024];
@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
     u32* st = starts + (size_t)j * nb1;
     const u32 per = (nb1 + 1023u) / 1024u;
     const u32 lo = t * per < nb1 ? t * per : nb1, hi = (lo + per < nb1) ? lo + per : nb1;
-    u32 sum = 0;
-    for (u32 b = lo; b < hi; ++b) sum += cnt[b];
+    u32 sum = 0, biggest = 0;
+    for (u32 b = lo; b < hi; ++b) { const u32 v = cnt[b]; sum += v; biggest = v > biggest ? v : biggest; }
+    if (oversize && biggest > bin_cap) atomicMax(oversize, biggest);  // a bin that does not fit the LDS of msm_bin_sort_kernel: chunked passes instead
     part[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -247,13 +248,15 @@ __device__ __forceinline__ u32 bin_of_position(const u32* __restrict__ bin_ends,
 template <bool SCATTER>
 __global__ void __launch_bounds__(BS_THREADS) msm_bucket_pass_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts,
                                                                      const u32* __restrict__ bin_ends, u32* __restrict__ bucket_cnt /* count: histogram; scatter: cursor */,
-                                                                     u32* __restrict__ sorted, size_t n, int k2, u32 nbins, int idx_bits, u32 nbk) {
+                                                                     u32* __restrict__ sorted, size_t n, int k2, u32 nbins, int idx_bits, u32 nbk,
+                                                                     const u32* __restrict__ oversize) {
     const size_t z = blockIdx.z;  // batch item
     {
         const size_t Wz = gridDim.y;
         parted += z * Wz * n; sorted += z * Wz * n; bin_starts += z * Wz * nbins; bin_ends += z * Wz * nbins;
         bucket_cnt += z * Wz * (nbk + 1);
     }
+    if (oversize && *oversize == 0u) return;  // every bin was sorted in LDS by msm_bin_sort_kernel
     __shared__ u32 cnt[128], tbase[128], gbase[128];
     __shared__ u32 stage[SCATTER ? BS_CHUNK : 1];
     const int j = blockIdx.y;
@@ -307,11 +310,92 @@ __global__ void __launch_bounds__(BS_THREADS) msm_bucket_pass_kernel(const u32* 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3b'. bucket sort, whole bin in LDS: when every level-1 bin of the launch fits (random scalars: 2^15 +- 200 entries at 2^24
+//      pairs), one workgroup sorts one bin -- entries into registers, LDS histogram over the <= 128 low bucket values, shuffle
+//      scan, scatter into the LDS stage, ONE coalesced copy of the whole bin region -- and publishes the bucket ranges of its
+//      bin itself (bin start + prefix), so the count pass, the global range scan and the per-piece run reservations of the
+//      chunked passes are not needed.  An oversize bin (skewed scalars) flips `oversize` in msm_offsets_kernel and this kernel
+//      returns; the chunked passes below, which return in the other case, then do the work.
+// ---------------------------------------------------------------------------------------
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_PER_MAX = 36;                        // entries per thread, kept in registers from the load to the last pass
+constexpr u32 BIN_CAP_MAX = BIN_THREADS * BIN_PER_MAX; // 36864 entries
+// (Tried: a stage of half a bin filled in two passes, two 512-thread workgroups per CU so that one loads while the other
+// scatters -- 72 entries per thread spill and the sort went from 1.61 to 2.29 ms at 2^24.)
+__global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts, const u32* __restrict__ bin_ends,
+                                                                   u32* __restrict__ sorted, u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2, u32 nbins,
+                                                                   int idx_bits, u32 nbk, const u32* __restrict__ oversize) {
+    if (*oversize != 0u) return;
+    extern __shared__ u32 bstage[];
+    __shared__ u32 cnt[128], tbase[128], wave0_total;
+    const size_t z = blockIdx.z, Wz = gridDim.y;
+    const int j = blockIdx.y;
+    const u32 bin = blockIdx.x;
+    const size_t wrow = z * Wz + j;
+    const u32 lo = bin_starts[wrow * nbins + bin], hi = bin_ends[wrow * nbins + bin];
+    const u32 count = hi - lo;
+    const u32 nsub = 1u << k2, low_mask = nsub - 1u, idx_mask = (1u << idx_bits) - 1u;
+    const u32* src = parted + wrow * n + lo;
+    u32* dst = sorted + wrow * n + lo;
+    const u32 lane = threadIdx.x & 63u;
+    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    u32 mine[BIN_PER_MAX];
+#pragma unroll
+    for (int q = 0; q < BIN_PER_MAX; ++q) {
+        const u32 i = threadIdx.x + (u32)q * BIN_THREADS;
+        mine[q] = 0u;
+        if (i < count) {
+            mine[q] = src[i];
+            atomicAdd(&cnt[(mine[q] >> idx_bits) & low_mask], 1u);
+        }
+    }
+    __syncthreads();
+    u32 v = 0, x = 0;
+    if (threadIdx.x < 128) {  // exclusive scan of the sub-bucket counts inside the two waves that hold them
+        v = threadIdx.x < nsub ? cnt[threadIdx.x] : 0u;
+        x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if ((int)lane >= off) x += y;
+        }
+        if (threadIdx.x == 63) wave0_total = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const u32 excl = x - v + (threadIdx.x >= 64 ? wave0_total : 0u);
+        tbase[threadIdx.x] = excl;
+        cnt[threadIdx.x] = 0;
+        if (threadIdx.x < nsub) {  // bucket (bin << k2) + sub lives at index + 1 of the range arrays (index 0: digit 0, nothing to add)
+            const size_t b = wrow * (nbk + 1) + ((size_t)bin << k2) + threadIdx.x + 1u;
+            starts[b] = lo + excl;
+            ends[b] = lo + excl + v;
+        }
+        if (bin == 0 && threadIdx.x == 0) { starts[wrow * (nbk + 1)] = 0; ends[wrow * (nbk + 1)] = 0; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BIN_PER_MAX; ++q) {
+        if (threadIdx.x + (u32)q * BIN_THREADS < count) {
+            const u32 e = mine[q];
+            const u32 sub = (e >> idx_bits) & low_mask;
+            const u32 r = atomicAdd(&cnt[sub], 1u);
+            bstage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < count; i += BIN_THREADS) dst[i] = bstage[i];
+}
+
 // per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts).  Two launches over
 // 1024-bucket blocks (coalesced): block totals, then every block adds the totals before it to its own LDS scan -- one
 // workgroup per window walking 64 buckets per thread was a 0.18 ms latency chain at 2^16 buckets.
 constexpr int RANGE_BLOCK = 1024;
-__global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ block_sums, u32 nbk) {
+__global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ block_sums, u32 nbk,
+                                                                            const u32* __restrict__ oversize) {
+    if (oversize && *oversize == 0u) return;
     __shared__ u32 part[RANGE_BLOCK / 64];
     const size_t z = blockIdx.z, Wz = gridDim.y;
     const u32 nb1 = nbk + 1, b = blockIdx.x * RANGE_BLOCK + threadIdx.x;
@@ -327,7 +411,8 @@ __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(cons
     }
 }
 __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_ranges_kernel(u32* __restrict__ bucket_cnt, const u32* __restrict__ block_sums, u32* __restrict__ starts,
-                                                                        u32* __restrict__ ends, u32 nbk) {
+                                                                        u32* __restrict__ ends, u32 nbk, const u32* __restrict__ oversize) {
+    if (oversize && *oversize == 0u) return;
     __shared__ u32 part[RANGE_BLOCK];
     __shared__ u32 before;
     const size_t z = blockIdx.z, Wz = gridDim.y;
@@ -802,7 +887,13 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
-    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4));
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + 4));  // + the oversize-bin flag of the LDS bin sort
+    u32* const oversize = L.counts.as<u32>() + chunk * Ws * nbins;
+    // LDS bin sort when the bins are big enough to fill a 1024-thread workgroup and fit with 6 % + 512 entries of slack
+    // (uniform digits: the largest of 8192 bins of 2^15 entries is 4.5 sigma = 800 entries above the mean)
+    const size_t avg_bin = ns / nbins;
+    u32 bin_cap = (u32)(((avg_bin + avg_bin / 16 + 512 + 1023) / 1024) * 1024);
+    const bool use_bin = avg_bin >= 4096 && bin_cap <= BIN_CAP_MAX && !getenv("TRH_NO_BIN_SORT");
     TRH_TRY(L.bin_starts.ensure(chunk * Ws * nbins * 4));
     TRH_TRY(L.starts.ensure(chunk * Ws * nb1 * 4));
     TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4));
@@ -823,6 +914,11 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (m.host_sums) (void)hipHostFree(m.host_sums);
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
         m.host_sums_cap = hs + 4096;
+    }
+    static bool bin_attr = false;
+    if (!bin_attr) {
+        TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_bin_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_CAP_MAX * 4));
+        bin_attr = true;
     }
     static bool part_attr = false;
     if (!part_attr) {
@@ -848,21 +944,26 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                            L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
                            tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins);
+        if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, 4, s));
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap);
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits);
         {
             const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), Ws, nb);
+            const u32* gate = use_bin ? oversize : nullptr;  // the chunked passes return at once when the bin sort did the work
+            if (use_bin)
+                hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, Ws, nb), dim3(BIN_THREADS), (size_t)bin_cap * 4, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
+                                   L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), ns, k2, nbins, idx_bits, nbk, oversize);
             TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk, gate);
             // block totals live in seg_bucket, which is only filled afterwards
-            hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), nbk);
+            hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), nbk, gate);
             hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), L.starts.as<u32>(),
-                               L.ends.as<u32>(), nbk);
+                               L.ends.as<u32>(), nbk, gate);
             hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, L.ends.as<u32>(), L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk);
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk, gate);
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
         if (b0 == 0 && !bases_z && !fb)
