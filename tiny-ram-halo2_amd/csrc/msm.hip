@@ -851,6 +851,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     while (((size_t)1 << idx_bits) < ns) ++idx_bits;
     int k2 = cb - 1 < 7 ? cb - 1 : 7;
     if (k2 > 31 - idx_bits) k2 = 31 - idx_bits;
+    if (const char* e = getenv("TRH_K2")) { int v = atoi(e); if (v >= 1 && v <= k2 && cb - 1 - v <= 11) k2 = v; }  // tuning knob
     const int k1 = cb - 1 - k2;
     const u32 nbins = 1u << k1;
     const size_t recode_lds = (size_t)Ws * nbins * 4;
