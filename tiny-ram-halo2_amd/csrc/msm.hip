@@ -653,7 +653,10 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __res
     }
 }
 
-template <class BF>
+// G lanes per bucket (1 or 4): a small MSM with few, long buckets (the IPA rounds: 512 buckets of 512 entries in segments
+// of 16) would otherwise add its 32 pieces one after the other in one thread -- a 0.15 ms latency chain per MSM; the lanes of
+// a group take the pieces round-robin and a shuffle tree adds the group's partial sums
+template <class BF, int G>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                           const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                           const XYZZzMem* __restrict__ direct, XYZZzMem* __restrict__ buckets,
@@ -664,7 +667,8 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
         starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
         direct += z * Wz * (nbk + 1); buckets += z * Wz * nbk; heavy += z * heavy_stride;
     }
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const u32 gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 b = gt / G + 1, sub = gt % G;  // nbk and the block size are multiples of G: a group is never split by the bound
     const int j = blockIdx.y;
     if (b > nbk) return;
     const u32 nb1 = nbk + 1;
@@ -673,14 +677,28 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict_
     if (E > S) {
         const u32 t_lo = S / seg_len, t_hi = (E - 1) / seg_len;
         if (t_hi - t_lo > HEAVY_PIECES) {  // skewed bucket: a whole workgroup adds its pieces (msm_combine_heavy_kernel)
-            heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)j * nb1 + b;
-            return;
+            if (sub == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)j * nb1 + b;
+            return;  // uniform over the group
         }
         const XYZZzMem* fj = first + (size_t)j * nseg;
-        if (S == t_lo * seg_len) acc = load_raw<BF>(fj + t_lo);
-        else if (E <= (t_lo + 1) * seg_len) acc = load_raw<BF>(direct + (size_t)j * nb1 + b);
-        else acc = load_raw<BF>(last + (size_t)j * nseg + t_lo);
-        for (u32 t = t_lo + 1; t <= t_hi; ++t) acc = xyzzz_add(acc, load_raw<BF>(fj + t));
+        if (sub == 0) {
+            if (S == t_lo * seg_len) acc = load_raw<BF>(fj + t_lo);
+            else if (E <= (t_lo + 1) * seg_len) acc = load_raw<BF>(direct + (size_t)j * nb1 + b);
+            else acc = load_raw<BF>(last + (size_t)j * nseg + t_lo);
+        }
+        for (u32 t = t_lo + 1 + sub; t <= t_hi; t += G) acc = xyzzz_add(acc, load_raw<BF>(fj + t));
+    }
+    if constexpr (G > 1) {
+        for (int off = G / 2; off > 0; off >>= 1) {
+            XYZZz<BF> o;
+#pragma unroll
+            for (int i = 0; i < NLIMBS; ++i) {
+                o.x.l[i] = __shfl_down(acc.x.l[i], off, G); o.y.l[i] = __shfl_down(acc.y.l[i], off, G);
+                o.zz.l[i] = __shfl_down(acc.zz.l[i], off, G); o.zzz.l[i] = __shfl_down(acc.zzz.l[i], off, G);
+            }
+            if ((int)sub + off < G) acc = xyzzz_add(acc, o);  // (a lane without a partner reads its own value back)
+        }
+        if (sub != 0) return;
     }
     store_raw(&buckets[(size_t)j * nbk + (b - 1)], acc);  // stays in the lazy domain for the reduction
 }
@@ -972,8 +990,17 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), ns, nbk, nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
-        hipLaunchKernelGGL((msm_combine_kernel<BF>), dim3((nbk + 255) / 256, Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
-                           L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
+        {
+            const size_t pieces = ns / ((size_t)nbk * seg_len);  // expected pieces per bucket
+#define TRH_LAUNCH_COMBINE(G)                                                                                                                          \
+    hipLaunchKernelGGL((msm_combine_kernel<BF, G>), dim3((unsigned)(((size_t)nbk * G + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), \
+                       L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride)
+            // measured on the IPA opening at k = 18 (32 pieces per bucket): 24.0 ms with one lane per bucket, 23.0 with 4, 26.1 with 16
+            // (idle lanes of the wider groups still occupy the SIMD)
+            if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
+            else TRH_LAUNCH_COMBINE(1);
+#undef TRH_LAUNCH_COMBINE
+        }
         hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
                            L.last.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
