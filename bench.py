@@ -263,7 +263,7 @@ def main():
                          "kernel_ms": acc, "algorithmic_bytes": 96 * n},
             # what actually bounds the kernel: VALU issue.  Per mixed add 8 fz_mul (126 v_mad_u64_u32 each) + 2 fz_sqr (90) =
             # 1188 half-rate multiply-adds and ~1130 other ALU instructions (SQ_INSTS_VALU: 2317 per mixed add and wave); peaks are the
-            # measured issue rates of tools/microbench.hip (profiles/microbench_r01.txt)
+            # measured issue rates of tools/microbench.hip (profiles/microbench_r01m.txt: v_mad_u64_u32 32.7 T/s, v_add_u32 65 T/s)
             "valu": {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc * 1e-3),
                      "mad_u64_u32_per_s": 1188 * madds / (acc * 1e-3), "mad_peak_per_s": 32.7e12,
                      "other_valu_per_s": 1130 * madds / (acc * 1e-3), "other_peak_per_s": 65e12,
