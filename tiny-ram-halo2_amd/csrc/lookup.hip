@@ -118,8 +118,17 @@ __global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ 
 
 struct Scratch {
     DevBuf planes_a, planes_s, keys_in, keys_out, perm_a, perm_s, perm_tmp, first, removed, flags, pos, rows_rep, rows_left, tmp, err;
+    u32* host = nullptr;  // pinned landing area of the few words the host reads back per lookup (pageable targets cost a staging copy each)
 };
 Scratch& scratch() { static Scratch s; return s; }
+int host_words(Scratch& sc) {
+    if (!sc.host) TRH_HIP_TRY(hipHostMalloc((void**)&sc.host, 256, hipHostMallocDefault));
+    return TRH_OK;
+}
+// the three words the placement needs: exclusive-scan tail and last flag of the repeated rows, the missing-value flag
+__global__ void collect_tail_kernel(const u32* __restrict__ pos, const u32* __restrict__ flags, size_t n, const u32* __restrict__ err, u32* __restrict__ out) {
+    out[0] = pos[n - 1]; out[1] = flags[n - 1]; out[2] = err[0];
+}
 
 // sort of the permutations of BOTH columns by their 256-bit keys.  Field elements are either small (range tables: only the low
 // limb varies) or spread over the whole field (compressed expressions: two different values practically never share their top
@@ -153,9 +162,11 @@ int sort_perm_pair(const u64* planes_a, u32* perm_a, const u64* planes_s, u32* p
     u32* flags = sc.err.as<u32>() + 1;  // [0] is the caller's error word; per column: varies[4], bad
     TRH_HIP_TRY(hipMemsetAsync(flags, 0, 40, s));
     for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(plane_varies_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, flags + 5 * c);
+    TRH_TRY(host_words(sc));
     u32 h[10];
-    TRH_HIP_TRY(hipMemcpyAsync(h, flags, 40, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipMemcpyAsync(sc.host, flags, 40, hipMemcpyDeviceToHost, s));
     TRH_HIP_TRY(hipStreamSynchronize(s));
+    memcpy(h, sc.host, 40);
     int primary[2];
     for (int c = 0; c < 2; ++c) {
         primary[c] = -1;
@@ -166,10 +177,9 @@ int sort_perm_pair(const u64* planes_a, u32* perm_a, const u64* planes_s, u32* p
         TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perms[c], out, n, 0, 64, s));
         hipLaunchKernelGGL(tie_check_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, out, primary[c], flags + 5 * c + 4);
     }
-    u32 bad[2] = {0, 0};
-    TRH_HIP_TRY(hipMemcpyAsync(&bad[0], flags + 4, 4, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipMemcpyAsync(&bad[1], flags + 9, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipMemcpyAsync(sc.host, flags + 4, 24, hipMemcpyDeviceToHost, s));  // bad[0] ... bad[1]: words 4 and 9
     TRH_HIP_TRY(hipStreamSynchronize(s));
+    const u32 bad[2] = {sc.host[0], sc.host[5]};
     for (int c = 0; c < 2; ++c) {
         if (primary[c] < 0) continue;
         if (!bad[c]) TRH_HIP_TRY(hipMemcpyAsync(perms[c], sc.perm_tmp.as<u32>() + (size_t)c * n, n * 4, hipMemcpyDeviceToDevice, s));
@@ -209,17 +219,16 @@ int lookup_permute_t(const void* input, const void* table, size_t n, void* out_i
     hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.first.as<u32>(), sc.flags.as<u32>(), n);
     TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
     hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_rep.as<u32>(), n);
-    u32 tail[2], last_flag;
-    TRH_HIP_TRY(hipMemcpyAsync(&tail[0], sc.pos.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipMemcpyAsync(&last_flag, sc.flags.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    TRH_TRY(host_words(sc));
+    u32* rec = sc.err.as<u32>() + 12;  // device record behind the error word and the sort flags
+    hipLaunchKernelGGL(collect_tail_kernel, dim3(1), dim3(1), 0, s, sc.pos.as<u32>(), sc.flags.as<u32>(), n, sc.err.as<u32>(), rec);
     hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.removed.as<u32>(), sc.flags.as<u32>(), n);
     TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
     hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_left.as<u32>(), n);
-    u32 err = 0;
-    TRH_HIP_TRY(hipMemcpyAsync(&err, sc.err.p, 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipMemcpyAsync(sc.host, rec, 12, hipMemcpyDeviceToHost, s));
     TRH_HIP_TRY(hipStreamSynchronize(s));
-    if (err) { set_error("lookup_permute: an input value does not occur in the table (halo2: Error::ConstraintSystemFailure)"); return TRH_EINVAL; }
-    const u32 n_rep = tail[0] + last_flag;  // repeated rows == left-over table elements (both n - #distinct inputs)
+    if (sc.host[2]) { set_error("lookup_permute: an input value does not occur in the table (halo2: Error::ConstraintSystemFailure)"); return TRH_EINVAL; }
+    const u32 n_rep = sc.host[0] + sc.host[1];  // repeated rows == left-over table elements (both n - #distinct inputs)
     hipLaunchKernelGGL(place_table_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)out_input, sc.first.as<u32>(), (const uint4*)table, sc.perm_s.as<u32>(), sc.rows_left.as<u32>(),
                        sc.rows_rep.as<u32>(), n_rep, (uint4*)out_table, n);
     TRH_HIP_TRY(hipGetLastError());
@@ -233,6 +242,7 @@ void lookup_release() {
     for (DevBuf* b : {&sc.planes_a, &sc.planes_s, &sc.keys_in, &sc.keys_out, &sc.perm_a, &sc.perm_s, &sc.perm_tmp, &sc.first, &sc.removed, &sc.flags, &sc.pos, &sc.rows_rep, &sc.rows_left, &sc.tmp,
                       &sc.err})
         b->release();
+    if (sc.host) { (void)hipHostFree(sc.host); sc.host = nullptr; }
 }
 
 }  // namespace trh
