@@ -392,6 +392,28 @@ def test_msm_witness_like_scalars(kind, log_n):
     assert (got[:8] == want).all()
 
 
+def test_msm_bin_sort_equals_chunked_passes(monkeypatch):
+    """the whole-bin LDS bucket sort and the chunked passes it replaces (TRH_NO_BIN_SORT=1; also its fallback for oversize bins)
+    sort the same entries: same point, single MSM and fixed-base batch"""
+    curve, n = "pallas", (1 << 20) + 7
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+    sc = synth.field_elements(0xB175, n)
+    d = api.DeviceBuffer.from_host(sc)
+    a = bases.msm_dev(d, n)
+    monkeypatch.setenv("TRH_NO_BIN_SORT", "1")
+    b = bases.msm_dev(d, n)
+    monkeypatch.delenv("TRH_NO_BIN_SORT")
+    assert (a == b).all()
+    m = 1 << 16
+    small = api.Bases.generate(curve, 5, 9, m)
+    small.precompute(0)
+    d4 = api.DeviceBuffer.from_host(synth.field_elements(0xB176, 4 * m))
+    a = small.msm_batch_dev(d4, m, 4)
+    monkeypatch.setenv("TRH_NO_BIN_SORT", "1")
+    b = small.msm_batch_dev(d4, m, 4)
+    assert (a == b).all()
+
+
 # ---------------------------------------------------------------------------------------
 # fixed-base tables (trh_bases_precompute): same group elements as the per-window path and the oracle
 # ---------------------------------------------------------------------------------------
