@@ -246,6 +246,7 @@ void trh_shutdown(void) {
     c.io.release();
     c.factors.release();
     if (c.pinned_ring) { (void)hipHostFree(c.pinned_ring); c.pinned_ring = nullptr; c.pinned_slot = 0; }
+    if (c.pinned_land) { (void)hipHostFree(c.pinned_land); c.pinned_land = nullptr; }
     c.pfft.release();
     c.scan.release(); c.scan2.release();
     c.inited = false;

@@ -110,6 +110,7 @@ struct Ctx {
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
     void* pinned_ring = nullptr;  // 64 x 2 KiB of pinned host memory mirroring the factor ring: constants are copied here first, so the
+    void* pinned_land = nullptr;  // 4 KiB pinned landing area for the few words the host reads back per IPA round (a pageable target costs a staging copy)
     unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;

@@ -188,6 +188,21 @@ int inner_product_t(const void* a, const void* b, size_t n, hipStream_t s, u64* 
     return TRH_OK;
 }
 
+// small device -> host read-back through the pinned landing area (callers hold the context lock)
+int read_back(void* out, const void* dev, size_t bytes, hipStream_t s) {
+    Ctx& c = ctx();
+    if (bytes > 4096) {
+        TRH_HIP_TRY(hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, s));
+        TRH_HIP_TRY(hipStreamSynchronize(s));
+        return TRH_OK;
+    }
+    if (!c.pinned_land) TRH_HIP_TRY(hipHostMalloc(&c.pinned_land, 4096, hipHostMallocDefault));
+    TRH_HIP_TRY(hipMemcpyAsync(c.pinned_land, dev, bytes, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out, c.pinned_land, bytes);
+    return TRH_OK;
+}
+
 template <class F>
 int inner_product2_t(const void* a0, const void* b0, const void* a1, const void* b1, size_t n, hipStream_t s, u64* out /* 2 x 4 */) {
     Ctx& c = ctx();
@@ -200,9 +215,7 @@ int inner_product2_t(const void* a0, const void* b0, const void* a1, const void*
     hipLaunchKernelGGL((inner_product2_kernel<F>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)a0, (const uint4*)b0, (const uint4*)a1, (const uint4*)b1, n, partial);
     hipLaunchKernelGGL((sum_partials_batch_kernel<F>), dim3(2), dim3(256), 0, s, partial, blocks, result);
     TRH_HIP_TRY(hipGetLastError());
-    TRH_HIP_TRY(hipMemcpyAsync(out, result, 64, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    return TRH_OK;
+    return read_back(out, result, 64, s);
 }
 
 // small per-call constant staged in the factor ring (see trh_field_scale_rows_dev)
@@ -252,9 +265,7 @@ int eval_batch_t(const void* polys, size_t n, size_t batch, const u64* x, hipStr
         hipLaunchKernelGGL((sum_partials_batch_kernel<F>), dim3(nb), dim3(256), 0, s, partial + 2 * b0 * blocks, blocks, result + 2 * b0);
     }
     TRH_HIP_TRY(hipGetLastError());
-    TRH_HIP_TRY(hipMemcpyAsync(out, result, batch * 32, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    return TRH_OK;
+    return read_back(out, result, batch * 32, s);
 }
 
 template <class SF, class BF>
