@@ -3,6 +3,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 PKG := tiny-ram-halo2_amd
 CSRC := $(PKG)/csrc
+# build id = hash of the library's sources (trh_version() reports it)
+BUILD_ID := $(shell cat $(CSRC)/*.hip $(CSRC)/*.h include/trh.h | sha1sum | cut -c1-12)
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-result
 OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h $(CSRC)/hostcombine.h include/trh.h
@@ -12,8 +14,12 @@ all: $(PKG)/libtrh.so oracle examples/replay
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# capi.o carries the build id: rebuilt whenever any source of the library changes
+$(CSRC)/capi.o: $(CSRC)/capi.hip $(HDRS) $(wildcard $(CSRC)/*.hip)
+	$(HIPCC) $(HIPFLAGS) -DTRH_BUILD_ID='"$(BUILD_ID)"' -c $< -o $@
+
 $(PKG)/libtrh.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -ldl -o $@
 
 # native (C++17, no Python) driver over include/trh.hpp
 examples/replay: examples/replay.cpp include/trh.hpp include/trh.h $(PKG)/libtrh.so

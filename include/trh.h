@@ -21,8 +21,21 @@
  * Errors: every function returns 0 on success or a negative TRH_E* code; the message is
  * available from trh_last_error() (thread-local).  Nothing aborts or throws across the ABI;
  * the Rust shim maps a non-zero return to the panic the reference would raise.
- * Threading: entry points may be called concurrently from several host threads; calls are
- * serialised per device context.
+ * Threading and contexts: a CONTEXT is bound to one GPU and owns every scratch buffer, table cache and
+ * in-flight state, behind one lock.  trh_init() makes the process default; every entry point may be
+ * called from any host thread (it makes the context's device current for the calling thread itself --
+ * hipSetDevice is per thread) and calls on one context are serialised, on the host by its lock and on
+ * the device by ordering each call's stream behind the stream of the previous call (they share the
+ * scratch).  One MSM may be in flight per context (trh_msm_dev_enqueue .. _finish); a second enqueue
+ * returns TRH_EBUSY.  Threads that want to OVERLAP work (an MSM beside an NTT, two MSMs) give each
+ * thread its own context: trh_ctx_create + trh_ctx_set_current (thread-local binding; several contexts
+ * per GPU are fine).  Handles (trh_bases_t, trh_domain_t, trh_expr_t) are device memory: usable from
+ * every context of the device they were created on.  Callbacks (trh_ipa_create_proof's transcript /
+ * rng) run with the context locked: they may call host-side helpers (trh_point_sum, trh_last_error)
+ * but must not start device work on the same context.
+ * Multi-GPU: trh_init_multi() binds a device group; base sets of at least trh_set_shard_min() points
+ * created afterwards are range-sharded over the group and trh_msm / trh_msm_dev / trh_best_multiexp_*
+ * run one local Pippenger per GPU and add the partial points on the host.
  * There is no CPU fallback: without a usable HIP device trh_init() fails and every compute
  * entry point returns TRH_ENODEV.
  */
@@ -41,6 +54,7 @@ extern "C" {
 #define TRH_ENODEV (-2)   /* no HIP device / trh_init not called */
 #define TRH_EHIP (-3)     /* HIP runtime error */
 #define TRH_ENOMEM (-4)
+#define TRH_EBUSY (-5)    /* the context already has an MSM in flight */
 
 #define TRH_PALLAS 0
 #define TRH_VESTA 1
@@ -48,11 +62,29 @@ extern "C" {
 #define TRH_FQ 1
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
-int trh_init(int device);            /* binds the calling process to one GPU; idempotent */
-void trh_shutdown(void);
+int trh_init(int device);            /* creates the process-default context on one GPU; idempotent */
+void trh_shutdown(void);             /* destroys the default context / the device group (not contexts made by trh_ctx_create) */
 const char* trh_last_error(void);
 int trh_device_count(void);
-const char* trh_version(void);
+const char* trh_version(void);       /* "trh <version> (gfx950, build <hash of the sources>)" */
+
+/* ---- device group: the MSM range-sharded over the GPUs of one node (one host process, as the reference's prover is:
+ * /root/reference/src/test_utils.rs:37-54).  devices[0] becomes the process default, exactly as trh_init(devices[0]);
+ * a device may be listed more than once (logical shards on one GPU).  Base sets with at least trh_set_shard_min()
+ * points (default 2^20) created afterwards by trh_bases_create_* / trh_bases_generate / trh_best_multiexp_* hold
+ * shard g = points [g * ceil(n / G), ...) on devices[g]; MSMs over them enqueue one local Pippenger per device on that
+ * device's own stream from the calling thread, copy the G partial points (96 B each) device-to-host and add them on
+ * the host.  Device-resident scalars (trh_msm_dev) are handed to the other GPUs with peer copies.                    */
+int trh_init_multi(const int* devices, int n_devices);
+int trh_group_size(void);
+int trh_set_shard_min(size_t n_points);
+
+/* ---- explicit contexts (see "Threading and contexts" above) ------------------------------------------------------- */
+typedef struct trh_ctx* trh_ctx_t;
+int trh_ctx_create(int device, trh_ctx_t* out);
+void trh_ctx_destroy(trh_ctx_t ctx);
+int trh_ctx_set_current(trh_ctx_t ctx_or_null);  /* binds the calling THREAD; NULL = back to the process default */
+int trh_ctx_device(trh_ctx_t ctx_or_null);       /* device index of the context (NULL: of the calling thread's), -1 if none */
 
 /* ---- halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------------
  * coeffs: n x 4 u64 (scalar field, Montgomery -- the memory image of `&[C::Scalar]`),
@@ -78,6 +110,7 @@ int trh_bases_generate(int curve, uint64_t s0, uint64_t d, uint64_t first, size_
 int trh_bases_download(trh_bases_t b, size_t offset, size_t n, uint64_t* xy_host);
 const void* trh_bases_device_ptr(trh_bases_t b);
 size_t trh_bases_len(trh_bases_t b);
+int trh_bases_shards(trh_bases_t b);  /* devices the set is range-sharded over (trh_init_multi); 1 for a single-device set */
 void trh_bases_destroy(trh_bases_t b);
 /* Fixed-base tables for an owned set (Params.g / g_lagrange serve ~500 commitments per proof): stores
  * 2^(c j) * P_i for every window j (W x n x 64 B of HBM), after which a full-range MSM over the handle puts the
@@ -95,7 +128,8 @@ int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size
 int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
                 int scalars_are_montgomery, void* stream, uint64_t out_xyz[12]);
 /* asynchronous halves of trh_msm_dev: enqueue leaves the per-window sums on the device,
- * finish synchronises, folds the windows on the host and returns the point.                 */
+ * finish synchronises, folds the windows on the host and returns the point.  One MSM in flight per
+ * context (TRH_EBUSY otherwise); finish must name the base set and be called on the context of its enqueue. */
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
                         int scalars_are_montgomery, void* stream);
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
@@ -167,7 +201,8 @@ int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t h
  * randomness callbacks.  g_w: resident bases g (2^k points) followed by w; u_xy: Params.u;
  * p_poly_dev / s_poly_dev: 2^k coefficients in device memory (s_poly: the caller's random polynomial,
  * its constant term is adjusted here so that s(x3) = 0); scalars are Montgomery limbs.
- * Writes to the transcript exactly what the Rust prover writes: S, then L_j, R_j per round, then c, f. */
+ * Writes to the transcript exactly what the Rust prover writes: S, then L_j, R_j per round, then c, f.
+ * A zero round challenge (the Rust prover's `u_j.invert().unwrap()` panics) returns TRH_EINVAL.          */
 typedef struct trh_transcript {
     void* ctx;
     void (*write_point)(void* ctx, const uint64_t xyz[12]);           /* normalised Jacobian, Z = 1 */

@@ -65,6 +65,13 @@ _SIGNATURES = {
     "trh_last_error": ([], ctypes.c_char_p),
     "trh_device_count": ([], ctypes.c_int),
     "trh_version": ([], ctypes.c_char_p),
+    "trh_init_multi": ([ctypes.POINTER(ctypes.c_int), ctypes.c_int], ctypes.c_int),
+    "trh_group_size": ([], ctypes.c_int),
+    "trh_set_shard_min": ([ctypes.c_size_t], ctypes.c_int),
+    "trh_ctx_create": ([ctypes.c_int, ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_ctx_destroy": ([_vp], None),
+    "trh_ctx_set_current": ([_vp], ctypes.c_int),
+    "trh_ctx_device": ([_vp], ctypes.c_int),
     "trh_best_multiexp_pallas": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_best_multiexp_vesta": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_best_fft_fp": ([_u64p, _u64p, ctypes.c_uint32], ctypes.c_int),
@@ -76,6 +83,7 @@ _SIGNATURES = {
     "trh_bases_download": ([_vp, ctypes.c_size_t, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_bases_device_ptr": ([_vp], _vp),
     "trh_bases_len": ([_vp], ctypes.c_size_t),
+    "trh_bases_shards": ([_vp], ctypes.c_int),
     "trh_bases_destroy": ([_vp], None),
     "trh_bases_precompute": ([_vp, ctypes.c_int], ctypes.c_int),
     "trh_bases_precomputed_window_bits": ([_vp], ctypes.c_int),
@@ -156,6 +164,47 @@ def _check(rc: int):
 
 def init(device: int = 0):
     _check(lib().trh_init(device))
+
+
+def init_multi(devices):
+    """trh_init_multi: the device group range-sharded base sets run on; devices[0] is the process default."""
+    arr = (ctypes.c_int * len(devices))(*devices)
+    _check(lib().trh_init_multi(arr, len(devices)))
+
+
+def group_size() -> int:
+    return int(lib().trh_group_size())
+
+
+def set_shard_min(n_points: int):
+    _check(lib().trh_set_shard_min(n_points))
+
+
+class Context:
+    """An independent libtrh context (own scratch, own lock) on one device; `with ctx:` binds the calling thread to it."""
+
+    def __init__(self, device: int = 0):
+        self.handle = _vp()
+        _check(lib().trh_ctx_create(device, ctypes.byref(self.handle)))
+
+    def bind(self):
+        _check(lib().trh_ctx_set_current(self.handle))
+
+    @staticmethod
+    def unbind():
+        _check(lib().trh_ctx_set_current(None))
+
+    def __enter__(self):
+        self.bind()
+        return self
+
+    def __exit__(self, *exc):
+        self.unbind()
+
+    def destroy(self):
+        if self.handle:
+            lib().trh_ctx_destroy(self.handle)
+            self.handle = _vp()
 
 
 def shutdown():
@@ -382,6 +431,9 @@ class Bases:
 
     def __len__(self):
         return int(lib().trh_bases_len(self.handle))
+
+    def shards(self) -> int:
+        return int(lib().trh_bases_shards(self.handle))
 
     def precompute(self, window_bits: int = 0) -> int:
         """Attach the fixed-base table (2^(c j) P_i for all windows j); returns the window width used."""

@@ -1,8 +1,17 @@
-// C ABI of libtrh.so (include/trh.h): argument checking, staging of host buffers, context.
+// C ABI of libtrh.so (include/trh.h): argument checking, staging of host buffers, contexts.
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
+
 #include "ctx.h"
+
+#ifndef TRH_BUILD_ID
+#define TRH_BUILD_ID "unknown"
+#endif
+
+struct trh_ctx : trh::Ctx {};
 
 namespace trh {
 
@@ -15,17 +24,142 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- context registry ------------------------------------------------------------------------------------------------
+static std::mutex g_reg_mu;
+static Ctx* g_default = nullptr;            // trh_init / trh_init_multi
+static std::vector<Ctx*> g_group;           // trh_init_multi: g_group[0] == g_default
+static size_t g_shard_min = (size_t)1 << 20;  // smaller base sets stay on the default device
+static thread_local Ctx* t_bound = nullptr;   // trh_ctx_set_current
+static thread_local Ctx* t_active = nullptr;  // innermost TRH_ENTER
+
+static Ctx* thread_ctx() { return t_bound ? t_bound : g_default; }
+
 Ctx& ctx() {
-    static Ctx c;
-    return c;
+    Ctx* c = t_active ? t_active : thread_ctx();
+    if (!c) {  // unreachable through the C ABI (every entry point enters first); keep the failure loud
+        fprintf(stderr, "libtrh: internal error: ctx() without a context\n");
+        abort();
+    }
+    return *c;
 }
 
 int require_init() {
-    if (!ctx().inited) {
+    Ctx* c = t_active ? t_active : thread_ctx();
+    if (!c || !c->inited) {
         set_error("trh_init() has not succeeded: no HIP device bound (libtrh has no CPU fallback)");
         return TRH_ENODEV;
     }
     return TRH_OK;
+}
+
+int Enter::begin(hipStream_t stream, Ctx* explicit_ctx) {
+    Ctx* cc = explicit_ctx ? explicit_ctx : thread_ctx();
+    if (!cc || !cc->inited) {
+        set_error("trh_init() has not succeeded: no HIP device bound (libtrh has no CPU fallback)");
+        return TRH_ENODEV;
+    }
+    cc->mu.lock();
+    locked = true;
+    c = cc;
+    prev_active = t_active;
+    t_active = cc;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != cc->device) {  // hipSetDevice is per thread: a rayon worker never called trh_init
+        prev_device = cur;
+        TRH_HIP_TRY(hipSetDevice(cc->device));
+    }
+    if (prev_active != cc) {  // outermost entry into this context
+        if (cc->last_stream_valid && cc->last_stream != stream) TRH_HIP_TRY(hipStreamWaitEvent(stream, cc->order_ev, 0));
+        entered_stream = stream;
+        outermost = true;
+    }
+    return TRH_OK;
+}
+
+Enter::~Enter() {
+    if (!locked) return;
+    if (outermost) {  // whatever this call enqueued is what the next stream entering the context has to wait for
+        if (hipEventRecord(c->order_ev, entered_stream) == hipSuccess) { c->last_stream = entered_stream; c->last_stream_valid = true; }
+        else c->last_stream_valid = false;
+    }
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    t_active = prev_active;
+    c->mu.unlock();
+}
+
+// ---- roctx ranges (rocprofv3 --marker-trace): resolved at first use, absent library = no-op -----------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+    if (const char* e = getenv("TRH_ROCTX")) if (atoi(e) == 0) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+    if (!g_roctx_push || !g_roctx_pop) { g_roctx_push = nullptr; g_roctx_pop = nullptr; }
+}
+}  // namespace
+Range::Range(const char* name) {
+    std::call_once(g_roctx_once, roctx_resolve);
+    if (g_roctx_push) g_roctx_push(name);
+}
+Range::~Range() {
+    if (g_roctx_pop) g_roctx_pop();
+}
+
+static int create_ctx(int device, Ctx** out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e)); return TRH_ENODEV; }
+    if (device < 0 || device >= n) { set_error("device %d out of range [0, %d)", device, n); return TRH_EINVAL; }
+    hipDeviceProp_t prop;
+    TRH_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("device %d is %s, libtrh is built for gfx950 only", device, prop.gcnArchName); return TRH_ENODEV; }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    TRH_HIP_TRY(hipSetDevice(device));
+    trh_ctx* h = new trh_ctx();
+    Ctx* c = h;
+    c->device = device;
+    hipError_t e1 = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    hipError_t e2 = hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    if (e1 != hipSuccess || e2 != hipSuccess) { delete h; set_error("context creation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return TRH_EHIP; }
+    c->inited = true;
+    *out = c;
+    return TRH_OK;
+}
+
+static void destroy_ctx(Ctx* c) {
+    if (!c) return;
+    {
+        Enter en;
+        if (en.begin(nullptr, c) == TRH_OK) {
+            (void)hipDeviceSynchronize();
+            msm_release();
+            lookup_release();
+            ntt_release_tables();
+            for (DevBuf& d : c->ipa) d.release();
+            c->io.release();
+            c->factors.release();
+            if (c->pinned_ring) { (void)hipHostFree(c->pinned_ring); c->pinned_ring = nullptr; c->pinned_slot = 0; }
+            if (c->pinned_land) { (void)hipHostFree(c->pinned_land); c->pinned_land = nullptr; }
+            c->pfft.release();
+            c->scan.release(); c->scan2.release();
+            c->last_stream_valid = false;
+            en.outermost = false;  // nothing to order behind: the streams are drained
+        }
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    c->inited = false;
+    if (t_bound == c) t_bound = nullptr;
+    delete static_cast<trh_ctx*>(c);
 }
 
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s);
@@ -89,9 +223,10 @@ int check_field(int field) {
 // ---- cache of base sets seen by the host-pointer entry points ---------------------------------------------------
 // `best_multiexp(coeffs, bases)` is called ~500 times per proof with the SAME `Params.g_lagrange` / `Params.g` slices.
 // The plain two-function shim passes host pointers every time; re-uploading 64 B per base
-// would cost as much as the MSM.  A set is recognised by (curve, pointer, length, fingerprint of 256 sampled points)
-// and kept resident (8 sets, LRU); from its fourth use it also gets the fixed-base tables.  TRH_BASES_CACHE=0 turns
-// the cache off (every call then uploads, as before).
+// would cost as much as the MSM.  OPT-IN (TRH_BASES_CACHE=1; the explicit form is trh_bases_create_*): a set is
+// recognised by (curve, pointer, length, FNV-1a hash of ALL n points -- recomputed on every call, so a base changed in
+// place is never served from the stale copy) and only becomes resident at its SECOND identical sighting, which keeps
+// the once-per-proof IPA slices out of the 8-entry LRU; from its fourth use a set also gets the fixed-base tables.
 struct BasesCacheEntry {
     int curve;
     const void* host;
@@ -101,17 +236,16 @@ struct BasesCacheEntry {
     uint64_t stamp;
     unsigned uses;
 };
+struct BasesCandidate { int curve; const void* host; size_t n; uint64_t fp; };
 std::mutex g_cache_mu;
 std::vector<BasesCacheEntry> g_cache;
+BasesCandidate g_seen[16];
+unsigned g_seen_next = 0;
 uint64_t g_cache_stamp = 0;
 
 uint64_t bases_fingerprint(const uint64_t* bases, size_t n) {
     uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
-    const size_t samples = n < 256 ? n : 256;
-    for (size_t k = 0; k < samples; ++k) {
-        const size_t i = samples == n ? k : (k * (n - 1)) / (samples - 1);  // includes the first and the last point
-        for (int w = 0; w < 8; ++w) { h ^= bases[8 * i + w]; h *= 0x100000001b3ull; }
-    }
+    for (size_t k = 0; k < n * 8; ++k) { h ^= bases[k]; h *= 0x100000001b3ull; }
     return h;
 }
 
@@ -119,13 +253,18 @@ void bases_cache_clear() {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (BasesCacheEntry& e : g_cache) trh_bases_destroy(e.h);
     g_cache.clear();
+    for (BasesCandidate& c : g_seen) c = BasesCandidate{0, nullptr, 0, 0};
 }
+
+int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out);
+int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out);
 
 int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t* out) {
     TRH_TRY(require_init());
+    Range range(curve == TRH_PALLAS ? "trh_best_multiexp_pallas" : "trh_best_multiexp_vesta");
     if (!out || (n && (!coeffs || !bases))) { set_error("best_multiexp: null pointer"); return TRH_EINVAL; }
     if (n >= ((size_t)1 << 31)) { set_error("best_multiexp: n too large"); return TRH_EINVAL; }
-    static const int cache_on = getenv("TRH_BASES_CACHE") ? atoi(getenv("TRH_BASES_CACHE")) : 1;
+    static const int cache_on = getenv("TRH_BASES_CACHE") ? atoi(getenv("TRH_BASES_CACHE")) : 0;
     if (cache_on && n >= 1024) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         const uint64_t fp = bases_fingerprint(bases, n);
@@ -133,23 +272,37 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
         for (BasesCacheEntry& e : g_cache)
             if (e.curve == curve && e.host == (const void*)bases && e.n == n && e.fp == fp) { hit = &e; break; }
         if (!hit) {
-            if (g_cache.size() >= 8) {
-                size_t victim = 0;
-                for (size_t i = 1; i < g_cache.size(); ++i) if (g_cache[i].stamp < g_cache[victim].stamp) victim = i;
-                trh_bases_destroy(g_cache[victim].h);
-                g_cache.erase(g_cache.begin() + victim);
+            bool seen = false;
+            for (const BasesCandidate& c : g_seen) if (c.host == (const void*)bases && c.curve == curve && c.n == n && c.fp == fp) seen = true;
+            if (!seen) g_seen[g_seen_next++ % 16] = BasesCandidate{curve, bases, n, fp};
+            else {
+                if (g_cache.size() >= 8) {
+                    size_t victim = 0;
+                    for (size_t i = 1; i < g_cache.size(); ++i) if (g_cache[i].stamp < g_cache[victim].stamp) victim = i;
+                    trh_bases_destroy(g_cache[victim].h);
+                    g_cache.erase(g_cache.begin() + victim);
+                }
+                trh_bases* h = nullptr;
+                TRH_TRY(curve == TRH_PALLAS ? trh_bases_create_pallas(bases, n, &h) : trh_bases_create_vesta(bases, n, &h));
+                g_cache.push_back(BasesCacheEntry{curve, bases, n, fp, h, 0, 0});
+                hit = &g_cache.back();
             }
-            trh_bases* h = nullptr;
-            TRH_TRY(curve == TRH_PALLAS ? trh_bases_create_pallas(bases, n, &h) : trh_bases_create_vesta(bases, n, &h));
-            g_cache.push_back(BasesCacheEntry{curve, bases, n, fp, h, 0, 0});
-            hit = &g_cache.back();
         }
-        hit->stamp = ++g_cache_stamp;
-        if (++hit->uses == 4) (void)trh_bases_precompute(hit->h, 0);  // outside the supported range: stays on the per-window path
-        return trh_msm(hit->h, 0, coeffs, n, 1, out);
+        if (hit) {
+            hit->stamp = ++g_cache_stamp;
+            if (++hit->uses == 4 && hit->h->shards.empty()) (void)trh_bases_precompute(hit->h, 0);  // outside the supported range: stays on the per-window path
+            return trh_msm(hit->h, 0, coeffs, n, 1, out);
+        }
     }
+    if (g_group.size() > 1 && n >= g_shard_min && thread_ctx() == g_default) {  // device group: every GPU takes a range of the pairs
+        trh_bases* h = nullptr;
+        TRH_TRY(sharded_create(curve, bases, 0, 0, 0, n, &h));
+        const int rc = msm_sharded(h, 0, coeffs, true, n, 1, nullptr, out);
+        trh_bases_destroy(h);
+        return rc;
+    }
+    TRH_ENTER(0);
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
     DevBuf bbuf;
     TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
     int rc = bbuf.ensure(n * 64 + 64);
@@ -167,11 +320,11 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
 }
 
 int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n) {
-    TRH_TRY(require_init());
+    Range range(field == TRH_FP ? "trh_best_fft_fp" : "trh_best_fft_fq");
     if (!a || !omega) { set_error("best_fft: null pointer"); return TRH_EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
     if (log_n > 27) { set_error("best_fft: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Ctx& c = ctx();
     const size_t bytes = (size_t)32 << log_n;
     TRH_TRY(c.io.ensure(bytes));
     TRH_HIP_TRY(hipMemcpy(c.io.p, a, bytes, hipMemcpyHostToDevice));
@@ -180,20 +333,108 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     return TRH_OK;
 }
 
-int bases_create(int curve, const uint64_t* xy, size_t n, trh_bases_t* out) {
-    TRH_TRY(require_init());
-    if (!out || (n && !xy)) { set_error("bases_create: null pointer"); return TRH_EINVAL; }
+// one resident set on the entered context's device: uploaded from the host, or generated (xy == null)
+int bases_create_local(int curve, const uint64_t* xy, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out) {
     trh_bases* b = new trh_bases{curve, nullptr, n, true};
+    b->owner = &ctx();
     hipError_t e = hipMalloc(&b->d_xy, n * 64 + 64);
-    if (e == hipSuccess && n) e = hipMemcpy(b->d_xy, xy, n * 64, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n && xy) e = hipMemcpy(b->d_xy, xy, n * 64, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (b->d_xy) (void)hipFree(b->d_xy);
         delete b;
         set_error("bases_create: %s", hipGetErrorString(e));
-        return TRH_EHIP;
+        return e == hipErrorOutOfMemory ? TRH_ENOMEM : TRH_EHIP;
+    }
+    if (!xy && n) {
+        int rc = bases_generate_device(curve, s0, d, first, n, b->d_xy, 0);
+        if (rc == TRH_OK && hipStreamSynchronize(0) != hipSuccess) { set_error("bases_generate: kernel failed"); rc = TRH_EHIP; }
+        if (rc != TRH_OK) { (void)hipFree(b->d_xy); delete b; return rc; }
     }
     *out = b;
     return TRH_OK;
+}
+
+// ---- range-sharded base sets over the device group (trh_init_multi) ---------------------------------------------------
+// Shard g of G owns the pairs [g * per, (g + 1) * per) (per = ceil(n / G)) on the group's g-th context -- the partition
+// best_multiexp itself makes per rayon thread.  An MSM enqueues one local Pippenger per shard on that context's own stream from
+// the calling host thread, then collects the G partial points with plain device-to-host copies into pinned memory and adds them
+// on the host (point_sum_host).  No RCCL here: EC addition is not a reduce op, the payload is 96 B per GPU, the result is
+// consumed by the host (transcript), and everything happens inside ONE process -- a collective would only add a rendezvous.
+// (bench.py's process-per-GPU harness does use RCCL's all_gather for the same 96-byte partials: there the ranks are processes.)
+int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out) {
+    const size_t G = g_group.size();
+    std::unique_ptr<trh_bases> B(new trh_bases{curve, nullptr, n, true});
+    B->owner = g_default;
+    const size_t per = (n + G - 1) / G;
+    B->shard_off.push_back(0);
+    for (size_t g = 0; g < G; ++g) {
+        const size_t lo = g * per < n ? g * per : n, hi = lo + per < n ? lo + per : n;
+        trh_bases* sh = nullptr;
+        int rc;
+        {
+            Enter en;
+            rc = en.begin(nullptr, g_group[g]);
+            if (rc == TRH_OK) rc = bases_create_local(curve, xy_host ? xy_host + 8 * lo : nullptr, s0, d, first + lo, hi - lo, &sh);
+        }
+        if (rc != TRH_OK) { for (trh_bases* q : B->shards) trh_bases_destroy(q); return rc; }
+        B->shards.push_back(sh);
+        B->shard_off.push_back(hi);
+    }
+    *out = B.release();
+    return TRH_OK;
+}
+
+const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s);
+const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n);
+
+int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out) {
+    Range range("trh_msm[sharded]");
+    const size_t G = B->shards.size();
+    int src_device = -1;
+    hipEvent_t ready = nullptr;
+    if (!scalars_on_host && n) {  // device scalars live where the caller's context is: the shards copy their range over xGMI once the caller's stream got there
+        Enter en;
+        TRH_TRY(en.begin(caller_stream));
+        src_device = ctx().device;
+        ready = ctx().order_ev;  // recorded below on caller_stream; the context stays locked until the shard streams were told to wait for it
+        TRH_HIP_TRY(hipEventRecord(ready, caller_stream));
+        for (size_t g = 0; g < G; ++g) TRH_HIP_TRY(hipStreamWaitEvent(B->shards[g]->owner->own_stream, ready, 0));
+        en.outermost = false;  // order_ev was just recorded by hand
+        ctx().last_stream = caller_stream; ctx().last_stream_valid = true;
+    }
+    // lock the shard contexts in group order (every sharded call takes them in this order), enqueue everywhere, then collect
+    std::vector<std::unique_ptr<Enter>> held(G);
+    std::vector<uint64_t> partial(12 * G, 0);
+    std::vector<char> active(G, 0);
+    for (size_t g = 0; g < G; ++g) {
+        const size_t lo = B->shard_off[g] > offset ? B->shard_off[g] : offset;
+        const size_t hi = B->shard_off[g + 1] < offset + n ? B->shard_off[g + 1] : offset + n;
+        if (hi <= lo) continue;
+        trh_bases* sh = B->shards[g];
+        Ctx* sc = sh->owner;
+        held[g].reset(new Enter());
+        TRH_TRY(held[g]->begin(sc->own_stream, sc));
+        const size_t cnt = hi - lo, local = lo - B->shard_off[g];
+        TRH_TRY(sc->msm.scalars.ensure(cnt * 32 + 32));
+        const char* src = (const char*)scalars + (lo - offset) * 32;
+        if (scalars_on_host) TRH_HIP_TRY(hipMemcpyAsync(sc->msm.scalars.p, src, cnt * 32, hipMemcpyHostToDevice, sc->own_stream));
+        else if (src_device == sc->device) TRH_HIP_TRY(hipMemcpyAsync(sc->msm.scalars.p, src, cnt * 32, hipMemcpyDeviceToDevice, sc->own_stream));
+        else TRH_HIP_TRY(hipMemcpyPeerAsync(sc->msm.scalars.p, sc->device, src, src_device, cnt * 32, sc->own_stream));
+        TRH_TRY(msm_enqueue(B->curve, (const char*)sh->d_xy + local * 64, lazy_bases(sh, local, sc->own_stream), sc->msm.scalars.p, cnt, 1, cnt, mont, sc->own_stream,
+                            fixed_base(sh, local, cnt)));
+        active[g] = 1;
+    }
+    size_t cntp = 0;
+    for (size_t g = 0; g < G; ++g) {
+        if (!active[g]) continue;
+        Ctx* sc = B->shards[g]->owner;
+        Enter en;
+        TRH_TRY(en.begin(sc->own_stream, sc));  // re-entrant: the context is still held above, this makes it the active one again
+        TRH_TRY(msm_finish(B->curve, sc->own_stream, partial.data() + 12 * cntp, 1));
+        ++cntp;
+    }
+    held.clear();
+    return point_sum_host(B->curve, partial.data(), cntp, out);
 }
 
 }  // namespace
@@ -203,7 +444,7 @@ using namespace trh;
 
 extern "C" {
 
-const char* trh_version(void) { return "trh 0.1.0 (gfx950)"; }
+const char* trh_version(void) { return "trh 0.2.0 (gfx950, build " TRH_BUILD_ID ")"; }
 const char* trh_last_error(void) { return g_err; }
 
 int trh_device_count(void) {
@@ -213,44 +454,90 @@ int trh_device_count(void) {
 }
 
 int trh_init(int device) {
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (c.inited) {
-        if (c.device == device) return TRH_OK;
-        set_error("trh_init: already bound to device %d", c.device);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_default) {
+        if (g_default->device == device) return TRH_OK;
+        set_error("trh_init: already bound to device %d", g_default->device);
         return TRH_EINVAL;
     }
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) { set_error("trh_init: no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e)); return TRH_ENODEV; }
-    if (device < 0 || device >= n) { set_error("trh_init: device %d out of range [0, %d)", device, n); return TRH_EINVAL; }
-    TRH_HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    TRH_HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("trh_init: device is %s, libtrh is built for gfx950 only", prop.gcnArchName); return TRH_ENODEV; }
-    c.device = device;
-    c.inited = true;
+    Ctx* c = nullptr;
+    int rc = create_ctx(device, &c);
+    if (rc != TRH_OK) {
+        char msg[400];
+        snprintf(msg, sizeof(msg), "%s", g_err);
+        set_error("trh_init: %s", msg);
+        return rc;
+    }
+    g_default = c;
+    g_group.assign(1, c);
     return TRH_OK;
 }
 
+int trh_init_multi(const int* devices, int n_devices) {
+    if (!devices || n_devices < 1 || n_devices > 64) { set_error("trh_init_multi: bad arguments"); return TRH_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_default) {
+        bool same = g_group.size() == (size_t)n_devices;
+        for (int i = 0; same && i < n_devices; ++i) same = g_group[i]->device == devices[i];
+        if (same) return TRH_OK;
+        set_error("trh_init_multi: already initialised with another device list (trh_shutdown first)");
+        return TRH_EINVAL;
+    }
+    std::vector<Ctx*> made;
+    for (int i = 0; i < n_devices; ++i) {  // the same device may be listed more than once: two lanes on one GPU
+        Ctx* c = nullptr;
+        const int rc = create_ctx(devices[i], &c);
+        if (rc != TRH_OK) {
+            for (Ctx* m : made) destroy_ctx(m);
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", g_err);
+            set_error("trh_init_multi: %s", msg);
+            return rc;
+        }
+        made.push_back(c);
+    }
+    for (int i = 0; i < n_devices; ++i)  // peer access for the scalar hand-over of device-resident scalars (best effort: the copy API works without it)
+        for (int j = 0; j < n_devices; ++j)
+            if (devices[i] != devices[j]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    int cur = -1;
+                    (void)hipGetDevice(&cur);
+                    if (hipSetDevice(devices[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
+                    if (cur >= 0) (void)hipSetDevice(cur);
+                }
+            }
+    g_group = made;
+    g_default = made[0];
+    return TRH_OK;
+}
+int trh_group_size(void) { return (int)g_group.size(); }
+int trh_set_shard_min(size_t n_pairs) { g_shard_min = n_pairs ? n_pairs : 1; return TRH_OK; }
+
 void trh_shutdown(void) {
-    bases_cache_clear();  // before the context lock: the cache lock is always taken first
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (!c.inited) return;
-    (void)hipDeviceSynchronize();
-    msm_release();
-    lookup_release();
-    ntt_release_tables();
-    for (DevBuf& d : ctx().ipa) d.release();
-    c.io.release();
-    c.factors.release();
-    if (c.pinned_ring) { (void)hipHostFree(c.pinned_ring); c.pinned_ring = nullptr; c.pinned_slot = 0; }
-    if (c.pinned_land) { (void)hipHostFree(c.pinned_land); c.pinned_land = nullptr; }
-    c.pfft.release();
-    c.scan.release(); c.scan2.release();
-    c.inited = false;
-    c.device = -1;
+    bases_cache_clear();  // before the registry lock: destroying a cached set enters its context
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (Ctx* c : g_group) destroy_ctx(c);
+    g_group.clear();
+    g_default = nullptr;
+}
+
+int trh_ctx_create(int device, trh_ctx_t* out) {
+    if (!out) { set_error("ctx_create: null pointer"); return TRH_EINVAL; }
+    Ctx* c = nullptr;
+    TRH_TRY(create_ctx(device, &c));
+    *out = static_cast<trh_ctx*>(c);
+    return TRH_OK;
+}
+void trh_ctx_destroy(trh_ctx_t c) { destroy_ctx(c); }
+int trh_ctx_set_current(trh_ctx_t c) {
+    if (c && !c->inited) { set_error("ctx_set_current: destroyed context"); return TRH_EINVAL; }
+    t_bound = c;
+    return TRH_OK;
+}
+int trh_ctx_device(trh_ctx_t c) {
+    Ctx* cc = c ? (Ctx*)c : thread_ctx();
+    return cc ? cc->device : -1;
 }
 
 int trh_best_multiexp_pallas(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out[12]) { return best_multiexp_host(TRH_PALLAS, coeffs, bases, n, out); }
@@ -258,14 +545,23 @@ int trh_best_multiexp_vesta(const uint64_t* coeffs, const uint64_t* bases, size_
 int trh_best_fft_fp(uint64_t* a, const uint64_t omega[4], uint32_t log_n) { return best_fft_host(TRH_FP, a, omega, log_n); }
 int trh_best_fft_fq(uint64_t* a, const uint64_t omega[4], uint32_t log_n) { return best_fft_host(TRH_FQ, a, omega, log_n); }
 
+static int bases_create(int curve, const uint64_t* xy, size_t n, trh_bases_t* out) {
+    TRH_TRY(require_init());
+    if (!out || (n && !xy)) { set_error("bases_create: null pointer"); return TRH_EINVAL; }
+    if (g_group.size() > 1 && n >= g_shard_min && thread_ctx() == g_default) return sharded_create(curve, xy, 0, 0, 0, n, out);
+    TRH_ENTER(0);
+    return bases_create_local(curve, xy, 0, 0, 0, n, out);
+}
 int trh_bases_create_pallas(const uint64_t* xy, size_t n, trh_bases_t* out) { return bases_create(TRH_PALLAS, xy, n, out); }
 int trh_bases_create_vesta(const uint64_t* xy, size_t n, trh_bases_t* out) { return bases_create(TRH_VESTA, xy, n, out); }
 
 int trh_bases_wrap_device(int curve, const void* xy_dev, size_t n, trh_bases_t* out) {
-    TRH_TRY(require_init());
     TRH_TRY(check_curve(curve));
     if (!out || (n && !xy_dev)) { set_error("bases_wrap_device: null pointer"); return TRH_EINVAL; }
-    *out = new trh_bases{curve, (void*)xy_dev, n, false};
+    TRH_ENTER(0);
+    trh_bases* b = new trh_bases{curve, (void*)xy_dev, n, false};
+    b->owner = &ctx();
+    *out = b;
     return TRH_OK;
 }
 
@@ -273,34 +569,43 @@ int trh_bases_generate(int curve, uint64_t s0, uint64_t d, uint64_t first, size_
     TRH_TRY(require_init());
     TRH_TRY(check_curve(curve));
     if (!out) { set_error("bases_generate: null pointer"); return TRH_EINVAL; }
-    trh_bases* b = new trh_bases{curve, nullptr, n, true};
-    hipError_t e = hipMalloc(&b->d_xy, n * 64 + 64);
-    if (e != hipSuccess) { delete b; set_error("bases_generate: %s", hipGetErrorString(e)); return TRH_ENOMEM; }
-    int rc = bases_generate_device(curve, s0, d, first, n, b->d_xy, 0);
-    if (rc == TRH_OK && hipStreamSynchronize(0) != hipSuccess) { set_error("bases_generate: kernel failed"); rc = TRH_EHIP; }
-    if (rc != TRH_OK) { (void)hipFree(b->d_xy); delete b; return rc; }
-    *out = b;
-    return TRH_OK;
+    if (g_group.size() > 1 && n >= g_shard_min && thread_ctx() == g_default) return sharded_create(curve, nullptr, s0, d, first, n, out);
+    TRH_ENTER(0);
+    return bases_create_local(curve, nullptr, s0, d, first, n, out);
 }
 
 int trh_bases_download(trh_bases_t b, size_t offset, size_t n, uint64_t* xy_host) {
-    TRH_TRY(require_init());
     if (!b || !xy_host || offset + n > b->n) { set_error("bases_download: bad range"); return TRH_EINVAL; }
+    if (!b->shards.empty()) {
+        for (size_t g = 0; g < b->shards.size(); ++g) {
+            const size_t lo = b->shard_off[g] > offset ? b->shard_off[g] : offset;
+            const size_t hi = b->shard_off[g + 1] < offset + n ? b->shard_off[g + 1] : offset + n;
+            if (hi > lo) TRH_TRY(trh_bases_download(b->shards[g], lo - b->shard_off[g], hi - lo, xy_host + 8 * (lo - offset)));
+        }
+        return TRH_OK;
+    }
+    TRH_ENTER_CTX(0, b->owner);
     TRH_HIP_TRY(hipMemcpy(xy_host, (const char*)b->d_xy + offset * 64, n * 64, hipMemcpyDeviceToHost));
     return TRH_OK;
 }
 const void* trh_bases_device_ptr(trh_bases_t b) { return b ? b->d_xy : nullptr; }
 size_t trh_bases_len(trh_bases_t b) { return b ? b->n : 0; }
+int trh_bases_shards(trh_bases_t b) { return b ? (b->shards.empty() ? 1 : (int)b->shards.size()) : 0; }
 void trh_bases_destroy(trh_bases_t b) {
     if (!b) return;
+    for (trh_bases* sh : b->shards) trh_bases_destroy(sh);
     if (b->owned && b->d_xy) (void)hipFree(b->d_xy);
     if (b->d_z) (void)hipFree(b->d_z);
     if (b->d_table) (void)hipFree(b->d_table);
     delete b;
 }
 
+}  // extern "C"
+
+namespace trh {
+namespace {
 // owned base sets are immutable: convert them to the lazy Montgomery domain once and keep the copy
-static const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
+const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
     if (!b->owned || b->n == 0) return nullptr;
     if (!b->d_z) {
         void* z = nullptr;
@@ -312,16 +617,34 @@ static const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
 }
 
 // the fixed-base table covers the whole set: used for full-range MSMs unless a window width is forced
-static const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n) {
+const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n) {
     return (b->d_table && offset == 0 && n == b->n && ctx().window_override == 0) ? &b->fb : nullptr;
 }
 
-int trh_bases_precompute(trh_bases_t b, int window_bits) {
+int msm_args(trh_bases_t bases, size_t offset, const void* scalars, size_t n, size_t batch, void* out) {
     TRH_TRY(require_init());
+    if (!bases || !out || (n && !scalars)) { set_error("msm: null pointer"); return TRH_EINVAL; }
+    if (offset + n > bases->n || offset + n < offset) { set_error("msm: range [%zu, %zu) exceeds the %zu resident bases", offset, offset + n, bases->n); return TRH_EINVAL; }
+    if (n >= ((size_t)1 << 31)) { set_error("msm: n too large"); return TRH_EINVAL; }
+    if (batch == 0) { set_error("msm: batch == 0"); return TRH_EINVAL; }
+    return TRH_OK;
+}
+int single_device(trh_bases_t bases, const char* what) {
+    if (!bases->shards.empty()) { set_error("%s: needs a base set on ONE device (this handle is range-sharded over %zu)", what, bases->shards.size()); return TRH_EINVAL; }
+    if (bases->owner && bases->owner->device != ctx().device) { set_error("%s: the base set lives on device %d, the calling context on device %d", what, bases->owner->device, ctx().device); return TRH_EINVAL; }
+    return TRH_OK;
+}
+}  // namespace
+}  // namespace trh
+
+extern "C" {
+
+int trh_bases_precompute(trh_bases_t b, int window_bits) {
     if (!b) { set_error("bases_precompute: null handle"); return TRH_EINVAL; }
     if (!b->owned) { set_error("bases_precompute: wrapped device memory may change under the table; create an owned set"); return TRH_EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    if (!b->shards.empty()) { set_error("bases_precompute: range-sharded sets keep the per-window path"); return TRH_EINVAL; }
+    TRH_ENTER_CTX(0, b->owner);
+    Range range("trh_bases_precompute");
     if (b->d_table) { (void)hipFree(b->d_table); b->d_table = nullptr; b->fb = MsmFixedBase{nullptr, 0, 0}; }
     if (b->n == 0) return TRH_OK;
     int cb = window_bits;
@@ -344,19 +667,13 @@ int trh_bases_precompute(trh_bases_t b, int window_bits) {
 }
 int trh_bases_precomputed_window_bits(trh_bases_t b) { return b && b->d_table ? b->fb.c : 0; }
 
-static int msm_args(trh_bases_t bases, size_t offset, const void* scalars, size_t n, size_t batch, void* out) {
-    TRH_TRY(require_init());
-    if (!bases || !out || (n && !scalars)) { set_error("msm: null pointer"); return TRH_EINVAL; }
-    if (offset + n > bases->n || offset + n < offset) { set_error("msm: range [%zu, %zu) exceeds the %zu resident bases", offset, offset + n, bases->n); return TRH_EINVAL; }
-    if (n >= ((size_t)1 << 31)) { set_error("msm: n too large"); return TRH_EINVAL; }
-    if (batch == 0) { set_error("msm: batch == 0"); return TRH_EINVAL; }
-    return TRH_OK;
-}
-
 int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n, int mont, uint64_t out[12]) {
     TRH_TRY(msm_args(bases, offset, scalars_host, n, 1, out));
+    if (!bases->shards.empty()) return msm_sharded(bases, offset, scalars_host, true, n, mont, nullptr, out);
+    TRH_ENTER(0);
+    Range range("trh_msm");
+    TRH_TRY(single_device(bases, "msm"));
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
     TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
     if (n) TRH_HIP_TRY(hipMemcpy(c.msm.scalars.p, scalars_host, n * 32, hipMemcpyHostToDevice));
     TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, 0), c.msm.scalars.p, n, 1, n, mont, 0, fixed_base(bases, offset, n)));
@@ -366,28 +683,37 @@ int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream) {
     uint64_t dummy;
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, &dummy));
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
-    return msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n));
+    TRH_ENTER(stream);
+    Range range("trh_msm_dev_enqueue");
+    TRH_TRY(single_device(bases, "msm_dev_enqueue"));
+    if (ctx().msm.pending_curve >= 0) { set_error("msm_dev_enqueue: this context already has an MSM in flight (finish it, or use a second context: trh_ctx_create)"); return TRH_EBUSY; }
+    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
+    ctx().msm.pending_owner = bases;
+    return TRH_OK;
 }
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out[12]) {
-    TRH_TRY(require_init());
     if (!bases || !out) { set_error("msm_dev_finish: null pointer"); return TRH_EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_ENTER(stream);
+    Range range("trh_msm_dev_finish");
+    if (ctx().msm.pending_curve < 0 || ctx().msm.pending_owner != (const void*)bases) { set_error("msm_dev_finish: no MSM over this base set is in flight on the calling context"); return TRH_EINVAL; }
     return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
 }
 int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream, uint64_t out[12]) {
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, 1, out));
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    if (!bases->shards.empty()) return msm_sharded(bases, offset, scalars_dev, false, n, mont, (hipStream_t)stream, out);
+    TRH_ENTER(stream);
+    Range range("trh_msm_dev");
+    TRH_TRY(single_device(bases, "msm_dev"));
+    if (ctx().msm.pending_curve >= 0) { set_error("msm_dev: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
     TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, 1, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, (hipStream_t)stream, out, 1);
 }
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch, int mont, void* stream, uint64_t* out) {
     TRH_TRY(msm_args(bases, offset, scalars_dev, n, batch, out));
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_ENTER(stream);
+    Range range("trh_msm_batch_dev");
+    TRH_TRY(single_device(bases, "msm_batch_dev"));
+    if (ctx().msm.pending_curve >= 0) { set_error("msm_batch_dev: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
     TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, (hipStream_t)stream), scalars_dev, n, batch, n, mont, (hipStream_t)stream, fixed_base(bases, offset, n)));
     return msm_finish(bases->curve, (hipStream_t)stream, out, batch);
 }
@@ -397,8 +723,11 @@ int trh_commit_batch_dev(trh_bases_t bases, const void* polys_dev, size_t n, siz
     TRH_TRY(msm_args(bases, 0, polys_dev, n + 1, batch, out));
     if (!blinds_host) { set_error("commit_batch: null blinds"); return TRH_EINVAL; }
     if (bases->n != n + 1) { set_error("commit_batch: the handle must hold n + 1 = %zu bases (g or g_lagrange followed by w), it holds %zu", n + 1, bases->n); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_commit_batch_dev");
+    TRH_TRY(single_device(bases, "commit_batch_dev"));
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.msm.pending_curve >= 0) { set_error("commit_batch_dev: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
     hipStream_t s = (hipStream_t)stream;
     TRH_TRY(c.msm.tails.ensure(batch * 32));
     TRH_HIP_TRY(hipMemcpyAsync(c.msm.tails.p, blinds_host, batch * 32, hipMemcpyHostToDevice, s));
@@ -409,7 +738,14 @@ int trh_commit_batch_dev(trh_bases_t bases, const void* polys_dev, size_t n, siz
 
 int trh_msm_set_window_bits(int cbits) {
     if (cbits != 0 && (cbits < 2 || cbits > 18)) { set_error("window bits must be 0 or in [2, 18]"); return TRH_EINVAL; }
-    ctx().window_override = cbits;
+    TRH_TRY(require_init());
+    if (g_group.size() > 1 && thread_ctx() == g_default) {  // the group's shards follow the default context
+        for (Ctx* g : g_group) { std::lock_guard<std::recursive_mutex> lk(g->mu); g->window_override = cbits; }
+        return TRH_OK;
+    }
+    Ctx* c = thread_ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    c->window_override = cbits;
     return TRH_OK;
 }
 
@@ -420,20 +756,18 @@ int trh_point_sum(int curve, const uint64_t* pts, size_t count, uint64_t out[12]
 }
 
 int trh_ntt_dev(int field, void* a_dev, uint32_t log_n, const uint64_t omega[4], size_t batch, void* stream) {
-    TRH_TRY(require_init());
     TRH_TRY(check_field(field));
     if (!a_dev || !omega) { set_error("ntt_dev: null pointer"); return TRH_EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    TRH_ENTER(stream);
+    Range range("trh_ntt_dev");
     return ntt_device(field, a_dev, log_n, omega, batch, (hipStream_t)stream);
 }
 
 int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const uint64_t* factors, uint32_t period, void* stream) {
-    TRH_TRY(require_init());
     TRH_TRY(check_field(field));
     if (!a_dev || !factors || period == 0 || period > 64 || active_len > row_len) { set_error("field_scale: bad arguments"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
     // factors are staged in a small ring so that back-to-back calls on one stream do not overwrite
     // a table a queued kernel still reads
     TRH_TRY(c.factors.ensure(16 * 64 * 32));
@@ -450,8 +784,8 @@ int trh_field_scale_dev(int field, void* a_dev, size_t n, const uint64_t factor[
 }
 
 int trh_field_op_dev(int field, int op, const void* a, const void* b, void* out, size_t n, void* stream) {
-    TRH_TRY(require_init());
     TRH_TRY(check_field(field));
+    TRH_ENTER(stream);
     if (!n) return TRH_OK;
     const unsigned gb = (unsigned)((n + 255) / 256);
     if (field == TRH_FP) hipLaunchKernelGGL((field_op_kernel<FpParams>), dim3(gb), dim3(256), 0, (hipStream_t)stream, op, (const uint4*)a, (const uint4*)b, (uint4*)out, n);
@@ -460,8 +794,8 @@ int trh_field_op_dev(int field, int op, const void* a, const void* b, void* out,
     return TRH_OK;
 }
 int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out, size_t n, void* stream) {
-    TRH_TRY(require_init());
     TRH_TRY(check_curve(curve));
+    TRH_ENTER(stream);
     if (!n) return TRH_OK;
     const unsigned gb = (unsigned)((n + 63) / 64);
     if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_kernel<FpParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
@@ -471,37 +805,46 @@ int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out,
 }
 
 int trh_malloc(void** dev, size_t bytes) {
-    TRH_TRY(require_init());
     if (!dev) { set_error("trh_malloc: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
     hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
     if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
     return TRH_OK;
 }
 int trh_free(void* dev) {
-    TRH_TRY(require_init());
+    TRH_ENTER(0);
     TRH_HIP_TRY(hipFree(dev));
     return TRH_OK;
 }
 int trh_memcpy_h2d(void* dev, const void* host, size_t bytes) {
-    TRH_TRY(require_init());
+    TRH_ENTER(0);
     TRH_HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     return TRH_OK;
 }
 int trh_memcpy_d2h(void* host, const void* dev, size_t bytes) {
-    TRH_TRY(require_init());
+    TRH_ENTER(0);
     TRH_HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return TRH_OK;
 }
 int trh_stream_synchronize(void* stream) {
-    TRH_TRY(require_init());
+    TRH_ENTER(stream);
     TRH_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return TRH_OK;
 }
 
-int trh_set_timing(int enabled) { ctx().timing = enabled; return TRH_OK; }
+int trh_set_timing(int enabled) {
+    TRH_TRY(require_init());
+    Ctx* c = thread_ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    c->timing = enabled;
+    return TRH_OK;
+}
 int trh_last_timing(trh_timing_t* out) {
     if (!out) { set_error("last_timing: null pointer"); return TRH_EINVAL; }
-    *out = ctx().last;
+    TRH_TRY(require_init());
+    Ctx* c = thread_ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    *out = c->last;
     return TRH_OK;
 }
 

@@ -1,4 +1,11 @@
-// Process-wide device context of libtrh: error reporting, grow-only scratch buffers, timing.
+// Device contexts of libtrh: error reporting, grow-only scratch buffers, timing.
+//
+// A context (Ctx) is bound to ONE device and owns every scratch buffer, table cache and pending state the entry points use,
+// behind one lock.  trh_init() creates the process default; trh_ctx_create() makes further ones (a second lane on the same
+// GPU so that two host threads overlap an MSM with an NTT, or one per GPU); trh_init_multi() makes the device group the
+// range-sharded base sets run on.  Every extern "C" entry point opens with TRH_ENTER(stream): it resolves the calling thread's
+// context, takes its lock, makes its device current for this thread (hipSetDevice is per thread: rayon workers never
+// called trh_init) and orders the caller's stream behind the last stream that used the context's scratch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -87,6 +94,8 @@ struct MsmScratch {
     // state of the enqueued-but-not-finished MSM
     int pending_curve = -1, pending_windows = 0, pending_c = 0;
     size_t pending_batch = 0;
+    hipStream_t pending_stream = nullptr;  // the finish must name the stream (and, through the C ABI, the base set) of its enqueue
+    const void* pending_owner = nullptr;
     // an MSM beyond MSM_TILE pairs runs as range tiles: the sum of the finished tiles (normalised Jacobian), added by msm_finish
     bool tile_sum_valid = false, in_tile = false;
     u64 tile_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -95,7 +104,7 @@ struct MsmScratch {
 };
 
 struct Ctx {
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: an entry point may call another one (and a transcript callback may call host-side helpers)
     bool inited = false;
     int device = -1;
     int timing = 0;
@@ -114,10 +123,42 @@ struct Ctx {
     unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;
+    void* lookup_scratch = nullptr;  // lookup.hip's buffers (opaque here)
+    unsigned attr_done = 0;          // hipFuncSetAttribute is per device: bit per kernel family already configured for this context's device
+    hipStream_t own_stream = nullptr;  // the multi-device MSM driver enqueues this context's shard here
+    // scratch is shared by every stream that enters this context: a call on another stream than the previous one waits for it
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t order_ev = nullptr;
 };
+enum { ATTR_MSM = 1u, ATTR_NTT = 2u, ATTR_EXPR = 4u };
 
-Ctx& ctx();
+Ctx& ctx();  // the context entered (TRH_ENTER) by the calling thread
 int require_init();
+
+// Scope of one entry point: resolve the thread's context (trh_ctx_set_current, else the process default of trh_init), lock it,
+// make its device current for the calling thread, order `stream` behind the context's previous stream.
+struct Enter {
+    Ctx* c = nullptr;
+    Ctx* prev_active = nullptr;
+    int prev_device = -1;
+    bool locked = false, outermost = false;
+    hipStream_t entered_stream = nullptr;
+    int begin(hipStream_t stream, Ctx* explicit_ctx = nullptr);
+    ~Enter();
+};
+#define TRH_ENTER(stream)  \
+    ::trh::Enter _trh_enter; \
+    TRH_TRY(_trh_enter.begin((hipStream_t)(stream)))
+#define TRH_ENTER_CTX(stream, cptr)  \
+    ::trh::Enter _trh_enter; \
+    TRH_TRY(_trh_enter.begin((hipStream_t)(stream), (cptr)))
+
+// roctx range around a primitive (rocprofv3 --marker-trace); resolved with dlopen, a no-op when the library is absent
+struct Range {
+    explicit Range(const char* name);
+    ~Range();
+};
 
 // ntt.hip
 // pointwise steps of EvaluationDomain fused into the first / last pass of a transform (lazy passes only:
@@ -162,4 +203,9 @@ struct trh_bases {
     void* d_z = nullptr;  // owned (immutable) sets: the bases converted once to the lazy Montgomery domain
     void* d_table = nullptr;  // trh_bases_precompute: W x n shifted copies (see MsmFixedBase)
     trh::MsmFixedBase fb{nullptr, 0, 0};
+    trh::Ctx* owner = nullptr;  // the context (device) the memory lives on
+    // range-sharded set (trh_init_multi): shard g holds bases [shard_off[g], shard_off[g + 1]) on its own context's device;
+    // d_xy is null and the per-shard handles carry the device memory
+    std::vector<trh_bases*> shards;
+    std::vector<size_t> shard_off;
 };

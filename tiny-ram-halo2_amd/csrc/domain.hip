@@ -22,6 +22,7 @@ struct trh_domain {
     std::vector<trh::FeMem> t_inv;            // (X^n - 1)^-1 on the coset, period 2^(extended_k - k)
     void* d_tables = nullptr;                  // device copy: into_coset[3], from_coset[3], divisors[2], t_inv[...], then the lazy-form block
     trh::FeMem z_into[3], z_idiv, z_from_div[3];  // lazy Montgomery form (x 2^270) for the steps fused into the NTT passes
+    int device = -1;                           // the tables live on this device
 };
 
 namespace trh {
@@ -99,7 +100,13 @@ int upload_tables(trh_domain* d) {
     t[T_ZIDIV] = d->z_idiv;
     for (size_t i = 0; i < d->t_inv.size(); ++i) t[T_TINV + i] = d->t_inv[i];
     TRH_HIP_TRY(hipMalloc(&d->d_tables, t.size() * sizeof(FeMem)));
-    TRH_HIP_TRY(hipMemcpy(d->d_tables, t.data(), t.size() * sizeof(FeMem), hipMemcpyHostToDevice));
+    const hipError_t e = hipMemcpy(d->d_tables, t.data(), t.size() * sizeof(FeMem), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d->d_tables);
+        d->d_tables = nullptr;
+        set_error("domain_create: table upload failed: %s", hipGetErrorString(e));
+        return TRH_EHIP;
+    }
     return TRH_OK;
 }
 const FeMem* tab(const trh_domain* d, int idx) { return (const FeMem*)d->d_tables + idx; }
@@ -107,6 +114,7 @@ const FeMem* tab(const trh_domain* d, int idx) { return (const FeMem*)d->d_table
 int check(const trh_domain* d, const void* a) {
     TRH_TRY(require_init());
     if (!d || !a) { set_error("domain: null pointer"); return TRH_EINVAL; }
+    if (d->device != ctx().device) { set_error("domain: created on device %d, called from a context on device %d", d->device, ctx().device); return TRH_EINVAL; }
     return TRH_OK;
 }
 
@@ -128,6 +136,9 @@ int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain** out) {
     if (ek > 27) { delete d; set_error("domain_create: extended_k %u > 27 unsupported", ek); return TRH_EINVAL; }
     d->extended_k = ek;
     if (field == TRH_FP) build_domain<FpParams>(d); else build_domain<FqParams>(d);
+    TRH_ENTER(0);
+    Range range("trh_domain_create");
+    d->device = ctx().device;
     int rc = upload_tables(d);
     if (rc != TRH_OK) { delete d; return rc; }
     *out = d;
@@ -151,8 +162,10 @@ int trh_domain_constant(trh_domain* d, int which, uint64_t out[4]) {
 /* EvaluationDomain::lagrange_to_coeff: iFFT with omega^-1, then * 2^-k; batch polynomials of 2^k, in place */
 int trh_domain_lagrange_to_coeff(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
+    TRH_ENTER(stream);
+    Range range("trh_domain_lagrange_to_coeff");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (ntt_can_fuse(d->k)) {  // x 2^-k on the final store of the last pass
         NttFusion fu;
         fu.post = tab(d, T_ZIDIV); fu.post_period = 1;
@@ -166,8 +179,10 @@ int trh_domain_lagrange_to_coeff(trh_domain* d, void* a_dev, size_t batch, void*
 int trh_domain_coeff_to_extended(trh_domain* d, const void* coeff_dev, void* ext_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, coeff_dev));
     if (!ext_dev) { set_error("domain: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_domain_coeff_to_extended");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     const size_t n = (size_t)1 << d->k, N = (size_t)1 << d->extended_k, total = batch * N;
     if (ntt_can_fuse(d->extended_k)) {  // zero-padding and the zeta-coset shift happen on the loads of pass 0 (which also skips the stages that only see zeros)
         NttFusion fu;
@@ -187,8 +202,10 @@ int trh_domain_coeff_to_extended(trh_domain* d, const void* coeff_dev, void* ext
  * (the caller truncates each polynomial to n * (j - 1) coefficients as the Rust code does) */
 int trh_domain_extended_to_coeff(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
+    TRH_ENTER(stream);
+    Range range("trh_domain_extended_to_coeff");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     const size_t N = (size_t)1 << d->extended_k;
     if (ntt_can_fuse(d->extended_k)) {  // 2^-extended_k * zeta^-(i mod 3) on the final store
         NttFusion fu;
@@ -202,8 +219,10 @@ int trh_domain_extended_to_coeff(trh_domain* d, void* a_dev, size_t batch, void*
 /* EvaluationDomain::divide_by_vanishing_poly: a[i] *= t_inv[i % 2^(extended_k - k)] */
 int trh_domain_divide_by_vanishing_poly(trh_domain* d, void* a_dev, size_t batch, void* stream) {
     TRH_TRY(check(d, a_dev));
+    TRH_ENTER(stream);
+    Range range("trh_domain_divide_by_vanishing_poly");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     const size_t N = (size_t)1 << d->extended_k;
     return field_scale_periodic(d->field, a_dev, batch, N, N, tab(d, T_TINV), (u32)d->t_inv.size(), (hipStream_t)stream);
 }

@@ -216,8 +216,10 @@ int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, cons
     e->field = field; e->n_insn = (uint32_t)n_insn; e->n_columns = (uint32_t)n_columns; e->n_outputs = (uint32_t)n_outputs;
     e->n_consts = (uint32_t)n_consts; e->lds_slots = slots;
     e->h_ptrs.resize(n_columns + n_outputs);
+    TRH_ENTER(0);
+    Range range("trh_expr_create");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     hipError_t err = hipMalloc(&e->d_prog, n_insn * sizeof(DevInsn));
     if (err == hipSuccess) err = hipMalloc(&e->d_consts, (n_consts ? n_consts : 1) * 32);
     if (err == hipSuccess) err = hipMalloc(&e->d_ptrs, (n_columns + n_outputs) * sizeof(void*));
@@ -231,11 +233,10 @@ int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, cons
         delete e;
         return TRH_EHIP;
     }
-    static bool attr = false;
-    if (!attr) {
+    if (!(ctx().attr_done & ATTR_EXPR)) {  // per device
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)expr_eval_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)expr_eval_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        ctx().attr_done |= ATTR_EXPR;
     }
     *out = e;
     return TRH_OK;
@@ -255,8 +256,10 @@ uint32_t trh_expr_lds_slots(trh_expr* e) { return e ? e->lds_slots : 0; }
 int trh_expr_set_const(trh_expr* e, uint32_t index, const uint64_t value[4]) {
     TRH_TRY(require_init());
     if (!e || !value || index >= e->n_consts) { set_error("expr_set_const: bad arguments"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_expr_set_const");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     TRH_HIP_TRY(hipMemcpy((char*)e->d_consts + (size_t)index * 32, value, 32, hipMemcpyHostToDevice));
     return TRH_OK;
 }
@@ -273,8 +276,10 @@ int trh_expr_eval_dev(trh_expr* e, const void* const* columns_dev, void* const* 
         if (!outputs_dev[i]) { set_error("expr_eval: output %u is null", i); return TRH_EINVAL; }
         e->h_ptrs[e->n_columns + i] = outputs_dev[i];
     }
+    TRH_ENTER(stream);
+    Range range("trh_expr_eval_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     hipStream_t s = (hipStream_t)stream;
     TRH_HIP_TRY(hipMemcpyAsync(e->d_ptrs, e->h_ptrs.data(), e->h_ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
     const size_t N = (size_t)1 << log_n;

@@ -383,7 +383,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         tr->write_point(tr->ctx, lr[0]);
         tr->write_point(tr->ctx, lr[1]);
         tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
-        const Fe<SF> u_j = fe_load<SF>(tmp), u_inv = fe_inv(u_j);
+        const Fe<SF> u_j = fe_load<SF>(tmp);
+        if (fe_is_zero(u_j)) { set_error("ipa_create_proof: round %u challenge is zero (the Rust prover's u_j.invert().unwrap() panics here)", j); return TRH_EINVAL; }
+        const Fe<SF> u_inv = fe_inv(u_j);
         TRH_TRY((axpy_t<SF>(pp.p, pph, half, stm(u_inv), s)));
         TRH_TRY((axpy_t<SF>(b.p, bh, half, stm(u_j), s)));
         {
@@ -418,8 +420,10 @@ int trh_poly_eval_batch_dev(int field, const void* polys_dev, size_t n, size_t b
     if (!out || !point || (n && batch && !polys_dev)) { set_error("poly_eval: null pointer"); return TRH_EINVAL; }
     if (!batch) return TRH_OK;
     if (!n) { memset(out, 0, batch * 32); return TRH_OK; }
+    TRH_ENTER(stream);
+    Range range("trh_poly_eval_batch_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return eval_batch_t<FpParams>(polys_dev, n, batch, point, (hipStream_t)stream, out);
     return eval_batch_t<FqParams>(polys_dev, n, batch, point, (hipStream_t)stream, out);
 }
@@ -428,8 +432,10 @@ int trh_field_inner_product_dev(int field, const void* a_dev, const void* b_dev,
     TRH_TRY(require_init());
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
     if (!out || (n && (!a_dev || !b_dev))) { set_error("inner_product: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_field_inner_product_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return inner_product_t<FpParams>(a_dev, b_dev, n, (hipStream_t)stream, out);
     return inner_product_t<FqParams>(a_dev, b_dev, n, (hipStream_t)stream, out);
 }
@@ -439,8 +445,10 @@ int trh_field_axpy_dev(int field, void* y_dev, const void* x_dev, size_t n, cons
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
     if (!c_mont || (n && (!y_dev || !x_dev))) { set_error("axpy: null pointer"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_axpy_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     FeMem cm;
     memcpy(&cm, c_mont, 32);
     if (field == TRH_FP) return axpy_t<FpParams>(y_dev, x_dev, n, cm, (hipStream_t)stream);
@@ -452,8 +460,10 @@ int trh_field_powers_dev(int field, void* out_dev, size_t n, const uint64_t x_mo
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
     if (!x_mont || (n && !out_dev)) { set_error("powers: null pointer"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_powers_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return powers_t<FpParams>(out_dev, n, x_mont, (hipStream_t)stream);
     return powers_t<FqParams>(out_dev, n, x_mont, (hipStream_t)stream);
 }
@@ -463,8 +473,10 @@ int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t h
     if (curve != TRH_PALLAS && curve != TRH_VESTA) { set_error("unknown curve id %d", curve); return TRH_EINVAL; }
     if (!u_mont || (half && (!g_lo_dev || !g_hi_dev))) { set_error("bases_fold: null pointer"); return TRH_EINVAL; }
     if (!half) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_bases_fold_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     // pallas: scalar field Fq, base field Fp
     if (curve == TRH_PALLAS) return bases_fold_t<FqParams, FpParams>(g_lo_dev, g_hi_dev, half, u_mont, (hipStream_t)stream);
     return bases_fold_t<FpParams, FqParams>(g_lo_dev, g_hi_dev, half, u_mont, (hipStream_t)stream);
@@ -477,8 +489,11 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
     if (!g_w || !u_xy || !p_poly_dev || !p_blind || !x3 || !s_poly_dev || !s_blind || !transcript || !rng ||
         !transcript->write_point || !transcript->write_scalar || !transcript->squeeze_challenge_scalar) { set_error("ipa_create_proof: null pointer"); return TRH_EINVAL; }
     if (k > 26 || g_w->n != ((size_t)1 << k) + 1) { set_error("ipa_create_proof: bases must hold g (2^k points) followed by w"); return TRH_EINVAL; }
-    Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    if (!g_w->shards.empty()) { set_error("ipa_create_proof: needs a base set on one device (the rounds are sequential: SURVEY 8e)"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_ipa_create_proof");
+    if (g_w->owner && g_w->owner->device != ctx().device) { set_error("ipa_create_proof: the base set lives on another device than the calling context"); return TRH_EINVAL; }
+    if (ctx().msm.pending_curve >= 0) { set_error("ipa_create_proof: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
     if (g_w->curve == TRH_PALLAS)
         return ipa_create_proof_t<FqParams, FpParams>(TRH_PALLAS, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);
     return ipa_create_proof_t<FpParams, FqParams>(TRH_VESTA, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);

@@ -120,7 +120,11 @@ struct Scratch {
     DevBuf planes_a, planes_s, keys_in, keys_out, perm_a, perm_s, perm_tmp, first, removed, flags, pos, rows_rep, rows_left, tmp, err;
     u32* host = nullptr;  // pinned landing area of the few words the host reads back per lookup (pageable targets cost a staging copy each)
 };
-Scratch& scratch() { static Scratch s; return s; }
+Scratch& scratch() {  // per context (device)
+    Ctx& c = ctx();
+    if (!c.lookup_scratch) c.lookup_scratch = new Scratch();
+    return *(Scratch*)c.lookup_scratch;
+}
 int host_words(Scratch& sc) {
     if (!sc.host) TRH_HIP_TRY(hipHostMalloc((void**)&sc.host, 256, hipHostMallocDefault));
     return TRH_OK;
@@ -238,11 +242,15 @@ int lookup_permute_t(const void* input, const void* table, size_t n, void* out_i
 }  // namespace
 
 void lookup_release() {
-    Scratch& sc = scratch();
+    Ctx& c = ctx();
+    if (!c.lookup_scratch) return;
+    Scratch& sc = *(Scratch*)c.lookup_scratch;
     for (DevBuf* b : {&sc.planes_a, &sc.planes_s, &sc.keys_in, &sc.keys_out, &sc.perm_a, &sc.perm_s, &sc.perm_tmp, &sc.first, &sc.removed, &sc.flags, &sc.pos, &sc.rows_rep, &sc.rows_left, &sc.tmp,
                       &sc.err})
         b->release();
     if (sc.host) { (void)hipHostFree(sc.host); sc.host = nullptr; }
+    delete &sc;
+    c.lookup_scratch = nullptr;
 }
 
 }  // namespace trh
@@ -256,8 +264,10 @@ extern "C" int trh_lookup_permute_dev(int field, const void* input_dev, const vo
     if (out_input_dev == input_dev || out_table_dev == table_dev || out_input_dev == out_table_dev) { set_error("lookup_permute: outputs must not alias the inputs"); return TRH_EINVAL; }
     if (usable_rows >= ((size_t)1 << 31)) { set_error("lookup_permute: too many rows"); return TRH_EINVAL; }
     if (!usable_rows) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_lookup_permute_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return lookup_permute_t<FpParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
     return lookup_permute_t<FqParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
 }

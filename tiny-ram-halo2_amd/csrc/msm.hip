@@ -934,15 +934,10 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
         m.host_sums_cap = hs + 4096;
     }
-    static bool bin_attr = false;
-    if (!bin_attr) {
+    if (!(c.attr_done & ATTR_MSM)) {  // per device
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_bin_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_CAP_MAX * 4));
-        bin_attr = true;
-    }
-    static bool part_attr = false;
-    if (!part_attr) {
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
-        part_attr = true;
+        c.attr_done |= ATTR_MSM;
     }
     const bool timing = c.timing && batch <= chunk;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
@@ -1014,6 +1009,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     m.pending_windows = Ws;
     m.pending_c = cb;
     m.pending_batch = batch;
+    m.pending_stream = s;
+    m.pending_owner = nullptr;
     m.ev_valid = timing;
     return TRH_OK;
 }
@@ -1029,7 +1026,7 @@ template <class BF>
 int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
-    if (m.pending_curve != BF::ID || m.pending_batch != batch) { set_error("msm_finish: no matching MSM enqueued"); return TRH_EINVAL; }
+    if (m.pending_curve != BF::ID || m.pending_batch != batch || m.pending_stream != s) { set_error("msm_finish: no matching MSM enqueued on this context and stream"); return TRH_EINVAL; }
     TRH_HIP_TRY(hipStreamSynchronize(s));
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     for (size_t bi = 0; bi < batch; ++bi) combine_windows_host<BF>(ws + bi * m.pending_windows, m.pending_windows, m.pending_c, out_xyz + 12 * bi);

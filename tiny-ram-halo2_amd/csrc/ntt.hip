@@ -692,8 +692,7 @@ bool ntt_can_fuse(uint32_t log_n) {
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu) {
     if (log_n > 27) { set_error("ntt: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
     if (fu && !ntt_can_fuse(log_n)) { set_error("ntt: fused pointwise steps need the lazy passes (log_n >= %d)", TILE_LOG); return TRH_EINVAL; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx().attr_done & ATTR_NTT)) {  // per device
         const int max_lds = (32 << TILE_LOG) + (32 << (TILE_LOG - 1));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -704,7 +703,7 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
         TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
 #undef TRH_PASSZ_ATTR
-        attr_set = true;
+        ctx().attr_done |= ATTR_NTT;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu);
     return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s, fu);

@@ -112,8 +112,10 @@ extern "C" int trh_point_fft_dev(int curve, void* points_dev, uint32_t log_n, co
     if (curve != TRH_PALLAS && curve != TRH_VESTA) { set_error("unknown curve id %d", curve); return TRH_EINVAL; }
     if (!points_dev || !omega) { set_error("point_fft: null pointer"); return TRH_EINVAL; }
     if (log_n > 24) { set_error("point_fft: log_n %u > 24 unsupported", log_n); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_point_fft_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     // pallas: scalar field Fq, base field Fp
     if (curve == TRH_PALLAS) return point_fft_t<FqParams, FpParams>(points_dev, log_n, omega, scale_or_null, (hipStream_t)stream);
     return point_fft_t<FpParams, FqParams>(points_dev, log_n, omega, scale_or_null, (hipStream_t)stream);

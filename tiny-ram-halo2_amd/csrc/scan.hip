@@ -199,8 +199,10 @@ int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream) {
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
     if (n && !a_dev) { set_error("batch_invert: null pointer"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_batch_invert_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return batch_invert_t<FpParams>(a_dev, n, (hipStream_t)stream);
     return batch_invert_t<FqParams>(a_dev, n, (hipStream_t)stream);
 }
@@ -211,8 +213,10 @@ int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, si
     if (n && (!a_dev || !out_dev)) { set_error("prefix_product: null pointer"); return TRH_EINVAL; }
     if (a_dev == out_dev) { set_error("prefix_product: in-place operation is not supported"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_prefix_product_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return prefix_scan_t<FpParams, OpMul<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream);
     return prefix_scan_t<FqParams, OpMul<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream);
 }
@@ -223,8 +227,10 @@ int trh_poly_lincomb_dev(int field, const void* polys_dev, size_t n, size_t batc
     if (n && (!out_dev || (batch && (!polys_dev || !coeffs_host)))) { set_error("poly_lincomb: null pointer"); return TRH_EINVAL; }
     if (batch > ((size_t)1 << 20)) { set_error("poly_lincomb: batch too large"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_poly_lincomb_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     hipStream_t s = (hipStream_t)stream;
     TRH_TRY(c.scan.ensure((batch ? batch : 1) * 32));
     if (batch) TRH_HIP_TRY(hipMemcpyAsync(c.scan.p, coeffs_host, batch * 32, hipMemcpyHostToDevice, s));
@@ -244,8 +250,10 @@ int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const voi
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
     if (n < 2) return TRH_OK;  // a constant has an empty quotient
     if (!a_dev || !pz_dev || !pzinv_dev || !scratch_dev || !q_dev) { set_error("kate_division: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_poly_kate_division_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     hipStream_t s = (hipStream_t)stream;
     uint4* t = (uint4*)scratch_dev;
     uint4* P = t + 2 * n;
@@ -269,8 +277,10 @@ int trh_field_prefix_product_rows_dev(int field, const void* a_dev, void* out_de
     if (n && rows && (!a_dev || !out_dev)) { set_error("prefix_product_rows: null pointer"); return TRH_EINVAL; }
     if (a_dev == out_dev) { set_error("prefix_product_rows: in-place operation is not supported"); return TRH_EINVAL; }
     if (!n || !rows) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_prefix_product_rows_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return prefix_scan_t<FpParams, OpMul<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream, rows);
     return prefix_scan_t<FqParams, OpMul<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream, rows);
 }
@@ -281,8 +291,10 @@ int trh_field_prefix_sum_dev(int field, const void* a_dev, void* out_dev, size_t
     if (n && (!a_dev || !out_dev)) { set_error("prefix_sum: null pointer"); return TRH_EINVAL; }
     if (a_dev == out_dev) { set_error("prefix_sum: in-place operation is not supported"); return TRH_EINVAL; }
     if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_prefix_sum_dev");
     Ctx& c = ctx();
-    std::lock_guard<std::mutex> lk(c.mu);
+    (void)c;
     if (field == TRH_FP) return prefix_scan_t<FpParams, OpAdd<FpParams>>(a_dev, out_dev, n, (hipStream_t)stream);
     return prefix_scan_t<FqParams, OpAdd<FqParams>>(a_dev, out_dev, n, (hipStream_t)stream);
 }
