@@ -9,7 +9,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functi
 OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h $(CSRC)/hostcombine.h include/trh.h
 
-all: $(PKG)/libtrh.so oracle examples/replay
+all: $(PKG)/libtrh.so oracle examples/replay tests/native/multi_ctx_test
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -25,11 +25,16 @@ $(PKG)/libtrh.so: $(OBJS)
 examples/replay: examples/replay.cpp include/trh.hpp include/trh.h $(PKG)/libtrh.so
 	g++ -O2 -std=c++17 -Wall -Iinclude $< -o $@ -L$(PKG) -ltrh -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
+# native test of the context layer (device group, per-thread contexts); run by tests/test_gpu_native.py
+tests/native/multi_ctx_test: tests/native/multi_ctx_test.cpp include/trh.h $(PKG)/libtrh.so
+	g++ -O1 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include $< -o $@ -L$(PKG) -ltrh -L/opt/rocm/lib -lamdhip64 -pthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -s -C oracle libtrh_oracle.so
 
 clean:
-	rm -f $(OBJS) $(PKG)/libtrh.so examples/replay
+	rm -f $(OBJS) $(PKG)/libtrh.so examples/replay tests/native/multi_ctx_test
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

@@ -500,3 +500,308 @@ int orc_gen_bases(int curve, u64 s0, u64 d, size_t n, int threads, u64* out) {
 int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 }  // extern "C"
+
+// ======================================================================================
+// Round-2 additions: the callers either side of best_multiexp / best_fft at REAL sizes
+// (k = 10 .. 18), so that the GPU path is compared with a restatement there and not only
+// at k <= 6 (Python big-int).  Same status as the rest of this file: test infrastructure,
+// parity unpinned by the reference, cross-checked against oracle/pasta.py at small k in
+// tests/test_oracle.py.
+// ======================================================================================
+namespace {
+
+template <class F>
+void parallel_for(size_t n, int threads, F&& body) {  // body(lo, hi)
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    if (threads == 1) { body((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per > n ? n : lo + per;
+        if (lo >= hi) break;
+        th.emplace_back([=, &body] { body(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// C::Curve::batch_normalize: Jacobian -> affine with one inversion per block (Montgomery's trick)
+template <class PB>
+void batch_normalize(const Jac<PB>* in, size_t n, u64* out_xy, int threads) {
+    parallel_for(n, threads, [&](size_t lo, size_t hi) {
+        const size_t B = 1024;
+        std::vector<Fe<PB>> pref(B);
+        for (size_t base = lo; base < hi; base += B) {
+            const size_t m = hi - base < B ? hi - base : B;
+            Fe<PB> acc = Fe<PB>::one();
+            for (size_t j = 0; j < m; ++j) { pref[j] = acc; if (!in[base + j].is_identity()) acc = acc.mul(in[base + j].Z); }
+            Fe<PB> inv = acc.inv();
+            for (size_t j = m; j-- > 0;) {
+                const Jac<PB>& p = in[base + j];
+                Aff<PB> a;
+                if (p.is_identity()) { a.inf = true; a.x = a.y = Fe<PB>::zero(); }
+                else {
+                    Fe<PB> zi = inv.mul(pref[j]);
+                    inv = inv.mul(p.Z);
+                    Fe<PB> zi2 = zi.sqr();
+                    a.x = p.X.mul(zi2); a.y = p.Y.mul(zi2).mul(zi); a.inf = false;
+                }
+                store_aff(a, out_xy + 8 * (base + j));
+            }
+        }
+    });
+}
+
+// `point * scalar` (pasta: double-and-add over the canonical bits of the scalar), scalar given in Montgomery form
+template <class PS, class PB>
+Jac<PB> scale_point(const Jac<PB>& p, const Fe<PS>& s_mont) {
+    u64 k[4];
+    s_mont.from_mont().store(k);
+    Jac<PB> acc = Jac<PB>::identity();
+    for (int i = 255; i >= 0; --i) {
+        acc = acc.dbl();
+        if ((k[i / 64] >> (i % 64)) & 1) acc = acc.add(p);
+    }
+    return acc;
+}
+
+// ---- unstructured bases: P_i = h_i * G with h_i = four SplitMix64 words of (seed, i) reduced below 2^254 ---------------
+// (fixed-base comb over a byte table of G: 32 mixed additions per point instead of a 255-bit double-and-add; the group
+// element is the definition's)
+static inline u64 splitmix(u64& s) { u64 z = (s += 0x9e3779b97f4a7c15ULL); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+static inline void hashed_scalar(u64 seed, size_t i, u64 k[4]) {
+    u64 s = seed ^ (0xD1B54A32D192ED03ULL * (u64)(i + 1));
+    k[0] = splitmix(s); k[1] = splitmix(s); k[2] = splitmix(s); k[3] = splitmix(s) >> 2;
+}
+template <class PB>
+void gen_bases_hashed(u64 seed, size_t n, int threads, u64* out) {
+    // table[j][d] = d * 2^(8 j) * G, d in 1..255, affine
+    std::vector<Jac<PB>> tj(32 * 255);
+    Jac<PB> base = Jac<PB>::from_affine(generator<PB>());
+    for (int j = 0; j < 32; ++j) {
+        Jac<PB> cur = base;
+        for (int d = 1; d <= 255; ++d) { tj[j * 255 + d - 1] = cur; cur = cur.add(base); }
+        base = cur;  // 256 * previous base
+    }
+    std::vector<u64> txy(8 * tj.size());
+    batch_normalize<PB>(tj.data(), tj.size(), txy.data(), threads);
+    std::vector<Jac<PB>> pts(n);
+    parallel_for(n, threads, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            u64 k[4];
+            hashed_scalar(seed, i, k);
+            Jac<PB> acc = Jac<PB>::identity();
+            for (int j = 0; j < 32; ++j) {
+                const unsigned d = (unsigned)(k[j / 8] >> (8 * (j % 8))) & 0xffu;
+                if (d) acc = acc.add_mixed(load_aff<PB>(&txy[8 * (j * 255 + d - 1)]));
+            }
+            pts[i] = acc;
+        }
+    });
+    batch_normalize<PB>(pts.data(), n, out, threads);
+}
+
+// ---- best_fft::<C::Curve> (arithmetic.rs): the same butterflies as for field elements, group_scale = point * scalar ----
+// points: n affine PODs in place; omega: scalar field, Montgomery.  Output normalised to affine (what Params::new does next).
+template <class PS, class PB>
+void best_fft_points(u64* xy, const u64* omega_limbs, uint32_t log_n, int threads) {
+    const size_t n = (size_t)1 << log_n;
+    std::vector<Jac<PB>> a(n);
+    for (size_t i = 0; i < n; ++i) a[i] = Jac<PB>::from_affine(load_aff<PB>(xy + 8 * i));
+    for (size_t k = 0; k < n; ++k) {
+        size_t rk = bitreverse32((uint32_t)k, log_n);
+        if (k < rk) std::swap(a[k], a[rk]);
+    }
+    const Fe<PS> omega = Fe<PS>::load(omega_limbs);
+    std::vector<Fe<PS>> tw(n / 2 ? n / 2 : 1);
+    Fe<PS> w = Fe<PS>::one();
+    for (size_t i = 0; i < n / 2; ++i) { tw[i] = w; w = w.mul(omega); }
+    size_t chunk = 2, twiddle_chunk = n / 2;
+    for (uint32_t st = 0; st < log_n; ++st) {
+        const size_t half = chunk / 2, nb = n / 2;  // nb butterflies per stage, all independent
+        parallel_for(nb, threads, [&](size_t lo, size_t hi) {
+            for (size_t q = lo; q < hi; ++q) {
+                const size_t blk = q / half, i = q % half;
+                Jac<PB>& x = a[blk * chunk + i];
+                Jac<PB>& y = a[blk * chunk + half + i];
+                Jac<PB> t = i == 0 ? y : scale_point<PS, PB>(y, tw[i * twiddle_chunk]);  // "case when twiddle factor is one"
+                Jac<PB> neg = t; neg.Y = neg.Y.neg();
+                y = x.add(neg);
+                x = x.add(t);
+            }
+        });
+        chunk *= 2; twiddle_chunk /= 2;
+    }
+    batch_normalize<PB>(a.data(), n, xy, threads);
+}
+
+// ---- poly::commitment::prover::create_proof (the IPA opening), restated literally: G' is materialised and collapsed
+//      with n / 2 + n / 4 + ... scalar multiplications per proof, the round MSMs run through best_multiexp above ----------
+struct OrcTranscript {
+    void* ctx;
+    void (*write_point)(void*, const u64* xyz);   // normalised Jacobian, Z = 1 (identity: all zero)
+    void (*write_scalar)(void*, const u64* s);    // Montgomery limbs
+    void (*squeeze)(void*, u64* out);             // challenge scalar, Montgomery limbs
+};
+typedef void (*OrcRng)(void*, u64* out);
+
+template <class PB>
+void write_point_norm(const OrcTranscript* tr, const Jac<PB>& p) {
+    u64 xyz[12];
+    const Aff<PB> a = p.to_affine();
+    if (a.inf) memset(xyz, 0, sizeof(xyz));
+    else { a.x.store(xyz); a.y.store(xyz + 4); Fe<PB>::one().store(xyz + 8); }
+    tr->write_point(tr->ctx, xyz);
+}
+
+template <class PS, class PB>
+Jac<PB> multiexp_j(const Fe<PS>* coeffs, const u64* bases, size_t n, int threads) {
+    u64 out[12];
+    best_multiexp<PS, PB>((const u64*)coeffs, bases, n, threads, out);
+    return load_jac<PB>(out);
+}
+
+template <class PS>
+Fe<PS> eval_poly(const std::vector<Fe<PS>>& p, const Fe<PS>& x) {
+    Fe<PS> acc = Fe<PS>::zero();
+    for (size_t i = p.size(); i-- > 0;) acc = acc.mul(x).add(p[i]);
+    return acc;
+}
+template <class PS>
+Fe<PS> inner_product(const Fe<PS>* a, const Fe<PS>* b, size_t n) {
+    Fe<PS> acc = Fe<PS>::zero();
+    for (size_t i = 0; i < n; ++i) acc = acc.add(a[i].mul(b[i]));
+    return acc;
+}
+
+template <class PS, class PB>
+int ipa_create_proof(uint32_t k, const u64* g_xy, const u64* w_xy, const u64* u_xy, const u64* p_poly, const u64* p_blind_l, const u64* x3_l,
+                     const u64* s_poly_l, const u64* s_blind_l, const OrcTranscript* tr, OrcRng rng, void* rng_ctx, int threads, u64* out_c, u64* out_f) {
+    const size_t n = (size_t)1 << k;
+    const Fe<PS> x3 = Fe<PS>::load(x3_l), p_blind = Fe<PS>::load(p_blind_l), s_blind = Fe<PS>::load(s_blind_l);
+    std::vector<Fe<PS>> s_poly(n), p_prime(n), b(n);
+    for (size_t i = 0; i < n; ++i) s_poly[i] = Fe<PS>::load(s_poly_l + 4 * i);
+    s_poly[0] = s_poly[0].sub(eval_poly(s_poly, x3));  // s(x3) = 0
+    {   // params.commit(&s_poly, s_poly_blind): multiexp over g || w
+        std::vector<u64> bases(8 * (n + 1));
+        memcpy(bases.data(), g_xy, 64 * n);
+        memcpy(bases.data() + 8 * n, w_xy, 64);
+        std::vector<Fe<PS>> sc(s_poly);
+        sc.push_back(s_blind);
+        write_point_norm(tr, multiexp_j<PS, PB>(sc.data(), bases.data(), n + 1, threads));
+    }
+    u64 tmp[4];
+    tr->squeeze(tr->ctx, tmp); const Fe<PS> xi = Fe<PS>::load(tmp);
+    tr->squeeze(tr->ctx, tmp); const Fe<PS> z = Fe<PS>::load(tmp);
+    for (size_t i = 0; i < n; ++i) p_prime[i] = s_poly[i].mul(xi).add(Fe<PS>::load(p_poly + 4 * i));
+    const Fe<PS> v = eval_poly(p_prime, x3);
+    p_prime[0] = p_prime[0].sub(v);
+    Fe<PS> f = s_blind.mul(xi).add(p_blind);
+    { Fe<PS> cur = Fe<PS>::one(); for (size_t i = 0; i < n; ++i) { b[i] = cur; cur = cur.mul(x3); } }
+    std::vector<u64> g_prime(g_xy, g_xy + 8 * n);
+    u64 uw[16];
+    memcpy(uw, u_xy, 64); memcpy(uw + 8, w_xy, 64);
+    for (uint32_t j = 0; j < k; ++j) {
+        const size_t half = (size_t)1 << (k - j - 1);
+        Jac<PB> l_j = multiexp_j<PS, PB>(&p_prime[half], g_prime.data(), half, threads);
+        Jac<PB> r_j = multiexp_j<PS, PB>(&p_prime[0], g_prime.data() + 8 * half, half, threads);
+        const Fe<PS> value_l = inner_product(&p_prime[half], &b[0], half), value_r = inner_product(&p_prime[0], &b[half], half);
+        rng(rng_ctx, tmp); const Fe<PS> l_rand = Fe<PS>::load(tmp);
+        rng(rng_ctx, tmp); const Fe<PS> r_rand = Fe<PS>::load(tmp);
+        { Fe<PS> sc[2] = {value_l.mul(z), l_rand}; l_j = l_j.add(multiexp_j<PS, PB>(sc, uw, 2, 1)); }
+        { Fe<PS> sc[2] = {value_r.mul(z), r_rand}; r_j = r_j.add(multiexp_j<PS, PB>(sc, uw, 2, 1)); }
+        write_point_norm(tr, l_j);
+        write_point_norm(tr, r_j);
+        tr->squeeze(tr->ctx, tmp);
+        const Fe<PS> u_j = Fe<PS>::load(tmp);
+        if (u_j.is_zero()) return -1;  // u_j.invert().unwrap()
+        const Fe<PS> u_inv = u_j.inv();
+        for (size_t i = 0; i < half; ++i) {
+            p_prime[i] = p_prime[i].add(p_prime[i + half].mul(u_inv));
+            b[i] = b[i].add(b[i + half].mul(u_j));
+        }
+        p_prime.resize(half); b.resize(half);
+        {   // parallel_generator_collapse(&mut g_prime, u_j); truncate; batch_normalize
+            std::vector<Jac<PB>> col(half);
+            parallel_for(half, threads, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    const Jac<PB> hi_pt = Jac<PB>::from_affine(load_aff<PB>(&g_prime[8 * (i + half)]));
+                    col[i] = scale_point<PS, PB>(hi_pt, u_j).add_mixed(load_aff<PB>(&g_prime[8 * i]));
+                }
+            });
+            g_prime.resize(8 * half);
+            batch_normalize<PB>(col.data(), half, g_prime.data(), threads);
+        }
+        f = f.add(l_rand.mul(u_inv)).add(r_rand.mul(u_j));
+    }
+    u64 c_l[4], f_l[4];
+    p_prime[0].store(c_l); f.store(f_l);
+    tr->write_scalar(tr->ctx, c_l);
+    tr->write_scalar(tr->ctx, f_l);
+    if (out_c) memcpy(out_c, c_l, 32);
+    if (out_f) memcpy(out_f, f_l, 32);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out: n x 8 limbs, P_i = h_i * G with h_i a hash of (seed, i): no arithmetic structure between the bases
+int orc_gen_bases_hashed(int curve, u64 seed, size_t n, int threads, u64* out) {
+    if (curve == 0) gen_bases_hashed<FpP>(seed, n, threads, out); else gen_bases_hashed<FqP>(seed, n, threads, out);
+    return 0;
+}
+// the discrete logs of the above (canonical limbs), for closed-form checks
+int orc_hashed_scalars(u64 seed, size_t n, u64* out_canonical) {
+    for (size_t i = 0; i < n; ++i) hashed_scalar(seed, i, out_canonical + 4 * i);
+    return 0;
+}
+// best_fft over curve points in place (affine in, affine out); omega: the curve's scalar field, Montgomery
+int orc_best_fft_points(int curve, u64* xy, const u64* omega, uint32_t log_n, int threads) {
+    if (curve == 0) best_fft_points<FqP, FpP>(xy, omega, log_n, threads); else best_fft_points<FpP, FqP>(xy, omega, log_n, threads);
+    return 0;
+}
+// out[i] = scalars[i] * base (scalars Montgomery), affine
+int orc_scale_points(int curve, const u64* base_xy, const u64* scalars_mont, size_t n, int threads, u64* out_xy) {
+    if (curve == 0) {
+        std::vector<Jac<FpP>> r(n);
+        const Jac<FpP> b = Jac<FpP>::from_affine(load_aff<FpP>(base_xy));
+        parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) r[i] = scale_point<FqP, FpP>(b, Fe<FqP>::load(scalars_mont + 4 * i)); });
+        batch_normalize<FpP>(r.data(), n, out_xy, threads);
+    } else {
+        std::vector<Jac<FqP>> r(n);
+        const Jac<FqP> b = Jac<FqP>::from_affine(load_aff<FqP>(base_xy));
+        parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) r[i] = scale_point<FpP, FqP>(b, Fe<FpP>::load(scalars_mont + 4 * i)); });
+        batch_normalize<FqP>(r.data(), n, out_xy, threads);
+    }
+    return 0;
+}
+// pointwise base[i] * scalars[i] (the generator-collapse primitive), affine out
+int orc_scale_points_each(int curve, const u64* bases_xy, const u64* scalars_mont, size_t n, int threads, u64* out_xy) {
+    if (curve == 0) {
+        std::vector<Jac<FpP>> r(n);
+        parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) r[i] = scale_point<FqP, FpP>(Jac<FpP>::from_affine(load_aff<FpP>(bases_xy + 8 * i)), Fe<FqP>::load(scalars_mont + 4 * i)); });
+        batch_normalize<FpP>(r.data(), n, out_xy, threads);
+    } else {
+        std::vector<Jac<FqP>> r(n);
+        parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) r[i] = scale_point<FpP, FqP>(Jac<FqP>::from_affine(load_aff<FqP>(bases_xy + 8 * i)), Fe<FpP>::load(scalars_mont + 4 * i)); });
+        batch_normalize<FqP>(r.data(), n, out_xy, threads);
+    }
+    return 0;
+}
+int orc_ipa_create_proof(int curve, uint32_t k, const u64* g_xy, const u64* w_xy, const u64* u_xy, const u64* p_poly, const u64* p_blind, const u64* x3,
+                         const u64* s_poly, const u64* s_blind, void* tr_ctx, void (*write_point)(void*, const u64*), void (*write_scalar)(void*, const u64*),
+                         void (*squeeze)(void*, u64*), void (*rng)(void*, u64*), void* rng_ctx, int threads, u64* out_c, u64* out_f) {
+    OrcTranscript tr{tr_ctx, write_point, write_scalar, squeeze};
+    if (curve == 0) return ipa_create_proof<FqP, FpP>(k, g_xy, w_xy, u_xy, p_poly, p_blind, x3, s_poly, s_blind, &tr, rng, rng_ctx, threads, out_c, out_f);
+    return ipa_create_proof<FpP, FqP>(k, g_xy, w_xy, u_xy, p_poly, p_blind, x3, s_poly, s_blind, &tr, rng, rng_ctx, threads, out_c, out_f);
+}
+// arithmetic::eval_polynomial / kate_division / the x-power folds of multiopen, over Montgomery limb arrays
+int orc_eval_polynomial(int field, const u64* poly, size_t n, const u64* x, u64* out) {
+    if (field == 0) { std::vector<Fe<FpP>> p(n); for (size_t i = 0; i < n; ++i) p[i] = Fe<FpP>::load(poly + 4 * i); eval_poly(p, Fe<FpP>::load(x)).store(out); }
+    else { std::vector<Fe<FqP>> p(n); for (size_t i = 0; i < n; ++i) p[i] = Fe<FqP>::load(poly + 4 * i); eval_poly(p, Fe<FqP>::load(x)).store(out); }
+    return 0;
+}
+
+}  // extern "C"

@@ -20,3 +20,16 @@ def test_native_replay_k10():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["k"] == 10 and out["checks_failed"] == 0
     assert set(out["ms"]) == {"lookup_permute", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "ipa"}
+
+
+def test_native_multi_context():
+    """tests/native/multi_ctx_test.cpp: device group ({0, 0} on a one-GPU box) with range-sharded base sets through trh_msm /
+    trh_msm_dev / trh_best_multiexp_*, two host threads on two contexts overlapping MSMs and NTTs, enqueue / finish bookkeeping,
+    a non-init thread on the last device -- from a compiled host, no Python in the process"""
+    exe = os.path.join(ROOT, "tests", "native", "multi_ctx_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "tests/native/multi_ctx_test"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["checks_failed"] == 0 and out["group"] >= 2

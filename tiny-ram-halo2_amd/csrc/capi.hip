@@ -480,15 +480,19 @@ int trh_init_multi(const int* devices, int n_devices) {
         bool same = g_group.size() == (size_t)n_devices;
         for (int i = 0; same && i < n_devices; ++i) same = g_group[i]->device == devices[i];
         if (same) return TRH_OK;
-        set_error("trh_init_multi: already initialised with another device list (trh_shutdown first)");
-        return TRH_EINVAL;
+        // after a plain trh_init(devices[0]) the group grows around the existing default context
+        if (g_group.size() != 1 || g_default->device != devices[0]) {
+            set_error("trh_init_multi: already initialised with another device list (trh_shutdown first)");
+            return TRH_EINVAL;
+        }
     }
     std::vector<Ctx*> made;
-    for (int i = 0; i < n_devices; ++i) {  // the same device may be listed more than once: two lanes on one GPU
+    if (g_default) made.push_back(g_default);
+    for (int i = (int)made.size(); i < n_devices; ++i) {  // the same device may be listed more than once: two lanes on one GPU
         Ctx* c = nullptr;
         const int rc = create_ctx(devices[i], &c);
         if (rc != TRH_OK) {
-            for (Ctx* m : made) destroy_ctx(m);
+            for (Ctx* m : made) if (m != g_default) destroy_ctx(m);
             char msg[400];
             snprintf(msg, sizeof(msg), "%s", g_err);
             set_error("trh_init_multi: %s", msg);
@@ -496,7 +500,7 @@ int trh_init_multi(const int* devices, int n_devices) {
         }
         made.push_back(c);
     }
-    for (int i = 0; i < n_devices; ++i)  // peer access for the scalar hand-over of device-resident scalars (best effort: the copy API works without it)
+    for (int i = 0; i < n_devices; ++i)  // peer access for the hand-over of device-resident scalars (best effort: the peer copy works without it)
         for (int j = 0; j < n_devices; ++j)
             if (devices[i] != devices[j]) {
                 int can = 0;
