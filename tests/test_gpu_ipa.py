@@ -10,6 +10,7 @@ import torch
 
 import cpu_ref
 import pasta as o
+from common import DeviceTranscript, HashTranscript, OracleTranscript
 from tiny_ram_halo2_amd import api, ipa, poly, synth
 
 pytestmark = pytest.mark.gpu
@@ -73,41 +74,6 @@ def test_bases_fold(curve):
     d2 = to_dev(np.concatenate([g[:half], g[:half]]))
     api.bases_fold_dev(curve, d2[:half], d2[half:], half, np.array(cv.scalar.limbs(cv.scalar.m - 1), np.uint64))
     assert (to_host(d2)[:half] == 0).all()
-
-
-class HashTranscript:
-    """stand-in for Blake2bWrite: challenges are a hash of everything written so far"""
-
-    def __init__(self, modulus):
-        self.h, self.m, self.log = hashlib.blake2b(b"trh-test-transcript"), modulus, []
-
-    def _absorb(self, tag, data):
-        self.h.update(tag + bytes(data))
-        self.log.append((tag, bytes(data)))
-
-    def squeeze_challenge_scalar(self):
-        self.h.update(b"challenge")
-        return int.from_bytes(self.h.digest(), "little") % self.m
-
-
-class DeviceTranscript(HashTranscript):
-    def write_point(self, jac):
-        self._absorb(b"P", np.ascontiguousarray(jac, dtype=np.uint64)[:8].tobytes())
-
-    def write_scalar(self, limbs):
-        self._absorb(b"S", np.ascontiguousarray(limbs, dtype=np.uint64).tobytes())
-
-
-class OracleTranscript(HashTranscript):
-    def __init__(self, curve):
-        super().__init__(curve.scalar.m)
-        self.curve = curve
-
-    def write_point(self, pt):
-        self._absorb(b"P", np.array(self.curve.affine_limbs(pt), dtype=np.uint64).tobytes())
-
-    def write_scalar(self, v):
-        self._absorb(b"S", np.array(self.curve.scalar.limbs(v), dtype=np.uint64).tobytes())
 
 
 @pytest.mark.parametrize("curve,k", [("vesta", 3), ("vesta", 6), ("pallas", 5)])

@@ -92,3 +92,106 @@ def test_replay_k10_matches_oracle():
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
     assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+
+
+def test_replay_k18_matches_oracle():
+    """BASELINE config 4 (WORD_BITS = 32: k = 18, extended_k = 21, /root/reference/src/test_utils.rs:20, src/circuits/mod.rs:367):
+    the same schedule with the first item of every primitive kind compared against the C++ oracle (oracle/cpu_ref.py:
+    best_multiexp, EvaluationDomain over best_fft, eval_polynomial; the lookup permutation and the product column against the
+    step-by-step big-int restatements)"""
+    seen = {}
+    ftab = {"fp": o.FIELDS["fp"], "fq": o.FIELDS["fq"]}
+
+    def hook(kind, inp, out):
+        seen[kind] = seen.get(kind, 0) + 1
+        if seen[kind] > 1 and kind in ("commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals"):
+            return  # the first item of each kind
+        if kind in ("commit_lagrange", "commit"):
+            want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], inp["bases"].download(), threads=cpu_ref.hardware_threads()))
+            assert (np.asarray(out)[:8] == want).all(), kind
+            return
+        if kind == "lookup_permute":
+            f = ftab[inp["field"]]
+            can = lambda a: synth_ints(cpu_ref.field_op(inp["field"], "from_mont", a))  # noqa: E731
+            a, t = can(inp["input"]), can(inp["table"])
+            want_a, want_s = o.permute_expression_pair(a, t, len(a))
+            assert can(out[0]) == want_a and can(out[1]) == want_s
+            del f
+            return
+        if kind == "product_column":
+            field, k = inp["field"], inp["k"]
+            f = ftab[field]
+            n = 1 << k
+            lim = lambda v: np.array(f.limbs(v), np.uint64)  # noqa: E731
+            mul = lambda x, y: cpu_ref.field_op(field, "mul", x, y)  # noqa: E731
+            add = lambda x, y: cpu_ref.field_op(field, "add", x, y)  # noqa: E731
+            rep = lambda v: np.tile(lim(v), (n, 1))  # noqa: E731
+            delta, w = pow(5, 1 << 32, f.m), f.omega(k)
+            wp = np.tile(lim(1), (n, 1))  # omega^i by doubling
+            span, cur = 1, w
+            while span < n:
+                wp[span:2 * span] = mul(wp[:span], np.tile(lim(cur), (span, 1)))
+                cur, span = cur * cur % f.m, span * 2
+            num = den = None
+            for j in range(4):
+                v, sg = inp["values"][j], inp["sigmas"][j]
+                nj = add(add(v, mul(wp, rep(inp["beta"] * pow(delta, inp["first_column"] + j, f.m)))), rep(inp["gamma"]))
+                dj = add(add(v, mul(sg, rep(inp["beta"]))), rep(inp["gamma"]))
+                num = nj if num is None else mul(num, nj)
+                den = dj if den is None else mul(den, dj)
+            ratio = mul(num, cpu_ref.field_op(field, "inv", den))
+            assert (np.asarray(out) == cpu_ref.prefix_product(field, ratio)).all()
+            return
+        if kind == "evals":
+            assert (np.asarray(out) == cpu_ref.eval_polynomial(inp["field"], np.asarray(inp["a"]).reshape(-1, 4), inp["x"])).all()
+            return
+        if kind == "h_eval":  # sampled rows against the oracle's Expression::evaluate restatement (only the rows the gates touch are converted)
+            f = ftab[inp["field"]]
+            n = 1 << inp["log_n"]
+            got = out.cpu().numpy().view(np.uint64)
+            gates = [to_tuple(g) for g in inp["gates"]]
+
+            class Lazy(dict):
+                def __missing__(self, key):
+                    t = inp["resident"][key]
+                    col = LazyColumn(f, t)
+                    self[key] = col
+                    return col
+
+            cols = Lazy()
+            for row in (0, 1, n - 1, 4097 % n, n // 2 + 3):
+                acc = 0
+                for g in gates:
+                    acc = (acc * inp["y"] + o.evaluate_expression(f, g, cols, row, n, inp["rot_step"])) % f.m
+                assert f.from_limbs(got[row]) == acc, row
+            return
+        field, j, k = inp["domain"]
+        dom = cpu_ref.EvaluationDomain(field, j, k)
+        a = np.asarray(inp["a"]).reshape(-1, 4)
+        if kind == "lagrange_to_coeff":
+            want = dom.lagrange_to_coeff(a)
+        elif kind == "coeff_to_extended":
+            want = dom.coeff_to_extended(a)
+        else:
+            want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
+        assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
+
+    res = replay.run(32, batch=32, hook=hook, verbose=False)
+    assert res["schedule"]["k"] == 18 and res["schedule"]["extended_k"] == 21 and res["schedule"]["msm_n_plus_1"] == 504
+    assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497 and res["counts"]["ipa"] == 1
+    assert set(seen) == {"lookup_permute", "product_column", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "divide_and_extended_to_coeff"}
+
+
+def synth_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192) for r in a]
+
+
+class LazyColumn:
+    """a resident device column read row by row (canonical ints), so that sampling five rows of 2^21 does not convert the column"""
+
+    def __init__(self, f, t):
+        self.f, self.t = f, t
+
+    def __getitem__(self, i):
+        return self.f.from_limbs(self.t[i].cpu().numpy().view(np.uint64))

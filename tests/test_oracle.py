@@ -177,3 +177,136 @@ def test_permutation_delta_is_the_published_constant():
         assert permutation.delta(field) == v
         f = o.FIELDS[field]
         assert pow(v, (f.m - 1) >> 32, f.m) == 1 and pow(v, (f.m - 1) >> 33, f.m) != 1 or ((f.m - 1) >> 32) % 2 == 1
+
+
+# ---- round-2 additions to the C++ oracle (IPA prover, curve-point FFT, hashed bases): pinned to the big-int restatements ----
+from common import LimbTranscript, OracleTranscript  # noqa: E402
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_cpp_hashed_bases_and_scaling(curve):
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 40
+    pts = cpu_ref.gen_bases_hashed(curve, 0xABCDEF, n, threads=2)
+    logs = cpu_ref.hashed_scalars(0xABCDEF, n)
+    assert len({tuple(r) for r in pts.tolist()}) == n
+    for i in (0, 1, 7, 39):
+        h = o.limbs_to_int(logs[i])
+        assert 0 < h < 1 << 254
+        assert cv.affine_from_limbs(pts[i]) == cv.mul(h, cv.generator)
+    ks = [3, fs.m - 1, 0, 0x1234567890ABCDEF1234567890ABCDEF % fs.m]
+    got = cpu_ref.scale_points(curve, cv.affine_limbs(cv.generator), np.array([fs.limbs(k) for k in ks], np.uint64), threads=2)
+    each = cpu_ref.scale_points_each(curve, pts[:4], np.array([fs.limbs(k) for k in ks], np.uint64), threads=2)
+    for i, k in enumerate(ks):
+        want = cv.mul(k, cv.generator)
+        assert (cv.affine_from_limbs(got[i]) if got[i].any() else None) == want
+        assert (cv.affine_from_limbs(each[i]) if each[i].any() else None) == cv.mul(k, cv.affine_from_limbs(pts[i]))
+
+
+@pytest.mark.parametrize("curve,k", [("pallas", 3), ("vesta", 4)])
+def test_cpp_point_fft_vs_bigint(curve, k):
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    g = cpu_ref.gen_bases_hashed(curve, 77 + k, n, threads=2)
+    g[2] = 0  # an identity among the inputs
+    omega = fs.inv(fs.omega(k))
+    got = cpu_ref.best_fft_points(curve, g, np.array(fs.limbs(omega), np.uint64), k, threads=3)
+    want = o.best_fft_points(cv, [cv.affine_from_limbs(r) if r.any() else None for r in g], omega, k)
+    for i in range(n):
+        assert (cv.affine_from_limbs(got[i]) if got[i].any() else None) == want[i], i
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 3), ("pallas", 4)])
+def test_cpp_ipa_prover_vs_bigint(curve, k):
+    """oracle/cpu_ref.cpp::ipa_create_proof (used by the GPU parity tests at k = 10 .. 18) writes the transcript of
+    oracle/pasta.py::ipa_create_proof, byte for byte"""
+    import random
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0xC0DE + k)
+    g_l = cpu_ref.gen_bases_hashed(curve, 5 + k, n, threads=2)
+    w_l = cpu_ref.gen_bases(curve, 424242, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 737373, 1, 1, threads=1)
+    p_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    s_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    draws = [rnd.randrange(fs.m) for _ in range(2 * k)]
+    it1, it2 = iter(draws), iter(draws)
+    lim = lambda v: np.array(fs.limbs(v), np.uint64)  # noqa: E731
+    t_cpp, t_ref = LimbTranscript(fs), OracleTranscript(cv)
+    c_cpp, f_cpp = cpu_ref.ipa_create_proof(curve, k, g_l, w_l[0], u_l[0], lambda: lim(next(it1)), t_cpp, np.array([fs.limbs(v) for v in p_poly], np.uint64), lim(p_blind),
+                                            lim(x3), np.array([fs.limbs(v) for v in s_poly], np.uint64), lim(s_blind), threads=2)
+    c_ref, f_ref = o.ipa_create_proof(cv, k, [cv.affine_from_limbs(r) for r in g_l], cv.affine_from_limbs(w_l[0]), cv.affine_from_limbs(u_l[0]),
+                                      lambda: next(it2), t_ref, p_poly, p_blind, x3, s_poly, s_blind)
+    assert (fs.from_limbs(c_cpp), fs.from_limbs(f_cpp)) == (c_ref, f_ref)
+    assert len(t_cpp.log) == 1 + 2 * k + 2
+    assert t_cpp.log == t_ref.log
+
+
+def test_fast_multiopen_and_verifier_vs_bigint():
+    """tests/common.py's C++-backed multiopen driver and verifier equation (used at k >= 10 on the GPU box) against the big-int
+    restatements, at k = 4"""
+    import random
+    from common import ipa_verify_fast, multiopen_create_proof_fast
+    curve, k = "vesta", 4
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0x0BE1)
+    g_l = cpu_ref.gen_bases_hashed(curve, 23, n, threads=2)
+    w_l = cpu_ref.gen_bases(curve, 818181, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 929292, 1, 1, threads=1)
+    keys = ["a", "b", "z"]
+    polys = {key: [rnd.randrange(fs.m) for _ in range(n)] for key in keys}
+    blinds = {key: rnd.randrange(fs.m) for key in keys}
+    x = rnd.randrange(fs.m)
+    xw = x * fs.omega(k) % fs.m
+    queries = [(x, "a"), (x, "b"), (xw, "b"), (x, "z"), (xw, "z")]
+    draws = [rnd.randrange(fs.m) for _ in range(2 + n + 1 + 2 * k)]
+    it1, it2 = iter(draws), iter(draws)
+    t_fast, t_ref = LimbTranscript(fs), OracleTranscript(cv)
+    got = multiopen_create_proof_fast(curve, k, g_l, w_l[0], u_l[0], lambda: next(it1), t_fast, queries, polys, blinds)
+    want = o.multiopen_create_proof(cv, k, [cv.affine_from_limbs(r) for r in g_l], cv.affine_from_limbs(w_l[0]), cv.affine_from_limbs(u_l[0]),
+                                    lambda: next(it2), t_ref, queries, polys, blinds)
+    assert got == want and t_fast.log == t_ref.log
+
+    # verifier equation: an honest opening from the big-int prover is accepted by both forms, a tampered one rejected by both
+    p_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    s_poly = [rnd.randrange(fs.m) for _ in range(n)]
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    rdraws = iter([rnd.randrange(fs.m) for _ in range(2 * k)])
+
+    class Rec(OracleTranscript):
+        def __init__(self, c):
+            super().__init__(c)
+            self.points, self.challenges = [], []
+
+        def write_point(self, pt):
+            self.points.append(pt)
+            super().write_point(pt)
+
+        def squeeze_challenge_scalar(self):
+            c = super().squeeze_challenge_scalar()
+            self.challenges.append(c)
+            return c
+
+    tr = Rec(cv)
+    g = [cv.affine_from_limbs(r) for r in g_l]
+    w, u = cv.affine_from_limbs(w_l[0]), cv.affine_from_limbs(u_l[0])
+    c, f = o.ipa_create_proof(cv, k, g, w, u, lambda: next(rdraws), tr, p_poly, p_blind, x3, s_poly, s_blind)
+    commitment = o.best_multiexp(cv, p_poly + [p_blind], g + [w])
+    v = 0
+    for cf in reversed(p_poly):
+        v = (v * x3 + cf) % fs.m
+    xi, z, ch = tr.challenges[0], tr.challenges[1], tr.challenges[2:]
+    rounds = [(tr.points[1 + 2 * j], tr.points[2 + 2 * j]) for j in range(k)]
+    assert o.ipa_verify_proof(cv, k, g, w, u, commitment, x3, v, tr.points[0], xi, z, rounds, ch, c, f)
+    xy = lambda p: np.array(cv.affine_limbs(p), np.uint64)  # noqa: E731
+    fast_args = (curve, k, g_l, w_l[0], u_l[0], xy(commitment), x3)
+    fast_tail = (xy(tr.points[0]), xi, z, [(xy(a), xy(b)) for a, b in rounds], ch)
+    assert ipa_verify_fast(*fast_args, v, *fast_tail, c, f)
+    assert not ipa_verify_fast(*fast_args, (v + 1) % fs.m, *fast_tail, c, f)
+    assert not ipa_verify_fast(*fast_args, v, *fast_tail, c, (f + 1) % fs.m)
