@@ -16,6 +16,16 @@ not an RCCL reduce op).  Rank 0 prints ONE JSON line.
 with HIP events on the launch stream inside the timed region (libtrh's timing hooks).
 `cpu_baseline` times oracle/cpu_ref.cpp (the C++ restatement of halo2_proofs' rayon
 best_multiexp; kind "port") on a bounded sample on this box's host cores.
+
+Outside the timed headline region the same process also reports
+  sweep            (N = 1) MSM at 2^20 / 2^22 / 2^26 and NTT at 2^20 / 2^24, each checked (closed form / inverse round trip) with
+                   its own roofline fraction -- north_star's 2^20 .. 2^26 size range;
+  strong           (N > 1) BASELINE config 5: ONE 2^26 Pallas MSM range-sharded over the N ranks (2^26 / N pairs each), same
+                   RCCL all-gather of the 96-byte partials;
+  single_process   (N > 1) the same 2^26 MSM through the C ABI's device group from rank 0 alone (trh_init_multi over the N GPUs:
+                   what a single Rust prover process linking libtrh.so gets), device-resident scalars handed over with peer copies.
+`--global-log-n L` makes the HEADLINE run strong-scaling instead (2^L pairs in total, split over the ranks); the JSON line
+says which mode produced `value`.  A failed result check prints the line with "check": "MISMATCH" and exits with status 1.
 """
 import argparse
 import json
@@ -105,6 +115,32 @@ def load_traffic(name: str):
         return None
 
 
+Q_MOD = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001  # Pallas scalar field
+P_MOD = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001  # Pallas base field = NTT field
+FP_ROOT = 0x2BCE74DEAC30EBDA362120830561F81AEA322BF2B7BB7584BDAD6FABD87EA32F
+
+
+def msm_roofline(n, acc_ms, tm, traffic):
+    """the dominant kernel against the tier's roofline (HBM, algorithmic 96 B per pair) and against what really limits it
+    (VALU issue: measured instruction mix x measured issue rates)"""
+    ach = 96.0 * n / (acc_ms * 1e-3) / 1e9
+    madds = n * min(int(tm["windows"]), -(-254 // int(tm["window_bits"])))  # the carry window above ceil(254 / c) is (almost surely) empty
+    roof = {"bound": "hbm", "kernel": "msm_accumulate_seg_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel_ms": acc_ms, "algorithmic_bytes": 96 * n,
+            # the kernel is limited by VALU issue, not by HBM (see `valu`): the counter traffic is what it actually pulls per launch
+            "limiter": "valu-issue", "traffic_gbs": (traffic / (acc_ms * 1e-3) / 1e9) if traffic else None}
+    valu = {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc_ms * 1e-3),
+            "mad_u64_u32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": 32.7e12,
+            "other_valu_per_s": OTHER_PER_MADD * madds / (acc_ms * 1e-3), "other_peak_per_s": 65e12,
+            "issue_frac": (MADS_PER_MADD * madds / 32.7e12 + OTHER_PER_MADD * madds / 65e12) / (acc_ms * 1e-3)}
+    return roof, valu
+
+
+# instruction mix of one lazy mixed addition (SQ_INSTS_VALU per wave and mixed add, profiles/): half-rate 32 x 32 multiply-adds, and the rest
+MADS_PER_MADD = 1188
+OTHER_PER_MADD = 1130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +150,8 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (keeps profiles free of the extra 1-pair MSM)")
+    ap.add_argument("--global-log-n", type=int, default=0, help="strong scaling: 2^L pairs in TOTAL, range-sharded over the ranks (default: weak, 2^log-n per GPU)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep / strong-scaling / single-process extras (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -142,142 +180,280 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     api.init(dev_index)
     stream = torch.cuda.current_stream().cuda_stream
-
     curve = "pallas"
-    log_n = args.log_n
-    n = 1 << log_n
-    first = rank * n  # this rank's slice of the global (scalar, base) range
-    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n, first=first)
-    sc_host = synth.field_elements(synth.SEED_MSM | log_n, n, start=first)
-    d_sc = torch.from_numpy(sc_host.view(np.int64)).to(dev)
-
-    def step():
-        # local Pippenger -> one Jacobian point; all-gather of the 96-byte partials + host add when world > 1
-        return sharded.sharded_msm(curve, lambda: bases.msm_dev(d_sc, n, stream=stream), device=coll_dev)
+    failed = []
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        result = step()
-    api.set_timing(True)
-    acc_ms, phase = [], {"digits_ms": 0.0, "sort_ms": 0.0, "accumulate_ms": 0.0, "reduce_ms": 0.0, "total_ms": 0.0}
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-        tm = api.last_timing()
-        acc_ms.append(tm["accumulate_kernel_ms"])
-        for k in phase:
-            phase[k] += tm[k] / args.steps
-    fence()
-    elapsed = time.perf_counter() - t0
-    api.set_timing(False)
-    tm = api.last_timing()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # closed-form check of the whole (global) MSM: bases are (s0 + i d) G with known logs
-    check = None
-    if not args.no_check:
+    def expected_point(total: int):
+        """(total mod q) G through a one-pair MSM over the generator (bases are (s0 + i d) G with known logs)"""
+        g = api.Bases.generate(curve, 1, 0, 1)
+        return g.msm(synth.ints_to_limbs([total % Q_MOD * ((1 << 256) % Q_MOD) % Q_MOD]))
+
+    def canonical(d_sc, count):
         d_can = torch.empty_like(d_sc)
-        api._check(api.lib().trh_field_op_dev(api.FQ, api.FIELD_OPS["from_mont"], api._devptr(d_sc), None, api._devptr(d_can), n, stream))
+        api._check(api.lib().trh_field_op_dev(api.FQ, api.FIELD_OPS["from_mont"], api._devptr(d_sc), None, api._devptr(d_can), count, stream))
         torch.cuda.synchronize()
-        can = d_can.cpu().numpy().view(np.uint64)
-        q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
-        total = synth.weighted_scalar_sum(can, synth.BASE_S0, synth.BASE_D, start=first) % q   # this rank's share of sum s_i (s0 + i d)
-        if world > 1:
+        return d_can.cpu().numpy().view(np.uint64)
+
+    class Workload:
+        """this rank's slice [first, first + n) of a global MSM: resident bases (s0 + i d) G and Montgomery scalars.  Above 2^24 pairs
+        per rank the scalars are a 2^22 block repeated (the host generator would take longer than the whole benchmark)"""
+
+        def __init__(self, first, n):
+            self.first, self.n = first, n
+            self.bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n, first=first)
+            if n <= (1 << 24):
+                lg = max(n - 1, 1).bit_length()
+                self.block, self.reps = n, 1
+                sc_host = synth.field_elements(synth.SEED_MSM | lg, n, start=first)
+                self.d_sc = torch.from_numpy(sc_host.view(np.int64)).to(dev)
+            else:
+                self.block = 1 << 22
+                assert n % self.block == 0
+                self.reps = n // self.block
+                blk = torch.from_numpy(synth.field_elements(synth.SEED_MSM | 22, self.block).view(np.int64)).to(dev)
+                self.d_sc = blk.repeat(self.reps, 1).contiguous()
+
+        def local_msm(self):
+            return self.bases.msm_dev(self.d_sc, self.n, stream=stream)
+
+        def weighted_sum(self) -> int:
+            """this slice's share of sum_i s_i (s0 + i d), exact"""
+            can = canonical(self.d_sc[: self.block], self.block)
+            if self.reps == 1:
+                return synth.weighted_scalar_sum(can, synth.BASE_S0, synth.BASE_D, start=self.first)
+            t0 = synth.weighted_scalar_sum(can, 1, 0)
+            t1 = synth.weighted_scalar_sum(can, 0, 1)
+            r = self.reps  # sum over repetitions of sum_i s_i (s0 + (first + rep * block + i) d)
+            return r * ((synth.BASE_S0 + self.first * synth.BASE_D) * t0 + synth.BASE_D * t1) + synth.BASE_D * self.block * t0 * (r * (r - 1) // 2)
+
+        def destroy(self):
+            self.bases.destroy()
+            del self.d_sc
+
+    def time_msm(wl, steps, warmup, collective=True):
+        """`steps` timed passes (after `warmup`): local Pippenger -> one point; all-gather of the 96-byte partials + host add when
+        `collective`; barrier + synchronize on both sides, MAX over ranks"""
+        def step():
+            if collective:
+                return sharded.sharded_msm(curve, wl.local_msm, device=coll_dev)
+            return wl.local_msm()
+        result = None
+        for _ in range(warmup):
+            result = step()
+        api.set_timing(True)
+        acc_ms, phase = [], {"digits_ms": 0.0, "sort_ms": 0.0, "accumulate_ms": 0.0, "reduce_ms": 0.0, "total_ms": 0.0}
+        fence() if collective else torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = step()
+            tm = api.last_timing()
+            acc_ms.append(tm["accumulate_kernel_ms"])
+            for k in phase:
+                phase[k] += tm[k] / steps
+        fence() if collective else torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        api.set_timing(False)
+        if collective:
+            elapsed = max_over_ranks(elapsed)
+        return result, elapsed, float(np.mean(acc_ms)), phase, api.last_timing()
+
+    def check_msm(wl, result, collective=True):
+        total = wl.weighted_sum()
+        if collective and world > 1:
             parts = [None] * world
             dist.all_gather_object(parts, total)
-            total = sum(parts) % q
-        if rank == 0:
-            R = (1 << 256) % q
-            g = api.Bases.generate(curve, 1, 0, 1)  # the generator itself
-            want = g.msm(synth.ints_to_limbs([total * R % q]))
-            check = "closed-form ok" if (want == result).all() else "MISMATCH"
+            total = sum(parts)
+        if rank != 0:
+            return None
+        ok = bool((expected_point(total) == result).all())
+        if not ok:
+            failed.append("msm")
+        return "closed-form ok" if ok else "MISMATCH"
+
+    # ---- headline: weak scaling (2^log_n pairs per GPU) unless --global-log-n ------------------------------------------------
+    if args.global_log_n:
+        n_total = 1 << args.global_log_n
+        lo, hi = sharded.shard_range(n_total, rank, world)
+        mode = "strong"
+    else:
+        n_total = world << args.log_n
+        lo, hi = rank << args.log_n, (rank + 1) << args.log_n
+        mode = "weak"
+    n = hi - lo
+    wl = Workload(lo, n)
+    result, elapsed, acc, phase, tm = time_msm(wl, args.steps, args.warmup)
+    check = None if args.no_check else check_msm(wl, result)
+    wl.destroy()
 
     # ---- secondary: Fp NTT @ 2^22 (same process, outside the MSM timed region) ----
     # every rank transforms its own column (create_proof's NTTs are independent per column: replicas, no collective);
     # the value is the whole-job rate over the slowest rank's time
-    ntt = None
-    ln = args.ntt_log_n
-    P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
-    root = 0x2BCE74DEAC30EBDA362120830561F81AEA322BF2B7BB7584BDAD6FABD87EA32F
-    omega = pow(root, 1 << (32 - ln), P)
-    w = synth.ints_to_limbs([omega * ((1 << 256) % P) % P])[0]
-    a = synth.ntt_input(ln)
-    d_a = torch.from_numpy(a.view(np.int64).copy()).to(dev)
-    for _ in range(max(args.warmup, 2)):
-        api.ntt_dev("fp", d_a, ln, w, stream=stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(args.steps, 5) * 4
-    fence()
-    e0.record()
-    for _ in range(reps):
-        api.ntt_dev("fp", d_a, ln, w, stream=stream)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    if world > 1:
-        t = torch.tensor([ms], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
-    if rank == 0:
+    def time_ntt(ln, reps, warm, with_check):
+        omega = pow(FP_ROOT, 1 << (32 - ln), P_MOD)
+        mont = lambda v: synth.ints_to_limbs([v % P_MOD * ((1 << 256) % P_MOD) % P_MOD])[0]  # noqa: E731
+        a = synth.ntt_input(ln)
+        d_a = torch.from_numpy(a.view(np.int64).copy()).to(dev)
+        chk = None
+        if with_check:  # inverse(forward(a)) * n^-1 == a, and the forward transform is not the identity
+            api.ntt_dev("fp", d_a, ln, mont(omega), stream=stream)
+            torch.cuda.synchronize()
+            moved = not bool((d_a[:4096].cpu().numpy().view(np.uint64) == a[:4096]).all())
+            api.ntt_dev("fp", d_a, ln, mont(pow(omega, -1, P_MOD)), stream=stream)
+            api.field_scale_dev("fp", d_a, 1 << ln, mont(pow(1 << ln, -1, P_MOD)), stream=stream)
+            torch.cuda.synchronize()
+            ok = moved and bool((d_a.cpu().numpy().view(np.uint64) == a).all())
+            if not ok:
+                failed.append(f"ntt 2^{ln}")
+            chk = "inverse round trip ok" if ok else "MISMATCH"
+        for _ in range(warm):
+            api.ntt_dev("fp", d_a, ln, mont(omega), stream=stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record()
+        for _ in range(reps):
+            api.ntt_dev("fp", d_a, ln, mont(omega), stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return max_over_ranks(e0.elapsed_time(e1) / reps), chk
+
+    def ntt_entry(ln, ms, chk):
         ach = 64.0 * (1 << ln) / (ms * 1e-3) / 1e9
-        ntt = {"metric": f"Fp NTT elems/s @ 2^{ln}", "value": world * (1 << ln) / (ms * 1e-3), "unit": "elems/s", "ms_per_transform": ms,
-               "mode": "one transform per GPU at a time (independent columns, no collective)" if world > 1 else "single GPU",
-               "roofline": {"bound": "hbm", "kernel": "ntt_passz_kernel (x3 passes)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                            "traffic": load_traffic(f"ntt_fp_2^{ln}")}}
+        traffic = load_traffic(f"ntt_fp_2^{ln}")
+        return {"metric": f"Fp NTT elems/s @ 2^{ln}", "value": world * (1 << ln) / (ms * 1e-3), "unit": "elems/s", "ms_per_transform": ms, "check": chk,
+                "roofline": {"bound": "hbm", "kernel": "ntt_passz_kernel (all passes of one transform)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": 64 << ln, "limiter": "valu-issue",
+                             "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}}
+
+    ln = args.ntt_log_n
+    ms, chk = time_ntt(ln, max(args.steps, 5) * 4, max(args.warmup, 2), not args.no_check)
+    ntt = None
+    if rank == 0:
+        ntt = ntt_entry(ln, ms, chk)
+        ntt["mode"] = "one transform per GPU at a time (independent columns, no collective)" if world > 1 else "single GPU"
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             ntt["cpu_baseline"] = cpu_baseline_ntt("fp", ln)
 
+    # ---- extras outside the timed headline region ---------------------------------------------------------------------------
+    sweep, strong, single = None, None, None
+    if not args.no_sweep and world == 1:
+        sweep = []
+        for lg in (20, 22, 26):
+            w2 = Workload(0, 1 << lg)
+            steps = 6 if lg < 26 else 3
+            res2, el2, acc2, ph2, tm2 = time_msm(w2, steps, 2, collective=False)
+            chk2 = check_msm(w2, res2, collective=False)
+            w2.destroy()
+            # beyond 2^25 pairs an MSM runs as range tiles of <= 2^25: the kernel time below is one tile's launch
+            per_launch = (1 << lg) if lg <= 25 else (1 << 25)
+            roof2, valu2 = msm_roofline(per_launch, acc2, tm2, load_traffic(f"msm_accumulate_2^{lg}"))
+            sweep.append({"op": "msm", "curve": curve, "log_n": lg, "value": (1 << lg) * steps / el2, "unit": "pairs/s", "ms": el2 / steps * 1e3, "check": chk2,
+                          "window_bits": tm2["window_bits"], "pairs_per_launch": per_launch, "roofline": roof2, "valu_issue_frac": valu2["issue_frac"]})
+        for lg in (20, 24):
+            ms2, chk2 = time_ntt(lg, 20, 3, True)
+            e = ntt_entry(lg, ms2, chk2)
+            sweep.append({"op": "ntt", "field": "fp", "log_n": lg, "value": e["value"], "unit": "elems/s", "ms": ms2, "check": chk2, "roofline": e["roofline"]})
+    if not args.no_sweep and world > 1 and mode == "weak":
+        # BASELINE config 5: ONE 2^26 MSM over the N ranks (strong scaling), the same path as the headline
+        L = 26
+        lo5, hi5 = sharded.shard_range(1 << L, rank, world)
+        w5 = Workload(lo5, hi5 - lo5)
+        res5, el5, acc5, ph5, tm5 = time_msm(w5, max(args.steps // 2, 3), 2)
+        chk5 = check_msm(w5, res5)
+        w5.destroy()
+        if rank == 0:
+            strong = {"workload": f"ONE 2^{L} Pallas MSM range-sharded over {world} ranks ({hi5 - lo5} pairs each), RCCL all-gather of the 96-byte partials, host add",
+                      "value": (1 << L) * max(args.steps // 2, 3) / el5, "unit": "pairs/s", "ms_per_msm": el5 / max(args.steps // 2, 3) * 1e3, "scaling": "strong", "check": chk5,
+                      "accumulate_kernel_ms": acc5, "window_bits": tm5["window_bits"]}
+        # the same MSM from ONE process through the C ABI's device group (rank 0 only; the other ranks wait on the store, no GPU spinning)
+        if os.environ.get("TRH_BENCH_SINGLE_PROCESS", "1") != "0":
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                try:
+                    api.init_multi(list(range(world)) if backend == "nccl" else [dev_index] * world)  # gloo runs fold the ranks onto the GPUs present
+                    api.set_shard_min(1 << 20)
+                    wsp = Workload(0, 1 << L)  # trh_bases_generate range-shards over the group; scalars resident on device 0
+                    assert wsp.bases.shards() == world
+                    for _ in range(2):
+                        rsp = wsp.local_msm()
+                    torch.cuda.synchronize()
+                    k5 = max(args.steps // 2, 3)
+                    t0 = time.perf_counter()
+                    for _ in range(k5):
+                        rsp = wsp.local_msm()
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                    ok = bool((expected_point(wsp.weighted_sum()) == rsp).all())
+                    if not ok:
+                        failed.append("single-process msm")
+                    single = {"workload": f"ONE 2^{L} Pallas MSM through trh_init_multi over {world} GPUs from one host process: bases range-sharded by the library, "
+                                          "scalars resident on GPU 0 and handed to the other GPUs with peer copies (included), partial points copied to the host and added",
+                              "value": (1 << L) * k5 / el, "unit": "pairs/s", "ms_per_msm": el / k5 * 1e3, "check": "closed-form ok" if ok else "MISMATCH"}
+                    wsp.destroy()
+                    api.set_shard_min(1 << 62)
+                except Exception as exc:  # reported, never fatal to the headline
+                    single = {"error": repr(exc)[:300]}
+                store.set("trh_single_process_done", "1")
+            else:
+                store.wait(["trh_single_process_done"])
+
     if rank == 0:
-        acc = float(np.mean(acc_ms))
-        # scalars are uniform below 2^254, so the carry window above ceil(254 / c) full windows is (almost surely) empty
-        madds = n * min(int(tm["windows"]), -(-254 // int(tm["window_bits"])))
-        ach = 96.0 * n / (acc * 1e-3) / 1e9
+        roof, valu = msm_roofline(n if n <= (1 << 25) else (1 << 25), acc, tm, load_traffic(f"msm_accumulate_2^{max(n - 1, 1).bit_length()}"))
+        shape = f"2^{args.log_n} pairs per GPU; global size {world}*2^{args.log_n}" if mode == "weak" else f"2^{args.global_log_n} pairs in total, {n} per GPU"
         out = {
             "metric": METRIC,
-            "value": world * n * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": mode,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"Pallas MSM, 2^{log_n} pairs per GPU, random 254-bit scalars, distinct bases (s0+i*d)G, "
-                                   f"inputs resident in HBM; global size {world}*2^{log_n}", "curve": curve,
-                       "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
-                       "parallelism": f"range-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_seg_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(f"msm_accumulate_2^{log_n}"),
-                         "kernel_ms": acc, "algorithmic_bytes": 96 * n},
+            "config": {"workload": f"Pallas MSM, {shape}, random 254-bit scalars, distinct bases (s0+i*d)G, inputs resident in HBM", "curve": curve,
+                       "pairs_per_gpu": n, "pairs_total": n_total, "mode": f"{mode} scaling" + (" (--global-log-n)" if mode == "strong" else " (default)"),
+                       "window_bits": tm["window_bits"], "windows": tm["windows"],
+                       "parallelism": f"range-shard x{world}, one process per GPU, RCCL all-gather of 96-byte partials" if world > 1 else "single GPU"},
+            "roofline": roof,
             # what actually bounds the kernel: VALU issue.  Per mixed add 8 fz_mul (126 v_mad_u64_u32 each) + 2 fz_sqr (90) =
             # 1188 half-rate multiply-adds and ~1130 other ALU instructions (SQ_INSTS_VALU: 2317 per mixed add and wave); peaks are the
             # measured issue rates of tools/microbench.hip (profiles/microbench_r01m.txt: v_mad_u64_u32 32.7 T/s, v_add_u32 65 T/s)
-            "valu": {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc * 1e-3),
-                     "mad_u64_u32_per_s": 1188 * madds / (acc * 1e-3), "mad_peak_per_s": 32.7e12,
-                     "other_valu_per_s": 1130 * madds / (acc * 1e-3), "other_peak_per_s": 65e12,
-                     "issue_frac": (1188 * madds / 32.7e12 + 1130 * madds / 65e12) / (acc * 1e-3)},
+            "valu": valu,
             "phases_ms": phase,
             "check": check,
             "secondary": ntt,
         }
+        if sweep is not None:
+            out["sweep"] = sweep
+        if strong is not None:
+            out["strong"] = strong
+        if single is not None:
+            out["single_process"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_msm(curve)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: result check FAILED: " + ", ".join(failed) + "\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -33,3 +33,20 @@ def test_native_multi_context():
     assert r.returncode == 0, r.stderr + r.stdout
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["checks_failed"] == 0 and out["group"] >= 2
+
+
+def test_bench_two_ranks_on_one_device():
+    """the process-per-GPU harness (bench.py under torch.distributed.run, sharded.sharded_msm over the HIP path) with two ranks
+    folded onto the GPUs present (gloo carries the 96-byte partials; the driver's scaling runs use RCCL): headline weak-scaling
+    step, the strong-scaling 2^26 leg and the single-process device-group leg all close their closed-form checks (exit code 0)"""
+    import sys
+    env = dict(os.environ, TRH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "20", "--ntt-log-n", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["check"] == "closed-form ok"
+    assert out["config"]["pairs_total"] == 2 << 20
+    assert out["strong"]["check"] == "closed-form ok" and out["strong"]["scaling"] == "strong"
+    assert out["single_process"].get("check") == "closed-form ok", out["single_process"]
