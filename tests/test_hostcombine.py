@@ -27,6 +27,17 @@ def test_trh_hpp_host_side():
     assert r.returncode == 0 and "trh.hpp host side: ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_lazy29_domain_matches_canonical():
+    """the MSM's signed 29-bit lazy arithmetic (field.h Fy, curve.h XYZZz: merged reductions, carry-free differences) against
+    the canonical Montgomery implementation, on the host"""
+    src = os.path.join(ROOT, "tests", "native", "lazy29_test.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "lazy29_test")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", src, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "lazy29: ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_side_under_sanitizers():
     """SURVEY section 5 (race / memory checking belongs on the CPU build): the host-side code of the boundary -- hostcombine.h,
     the shared field / curve headers as the host compiles them, trh.hpp's host arithmetic and Expression lowering -- built with
@@ -34,7 +45,8 @@ def test_host_side_under_sanitizers():
     flags = ["-O1", "-g", "-std=c++17", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     with tempfile.TemporaryDirectory() as tmp:
-        for name, inc, banner in (("hostcombine_test", [], "hostcombine: ok"), ("trh_hpp_host_test", ["-I" + os.path.join(ROOT, "include")], "trh.hpp host side: ok")):
+        for name, inc, banner in (("hostcombine_test", [], "hostcombine: ok"), ("trh_hpp_host_test", ["-I" + os.path.join(ROOT, "include")], "trh.hpp host side: ok"),
+                                  ("lazy29_test", [], "lazy29: ok")):
             exe = os.path.join(tmp, name + "_san")
             subprocess.check_call(["g++", *flags, *inc, os.path.join(ROOT, "tests", "native", name + ".cpp"), "-o", exe])
             r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)

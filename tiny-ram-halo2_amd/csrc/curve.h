@@ -166,98 +166,98 @@ template <class F> TRH_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F>& j) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Lazy-domain points (field.h "Lazy domain"): MSM bucket accumulation only.
-// Invariants of a stored XYZZz: x < 8m, y < 8m, zz < 1.01m, zzz < 1.01m; identity <=> zz is
-// exactly zero.  AffineZ coordinates are < 1.01m; identity <=> x and y exactly zero.
-// The exceptional cases (P + P, P + (-P)) go through the canonical formulas above.
+// Lazy-domain points (field.h "Signed lazy domain with 29-bit limbs"): the MSM's bucket arithmetic.
+// Coordinates are NORMALISED Fy values (signed, |x| < 4 m, |y| < 1.5 m, zz, zzz in (-0.02 m, 1.02 m) -- loose enough: the
+// arithmetic tolerates 16 m); identity <=> zz is exactly zero.  AffineZ coordinates are in [0, 1.01 m); identity <=> x and y
+// exactly zero.  Differences that only feed one multiplication stay lazy (no carry chain), and every y3 = A B - C D shares one
+// Montgomery reduction (fy_mul2).  The exceptional cases of the full addition (P + P, P + (-P)) go through the canonical formulas.
 // ---------------------------------------------------------------------------------------
 template <class F>
 struct AffineZ {
-    Fz<F> x, y;
+    Fy<F> x, y;
 };
 template <class F>
 struct XYZZz {
-    Fz<F> x, y, zz, zzz;
+    Fy<F> x, y, zz, zzz;
 };
 struct alignas(16) XYZZzMem { u32 w[36]; };  // raw limbs of x, y, zz, zzz (accumulate -> combine scratch)
 
 template <class F> TRH_HD XYZZz<F> xyzzz_identity() {
-    XYZZz<F> r; r.x = fz_zero<F>(); r.y = fz_zero<F>(); r.zz = fz_zero<F>(); r.zzz = fz_zero<F>(); return r;
+    XYZZz<F> r; r.x = fy_zero<F>(); r.y = fy_zero<F>(); r.zz = fy_zero<F>(); r.zzz = fy_zero<F>(); return r;
 }
-template <class F> TRH_HD bool xyzzz_is_identity(const XYZZz<F>& p) { return fz_is_exact_zero(p.zz); }
+template <class F> TRH_HD bool xyzzz_is_identity(const XYZZz<F>& p) { return fy_is_exact_zero(p.zz); }
 template <class F> TRH_HD XYZZ<F> xyzzz_to_canonical(const XYZZz<F>& p) {
     XYZZ<F> r;
     if (xyzzz_is_identity(p)) return xyzz_identity<F>();
-    r.x = fz_to_fe(p.x); r.y = fz_to_fe(p.y); r.zz = fz_to_fe(p.zz); r.zzz = fz_to_fe(p.zzz);
+    r.x = fy_to_fe(p.x); r.y = fy_to_fe(p.y); r.zz = fy_to_fe(p.zz); r.zzz = fy_to_fe(p.zzz);
     return r;
 }
 template <class F> TRH_HD XYZZz<F> xyzzz_from_canonical(const XYZZ<F>& p) {
     XYZZz<F> r;
     if (xyzz_is_identity(p)) return xyzzz_identity<F>();
-    r.x = fz_from_fe(p.x); r.y = fz_from_fe(p.y); r.zz = fz_from_fe(p.zz); r.zzz = fz_from_fe(p.zzz);
+    r.x = fy_from_fe(p.x); r.y = fy_from_fe(p.y); r.zz = fy_from_fe(p.zz); r.zzz = fy_from_fe(p.zzz);
     return r;
 }
 
-// 2 p for an affine point of the lazy domain (x, y < 1.01m, not the identity; y != 0: no points of order two):
-// dbl-2008-s-1 with Z = 1.  Result within the XYZZz invariants (x < 4.01m, y < 3.01m, zz, zzz < 1.01m).
+// 2 p for an affine point of the lazy domain (not the identity; y != 0: no points of order two): dbl-2008-s-1 with Z = 1
 template <class F> TRH_HD XYZZz<F> xyzzz_dbl_affine(const AffineZ<F>& p) {
     XYZZz<F> r;
-    const Fz<F> U = fz_add(p.y, p.y);                                  // < 2.02m
-    const Fz<F> V = fz_sqr(U), W = fz_mul(U, V), S = fz_mul(p.x, V);
-    const Fz<F> xx = fz_sqr(p.x), M = fz_add(fz_add(xx, xx), xx);       // < 3.02m
-    r.x = fz_sub<F, 3>(fz_sqr(M), fz_add(S, S));                        // < 4.01m
-    r.y = fz_sub<F, 2>(fz_mul(M, fz_sub<F, 5>(S, r.x)), fz_mul(W, p.y));  // < 3.01m
+    const Fy<F> U = fy_add(p.y, p.y);
+    const Fy<F> V = fy_sqr(U), W = fy_mul(U, V), S = fy_mul(p.x, V);
+    const Fy<F> xx = fy_sqr(p.x), M = fy_add(fy_add(xx, xx), xx);
+    r.x = fy_sub_sub2(fy_sqr(M), fy_zero<F>(), S);                                        // M^2 - 2 S
+    r.y = fy_mul2(fy_sub_lazy(S, r.x), M, fy_neg_lazy(W), p.y);                           // M (S - x3) - W y
     r.zz = V; r.zzz = W;
     return r;
 }
 
-// 2 p for a lazy XYZZ point (dbl-2008-s-1, a = 0); inputs and result within the XYZZz invariants
+// 2 p for a lazy XYZZ point (dbl-2008-s-1, a = 0)
 template <class F> TRH_HD XYZZz<F> xyzzz_dbl(const XYZZz<F>& p) {
     if (xyzzz_is_identity(p)) return p;
     XYZZz<F> r;
-    const Fz<F> U = fz_add(p.y, p.y);                                  // < 16m
-    const Fz<F> V = fz_sqr(U), W = fz_mul(U, V), S = fz_mul(p.x, V);
-    const Fz<F> xx = fz_sqr(p.x), M = fz_add(fz_add(xx, xx), xx);       // < 3.02m
-    r.x = fz_sub<F, 3>(fz_sqr(M), fz_add(S, S));                        // < 4.01m
-    r.y = fz_sub<F, 2>(fz_mul(M, fz_sub<F, 5>(S, r.x)), fz_mul(W, p.y));  // < 3.01m
-    r.zz = fz_mul(V, p.zz);
-    r.zzz = fz_mul(W, p.zzz);
+    const Fy<F> U = fy_add(p.y, p.y);
+    const Fy<F> V = fy_sqr(U), W = fy_mul(U, V), S = fy_mul(p.x, V);
+    const Fy<F> xx = fy_sqr(p.x), M = fy_add(fy_add(xx, xx), xx);
+    r.x = fy_sub_sub2(fy_sqr(M), fy_zero<F>(), S);
+    r.y = fy_mul2(fy_sub_lazy(S, r.x), M, fy_neg_lazy(W), p.y);
+    r.zz = fy_mul(V, p.zz);
+    r.zzz = fy_mul(W, p.zzz);
     return r;
 }
 
-// acc += p, p affine in the lazy domain
+// acc += p, p affine in the lazy domain: 9 reductions for the 8M + 2S of madd-2008-s
 template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
-    if (fz_is_exact_zero(p.x) && fz_is_exact_zero(p.y)) return;
-    if (xyzzz_is_identity(acc)) { acc.x = p.x; acc.y = p.y; acc.zz = fz_one<F>(); acc.zzz = fz_one<F>(); return; }
-    const Fz<F> U2 = fz_mul(p.x, acc.zz), S2 = fz_mul(p.y, acc.zzz);
-    const Fz<F> P = fz_sub<F, 8>(U2, acc.x), R = fz_sub<F, 8>(S2, acc.y);  // < 9.01m
-    if (fz_is_zero_mod(P)) {  // same x: acc is p (the sum is 2 p, which only needs p) or -p (the sum is the identity)
-        if (fz_is_zero_mod(R)) acc = xyzzz_dbl_affine(p);
+    if (fy_is_exact_zero(p.x) && fy_is_exact_zero(p.y)) return;
+    if (xyzzz_is_identity(acc)) { acc.x = p.x; acc.y = p.y; acc.zz = fy_one<F>(); acc.zzz = fy_one<F>(); return; }
+    const Fy<F> U2 = fy_mul(p.x, acc.zz), S2 = fy_mul(p.y, acc.zzz);
+    const Fy<F> P = fy_sub(U2, acc.x), R = fy_sub(S2, acc.y);  // normalised: both are squared
+    if (fy_is_zero_mod(P)) {  // same x: acc is p (the sum is 2 p, which only needs p) or -p (the sum is the identity)
+        if (fy_is_zero_mod(R)) acc = xyzzz_dbl_affine(p);
         else acc = xyzzz_identity<F>();
         return;
     }
-    const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(acc.x, PP);
-    const Fz<F> x3 = fz_sub<F, 4>(fz_sqr(R), fz_add_dbl(PPP, Q));             // < 5.01m
-    acc.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, x3)), fz_mul(acc.y, PPP));         // < 3.01m
+    const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(acc.x, PP);
+    const Fy<F> x3 = fy_sub_sub2(fy_sqr(R), PPP, Q);                                       // R^2 - PPP - 2 Q
+    acc.y = fy_mul2(fy_sub_lazy(Q, x3), R, fy_neg_lazy(acc.y), PPP);                       // R (Q - x3) - Y PPP, one reduction
     acc.x = x3;
-    acc.zz = fz_mul(acc.zz, PP);
-    acc.zzz = fz_mul(acc.zzz, PPP);
+    acc.zz = fy_mul(acc.zz, PP);
+    acc.zzz = fy_mul(acc.zzz, PPP);
 }
 
 // a + b, both lazy XYZZ
 template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& b) {
     if (xyzzz_is_identity(a)) return b;
     if (xyzzz_is_identity(b)) return a;
-    const Fz<F> U1 = fz_mul(a.x, b.zz), U2 = fz_mul(b.x, a.zz);
-    const Fz<F> S1 = fz_mul(a.y, b.zzz), S2 = fz_mul(b.y, a.zzz);
-    const Fz<F> P = fz_sub<F, 2>(U2, U1), R = fz_sub<F, 2>(S2, S1);  // < 3.01m
-    if (fz_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
-    const Fz<F> PP = fz_sqr(P), PPP = fz_mul(P, PP), Q = fz_mul(U1, PP);
+    const Fy<F> U1 = fy_mul(a.x, b.zz), U2 = fy_mul(b.x, a.zz);
+    const Fy<F> S1 = fy_mul(a.y, b.zzz), S2 = fy_mul(b.y, a.zzz);
+    const Fy<F> P = fy_sub(U2, U1), R = fy_sub(S2, S1);
+    if (fy_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
+    const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(U1, PP);
     XYZZz<F> r;
-    r.x = fz_sub<F, 4>(fz_sqr(R), fz_add_dbl(PPP, Q));
-    r.y = fz_sub<F, 2>(fz_mul(R, fz_sub<F, 6>(Q, r.x)), fz_mul(S1, PPP));
-    r.zz = fz_mul(fz_mul(a.zz, b.zz), PP);
-    r.zzz = fz_mul(fz_mul(a.zzz, b.zzz), PPP);
+    r.x = fy_sub_sub2(fy_sqr(R), PPP, Q);
+    r.y = fy_mul2(fy_sub_lazy(Q, r.x), R, fy_neg_lazy(S1), PPP);
+    r.zz = fy_mul(fy_mul(a.zz, b.zz), PP);
+    r.zzz = fy_mul(fy_mul(a.zzz, b.zzz), PPP);
     return r;
 }
 

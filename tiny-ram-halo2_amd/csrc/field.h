@@ -60,6 +60,8 @@ struct FpParams {  // Pallas base field = Vesta scalar field
     // pasta_curves ROOT_OF_UNITY (primitive 2^32-th root) and ZETA (cube root of unity), Montgomery form
     static constexpr u32 ROOT_OF_UNITY[8] = {0xbad6dbf0u, 0xa28db849u, 0xd3b539dfu, 0x9083cd03u, 0x9dc8448eu, 0xfba6b9cau, 0x7b89c6dau, 0x3ec92874u};
     static constexpr u32 ZETA[8] = {0x619a153du, 0x02021cf6u, 0x4980b78eu, 0x9e8c2697u, 0xc87a4666u, 0x2a676d5cu, 0xa7a17876u, 0x15d8049du};
+    static constexpr u32 TO_LAZY29[8] = {0xfffff001u, 0xc61e60ecu, 0x39bb3f88u, 0xb8b6d867u, 0xfffffddbu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};   // 2^266 mod p
+    static constexpr u32 LAZY29_ONE[8] = {0xffffff81u, 0x0294ba6cu, 0x62d06b4fu, 0xfefa1af7u, 0xffffffeeu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // 2^261 mod p
 };
 struct FqParams {  // Vesta base field = Pallas scalar field
     static constexpr int ID = 1;
@@ -70,6 +72,8 @@ struct FqParams {  // Vesta base field = Pallas scalar field
     static constexpr u32 LAZY_ONE[8] = {0xffff0001u, 0xa125eb20u, 0x60b71c96u, 0x894a8f67u, 0xffffddb9u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
     static constexpr u32 ROOT_OF_UNITY[8] = {0x8c9942deu, 0x21807742u, 0x21b60494u, 0xcc495789u, 0xb2efbee2u, 0xac2e5d27u, 0x7f2db056u, 0x0b79fa89u};
     static constexpr u32 ZETA[8] = {0x80111122u, 0x7c541a84u, 0x56ed29dau, 0x40630b9cu, 0x135b2b29u, 0x02c275fbu, 0x88245b10u, 0x121d29f8u};
+    static constexpr u32 TO_LAZY29[8] = {0xfffff001u, 0x1d94db20u, 0xbf06d019u, 0xb8b6d862u, 0xfffffddbu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};   // 2^266 mod q
+    static constexpr u32 LAZY29_ONE[8] = {0xffffff81u, 0x68d15aa0u, 0x3f403a17u, 0xfefa1af7u, 0xffffffeeu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // 2^261 mod q
 };
 
 template <class F, int K> struct ModLimb { static constexpr u32 v = limb30_of(F::MOD, K); };
@@ -488,6 +492,283 @@ template <class F> TRH_HD Fe<F> fz_to_fe(const Fz<F>& a) {
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < NLIMBS; ++i) r.l[i] = t.l[i];
+    fe_cond_sub(r);
+    return r;
+}
+
+
+// =========================================================================================
+// Signed lazy domain with 29-bit limbs (the MSM's bucket arithmetic, curve.h "XYZZz").
+//
+// Fy holds a residue in Montgomery form with R'' = 2^261 = (2^29)^9 as nine SIGNED 32-bit limbs.
+//   normalised (N): l[0..7] in [0, 2^29), l[8] signed and small; the VALUE may be negative and is only bounded (|v| < 16 m)
+//   lazy (L1):      the limb-wise sum or difference of two normalised values, no carry propagation: |l[k]| < 2^30
+// Why 29 bits: a column of the schoolbook product of a normalised and a lazy operand is < 9 * 2^59, and the column of TWO
+// normalised products < 18 * 2^58 -- both below 2^63 with the reduction terms on top, so
+//   * additions / subtractions that only feed a multiplication need no carry chain at all (fy_sub_lazy), and
+//   * a * b + c * d shares ONE Montgomery reduction (fy_mul2: y3 = R (Q - x3) - Y PPP of the mixed addition).
+// A reduction is more than half of a multiplication (45 of 126 multiply-adds and all of the 64-bit carry work), which is what
+// this buys over the 30-bit unsigned domain above (still used by the NTT, whose butterflies have no such pairs).
+// fy_mul(a, b) = a b / 2^261 (mod m) in (-|a b| / 2^261, |a b| / 2^261 + m): |a|, |b| < 16 m gives (-2 m, 3 m).
+// =========================================================================================
+constexpr u32 YBITS = 29;
+constexpr i32 YMASK = (1 << YBITS) - 1;
+typedef int64_t i64;
+
+constexpr u32 limb29_of(const u32 (&w)[8], int k) {
+    const int bit = 29 * k, word = bit >> 5, sh = bit & 31;
+    u64 v = w[word];
+    if (word + 1 < 8) v |= (u64)w[word + 1] << 32;
+    return (u32)(v >> sh) & (u32)YMASK;
+}
+template <class F, int K> struct YModLimb { static constexpr i32 v = (i32)limb29_of(F::MOD, K); };
+template <class F, int K> struct YToLazyLimb { static constexpr i32 v = (i32)limb29_of(F::TO_LAZY29, K); };
+template <class F, int K> struct YOneLimb { static constexpr i32 v = (i32)limb29_of(F::LAZY29_ONE, K); };
+template <class F, int K> struct YMontOneLimb { static constexpr i32 v = (i32)limb29_of(F::ONE, K); };
+static_assert(YModLimb<FpParams, 0>::v == 1 && YModLimb<FpParams, 5>::v == 0 && YModLimb<FpParams, 6>::v == 0 && YModLimb<FpParams, 7>::v == 0 &&
+              YModLimb<FpParams, 8>::v == (1 << 22), "Fp modulus shape (radix 2^29)");
+static_assert(YModLimb<FqParams, 0>::v == 1 && YModLimb<FqParams, 5>::v == 0 && YModLimb<FqParams, 6>::v == 0 && YModLimb<FqParams, 7>::v == 0 &&
+              YModLimb<FqParams, 8>::v == (1 << 22), "Fq modulus shape (radix 2^29)");
+template <class F> TRH_HD constexpr i32 ymod_limb(int k) {
+    return k == 0 ? YModLimb<F, 0>::v : k == 1 ? YModLimb<F, 1>::v : k == 2 ? YModLimb<F, 2>::v : k == 3 ? YModLimb<F, 3>::v :
+           k == 4 ? YModLimb<F, 4>::v : k == 5 ? YModLimb<F, 5>::v : k == 6 ? YModLimb<F, 6>::v : k == 7 ? YModLimb<F, 7>::v : YModLimb<F, 8>::v;
+}
+
+template <class F>
+struct Fy {
+    i32 l[NLIMBS];
+};
+
+template <class F> TRH_HD Fy<F> fy_zero() {
+    Fy<F> r;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = 0;
+    return r;
+}
+template <class F> TRH_HD Fy<F> fy_one() {
+    Fy<F> r;
+    r.l[0] = YOneLimb<F, 0>::v; r.l[1] = YOneLimb<F, 1>::v; r.l[2] = YOneLimb<F, 2>::v; r.l[3] = YOneLimb<F, 3>::v; r.l[4] = YOneLimb<F, 4>::v;
+    r.l[5] = YOneLimb<F, 5>::v; r.l[6] = YOneLimb<F, 6>::v; r.l[7] = YOneLimb<F, 7>::v; r.l[8] = YOneLimb<F, 8>::v;
+    return r;
+}
+template <class F> TRH_HD bool fy_is_exact_zero(const Fy<F>& a) {
+    i32 o = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) o |= a.l[i];
+    return o == 0;
+}
+
+// 2^22 in a register the compiler cannot see through: `q * two22 + acc` stays ONE multiply-add (the top modulus limb is 2^22)
+TRH_HD i32 opaque_two22() {
+    i32 v = 1 << 22;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// nine uniform 29-bit rounds on signed columns; result = value / 2^261 (mod m), normalised
+template <class F> TRH_HD Fy<F> fy_reduce(i64 (&acc)[18]) {
+    constexpr i32 P1 = YModLimb<F, 1>::v, P2 = YModLimb<F, 2>::v, P3 = YModLimb<F, 3>::v, P4 = YModLimb<F, 4>::v;
+    const i32 two22 = opaque_two22();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const i32 q = (i32)((0u - (u32)acc[i]) & (u32)YMASK);
+        // column i + q is a multiple of 2^29: its quotient is ceil(acc[i] / 2^29) (arithmetic shift = floor)
+        acc[i + 1] += ((acc[i] + YMASK) >> YBITS) + (i64)q * P1;
+        acc[i + 2] += (i64)q * P2;
+        acc[i + 3] += (i64)q * P3;
+        acc[i + 4] += (i64)q * P4;
+        acc[i + 8] += (i64)q * two22;
+    }
+    Fy<F> r;
+    i64 c = 0;
+#pragma unroll
+    for (int k = 0; k < NLIMBS - 1; ++k) {
+        c += acc[9 + k];
+        r.l[k] = (i32)((u32)c & (u32)YMASK);
+        c >>= YBITS;
+    }
+    r.l[8] = (i32)(c + acc[17]);  // signed top limb: |value| < 2^260
+    return r;
+}
+// a normalised or lazy, b normalised (or the other way round): |a_i b_j| < 2^59
+template <class F> TRH_HD Fy<F> fy_mul(const Fy<F>& a, const Fy<F>& b) {
+    i64 acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i)
+#pragma unroll
+        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
+    return fy_reduce<F>(acc);
+}
+// a normalised
+template <class F> TRH_HD Fy<F> fy_sqr(const Fy<F>& a) {
+    i64 acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) {
+        acc[2 * i] += (i64)a.l[i] * a.l[i];
+        const i32 a2 = a.l[i] * 2;  // < 2^30 in magnitude (the top limb is small)
+#pragma unroll
+        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (i64)a2 * a.l[j];
+    }
+    return fy_reduce<F>(acc);
+}
+// a b + c d with ONE reduction.  Column bound: (a or b lazy, the other normalised) + (c, d normalised) <= 9 * 2^59 + 9 * 2^58 < 2^62.8
+template <class F> TRH_HD Fy<F> fy_mul2(const Fy<F>& a, const Fy<F>& b, const Fy<F>& c, const Fy<F>& d) {
+    i64 acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i)
+#pragma unroll
+        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i)
+#pragma unroll
+        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)c.l[i] * d.l[j];
+    return fy_reduce<F>(acc);
+}
+// carry propagation: any limbs (|l[k]| < 2^31 - 2^3) -> normalised
+template <class F> TRH_HD Fy<F> fy_norm(const Fy<F>& a) {
+    Fy<F> r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 v = a.l[i] + c;
+        r.l[i] = v & YMASK;
+        c = v >> YBITS;
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+// limb-wise, no carries: the result only feeds ONE multiplication (as its lazy operand) or a fy_norm
+template <class F> TRH_HD Fy<F> fy_add_lazy(const Fy<F>& a, const Fy<F>& b) {
+    Fy<F> r;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <class F> TRH_HD Fy<F> fy_sub_lazy(const Fy<F>& a, const Fy<F>& b) {
+    Fy<F> r;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+template <class F> TRH_HD Fy<F> fy_neg_lazy(const Fy<F>& a) {
+    Fy<F> r;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = -a.l[i];
+    return r;
+}
+// normalising forms (one carry chain)
+template <class F> TRH_HD Fy<F> fy_add(const Fy<F>& a, const Fy<F>& b) {
+    Fy<F> r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 v = a.l[i] + b.l[i] + c;
+        r.l[i] = v & YMASK;
+        c = v >> YBITS;
+    }
+    r.l[8] = a.l[8] + b.l[8] + c;
+    return r;
+}
+template <class F> TRH_HD Fy<F> fy_sub(const Fy<F>& a, const Fy<F>& b) {
+    Fy<F> r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 v = a.l[i] - b.l[i] + c;
+        r.l[i] = v & YMASK;
+        c = v >> YBITS;
+    }
+    r.l[8] = a.l[8] - b.l[8] + c;
+    return r;
+}
+// a - b - 2 c, normalised (x3 = R^2 - PPP - 2 Q in one chain)
+template <class F> TRH_HD Fy<F> fy_sub_sub2(const Fy<F>& a, const Fy<F>& b, const Fy<F>& c2) {
+    Fy<F> r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 v = a.l[i] - b.l[i] - 2 * c2.l[i] + c;  // > -2^31
+        r.l[i] = v & YMASK;
+        c = v >> YBITS;
+    }
+    r.l[8] = a.l[8] - b.l[8] - 2 * c2.l[8] + c;
+    return r;
+}
+// normalised value == 0 (mod m)?  |value| < 16 m, so it would be j m with |j| <= 16, whose low limb is j mod 2^29 (m = 1 mod 2^29)
+template <class F> TRH_HD bool fy_is_zero_mod(const Fy<F>& a) {
+    const i32 l0 = a.l[0];
+    i32 j;
+    if (l0 <= 16) j = l0;
+    else if (l0 >= YMASK + 1 - 16) j = l0 - (YMASK + 1);
+    else return false;
+    i64 carry = 0;
+    i32 diff = 0;
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i64 t = (i64)j * ymod_limb<F>(i) + carry;
+        diff |= (i32)((u32)t & (u32)YMASK) ^ a.l[i];
+        carry = t >> YBITS;
+    }
+    diff |= (i32)((i64)j * ymod_limb<F>(8) + carry) ^ a.l[8];
+    return diff == 0;
+}
+// memory words <-> limbs; the stored value must be in [0, 2^256)
+template <class F> TRH_HD Fy<F> fy_load(u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5, u32 w6, u32 w7) {
+    Fy<F> r;
+    const u32 M = (u32)YMASK;
+    r.l[0] = (i32)(w0 & M);
+    r.l[1] = (i32)(((w0 >> 29) | (w1 << 3)) & M);
+    r.l[2] = (i32)(((w1 >> 26) | (w2 << 6)) & M);
+    r.l[3] = (i32)(((w2 >> 23) | (w3 << 9)) & M);
+    r.l[4] = (i32)(((w3 >> 20) | (w4 << 12)) & M);
+    r.l[5] = (i32)(((w4 >> 17) | (w5 << 15)) & M);
+    r.l[6] = (i32)(((w5 >> 14) | (w6 << 18)) & M);
+    r.l[7] = (i32)(((w6 >> 11) | (w7 << 21)) & M);
+    r.l[8] = (i32)(w7 >> 8);
+    return r;
+}
+template <class F> TRH_HD void fy_store(const Fy<F>& a, u32* w) {
+    const u32* l = (const u32*)a.l;
+    w[0] = l[0] | (l[1] << 29);
+    w[1] = (l[1] >> 3) | (l[2] << 26);
+    w[2] = (l[2] >> 6) | (l[3] << 23);
+    w[3] = (l[3] >> 9) | (l[4] << 20);
+    w[4] = (l[4] >> 12) | (l[5] << 17);
+    w[5] = (l[5] >> 15) | (l[6] << 14);
+    w[6] = (l[6] >> 18) | (l[7] << 11);
+    w[7] = (l[7] >> 21) | (l[8] << 8);
+}
+// canonical Montgomery-R element -> this domain (result in [0, m (1 + 2^-7)))
+template <class F> TRH_HD Fy<F> fy_from_fe(const Fe<F>& a) {
+    u32 w[8];
+    fe_store(a, w);
+    const Fy<F> x = fy_load<F>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+    Fy<F> c;
+    c.l[0] = YToLazyLimb<F, 0>::v; c.l[1] = YToLazyLimb<F, 1>::v; c.l[2] = YToLazyLimb<F, 2>::v; c.l[3] = YToLazyLimb<F, 3>::v; c.l[4] = YToLazyLimb<F, 4>::v;
+    c.l[5] = YToLazyLimb<F, 5>::v; c.l[6] = YToLazyLimb<F, 6>::v; c.l[7] = YToLazyLimb<F, 7>::v; c.l[8] = YToLazyLimb<F, 8>::v;
+    return fy_mul(x, c);
+}
+// normalised (|value| < 16 m) -> canonical Montgomery-R element: multiply by 2^256 mod m here, then bring (-m/8, 9 m / 8) into [0, m)
+template <class F> TRH_HD Fe<F> fy_to_fe(const Fy<F>& a) {
+    Fy<F> c;
+    c.l[0] = YMontOneLimb<F, 0>::v; c.l[1] = YMontOneLimb<F, 1>::v; c.l[2] = YMontOneLimb<F, 2>::v; c.l[3] = YMontOneLimb<F, 3>::v; c.l[4] = YMontOneLimb<F, 4>::v;
+    c.l[5] = YMontOneLimb<F, 5>::v; c.l[6] = YMontOneLimb<F, 6>::v; c.l[7] = YMontOneLimb<F, 7>::v; c.l[8] = YMontOneLimb<F, 8>::v;
+    Fy<F> t = fy_mul(a, c);
+    Fy<F> mm;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) mm.l[i] = ymod_limb<F>(i);
+    t = fy_add(t, mm);  // (7 m / 8, 17 m / 8): non-negative, below 2^256
+    u32 w[8];
+    fy_store(t, w);
+    Fe<F> r = fe_load<F>(w);
+    fe_cond_sub(r);  // [0, 2m) steps
     fe_cond_sub(r);
     return r;
 }

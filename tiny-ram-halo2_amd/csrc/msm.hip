@@ -523,8 +523,8 @@ __global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint4* __r
     const uint4* p = in + i * 4;
     uint4 a = p[0], b = p[1], c = p[2], d = p[3];
     u32 wx[8], wy[8];
-    fz_store(fz_from_fe(fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)), wx);  // 0 -> 0: identity stays (0, 0)
-    fz_store(fz_from_fe(fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w)), wy);
+    fy_store(fy_from_fe(fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)), wx);  // 0 -> 0: identity stays (0, 0)
+    fy_store(fy_from_fe(fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w)), wy);
     uint4* q = out + i * 4;
     q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
     q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
@@ -597,13 +597,18 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
         }
         const u32 ce = sl.e;
         AffineZ<BF> cur;
-        cur.x = fz_load<BF>(sl.a.x, sl.a.y, sl.a.z, sl.a.w, sl.b.x, sl.b.y, sl.b.z, sl.b.w);
-        cur.y = fz_load<BF>(sl.c.x, sl.c.y, sl.c.z, sl.c.w, sl.d.x, sl.d.y, sl.d.z, sl.d.w);
+        cur.x = fy_load<BF>(sl.a.x, sl.a.y, sl.a.z, sl.a.w, sl.b.x, sl.b.y, sl.b.z, sl.b.w);
+        cur.y = fy_load<BF>(sl.c.x, sl.c.y, sl.c.z, sl.c.w, sl.d.x, sl.d.y, sl.d.z, sl.d.w);
         if (pos + 2 < stop) {
             issue(sl, e_ahead);
             if (pos + 3 < stop) e_ahead = lst[pos + 3];
         }
-        if ((ce & SIGN_BIT) && !(fz_is_exact_zero(cur.x) && fz_is_exact_zero(cur.y))) cur.y = fz_sub<BF, 2>(fz_zero<BF>(), cur.y);
+        {   // negative digit: -P.  Limb-wise two's complement negation (branch-free; the identity (0, 0) stays (0, 0)); the lazy
+            // limbs in (-2^29, 0] are as good as normalised ones wherever y is used (field.h "Signed lazy domain")
+            const i32 neg = -(i32)(ce >> 31);
+#pragma unroll
+            for (int i = 0; i < NLIMBS; ++i) cur.y.l[i] = (cur.y.l[i] ^ neg) - neg;
+        }
         xyzzz_madd(acc, cur);
         ++pos;
     };
@@ -805,8 +810,8 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
             a = xyzz_to_affine(acc);
         }
         u32 wx[8], wy[8];
-        fz_store(fz_from_fe(a.x), wx);
-        fz_store(fz_from_fe(a.y), wy);
+        fy_store(fy_from_fe(a.x), wx);
+        fy_store(fy_from_fe(a.y), wy);
         uint4* q = out + ((size_t)j * n + i) * 4;
         q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
         q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
