@@ -52,6 +52,8 @@ static int run(const char* name) {
         if (!same(fy_to_fe(fy_mul2(fy_sub_lazy(ya, yc), yb, fy_neg_lazy(yc), yd)), fe_sub(fe_mul(fe_sub(a, c), b), fe_mul(c, d)))) fail("mul2 lazy / negated", i);
         if (!same(fy_to_fe(fy_sub(ya, yb)), fe_sub(a, b)) || !same(fy_to_fe(fy_add(ya, yb)), fe_add(a, b))) fail("add / sub", i);
         if (!same(fy_to_fe(fy_sub_sub2(ya, yb, yc)), fe_sub(fe_sub(a, b), fe_dbl(c)))) fail("sub_sub2", i);
+        if (!same(fy_to_fe(fy_mul_sub(ya, yb, yc)), fe_sub(fe_mul(a, b), c))) fail("mul_sub", i);
+        if (!same(fy_to_fe(fy_sqr_sub_sub2(ya, yb, yc)), fe_sub(fe_sub(fe_sqr(a), b), fe_dbl(c))) || !normalised(fy_sqr_sub_sub2(ya, yb, yc), 25)) fail("sqr_sub_sub2", i);
         if (!same(fy_to_fe(fy_mul(fy_sub_lazy(ya, yb), yc)), fe_mul(fe_sub(a, b), c))) fail("lazy operand", i);
         // zero test: k m for small |k| and near misses
         Fy<F> mm;

@@ -229,15 +229,14 @@ template <class F> TRH_HD XYZZz<F> xyzzz_dbl(const XYZZz<F>& p) {
 template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
     if (fy_is_exact_zero(p.x) && fy_is_exact_zero(p.y)) return;
     if (xyzzz_is_identity(acc)) { acc.x = p.x; acc.y = p.y; acc.zz = fy_one<F>(); acc.zzz = fy_one<F>(); return; }
-    const Fy<F> U2 = fy_mul(p.x, acc.zz), S2 = fy_mul(p.y, acc.zzz);
-    const Fy<F> P = fy_sub(U2, acc.x), R = fy_sub(S2, acc.y);  // normalised: both are squared
+    const Fy<F> P = fy_mul_sub(p.x, acc.zz, acc.x), R = fy_mul_sub(p.y, acc.zzz, acc.y);  // U2 - X, S2 - Y, normalised: both are squared
     if (fy_is_zero_mod(P)) {  // same x: acc is p (the sum is 2 p, which only needs p) or -p (the sum is the identity)
         if (fy_is_zero_mod(R)) acc = xyzzz_dbl_affine(p);
         else acc = xyzzz_identity<F>();
         return;
     }
     const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(acc.x, PP);
-    const Fy<F> x3 = fy_sub_sub2(fy_sqr(R), PPP, Q);                                       // R^2 - PPP - 2 Q
+    const Fy<F> x3 = fy_sqr_sub_sub2(R, PPP, Q);                                           // R^2 - PPP - 2 Q
     acc.y = fy_mul2(fy_sub_lazy(Q, x3), R, fy_neg_lazy(acc.y), PPP);                       // R (Q - x3) - Y PPP, one reduction
     acc.x = x3;
     acc.zz = fy_mul(acc.zz, PP);
@@ -254,7 +253,7 @@ template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& 
     if (fy_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
     const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(U1, PP);
     XYZZz<F> r;
-    r.x = fy_sub_sub2(fy_sqr(R), PPP, Q);
+    r.x = fy_sqr_sub_sub2(R, PPP, Q);
     r.y = fy_mul2(fy_sub_lazy(Q, r.x), R, fy_neg_lazy(S1), PPP);
     r.zz = fy_mul(fy_mul(a.zz, b.zz), PP);
     r.zzz = fy_mul(fy_mul(a.zzz, b.zzz), PPP);

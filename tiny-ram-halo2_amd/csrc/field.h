@@ -567,8 +567,9 @@ TRH_HD i32 opaque_two22() {
     return v;
 }
 
-// nine uniform 29-bit rounds on signed columns; result = value / 2^261 (mod m), normalised
-template <class F> TRH_HD Fy<F> fy_reduce(i64 (&acc)[18]) {
+// nine uniform 29-bit rounds on signed columns; result = value / 2^261 (mod m) - s1 - 2 s2, normalised.  The subtrahends ride in the
+// final carry chain (the difference that follows a product would otherwise be a second chain): SUB 0 none, 1 s1, 2 s1 and 2 s2
+template <class F, int SUB> TRH_HD Fy<F> fy_reduce_sub(i64 (&acc)[18], const Fy<F>* s1, const Fy<F>* s2) {
     constexpr i32 P1 = YModLimb<F, 1>::v, P2 = YModLimb<F, 2>::v, P3 = YModLimb<F, 3>::v, P4 = YModLimb<F, 4>::v;
     const i32 two22 = opaque_two22();
 #pragma unroll
@@ -584,14 +585,19 @@ template <class F> TRH_HD Fy<F> fy_reduce(i64 (&acc)[18]) {
     Fy<F> r;
     i64 c = 0;
 #pragma unroll
-    for (int k = 0; k < NLIMBS - 1; ++k) {
+    for (int k = 0; k < NLIMBS; ++k) {
         c += acc[9 + k];
-        r.l[k] = (i32)((u32)c & (u32)YMASK);
-        c >>= YBITS;
+        if (SUB == 1) c -= s1->l[k];
+        if (SUB == 2) c -= s1->l[k] + 2 * s2->l[k];  // > -2^31: s1, s2 normalised
+        if (k < NLIMBS - 1) {
+            r.l[k] = (i32)((u32)c & (u32)YMASK);
+            c >>= YBITS;
+        }
     }
-    r.l[8] = (i32)(c + acc[17]);  // signed top limb: |value| < 2^260
+    r.l[8] = (i32)c;  // signed top limb: |value| < 2^260
     return r;
 }
+template <class F> TRH_HD Fy<F> fy_reduce(i64 (&acc)[18]) { return fy_reduce_sub<F, 0>(acc, nullptr, nullptr); }
 // a normalised or lazy, b normalised (or the other way round): |a_i b_j| < 2^59
 template <class F> TRH_HD Fy<F> fy_mul(const Fy<F>& a, const Fy<F>& b) {
     i64 acc[18];
@@ -631,6 +637,31 @@ template <class F> TRH_HD Fy<F> fy_mul2(const Fy<F>& a, const Fy<F>& b, const Fy
 #pragma unroll
         for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)c.l[i] * d.l[j];
     return fy_reduce<F>(acc);
+}
+// a b - s (U2 - X, S2 - Y of the mixed addition): the subtraction rides in the product's carry chain
+template <class F> TRH_HD Fy<F> fy_mul_sub(const Fy<F>& a, const Fy<F>& b, const Fy<F>& s) {
+    i64 acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i)
+#pragma unroll
+        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
+    return fy_reduce_sub<F, 1>(acc, &s, nullptr);
+}
+// a^2 - s1 - 2 s2 (x3 = R^2 - PPP - 2 Q)
+template <class F> TRH_HD Fy<F> fy_sqr_sub_sub2(const Fy<F>& a, const Fy<F>& s1, const Fy<F>& s2) {
+    i64 acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) {
+        acc[2 * i] += (i64)a.l[i] * a.l[i];
+        const i32 a2 = a.l[i] * 2;
+#pragma unroll
+        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (i64)a2 * a.l[j];
+    }
+    return fy_reduce_sub<F, 2>(acc, &s1, &s2);
 }
 // carry propagation: any limbs (|l[k]| < 2^31 - 2^3) -> normalised
 template <class F> TRH_HD Fy<F> fy_norm(const Fy<F>& a) {
