@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrh.so")
+LIB_PATH = os.environ.get("TRH_LIB_PATH") or os.path.join(_HERE, "libtrh.so")  # the override serves same-box A/B measurements of two builds
 
 PALLAS, VESTA = 0, 1
 FP, FQ = 0, 1
