@@ -24,7 +24,10 @@ def to_tuple(e):
     return ("scaled", to_tuple(e.e), e.value)
 
 
-def test_replay_k10_matches_oracle():
+@pytest.mark.parametrize("columns", ["random", "witness"])
+def test_replay_k10_matches_oracle(columns):
+    """`witness`: the value classes of the reference's tables (flags / words on n / 4 live rows, zero padding, blinding rows) --
+    commitments whose pairs fall into a handful of buckets -- through the same oracle comparison"""
     seen = {}
 
     def hook(kind, inp, out):
@@ -88,15 +91,16 @@ def test_replay_k10_matches_oracle():
             want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert [f.from_limbs(r) for r in np.asarray(out).reshape(-1, 4)] == want, kind
 
-    res = replay.run(16, batch=32, hook=hook, verbose=False)
-    assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504
+    res = replay.run(16, batch=32, hook=hook, verbose=False, columns=columns)
+    assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504 and res["columns"] == columns
+    assert res["counts"]["multiopen_folds"] == 4 and res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
     assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
 
 
 def test_replay_k18_matches_oracle():
     """BASELINE config 4 (WORD_BITS = 32: k = 18, extended_k = 21, /root/reference/src/test_utils.rs:20, src/circuits/mod.rs:367):
-    the same schedule with the first item of every primitive kind compared against the C++ oracle (oracle/cpu_ref.py:
+    the same schedule over WITNESS-SHAPED columns with the first item of every primitive kind compared against the C++ oracle (oracle/cpu_ref.py:
     best_multiexp, EvaluationDomain over best_fft, eval_polynomial; the lookup permutation and the product column against the
     step-by-step big-int restatements)"""
     seen = {}
@@ -176,7 +180,7 @@ def test_replay_k18_matches_oracle():
             want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
 
-    res = replay.run(32, batch=32, hook=hook, verbose=False)
+    res = replay.run(32, batch=32, hook=hook, verbose=False, columns="witness", keygen=False)
     assert res["schedule"]["k"] == 18 and res["schedule"]["extended_k"] == 21 and res["schedule"]["msm_n_plus_1"] == 504
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497 and res["counts"]["ipa"] == 1
     assert set(seen) == {"lookup_permute", "product_column", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "divide_and_extended_to_coeff"}

@@ -83,7 +83,21 @@ def construct_intermediate_sets(queries):
     return commitments, point_sets
 
 
-def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict):
+def _stack(tensors):
+    """(batch, n, 4) view of the polynomials of one point set: in place when they are consecutive rows of one buffer (the prover keeps
+    the coefficient forms of a set back to back), a copy otherwise"""
+    import torch
+    t0 = tensors[0]
+    step = t0.numel() * t0.element_size()
+    if all(t.is_contiguous() and t.data_ptr() == t0.data_ptr() + i * step and t.shape == t0.shape for i, t in enumerate(tensors)):
+        try:
+            return torch.as_strided(t0, (len(tensors),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
+        except RuntimeError:
+            pass  # the rows belong to different allocations that merely happen to be adjacent
+    return torch.stack(tensors).contiguous()
+
+
+def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict, s_poly=None):
     """queries: list of (point, key) in the prover's order; polys[key]: device tensor (n, 4) of coefficients; blinds[key]: int.
     Mirrors poly/multiopen/prover.rs: x1 / x2 squeezes, per-set Horner fold in x1, kate_division by every point of the set,
     x2 fold, commitment of q'(X), x3, the evaluations of the q_i at x3, x4 fold and the IPA opening at x3.  Returns what the
@@ -101,7 +115,7 @@ def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict):
     q_polys, q_blinds = [], []
     for keys in members:  # q = (((p_0 x1 + p_1) x1 + p_2) ...): coefficient of p_j is x1^(len - 1 - j)
         coeffs = [pow(x1, len(keys) - 1 - j, m) for j in range(len(keys))]
-        stack = torch.stack([polys[k] for k in keys]).contiguous()
+        stack = _stack([polys[k] for k in keys])
         q_polys.append(lincomb(sf, stack, coeffs))
         q_blinds.append(sum(c * blinds[k] for c, k in zip(coeffs, keys)) % m)
     dev = q_polys[0].device
@@ -124,5 +138,6 @@ def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict):
     # p = ((q' x4 + q_0) x4 + q_1) ...: q' gets x4^nsets, q_i gets x4^(nsets - 1 - i)
     p_poly = lincomb(sf, torch.stack([q_prime] + q_polys).contiguous(), [pow(x4, nsets - i, m) for i in range(nsets + 1)])
     p_blind = (q_prime_blind * pow(x4, nsets, m) + sum(pow(x4, nsets - 1 - i, m) * b for i, b in enumerate(q_blinds))) % m
-    s_poly = np.stack([_limbs(sf, rng()) for _ in range(n)])
+    if s_poly is None:  # the prover's random s(X): n draws (a caller that times the phase hands the host array in)
+        s_poly = np.stack([_limbs(sf, rng()) for _ in range(n)])
     return ipa.create_proof_native(params, rng, transcript, p_poly, p_blind, x3, s_poly, rng())

@@ -15,6 +15,15 @@ extract.  Witness generation and the transcript stay on the host and are not par
 
     python -m tiny_ram_halo2_amd.replay --word-bits 32           # k = 18, the 2^14-cycle configuration
     python -m tiny_ram_halo2_amd.replay --word-bits 16           # k = 10 (BASELINE config 1's circuit size)
+    python -m tiny_ram_halo2_amd.replay --columns witness        # columns shaped like the reference's witness (see witness_columns)
+
+`--columns witness` replaces the uniformly random columns by the value classes the reference's tables really hold: flags and
+<= WORD_BITS-bit words on the n / 4 live rows, zero padding behind them, a few blinding rows at the end, sorted small values
+for the permuted lookup columns, and full-size field elements only for the grand-product columns -- which is what puts
+almost every pair of a commitment into a handful of buckets (the skew paths of the MSM).  The `keygen` section replays
+keygen_vk / keygen_pk (fixed and sigma columns: commit, iNTT, coset NTT; the l0 / l_blind / l_last cosets), once per proving
+key; the `multiopen` entry runs the whole poly::multiopen::create_proof (x1 folds over every queried column, kate divisions,
+x2 fold, q' commitment, evaluations, x4 fold, IPA) on the resident coefficient forms.
 
 `run(..., hook=f)` calls f(kind, inputs, outputs) on the first items of every primitive kind so that a test
 can compare them with the oracle (tests/test_gpu_replay.py); the module itself never touches the oracle.
@@ -32,7 +41,50 @@ from . import api, expr, ipa, permutation, poly, synth
 # Appendix B counts for TinyRamCircuit<WB, 8>
 N_INSTANCE, N_ADVICE, N_LOOKUPS, N_PERM_PRODUCTS, N_H_PIECES = 94, 263, 31, 47, 5
 N_SYNTH_GATES = 300  # gate polynomials of the synthetic h(X) step (the real count is a property of the circuit definition)
+# keygen: fixed columns (pc, time, the selectors, the out / even-bits / pow lookup tables, the constants column:
+# /root/reference/src/circuits/tables/prog.rs:140-144, exe.rs:538-551, aux/out_table.rs:98-100, even_bits.rs:51, 330, pow.rs:16-17,
+# assign.rs:25) and one sigma polynomial per equality-enabled column (prog.rs:151-152: 188)
+N_FIXED, N_SIGMA = 25, 188
+BLINDING_ROWS = 6  # cs.blinding_factors() + 1 rows at the end of every advice / permuted / product column hold random values
 QUOTIENT_J = 6  # cs.degree() = 6 => EvaluationDomain::new(6, k): quotient_poly_degree 5, extended_k = k + 3
+
+
+def column_classes(word_bits: int):
+    """value classes of the 497 Lagrange-basis columns of one proof, in commitment order (instance, advice, permuted lookup
+    columns, product columns): (count, kind, blinded).  Counted from the reference's tables: the exe table's 169 advice columns are
+    the instruction-decoding flags of the 94-column program line, flag / selector bits of the temp-var machinery and the signed /
+    logic / shift chips, and WORD_BITS-bit words (pc, registers, address, value, temp a..d, decompositions) with their even / odd
+    halves as even-bits words (/root/reference/src/circuits/tables/exe.rs:538-741, exe/temp_vars.rs:42-119, even_bits.rs:90-107);
+    the prog table mirrors the program line as instance + advice (tables/prog.rs:139-161).  29 of the 31 lookups compare ONE
+    even-bits / shift expression with a range table (sorted small values), the CorrectOut and program lookups compress 15 / 94
+    expressions with theta (full-size values)."""
+    return [
+        (70, "flag", False), (24, "word", False),                       # instance: the program (flags of the decoded line, immediates)
+        (150, "flag", True), (90, "word", True), (23, "even", True),     # advice
+        (58, "sorted", True), (4, "full", True),                         # permuted input / table columns of the lookups
+        (N_LOOKUPS + N_PERM_PRODUCTS, "full", True),                     # grand-product columns z
+    ]
+
+
+def witness_columns(kind: str, blinded: bool, seed: int, b: int, n: int, word_bits: int) -> np.ndarray:
+    """(b, n, 4) CANONICAL limbs of b columns of one class: live rows are the first n / 4 (exe.rs:106, prog.rs:137), zero behind
+    them, BLINDING_ROWS random rows at the very end"""
+    live = n // 4
+    out = np.zeros((b, n, 4), dtype=np.uint64)
+    raw = synth.splitmix64_stream(seed, 0, b * live).reshape(b, live)
+    if kind == "flag":
+        out[:, :live, 0] = raw & np.uint64(1)
+    elif kind == "word":
+        out[:, :live, 0] = raw & np.uint64((1 << word_bits) - 1)
+    elif kind == "even":   # bits at even positions only (EvenBitsConfig decompositions)
+        out[:, :live, 0] = raw & np.uint64(int("01" * (word_bits // 2), 2))
+    elif kind == "sorted":  # permuted lookup column: the sorted multiset of a range-table lookup
+        out[:, :live, 0] = np.sort(raw & np.uint64((1 << (word_bits // 2)) - 1), axis=1)
+    else:
+        out[:] = synth.field_elements(seed, b * n).reshape(b, n, 4)
+    if blinded and kind != "full":
+        out[:, n - BLINDING_ROWS:] = synth.field_elements(seed ^ 0xB11D, b * BLINDING_ROWS).reshape(b, BLINDING_ROWS, 4)
+    return out
 
 
 def schedule(k: int) -> dict:
@@ -62,8 +114,12 @@ class _FixedTranscript:
         return (w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192) % self.m
 
 
-def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True) -> dict:
+def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True, columns: str = "random",
+        keygen: bool = True) -> dict:
     import torch
+
+    from . import multiopen
+    assert columns in ("random", "witness")
 
     k = 2 + word_bits // 2
     sch = schedule(k)
@@ -97,7 +153,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         return e
 
     times = {"lookup_permute": 0.0, "product_columns": 0.0, "commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0, "h_eval": 0.0, "commit": 0.0,
-             "extended_to_coeff": 0.0, "ipa": 0.0}
+             "extended_to_coeff": 0.0, "multiopen_folds": 0.0, "ipa": 0.0}
     counts = {kk: 0 for kk in times}
     checked = 0
     torch.cuda.synchronize()
@@ -152,11 +208,36 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     lag_total = sch["intt_n"]
     done = 0
     seed = 0xC01
+    # the coefficient forms stay resident for the multiopen argument at the end (497 x 2^k x 32 B: 4.2 GB at k = 18)
+    coeff_all = torch.empty((lag_total + 1 + N_H_PIECES, n, 4), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    if columns == "witness":  # (kind, blinded) of every column, in commitment order
+        kinds = [(kind, blinded) for count, kind, blinded in column_classes(word_bits) for _ in range(count)]
+        assert len(kinds) == lag_total
+
+    def make_columns(first, b):
+        """-> (host limbs (b, n, 4) Montgomery, device tensor).  Witness-shaped columns are built as small canonical integers and
+        brought to the Montgomery form on the device (what the prover's field elements are in memory)"""
+        if columns == "random":
+            h = synth.field_elements(seed + first, b * n).reshape(b, n, 4)
+            return h, torch.from_numpy(h.view(np.int64)).to(dev)
+        can = np.empty((b, n, 4), dtype=np.uint64)
+        i = 0
+        while i < b:  # runs of one class
+            j = i
+            while j < b and kinds[first + j] == kinds[first + i]:
+                j += 1
+            can[i:j] = witness_columns(kinds[first + i][0], kinds[first + i][1], seed + first + i, j - i, n, word_bits)
+            i = j
+        d = torch.from_numpy(can.view(np.int64)).to(dev)
+        api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["to_mont"], api._devptr(d), None, api._devptr(d), b * n, stream))
+        torch.cuda.synchronize()
+        return (d.cpu().numpy().view(np.uint64).reshape(b, n, 4) if hook is not None and first == 0 else None), d
+
     while done < lag_total:
         b = min(batch, lag_total - done)
-        cols_h = synth.field_elements(seed + done, b * n).reshape(b, n, 4)
+        cols_h, cols = make_columns(done, b)
         blinds = synth.field_elements(seed + 0x100000 + done, b)
-        cols = torch.from_numpy(cols_h.view(np.int64)).to(dev)
         e0 = ev()
         pts = params.commit_lagrange_batch(cols, blinds)
         e1 = ev()
@@ -187,6 +268,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
                 checked += 4
         if done + b >= lag_total:
             ext_keep = ext  # the last batch of extended cosets stays resident for the h(X) step below
+        coeff_all[done:done + b].copy_(coeff)
         del coeff, cols
         done += b
 
@@ -216,6 +298,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     cols_h = synth.field_elements(0xABC, ncoef * n).reshape(ncoef, n, 4)
     blinds = synth.field_elements(0xABD, ncoef)
     cols = torch.from_numpy(cols_h.view(np.int64)).to(dev)
+    coeff_all[lag_total:].copy_(cols)
     e0 = ev()
     pts = params.commit_batch(cols, blinds)
     e1 = ev()
@@ -240,24 +323,103 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         hook("divide_and_extended_to_coeff", dict(a=h_h, domain=(field, QUOTIENT_J, k)), hc[0].cpu().numpy().view(np.uint64))
         checked += 1
 
-    # --- IPA opening of the final polynomial ---
+    # --- poly::multiopen::create_proof over everything the prover opened: every column at x; the rotated advice queries and the
+    # product columns also at omega x, the permuted lookup inputs at omega^-1 x, the permutation products (but the last) at
+    # omega^last x -- four point sets; then the IPA opening of the folded polynomial.  Polynomials of one point set are stored
+    # back to back so that the x1 fold reads them in place ---
     m = poly._MODULUS[field]
-    p_h = synth.field_elements(0x1FA, n)
-    p_dev = torch.from_numpy(p_h.view(np.int64)).to(dev)
+    x = int.from_bytes(synth.field_elements(0xE7A, 1)[0].tobytes(), "little") % m
+    w = dom.omega
+    xw, xwi, xlast = x * w % m, x * pow(w, -1, m) % m, x * pow(w, n - BLINDING_ROWS - 1, m) % m
+    c0 = N_INSTANCE                                   # advice starts here
+    rot = range(c0, c0 + 40)                          # advice columns queried at the next row as well (program counter, registers, flags)
+    lk0 = N_INSTANCE + N_ADVICE                       # permuted lookup columns: input / table pairs
+    z0 = lk0 + 2 * N_LOOKUPS                          # lookup products, then permutation products
+    queries = []
+    for c in range(coeff_all.shape[0]):
+        queries.append((x, c))
+        if c in rot or c >= z0 and c < lag_total:
+            queries.append((xw, c))
+        if lk0 <= c < z0 and (c - lk0) % 2 == 0:
+            queries.append((xwi, c))
+        if z0 + N_LOOKUPS <= c < lag_total - 1:
+            queries.append((xlast, c))
+    # group the polynomials by point set, contiguously (a permutation of the rows: which column is which does not matter any more)
+    commitments, point_sets = multiopen.construct_intermediate_sets(queries)
+    order = sorted(range(len(commitments)), key=lambda i: commitments[i][1])
+    remap = {commitments[i][0]: pos for pos, i in enumerate(order)}
+    queries = [(pt, remap[c]) for pt, c in queries]
+    queries.sort(key=lambda q: q[1])  # first appearance in storage order: every set's members are consecutive rows
+    polys = {c: coeff_all[c] for c in range(coeff_all.shape[0])}
+    blinds_mo = {c: (0x1000 + c) % m for c in polys}
     draws = iter(range(7, 10 ** 9, 13))
     s_h = synth.field_elements(0x5A, n)  # the prover's random s(X), drawn on the host
+    ipa_ms = []
+    real_ipa = ipa.create_proof_native
+
+    def timed_ipa(*a, **kw):
+        t0 = ev()
+        r = real_ipa(*a, **kw)
+        t1 = ev()
+        torch.cuda.synchronize()
+        ipa_ms.append(t0.elapsed_time(t1))
+        return r
+
     torch.cuda.synchronize()
     e0 = ev()
-    ipa.create_proof_native(params, lambda: next(draws), _FixedTranscript(m), p_dev, 0x1234, 0x77777, s_h, 0x99)
+    ipa.create_proof_native = timed_ipa
+    try:
+        multiopen.create_proof(params, lambda: next(draws), _FixedTranscript(m), queries, polys, blinds_mo, s_poly=s_h)
+    finally:
+        ipa.create_proof_native = real_ipa
     e1 = ev()
     torch.cuda.synchronize()
-    times["ipa"] += e0.elapsed_time(e1)
+    times["ipa"] += ipa_ms[0]
+    times["multiopen_folds"] += e0.elapsed_time(e1) - ipa_ms[0]
     counts["ipa"] += 1
+    counts["multiopen_folds"] += len(point_sets)
+    del coeff_all, polys
+
+    # --- keygen_vk / keygen_pk, once per proving key (not part of gpu_ms_total): fixed and sigma columns are committed, brought to
+    # coefficient form and extended to the coset; l0, l_blind, l_last are extended (/root/reference/src/test_utils.rs:23-25).
+    # Fixed columns are selectors / range tables (small values), sigma columns full-size field elements ---
+    keygen_ms = None
+    if keygen:
+        kg = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0}
+        kext = torch.empty((min(batch, N_FIXED + N_SIGMA), 1 << ek, 4), dtype=torch.int64, device=dev)
+        todo = [(N_FIXED, "flag" if columns == "witness" else "full"), (N_SIGMA, "full"), (3, "flag" if columns == "witness" else "full")]
+        for count, kind in todo:
+            first = 0
+            while first < count:
+                b = min(batch, count - first)
+                can = witness_columns(kind, False, 0x6E9 + first, b, n, word_bits)
+                d = torch.from_numpy(can.view(np.int64)).to(dev)
+                if kind != "full":
+                    api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["to_mont"], api._devptr(d), None, api._devptr(d), b * n, stream))
+                t0 = ev()
+                if count != 3:  # l0 / l_blind / l_last are not committed
+                    params.commit_lagrange_batch(d, synth.field_elements(0x6EA + first, b))
+                t1 = ev()
+                cf = dom.lagrange_to_coeff(d)
+                t2 = ev()
+                dom.coeff_to_extended(cf, out=kext)
+                t3 = ev()
+                torch.cuda.synchronize()
+                kg["commit_lagrange"] += t0.elapsed_time(t1)
+                kg["lagrange_to_coeff"] += t1.elapsed_time(t2)
+                kg["coeff_to_extended"] += t2.elapsed_time(t3)
+                first += b
+        keygen_ms = {kk: round(v, 3) for kk, v in kg.items()}
+        keygen_ms["total"] = round(sum(kg.values()), 3)
+        keygen_ms["columns"] = {"fixed": N_FIXED, "sigma": N_SIGMA, "l0_l_blind_l_last": 3}
+        del kext
 
     wall = time.perf_counter() - t_wall
-    out = {"word_bits": word_bits, "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
-           "gpu_ms_total": round(sum(times.values()), 3), "fixed_base_tables": bool(precompute), "setup_precompute_ms": round(precompute_ms, 3), "wall_s_including_host_input_generation": round(wall, 3),
-           "checked_against_oracle": checked}
+    out = {"word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
+           "gpu_ms_total": round(sum(times.values()), 3),
+           "scope": "GPU time of the offloaded arithmetic of ONE create_proof incl. the multiopen folds / divisions; witness generation, the transcript and PCIe are not in it",
+           "keygen_gpu_ms": keygen_ms, "fixed_base_tables": bool(precompute), "setup_precompute_ms": round(precompute_ms, 3),
+           "wall_s_including_host_input_generation": round(wall, 3), "checked_against_oracle": checked}
     if verbose:
         print(json.dumps(out))
     return out
@@ -268,8 +430,10 @@ def main():
     ap.add_argument("--word-bits", type=int, default=32)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-precompute", action="store_true", help="commit over the plain per-window path (no fixed-base tables)")
+    ap.add_argument("--columns", choices=("random", "witness"), default="random", help="uniformly random columns, or the value classes of the reference's witness")
+    ap.add_argument("--no-keygen", action="store_true")
     a = ap.parse_args()
-    run(a.word_bits, a.batch, precompute=not a.no_precompute)
+    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen)
 
 
 if __name__ == "__main__":
