@@ -5,7 +5,13 @@
 // sizes and counts as tiny-ram-halo2_amd/replay.py, each kind self-checked once with the host arithmetic of trh.hpp
 // or against a second libtrh path (the bit-exact parity against the oracle lives in tests/).
 //
-//   ./examples/replay [--word-bits 16|32] [--batch 64]      -> one JSON line, exit code 0 iff every check passed
+//   ./examples/replay [--word-bits 16|32] [--batch 64] [--columns random|witness]   -> one JSON line, exit code 0 iff every check passed
+// `--columns witness`: the value classes the reference's tables hold (flags / WORD_BITS-bit words on the n / 4 live rows, zero padding,
+// blinding rows; /root/reference/src/circuits/tables/exe.rs:538-741, tables/prog.rs:139-161) instead of uniformly random columns.
+// Besides the per-proof schedule the driver replays keygen_vk / keygen_pk (fixed and sigma columns, the l0 / l_blind / l_last cosets:
+// /root/reference/src/test_utils.rs:23-25) and the polynomial side of poly::multiopen::create_proof (x1 fold per point set, kate
+// divisions, x2 fold, q' commitment, evaluations at x3, x4 fold) in front of the IPA opening.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +24,13 @@ using namespace trh;
 namespace {
 
 constexpr int N_INSTANCE = 94, N_ADVICE = 263, N_LOOKUPS = 31, N_PERM_PRODUCTS = 47, N_H_PIECES = 5, QUOTIENT_J = 6, N_SYNTH_GATES = 300;
+constexpr int N_FIXED = 25, N_SIGMA = 188, BLINDING_ROWS = 6;  // see tiny-ram-halo2_amd/replay.py
+
+// value classes of the 497 Lagrange-basis columns in commitment order (replay.py column_classes)
+enum class Kind { Flag, Word, Even, Sorted, Full };
+struct ColumnClass { int count; Kind kind; bool blinded; };
+const ColumnClass WITNESS_CLASSES[] = {{70, Kind::Flag, false}, {24, Kind::Word, false}, {150, Kind::Flag, true}, {90, Kind::Word, true}, {23, Kind::Even, true},
+                                       {58, Kind::Sorted, true}, {4, Kind::Full, true}, {N_LOOKUPS + N_PERM_PRODUCTS, Kind::Full, true}};
 
 struct SplitMix {
     uint64_t s;
@@ -42,6 +55,23 @@ void tr_write_point(void* c, const uint64_t*) { ++((Transcript*)c)->points; }
 void tr_write_scalar(void* c, const uint64_t*) { ++((Transcript*)c)->scalars; }
 void tr_squeeze(void* c, uint64_t* out) { const Limbs v = ((Transcript*)c)->rng.element(); std::memcpy(out, v.data(), 32); }
 void rng_scalar(void* c, uint64_t* out) { const Limbs v = ((SplitMix*)c)->element(); std::memcpy(out, v.data(), 32); }
+
+// one column of a class as CANONICAL limbs (small integers; `to_montgomery` on the device makes them field elements): live rows are
+// the first n / 4, zero behind them, BLINDING_ROWS random rows at the very end
+void fill_witness_column(Kind kind, bool blinded, SplitMix& r, int word_bits, size_t n, Limbs* out) {
+    const size_t live = n / 4;
+    const uint64_t word_mask = word_bits >= 64 ? ~0ull : ((1ull << word_bits) - 1);
+    uint64_t even_mask = 0;
+    for (int b = 0; b < word_bits; b += 2) even_mask |= 1ull << b;
+    for (size_t i = 0; i < n; ++i) out[i] = Limbs{0, 0, 0, 0};
+    if (kind == Kind::Full) { for (size_t i = 0; i < n; ++i) out[i] = r.element(); return; }
+    for (size_t i = 0; i < live; ++i) {
+        const uint64_t v = r.next();
+        out[i][0] = kind == Kind::Flag ? (v & 1) : kind == Kind::Word ? (v & word_mask) : kind == Kind::Even ? (v & even_mask) : (v & ((1ull << (word_bits / 2)) - 1));
+    }
+    if (kind == Kind::Sorted) std::sort(out, out + live, [](const Limbs& a, const Limbs& b) { return a[0] < b[0]; });
+    if (blinded) for (size_t i = n - BLINDING_ROWS; i < n; ++i) out[i] = r.element();
+}
 
 // synthetic gate set with the shape of the reference's (selector-gated constraints up to degree 6)
 std::vector<Expr> synthetic_gates(Field f, uint32_t n_advice, uint32_t n_fixed, int n_gates) {
@@ -85,9 +115,11 @@ Limbs eval_host(Field f, const Expr& e, const std::vector<std::vector<Limbs>>& c
 int main(int argc, char** argv) {
     int word_bits = 32;
     size_t batch = 64;
+    bool witness = false;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
         else if (std::string(argv[i]) == "--batch") batch = (size_t)std::atol(argv[i + 1]);
+        else if (std::string(argv[i]) == "--columns") witness = std::string(argv[i + 1]) == "witness";
     }
     try {
         init(0);
@@ -109,6 +141,22 @@ int main(int argc, char** argv) {
         DeviceBuffer cols(batch * n * 32), ext(batch * N * 32), h_num(N * 32);
         std::vector<Limbs> host_cols(batch * n), blinds(batch);
         SplitMix rng{0xc01};
+        // the coefficient forms stay resident for the multiopen argument (497 + 6 polynomials)
+        DeviceBuffer coeff_all((size_t)(lag_total + 1 + N_H_PIECES) * n * 32);
+        std::vector<std::pair<Kind, bool>> kinds;
+        for (const ColumnClass& c : WITNESS_CLASSES) for (int i = 0; i < c.count; ++i) kinds.push_back({c.kind, c.blinded});
+        require((int)kinds.size() == lag_total, "column classes cover the 497 columns");
+        auto upload_columns = [&](int first, size_t b) {  // this batch's columns -> `cols` (Montgomery form), host copy in host_cols
+            if (!witness) {
+                for (size_t i = 0; i < b * n; ++i) host_cols[i] = rng.element();
+                cols.upload(host_cols.data(), b * n * 32);
+                return;
+            }
+            for (size_t c = 0; c < b; ++c) fill_witness_column(kinds[first + c].first, kinds[first + c].second, rng, word_bits, n, host_cols.data() + c * n);
+            cols.upload(host_cols.data(), b * n * 32);
+            check(trh_field_op_dev((int)field, 6 /* to_montgomery */, cols.data(), nullptr, cols.data(), b * n, nullptr), "to_mont");
+            cols.download(host_cols.data(), b * n * 32);  // the checks below compare against what the device was given
+        };
         const Limbs x_eval = rng.element();
         double ms_commit = 0, ms_intt = 0, ms_ext = 0, ms_evals = 0, ms_h = 0, ms_commit_coeff = 0, ms_ext_inv = 0, ms_ipa = 0, ms_lookup = 0;
         {   // lookup argument: permuted columns of the 31 lookups; inputs drawn from the table's values
@@ -142,9 +190,8 @@ int main(int argc, char** argv) {
 
         for (int done = 0; done < lag_total; done += (int)batch) {
             const size_t b = std::min(batch, (size_t)(lag_total - done));
-            for (size_t i = 0; i < b * n; ++i) host_cols[i] = rng.element();
+            upload_columns(done, b);
             for (size_t i = 0; i < b; ++i) blinds[i] = rng.element();
-            cols.upload(host_cols.data(), b * n * 32);
             Timer t1;
             const std::vector<Point> pts = params.commit_lagrange_batch(cols, b, std::vector<Limbs>(blinds.begin(), blinds.begin() + b));
             { const double dt = t1.stop(); ms_commit += dt; if (std::getenv("TRH_REPLAY_VERBOSE")) std::fprintf(stderr, "batch at %d: commit %.2f ms\n", done, dt); }
@@ -157,6 +204,13 @@ int main(int argc, char** argv) {
             dom.lagrange_to_coeff(cols.data(), b);
             ms_intt += t2.stop();
             if (done == 0) { first_coeff.resize(n); cols.download(first_coeff.data(), n * 32); }
+            check(trh_stream_synchronize(nullptr), "sync");
+            {   // keep the coefficient forms (device-to-device through the ABI's copy helpers would bounce over the host: one kernel instead)
+                const Limbs one = host::one(field);
+                (void)one;
+                std::vector<Limbs> unit(1, host::one(field));
+                for (size_t c = 0; c < b; ++c) lincomb(field, cols.at(c * n * 32), n, unit, coeff_all.at(((size_t)done + c) * n * 32));
+            }
             Timer t3;
             dom.coeff_to_extended(cols.data(), ext.data(), b);
             ms_ext += t3.stop();
@@ -239,6 +293,10 @@ int main(int argc, char** argv) {
         DeviceBuffer cf(ncoef * n * 32);
         for (size_t i = 0; i < ncoef * n; ++i) host_cols[i % host_cols.size()] = rng.element();
         cf.upload(host_cols.data(), ncoef * n * 32);
+        {
+            std::vector<Limbs> unit(1, host::one(field));
+            for (size_t c = 0; c < ncoef; ++c) lincomb(field, cf.at(c * n * 32), n, unit, coeff_all.at(((size_t)lag_total + c) * n * 32));
+        }
         std::vector<Limbs> bl(ncoef);
         for (auto& v : bl) v = rng.element();
         Timer t6;
@@ -262,9 +320,94 @@ int main(int argc, char** argv) {
             expect(ok, "extended_to_coeff(coeff_to_extended(a)) == a || 0");
         }
 
-        // IPA opening of the final polynomial
+        // poly::multiopen::create_proof, polynomial side: four point sets ({x}, {x, wx}, {x, w^-1 x}, {x, wx, w^last x}) over the resident
+        // coefficient forms stored set by set; x1 fold, divisions, x2 fold, commitment of q', evaluations at x3, x4 fold
+        double ms_multiopen = 0;
         DeviceBuffer p_poly(n * 32), s_poly(n * 32);
-        p_poly.upload(first_coeff.data(), n * 32);
+        {
+            const size_t total = (size_t)lag_total + ncoef;
+            // set sizes as replay.py builds them: 40 rotated advice + 31 lookup products + 1 permutation product at {x, wx}; 31 permuted inputs
+            // at {x, w^-1 x}; 46 permutation products at {x, wx, w^last x}; everything else at {x}
+            const size_t set_sizes[4] = {total - 72 - 31 - 46, 72, 31, 46};
+            const Limbs omega = dom.get_omega();
+            const Limbs x = x_eval, xw = host::mul(field, x, omega), xwi = host::mul(field, x, host::inv(field, omega));
+            Limbs xlast = x;
+            for (size_t i = 0; i + BLINDING_ROWS + 1 < n; ++i) xlast = host::mul(field, xlast, omega);
+            const std::vector<std::vector<Limbs>> set_points = {{x}, {x, xw}, {x, xwi}, {x, xw, xlast}};
+            SplitMix cr{0x3a1};
+            const Limbs x1 = cr.element(), x2 = cr.element(), x3 = cr.element(), x4 = cr.element();
+            DeviceBuffer q(4 * n * 32), divided(4 * n * 32), tmp(n * 32), qprime(n * 32), fold_in(5 * n * 32);
+            Timer tm;
+            size_t row = 0;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                std::vector<Limbs> pw(set_sizes[sidx]);  // q = ((p_0 x1 + p_1) x1 + ...): coefficient of p_j is x1^(len - 1 - j)
+                Limbs acc = host::one(field);
+                for (size_t j = set_sizes[sidx]; j-- > 0;) { pw[j] = acc; acc = host::mul(field, acc, x1); }
+                lincomb(field, coeff_all.at(row * n * 32), n, pw, q.at((size_t)sidx * n * 32));
+                row += set_sizes[sidx];
+                // divide by (X - z) for every point of the set; pad back to n coefficients
+                check(trh_memcpy_d2h(host_cols.data(), q.at((size_t)sidx * n * 32), 32), "d2h");  // (orders the default stream)
+                const void* cur = q.at((size_t)sidx * n * 32);
+                size_t len = n;
+                for (const Limbs& z : set_points[sidx]) {
+                    KateDivider kd(field, len, z, host::inv(field, z));
+                    kd.divide(cur, tmp.data());
+                    --len;
+                    std::vector<Limbs> unit(1, host::one(field));
+                    lincomb(field, tmp.data(), len, unit, divided.at((size_t)sidx * n * 32));
+                    cur = divided.at((size_t)sidx * n * 32);
+                }
+                const std::vector<Limbs> zeros(n - len, Limbs{0, 0, 0, 0});
+                check(trh_stream_synchronize(nullptr), "sync");
+                check(trh_memcpy_h2d((char*)divided.at((size_t)sidx * n * 32) + len * 32, zeros.data(), (n - len) * 32), "pad");
+            }
+            std::vector<Limbs> p2(4);
+            { Limbs acc = host::one(field); for (int j = 3; j >= 0; --j) { p2[j] = acc; acc = host::mul(field, acc, x2); } }
+            lincomb(field, divided.data(), n, p2, qprime.data());
+            const Point qc = params.commit_batch(qprime, 1, {cr.element()})[0];
+            (void)qc;
+            const std::vector<Limbs> ev3 = eval_polynomials(field, q.data(), n, 4, x3);
+            (void)ev3;
+            // p = ((q' x4 + q_0) x4 + q_1) ...
+            std::vector<Limbs> unit(1, host::one(field));
+            lincomb(field, qprime.data(), n, unit, fold_in.data());
+            for (int j = 0; j < 4; ++j) lincomb(field, q.at((size_t)j * n * 32), n, unit, fold_in.at((size_t)(j + 1) * n * 32));
+            std::vector<Limbs> p4(5);
+            { Limbs acc = host::one(field); for (int j = 4; j >= 0; --j) { p4[j] = acc; acc = host::mul(field, acc, x4); } }
+            lincomb(field, fold_in.data(), n, p4, p_poly.data());
+            ms_multiopen = tm.stop();
+            // the fold is linear: p(x3) == sum_j x4-power_j * (folded inputs)(x3)
+            const std::vector<Limbs> parts = eval_polynomials(field, fold_in.data(), n, 5, x3);
+            Limbs want{0, 0, 0, 0};
+            for (int j = 0; j < 5; ++j) want = host::add(field, want, host::mul(field, p4[j], parts[j]));
+            expect(eval_polynomials(field, p_poly.data(), n, 1, x3)[0] == want, "multiopen x4 fold evaluates consistently");
+            // a division is exact up to the dropped remainder: q_0(X) == divided_0(X) (X - x) + q_0(x) at the point x3
+            const Limbs d0 = eval_polynomials(field, divided.data(), n, 1, x3)[0], q0x = eval_polynomials(field, q.data(), n, 1, x)[0];
+            expect(ev3[0] == host::add(field, host::mul(field, d0, host::sub(field, x3, x)), q0x), "kate_division identity at x3");
+        }
+
+        // keygen_vk / keygen_pk once per proving key: fixed + sigma columns (commit, iNTT, coset NTT), l0 / l_blind / l_last cosets
+        double ms_keygen = 0;
+        {
+            SplitMix kr{0x6e9};
+            const struct { int count; Kind kind; bool commit; } groups[3] = {{N_FIXED, witness ? Kind::Flag : Kind::Full, true}, {N_SIGMA, Kind::Full, true}, {3, witness ? Kind::Flag : Kind::Full, false}};
+            for (const auto& g : groups) {
+                for (int first = 0; first < g.count; first += (int)batch) {
+                    const size_t b = std::min(batch, (size_t)(g.count - first));
+                    for (size_t c = 0; c < b; ++c) fill_witness_column(g.kind, false, kr, word_bits, n, host_cols.data() + c * n);
+                    cols.upload(host_cols.data(), b * n * 32);
+                    if (g.kind != Kind::Full) check(trh_field_op_dev((int)field, 6, cols.data(), nullptr, cols.data(), b * n, nullptr), "to_mont");
+                    for (size_t i = 0; i < b; ++i) blinds[i] = kr.element();
+                    Timer tk;
+                    if (g.commit) params.commit_lagrange_batch(cols, b, std::vector<Limbs>(blinds.begin(), blinds.begin() + b));
+                    dom.lagrange_to_coeff(cols.data(), b);
+                    dom.coeff_to_extended(cols.data(), ext.data(), b);
+                    ms_keygen += tk.stop();
+                }
+            }
+        }
+
+        // IPA opening of the folded polynomial
         for (size_t i = 0; i < n; ++i) host_cols[i] = rng.element();
         s_poly.upload(host_cols.data(), n * 32);
         Transcript tr;
@@ -276,11 +419,11 @@ int main(int argc, char** argv) {
         (void)cfp;
         expect(tr.points == 1 + 2 * (int)k && tr.scalars == 2, "IPA transcript: S, L_j / R_j per round, then c and f");
 
-        const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_ipa;
-        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"checks_failed\": %d, \"setup_ms\": %.3f, "
+        const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_multiopen + ms_ipa;
+        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"keygen_ms\": %.3f, "
                     "\"ms\": {\"lookup_permute\": %.3f, \"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
-                    "\"extended_to_coeff\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f}\n",
-                    word_bits, k, batch, failures, setup_ms, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_ipa, total);
+                    "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f}\n",
+                    word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total);
         trh_shutdown();
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

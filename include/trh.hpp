@@ -96,6 +96,17 @@ inline Limbs one(Field f) {  // R mod m = 2^256 - m * floor(2^256 / m) = 2^256 -
     Limbs z{0, 0, 0, 0}, r = sub_raw(z, m); r = sub_raw(r, m); r = sub_raw(r, m);
     return r;
 }
+// a^(m - 2) (Fermat); inv(0) = 0
+inline Limbs inv(Field f, const Limbs& a) {
+    Limbs e = modulus(f);
+    e[0] -= 2;  // the low limbs of both moduli are far above 2: no borrow
+    Limbs r = one(f);
+    for (int i = 255; i >= 0; --i) {
+        r = mul(f, r, r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = mul(f, r, a);
+    }
+    return r;
+}
 inline Limbs from_u64(Field f, uint64_t v) {  // v * R: double-and-add on the Montgomery one
     Limbs acc{0, 0, 0, 0}, base = one(f);
     for (int i = 0; i < 64; ++i) { if ((v >> i) & 1) acc = add(f, acc, base); base = add(f, base, base); }
@@ -410,19 +421,33 @@ private:
     DeviceBuffer num_, den_, ratio_;
 };
 
-// arithmetic::kate_division by (X - z) for polynomials of n coefficients (z != 0; the powers of z and 1/z are built once)
+// arithmetic::kate_division by (X - z) for polynomials of n coefficients.  The powers of z and 1 / z are built once, on the stream
+// the divisions will run on (the constructor takes it: tables built on another stream could still be in flight when divide() reads
+// them); z = 0 (z_inv ignored) divides by X: the quotient is the coefficient list shifted down by one.
 class KateDivider {
 public:
-    KateDivider(Field f, size_t n, const Limbs& z, const Limbs& z_inv) : field(f), n(n), pz_(n * 32), pzinv_(n * 32), scratch_(2 * n * 32) {
-        check(trh_field_powers_dev((int)f, pz_.data(), n, z.data(), nullptr), "powers");
-        check(trh_field_powers_dev((int)f, pzinv_.data(), n, z_inv.data(), nullptr), "powers");
+    KateDivider(Field f, size_t n, const Limbs& z, const Limbs& z_inv, void* stream = nullptr)
+        : field(f), n(n), zero_(z == Limbs{0, 0, 0, 0}), stream_(stream), pz_(zero_ ? 32 : n * 32), pzinv_(zero_ ? 32 : n * 32), scratch_(zero_ ? 32 : 2 * n * 32) {
+        if (zero_) return;
+        check(trh_field_powers_dev((int)f, pz_.data(), n, z.data(), stream), "powers");
+        check(trh_field_powers_dev((int)f, pzinv_.data(), n, z_inv.data(), stream), "powers");
     }
-    void divide(const void* a_dev, void* q_dev /* n - 1 coefficients */, void* stream = nullptr) {
-        check(trh_poly_kate_division_dev((int)field, a_dev, n, pz_.data(), pzinv_.data(), scratch_.data(), q_dev, stream), "kate_division");
+    // a_dev: n coefficients, q_dev: n - 1 coefficients; runs on the constructor's stream
+    void divide(const void* a_dev, void* q_dev) {
+        if (zero_) {  // a(X) / X, remainder a_0 dropped: host-ordered device-to-device copy through the ABI's helpers
+            std::vector<Limbs> tmp(n);
+            check(trh_stream_synchronize(stream_), "sync");
+            check(trh_memcpy_d2h(tmp.data(), a_dev, n * 32), "d2h");
+            check(trh_memcpy_h2d(q_dev, tmp.data() + 1, (n - 1) * 32), "h2d");
+            return;
+        }
+        check(trh_poly_kate_division_dev((int)field, a_dev, n, pz_.data(), pzinv_.data(), scratch_.data(), q_dev, stream_), "kate_division");
     }
     Field field;
     size_t n;
 private:
+    bool zero_;
+    void* stream_;
     DeviceBuffer pz_, pzinv_, scratch_;
 };
 

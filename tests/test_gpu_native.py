@@ -11,15 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_native_replay_k10():
+@pytest.mark.parametrize("columns", ["random", "witness"])
+def test_native_replay_k10(columns):
     exe = os.path.join(ROOT, "examples", "replay")
     if not os.path.exists(exe):  # normally built by `make` / __graft_entry__.build(); g++ only, libtrh.so must already be there
         subprocess.check_call(["make", "-s", "-C", ROOT, "examples/replay"])
-    r = subprocess.run([exe, "--word-bits", "16", "--batch", "32"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, "--word-bits", "16", "--batch", "32", "--columns", columns], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr + r.stdout
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["k"] == 10 and out["checks_failed"] == 0
-    assert set(out["ms"]) == {"lookup_permute", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "ipa"}
+    assert out["k"] == 10 and out["checks_failed"] == 0 and out["columns"] == columns and out["keygen_ms"] > 0
+    assert set(out["ms"]) == {"lookup_permute", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "extended_to_coeff", "multiopen_folds", "ipa"}
 
 
 def test_native_multi_context():
