@@ -245,6 +245,12 @@ int trh_poly_kate_division_dev(int field, const void* a_dev, size_t n, const voi
  * rows behind usable_rows are the caller's.  Synchronises the stream.                                                       */
 int trh_lookup_permute_dev(int field, const void* input_dev, const void* table_dev, size_t usable_rows, void* out_input_dev,
                            void* out_table_dev, void* stream);
+/* every lookup of a proof at once (the reference's circuit has 31): `batch` input columns and `batch` table columns, column l at
+ * element offset l * row_stride (row_stride >= usable_rows: whole 2^k-row columns can be passed with usable_rows < 2^k; the rows behind
+ * usable_rows are not touched in the outputs, which use the same stride).  One set of launches and one host synchronisation for
+ * the whole batch; TRH_EINVAL names the first lookup with an input value that does not occur in its table.                        */
+int trh_lookup_permute_batch_dev(int field, const void* inputs_dev, const void* tables_dev, size_t usable_rows, size_t row_stride, size_t batch,
+                                 void* out_inputs_dev, void* out_tables_dev, void* stream);
 
 /* ---- gate expressions over resident columns: the h(X) numerator of plonk::create_proof ---------
  * halo2's `Expression<F>` (Constant / Selector / Fixed / Advice / Instance query at a Rotation, Negated, Sum,

@@ -277,6 +277,47 @@ def test_lookup_permuted_columns(field):
         permutation.lookup_permute(field, dev([1, 2, 3, 4]), dev([1, 2, 3, 3]))
 
 
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_lookup_permuted_columns_batch(field):
+    """trh_lookup_permute_batch_dev: several lookups of different character in ONE call (a 16-bit range table, full-size values, a
+    single run, values that share their top limb -- the tie that sends a lookup through the all-limbs sort --, a constant column),
+    usable_rows below the column length, every lookup against the oracle; an input missing from its table names the lookup"""
+    from tiny_ram_halo2_amd import permutation
+    f = o.FIELDS[field]
+    rng = random.Random(0xBA7C4)
+    rows, n = 5000, 4700   # ragged: not a multiple of the sort tile, usable rows below the column length
+    def column_pair(kind):
+        if kind == "range":
+            distinct = [rng.randrange(1 << 16) for _ in range(300)]
+        elif kind == "wide":
+            distinct = [rng.randrange(f.m) for _ in range(700)] + [0, f.m - 1, 1 << 64, (1 << 64) - 1, 1 << 128, (1 << 192) + 5]
+        elif kind == "ties":   # same top limb, different low limbs: the fast sort cannot order these
+            top = rng.randrange(1 << 60) << 192
+            distinct = [top + rng.randrange(1 << 190) for _ in range(50)] + [top + (v << 64) + 7 for v in range(20)] + [top + 7 + v for v in range(20)]
+        elif kind == "one-run":
+            distinct = [5]
+        else:  # "constant": input constant, table with one more value
+            distinct = [12345, 99]
+        table = [distinct[i % len(distinct)] for i in range(n)]
+        rng.shuffle(table)
+        inp = [distinct[0]] * n if kind == "constant" else [rng.choice(distinct) for _ in range(n)]
+        pad = [rng.randrange(f.m) for _ in range(rows - n)]   # rows behind usable_rows: ignored
+        return inp + pad, table + pad[::-1]
+    kinds = ["range", "wide", "ties", "one-run", "constant", "range", "ties", "wide"]
+    pairs = [column_pair(kd) for kd in kinds]
+    to_t = lambda cols: torch.from_numpy(np.array([[f.limbs(v) for v in c] for c in cols], dtype=np.uint64).view(np.int64)).cuda()
+    a, s = permutation.lookup_permute_batch(field, to_t([p[0] for p in pairs]), to_t([p[1] for p in pairs]), n)
+    torch.cuda.synchronize()
+    for li, (inp, table) in enumerate(pairs):
+        want_a, want_s = o.permute_expression_pair(inp, table, n)
+        assert from_dev(f, a[li][:n]) == want_a and from_dev(f, s[li][:n]) == want_s, (li, kinds[li])
+        assert not a[li][n:].any() and not s[li][n:].any()
+    bad = [list(p) for p in pairs]
+    bad[5] = ([1, 2, 3, 4] * (rows // 4), [1, 2, 3, 3] * (rows // 4))
+    with pytest.raises(api.TrhError, match="lookup 5"):
+        permutation.lookup_permute_batch(field, to_t([p[0] for p in bad]), to_t([p[1] for p in bad]), n)
+
+
 @pytest.mark.parametrize("k", [9, 14])
 def test_quotient_identity_end_to_end(k):
     """The chain create_proof runs for h(X), on a satisfied toy circuit, checked through an identity no single kernel can fake:

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "trh_field_batch_invert_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_field_prefix_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_lookup_permute_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp], ctypes.c_int),
+    "trh_lookup_permute_batch_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp], ctypes.c_int),
     "trh_expr_create": ([ctypes.c_int, _vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
                          ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
     "trh_expr_destroy": ([_vp], None),

@@ -7,20 +7,29 @@
 //   the other rows receive the left-over table values in ascending order, the LAST repeated row first
 //   (the Rust code pops the rows of a Vec and walks a BTreeMap);  an input value missing from the table is an error.
 //
-// A sort of 256-bit keys, not a hot kernel of this path: the 64-bit limb sorts are rocPRIM's radix sort (four stable
-// least-significant-limb-first passes over (limb, index) pairs), everything else (canonical form, run flags, membership
-// by binary search, compaction by prefix sums, the final placement) is a handful of small kernels here.
+// All lookups of a proof go through ONE set of launches (blockIdx.y = column: the `batch` inputs, then the `batch` tables) and
+// one host synchronisation (the error / tie flags).  Sorting 256-bit keys: field elements are either small (range tables: only
+// the low limb varies) or spread over the whole field (compressed expressions: two different values practically never share
+// their top limb), so a stable LSD radix sort of (most significant varying 64-bit limb, row) pairs is almost always the complete
+// order -- checked on the device; a column with a tie between different values is redone with the general form, the same sort
+// over every varying limb, least significant first.  The radix sort is this file's own (4-bit digits, per-thread digit counts
+// in LDS for a stable block-local rank, one scan of the (digit, block) histogram per pass); a pass whose digit is constant over
+// a column -- all but four of the sixteen for a 16-bit range table -- returns at once, the ping-pong side of every column being
+// tracked on the device.  Not a hot kernel of the path (18 ms of a 390 ms proof before, a few ms now).
 #include <string.h>
 
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include <vector>
 
 #include "ctx.h"
 
 namespace trh {
 namespace {
+
+constexpr int TILE = 2048;      // elements per workgroup of the sort / scan kernels
+constexpr int THREADS = 256;
+constexpr int ITEMS = TILE / THREADS;
+constexpr int RADIX_BITS = 4, RADIX = 1 << RADIX_BITS, PASSES = 64 / RADIX_BITS;
 
 template <class F>
 __device__ __forceinline__ Fe<F> ldf(const uint4* p) {
@@ -28,214 +37,455 @@ __device__ __forceinline__ Fe<F> ldf(const uint4* p) {
     return fe_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
 }
 
+// column c of the batch: c < batch the input of lookup c, else the table of lookup c - batch
+__device__ __forceinline__ const uint4* column_ptr(const uint4* in, const uint4* tab, size_t stride, u32 batch, u32 c) {
+    return c < batch ? in + 2 * (size_t)c * stride : tab + 2 * (size_t)(c - batch) * stride;
+}
+
 // canonical limbs of a[i] (Montgomery -> integer), one u64 plane per limb; perm = identity
 template <class F>
-__global__ void __launch_bounds__(256) canon_planes_kernel(const uint4* __restrict__ a, size_t n, u64* __restrict__ planes /* 4 x n */, u32* __restrict__ perm) {
+__global__ void __launch_bounds__(256) canon_planes_kernel(const uint4* __restrict__ in, const uint4* __restrict__ tab, size_t stride, u32 batch, size_t n,
+                                                           u64* __restrict__ planes /* cols x 4 x n */, u32* __restrict__ perm /* cols x n */) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 c = blockIdx.y;
     if (i >= n) return;
     u32 w[8];
-    fe_store(fe_from_mont(ldf<F>(a + 2 * i)), w);
-    for (int k = 0; k < 4; ++k) planes[(size_t)k * n + i] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
-    perm[i] = (u32)i;
+    fe_store(fe_from_mont(ldf<F>(column_ptr(in, tab, stride, batch, c) + 2 * i)), w);
+    u64* pl = planes + (size_t)c * 4 * n;
+    for (int k = 0; k < 4; ++k) pl[(size_t)k * n + i] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+    perm[(size_t)c * n + i] = (u32)i;
 }
-__global__ void __launch_bounds__(256) gather_u64_kernel(const u64* __restrict__ src, const u32* __restrict__ perm, u64* __restrict__ dst, size_t n) {
+// varies[c][k] = OR over the column of (limb k XOR limb k of row 0): the bits in which the column is not constant
+__global__ void __launch_bounds__(256) plane_varies_kernel(const u64* __restrict__ planes, size_t n, u64* __restrict__ varies) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[perm[i]];
+    const u32 c = blockIdx.y;
+    const u64* pl = planes + (size_t)c * 4 * n;
+    for (int k = 0; k < 4; ++k) {
+        u64 x = i < n ? pl[(size_t)k * n + i] ^ pl[(size_t)k * n] : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x |= __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicOr((unsigned long long*)&varies[c * 4 + k], (unsigned long long)x);
+    }
 }
-__global__ void __launch_bounds__(256) gather_elems_kernel(const uint4* __restrict__ src, const u32* __restrict__ perm, uint4* __restrict__ dst, size_t n) {
+// which limb a column is sorted by in this step, and the bits of it that vary.  step < 0: the most significant varying limb (the fast
+// path); step = 0 .. 3: limb `step` of the general path (key_limb = -1 when that limb is constant: the step is an identity)
+__global__ void select_limb_kernel(const u64* __restrict__ varies, u32 cols, int step, int* __restrict__ key_limb, u64* __restrict__ key_mask, u32* __restrict__ side) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    int k = -1;
+    if (step < 0) { for (int j = 3; j >= 0; --j) if (varies[c * 4 + j]) { k = j; break; } }
+    else if (varies[c * 4 + step]) k = step;
+    key_limb[c] = k;
+    key_mask[c] = k >= 0 ? varies[c * 4 + k] : 0ull;
+    (void)side;
+}
+// keys[side[c]][c][i] = limb key_limb[c] of the element the current order has at position i
+__global__ void __launch_bounds__(256) gather_keys_kernel(const u64* __restrict__ planes, size_t n, u32 cols, const int* __restrict__ key_limb, const u32* __restrict__ side,
+                                                          const u32* __restrict__ perm0, const u32* __restrict__ perm1, u64* __restrict__ keys0, u64* __restrict__ keys1) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4* p = src + 2 * (size_t)perm[i];
-    dst[2 * i] = p[0]; dst[2 * i + 1] = p[1];
+    const u32 c = blockIdx.y;
+    const int k = key_limb[c];
+    if (i >= n || k < 0) return;
+    const u32 sd = side[c];
+    const u32* perm = (sd ? perm1 : perm0) + (size_t)c * n;
+    u64* keys = (sd ? keys1 : keys0) + (size_t)c * n;
+    keys[i] = planes[((size_t)c * 4 + k) * n + perm[i]];
 }
-// sorted canonical keys as 4 planes gathered through perm: cmp(i, j) on the planes
-__device__ __forceinline__ int cmp_keys(const u64* __restrict__ pa, size_t na, const u32* __restrict__ perma, size_t i, const u64* __restrict__ pb, size_t nb, const u32* __restrict__ permb, size_t j) {
+
+__device__ __forceinline__ bool pass_is_identity(u64 mask, int pass) { return ((mask >> (RADIX_BITS * pass)) & (u64)(RADIX - 1)) == 0; }
+
+// ---- one pass of the stable LSD radix sort of (key, row) pairs, every column of the batch at once ---------------------------------
+// hist[c][digit][block] = entries of the block's tile with that digit
+__global__ void __launch_bounds__(THREADS) radix_hist_kernel(const u64* __restrict__ keys0, const u64* __restrict__ keys1, const u32* __restrict__ side, const u64* __restrict__ key_mask,
+                                                             size_t n, int pass, u32* __restrict__ hist) {
+    const u32 c = blockIdx.y, nblk = gridDim.x;
+    if (pass_is_identity(key_mask[c], pass)) return;
+    __shared__ u32 tot[RADIX];
+    if (threadIdx.x < RADIX) tot[threadIdx.x] = 0;
+    __syncthreads();
+    const u64* keys = (side[c] ? keys1 : keys0) + (size_t)c * n;
+    const size_t base = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * ITEMS;
+    u32 cnt[RADIX];
+#pragma unroll
+    for (int d = 0; d < RADIX; ++d) cnt[d] = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q)
+        if (base + q < n) {
+            const u32 d = (u32)(keys[base + q] >> (RADIX_BITS * pass)) & (RADIX - 1);
+#pragma unroll
+            for (int e = 0; e < RADIX; ++e) cnt[e] += (d == (u32)e);
+        }
+#pragma unroll
+    for (int d = 0; d < RADIX; ++d) {
+        u32 v = cnt[d];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&tot[d], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < RADIX) hist[((size_t)c * RADIX + threadIdx.x) * nblk + blockIdx.x] = tot[threadIdx.x];
+}
+// exclusive scan of hist[c][..] in (digit, block) order -> global base of every (digit, block) run; fixes which side the scatter of
+// this pass reads (sel[pass][c]) and flips the column's side for the next pass
+__global__ void __launch_bounds__(THREADS) radix_scan_kernel(u32* __restrict__ hist, u32 nblk, const u64* __restrict__ key_mask, int pass, u32* __restrict__ side, u32* __restrict__ sel) {
+    const u32 c = blockIdx.x;
+    if (threadIdx.x == 0) sel[(size_t)pass * gridDim.x + c] = side[c];
+    if (pass_is_identity(key_mask[c], pass)) return;
+    __shared__ u32 part[THREADS];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    u32* h = hist + (size_t)c * RADIX * nblk;
+    const u32 total = RADIX * nblk;
+    for (u32 b0 = 0; b0 < total; b0 += THREADS * 8) {
+        const u32 lo = b0 + threadIdx.x * 8;
+        u32 v[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v[q] = lo + q < total ? h[lo + q] : 0u; sum += v[q]; }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < THREADS; off <<= 1) {
+            const u32 t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        u32 run = carry + part[threadIdx.x] - sum;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if (lo + q < total) h[lo + q] = run; run += v[q]; }
+        __syncthreads();
+        if (threadIdx.x == THREADS - 1) carry += part[THREADS - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) side[c] ^= 1u;
+}
+// stable scatter: the tile's pairs go to base(digit, block) + rank inside the tile (threads own consecutive items, so the rank is the
+// prefix of the per-thread digit counts in (digit, thread) order plus the item's position among the thread's own)
+__global__ void __launch_bounds__(THREADS) radix_scatter_kernel(const u64* __restrict__ keys0, const u64* __restrict__ keys1, const u32* __restrict__ perm0, const u32* __restrict__ perm1,
+                                                                u64* __restrict__ okeys0, u64* __restrict__ okeys1, u32* __restrict__ operm0, u32* __restrict__ operm1,
+                                                                const u32* __restrict__ sel, const u64* __restrict__ key_mask, size_t n, int pass, const u32* __restrict__ hist) {
+    const u32 c = blockIdx.y, nblk = gridDim.x;
+    if (pass_is_identity(key_mask[c], pass)) return;
+    __shared__ u32 cntT[RADIX * THREADS];  // [digit][thread], then its exclusive scan
+    __shared__ u32 part[THREADS];
+    const u32 sd = sel[(size_t)pass * gridDim.y + c];
+    const u64* keys = (sd ? keys1 : keys0) + (size_t)c * n;
+    const u32* perm = (sd ? perm1 : perm0) + (size_t)c * n;
+    u64* okeys = (sd ? okeys0 : okeys1) + (size_t)c * n;  // the other side
+    u32* operm = (sd ? operm0 : operm1) + (size_t)c * n;
+    const size_t base = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * ITEMS;
+    u64 k[ITEMS];
+    u32 p[ITEMS], dg[ITEMS], cnt[RADIX];
+#pragma unroll
+    for (int d = 0; d < RADIX; ++d) cnt[d] = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        dg[q] = RADIX;  // beyond the column: no digit
+        if (base + q < n) {
+            k[q] = keys[base + q]; p[q] = perm[base + q];
+            dg[q] = (u32)(k[q] >> (RADIX_BITS * pass)) & (RADIX - 1);
+#pragma unroll
+            for (int e = 0; e < RADIX; ++e) cnt[e] += (dg[q] == (u32)e);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < RADIX; ++d) cntT[d * THREADS + threadIdx.x] = cnt[d];
+    __syncthreads();
+    {   // exclusive scan of the RADIX * THREADS counters: thread t owns entries [16 t, 16 t + 16)
+        u32 v[RADIX], sum = 0;
+#pragma unroll
+        for (int q = 0; q < RADIX; ++q) { v[q] = cntT[threadIdx.x * RADIX + q]; sum += v[q]; }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < THREADS; off <<= 1) {
+            const u32 t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        u32 run = part[threadIdx.x] - sum;
+#pragma unroll
+        for (int q = 0; q < RADIX; ++q) { cntT[threadIdx.x * RADIX + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    u32 next[RADIX];
+#pragma unroll
+    for (int d = 0; d < RADIX; ++d)  // global base of the run + rank of this thread's first item of the digit inside the tile
+        next[d] = hist[((size_t)c * RADIX + d) * nblk + blockIdx.x] + cntT[d * THREADS + threadIdx.x] - cntT[d * THREADS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        if (dg[q] == RADIX) continue;
+        u32 dst = 0;
+#pragma unroll
+        for (int e = 0; e < RADIX; ++e) if (dg[q] == (u32)e) { dst = next[e]; next[e] = dst + 1; }
+        okeys[dst] = k[q]; operm[dst] = p[q];
+    }
+}
+
+// the sorted order of column c lives on side[c] after the passes: bring it to side 0 (perm0) for the steps that follow
+__global__ void __launch_bounds__(256) settle_perm_kernel(u32* __restrict__ perm0, const u32* __restrict__ perm1, u32* __restrict__ side, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 c = blockIdx.y;
+    if (i < n && side[c]) perm0[(size_t)c * n + i] = perm1[(size_t)c * n + i];
+}
+__global__ void reset_side_kernel(u32* __restrict__ side, u32 cols) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cols) side[c] = 0;
+}
+
+// compare two elements of (possibly different) columns by their canonical 256-bit values
+__device__ __forceinline__ int cmp_keys(const u64* __restrict__ pa, const u32* __restrict__ perma, size_t i, const u64* __restrict__ pb, const u32* __restrict__ permb, size_t j, size_t n) {
     const u32 ia = perma[i], ib = permb[j];
     for (int k = 3; k >= 0; --k) {
-        const u64 x = pa[(size_t)k * na + ia], y = pb[(size_t)k * nb + ib];
+        const u64 x = pa[(size_t)k * n + ia], y = pb[(size_t)k * n + ib];
         if (x != y) return x < y ? -1 : 1;
     }
     return 0;
 }
-// first[i] = 1 when sorted element i starts a run of equal values
-__global__ void __launch_bounds__(256) run_flags_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, u32* __restrict__ first) {
+// after the fast path: bad[c] = 1 when two neighbours agree in the limb sorted by but are different values (their order is then unknown)
+__global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, const int* __restrict__ key_limb, u32* __restrict__ bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    first[i] = (i == 0 || cmp_keys(planes, n, perm, i, planes, n, perm, i - 1) != 0) ? 1u : 0u;
+    const u32 c = blockIdx.y;
+    const int primary = key_limb[c];
+    if (i == 0 || i >= n || primary < 0) return;
+    const u64* pl = planes + (size_t)c * 4 * n;
+    const u32 a = perm[(size_t)c * n + i - 1], b = perm[(size_t)c * n + i];
+    if (pl[(size_t)primary * n + a] != pl[(size_t)primary * n + b]) return;
+    for (int k = 0; k < 4; ++k)
+        if (pl[(size_t)k * n + a] != pl[(size_t)k * n + b]) { bad[c] = 1u; return; }
 }
-// every run start of the sorted input removes the first table instance of its value: removed[pos] = 1; missing -> *err = 1
-__global__ void __launch_bounds__(256) remove_from_table_kernel(const u64* __restrict__ pa, const u32* __restrict__ perma, const u32* __restrict__ first, size_t n,
-                                                                const u64* __restrict__ ps, const u32* __restrict__ perms, u32* __restrict__ removed, u32* __restrict__ err) {
+// out[l][i] = column l's element at sorted position i
+__global__ void __launch_bounds__(256) gather_elems_kernel(const uint4* __restrict__ in, size_t stride, const u32* __restrict__ perm, uint4* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !first[i]) return;
+    const u32 l = blockIdx.y;
+    if (i >= n) return;
+    const uint4* p = in + 2 * ((size_t)l * stride + perm[(size_t)l * n + i]);
+    uint4* o = out + 2 * ((size_t)l * stride + i);
+    o[0] = p[0]; o[1] = p[1];
+}
+// flags[l][i] = 1 when sorted input element i REPEATS its predecessor (0 at run starts)
+__global__ void __launch_bounds__(256) repeat_flags_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, u32* __restrict__ flags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 l = blockIdx.y;
+    if (i >= n) return;
+    const u64* pl = planes + (size_t)l * 4 * n;
+    const u32* pm = perm + (size_t)l * n;
+    flags[(size_t)l * n + i] = (i != 0 && cmp_keys(pl, pm, i, pl, pm, i - 1, n) == 0) ? 1u : 0u;
+}
+// every run start of the sorted input removes the first table instance of its value: keep[l][pos] = 0 (initialised to 1); missing -> err[l] = 1
+__global__ void __launch_bounds__(256) remove_from_table_kernel(const u64* __restrict__ planes, const u32* __restrict__ perm, const u32* __restrict__ repeats, size_t n, u32 batch,
+                                                                u32* __restrict__ keep, u32* __restrict__ err) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 l = blockIdx.y;
+    if (i >= n || repeats[(size_t)l * n + i]) return;
+    const u64 *pa = planes + (size_t)l * 4 * n, *ps = planes + (size_t)(batch + l) * 4 * n;
+    const u32 *perma = perm + (size_t)l * n, *perms = perm + (size_t)(batch + l) * n;
     size_t lo = 0, hi = n;  // lower bound of the value in the sorted table
     while (lo < hi) {
         const size_t mid = (lo + hi) >> 1;
-        if (cmp_keys(ps, n, perms, mid, pa, n, perma, i) < 0) lo = mid + 1; else hi = mid;
+        if (cmp_keys(ps, perms, mid, pa, perma, i, n) < 0) lo = mid + 1; else hi = mid;
     }
-    if (lo < n && cmp_keys(ps, n, perms, lo, pa, n, perma, i) == 0) removed[lo] = 1u;  // distinct run starts hit distinct positions
-    else *err = 1u;
+    if (lo < n && cmp_keys(ps, perms, lo, pa, perma, i, n) == 0) keep[(size_t)l * n + lo] = 0u;  // distinct run starts hit distinct positions
+    else err[l] = 1u;
 }
-__global__ void __launch_bounds__(256) invert_flags_kernel(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) fill_u32_kernel(u32* __restrict__ a, size_t count, u32 v) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i] ? 0u : 1u;
-}
-// rows[] of the flagged positions in ascending order (pos = exclusive prefix sum of the flags)
-__global__ void __launch_bounds__(256) compact_kernel(const u32* __restrict__ flags, const u32* __restrict__ pos, u32* __restrict__ rows, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flags[i]) rows[pos[i]] = (u32)i;
-}
-// S'[row] = A'[row] at run starts; left-over table element k (ascending) goes to the (count - 1 - k)-th repeated row
-__global__ void __launch_bounds__(256) place_table_kernel(const uint4* __restrict__ a_sorted, const u32* __restrict__ first, const uint4* __restrict__ table, const u32* __restrict__ perms,
-                                                          const u32* __restrict__ left_rows /* positions in the sorted table */, const u32* __restrict__ rep_rows, u32 n_rep,
-                                                          uint4* __restrict__ out_table, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (first[i]) { out_table[2 * i] = a_sorted[2 * i]; out_table[2 * i + 1] = a_sorted[2 * i + 1]; }
-    if (i < n_rep) {
-        const uint4* src = table + 2 * (size_t)perms[left_rows[i]];
-        const size_t dst = rep_rows[n_rep - 1 - i];
-        out_table[2 * dst] = src[0]; out_table[2 * dst + 1] = src[1];
-    }
+    if (i < count) a[i] = v;
 }
 
-// varies[k] = 1 when limb plane k is not constant over the column
-__global__ void __launch_bounds__(256) plane_varies_kernel(const u64* __restrict__ planes, size_t n, u32* __restrict__ varies) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int k = 0; k < 4; ++k)
-        if (planes[(size_t)k * n + i] != planes[(size_t)k * n] && !varies[k]) varies[k] = 1u;  // benign race: every writer stores 1
+// ---- exclusive scan of u32 flags, every row of the batch at once: tile scans, scan of the tile sums, add ------------------------------
+__global__ void __launch_bounds__(THREADS) scan_tiles_kernel(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ tile_sums) {
+    __shared__ u32 part[THREADS];
+    const u32 l = blockIdx.y;
+    const size_t base = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * ITEMS;
+    u32 v[ITEMS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) { v[q] = base + q < n ? in[(size_t)l * n + base + q] : 0u; sum += v[q]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < THREADS; off <<= 1) {
+        const u32 t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    u32 run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) { if (base + q < n) out[(size_t)l * n + base + q] = run; run += v[q]; }
+    if (threadIdx.x == THREADS - 1) tile_sums[(size_t)l * gridDim.x + blockIdx.x] = part[THREADS - 1];
 }
-// after a sort by ONE limb: *bad = 1 when two neighbours agree in that limb but are different values (the order inside the tie is then unknown)
-__global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, int primary, u32* __restrict__ bad) {
+__global__ void __launch_bounds__(THREADS) scan_sums_kernel(u32* __restrict__ tile_sums, u32 ntiles, u32* __restrict__ totals) {
+    __shared__ u32 part[THREADS];
+    __shared__ u32 carry;
+    const u32 l = blockIdx.x;
+    u32* s = tile_sums + (size_t)l * ntiles;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < ntiles; b0 += THREADS) {
+        const u32 v = b0 + threadIdx.x < ntiles ? s[b0 + threadIdx.x] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < THREADS; off <<= 1) {
+            const u32 t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (b0 + threadIdx.x < ntiles) s[b0 + threadIdx.x] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == THREADS - 1) carry += part[THREADS - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[l] = carry;
+}
+// rows[l][pos] = i for the flagged positions, ascending (pos = tile-local exclusive scan + scanned tile sum)
+__global__ void __launch_bounds__(256) compact_kernel(const u32* __restrict__ flags, const u32* __restrict__ pos, const u32* __restrict__ tile_sums, u32 ntiles, u32* __restrict__ rows, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 || i >= n) return;
-    const u32 a = perm[i - 1], b = perm[i];
-    if (planes[(size_t)primary * n + a] != planes[(size_t)primary * n + b]) return;
-    for (int k = 0; k < 4; ++k)
-        if (planes[(size_t)k * n + a] != planes[(size_t)k * n + b]) { *bad = 1u; return; }
+    const u32 l = blockIdx.y;
+    if (i < n && flags[(size_t)l * n + i]) rows[(size_t)l * n + pos[(size_t)l * n + i] + tile_sums[(size_t)l * ntiles + i / TILE]] = (u32)i;
+}
+// S'[row] = A'[row] at run starts; left-over table element k (ascending) goes to the (count - 1 - k)-th repeated row
+__global__ void __launch_bounds__(256) place_table_kernel(const uint4* __restrict__ a_sorted, const u32* __restrict__ repeats, const uint4* __restrict__ table, size_t stride,
+                                                          const u32* __restrict__ perm_tables, const u32* __restrict__ left_rows, const u32* __restrict__ rep_rows,
+                                                          const u32* __restrict__ n_rep, const u32* __restrict__ n_left, uint4* __restrict__ out_table, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 l = blockIdx.y;
+    if (i >= n) return;
+    uint4* ot = out_table + 2 * (size_t)l * stride;
+    if (!repeats[(size_t)l * n + i]) {
+        const uint4* a = a_sorted + 2 * ((size_t)l * stride + i);
+        ot[2 * i] = a[0]; ot[2 * i + 1] = a[1];
+    }
+    // repeated rows == left-over table elements (both usable_rows - #distinct inputs) unless an input value is missing from the table:
+    // that lookup is reported as an error, its columns are not used -- only keep the indices inside the arrays
+    const u32 count = n_rep[l] < n_left[l] ? n_rep[l] : n_left[l];
+    if (i < count) {
+        const uint4* src = table + 2 * ((size_t)l * stride + perm_tables[(size_t)l * n + left_rows[(size_t)l * n + i]]);
+        const size_t dst = rep_rows[(size_t)l * n + count - 1 - i];
+        ot[2 * dst] = src[0]; ot[2 * dst + 1] = src[1];
+    }
 }
 
 struct Scratch {
-    DevBuf planes_a, planes_s, keys_in, keys_out, perm_a, perm_s, perm_tmp, first, removed, flags, pos, rows_rep, rows_left, tmp, err;
-    u32* host = nullptr;  // pinned landing area of the few words the host reads back per lookup (pageable targets cost a staging copy each)
+    DevBuf planes, keys0, keys1, perm0, perm1, hist, flags, keep, pos, tile_sums, rows_rep, rows_left, small;
+    u32* host = nullptr;  // pinned landing area of the flag words the host reads back per batch
+    size_t host_words = 0;
 };
 Scratch& scratch() {  // per context (device)
     Ctx& c = ctx();
     if (!c.lookup_scratch) c.lookup_scratch = new Scratch();
     return *(Scratch*)c.lookup_scratch;
 }
-int host_words(Scratch& sc) {
-    if (!sc.host) TRH_HIP_TRY(hipHostMalloc((void**)&sc.host, 256, hipHostMallocDefault));
-    return TRH_OK;
-}
-// the three words the placement needs: exclusive-scan tail and last flag of the repeated rows, the missing-value flag
-__global__ void collect_tail_kernel(const u32* __restrict__ pos, const u32* __restrict__ flags, size_t n, const u32* __restrict__ err, u32* __restrict__ out) {
-    out[0] = pos[n - 1]; out[1] = flags[n - 1]; out[2] = err[0];
-}
 
-// sort of the permutations of BOTH columns by their 256-bit keys.  Field elements are either small (range tables: only the low
-// limb varies) or spread over the whole field (compressed expressions: two different values practically never share their top
-// limb), so ONE radix sort by the most significant limb that varies is almost always the complete order -- checked, with the
-// stable least-significant-limb-first passes as the fallback.  The two columns go through the phases together so that the
-// host reads the flags of both with one synchronisation per phase.
-int sort_perm_fallback(const u64* planes, size_t n, u32* perm, const u32* varies, size_t tmp_bytes, hipStream_t s) {
-    Scratch& sc = scratch();
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    u32* cur = perm;  // still the identity order
-    u32* nxt = sc.perm_tmp.as<u32>();
-    for (int k = 0; k < 4; ++k) {
-        if (!varies[k]) continue;
-        hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes + (size_t)k * n, cur, sc.keys_in.as<u64>(), n);
-        TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), cur, nxt, n, 0, 64, s));
-        u32* t = cur; cur = nxt; nxt = t;
+// the sort of `cols` columns: one step by the most significant varying limb (general = false), or one stable step per varying limb,
+// least significant first (general = true).  Leaves the order in perm0.
+int sort_columns(Scratch& sc, size_t n, u32 cols, bool general, u64* varies, int* key_limb, u64* key_mask, u32* side, u32* sel, hipStream_t s) {
+    const unsigned gb = (unsigned)((n + 255) / 256), nblk = (unsigned)((n + TILE - 1) / TILE);
+    u64 *keys0 = sc.keys0.as<u64>(), *keys1 = sc.keys1.as<u64>();
+    u32 *perm0 = sc.perm0.as<u32>(), *perm1 = sc.perm1.as<u32>(), *hist = sc.hist.as<u32>();
+    hipLaunchKernelGGL(reset_side_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, side, cols);
+    for (int step = general ? 0 : -1; step < (general ? 4 : 0); ++step) {
+        hipLaunchKernelGGL(select_limb_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, varies, cols, step, key_limb, key_mask, side);
+        hipLaunchKernelGGL(gather_keys_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, cols, key_limb, side, perm0, perm1, keys0, keys1);
+        for (int pass = 0; pass < PASSES; ++pass) {
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk, cols), dim3(THREADS), 0, s, keys0, keys1, side, key_mask, n, pass, hist);
+            hipLaunchKernelGGL(radix_scan_kernel, dim3(cols), dim3(THREADS), 0, s, hist, nblk, key_mask, pass, side, sel);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk, cols), dim3(THREADS), 0, s, keys0, keys1, perm0, perm1, keys0, keys1, perm0, perm1, sel, key_mask, n, pass, hist);
+        }
     }
-    if (cur != perm) TRH_HIP_TRY(hipMemcpyAsync(perm, cur, n * 4, hipMemcpyDeviceToDevice, s));
-    return TRH_OK;
-}
-
-int sort_perm_pair(const u64* planes_a, u32* perm_a, const u64* planes_s, u32* perm_s, size_t n, hipStream_t s) {
-    Scratch& sc = scratch();
-    TRH_TRY(sc.keys_in.ensure(n * 8)); TRH_TRY(sc.keys_out.ensure(n * 8)); TRH_TRY(sc.perm_tmp.ensure(2 * n * 4)); TRH_TRY(sc.err.ensure(64));
-    size_t tmp_bytes = 0;
-    TRH_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perm_a, sc.perm_tmp.as<u32>(), n, 0, 64, s));
-    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    const u64* planes[2] = {planes_a, planes_s};
-    u32* perms[2] = {perm_a, perm_s};
-    u32* flags = sc.err.as<u32>() + 1;  // [0] is the caller's error word; per column: varies[4], bad
-    TRH_HIP_TRY(hipMemsetAsync(flags, 0, 40, s));
-    for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(plane_varies_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, flags + 5 * c);
-    TRH_TRY(host_words(sc));
-    u32 h[10];
-    TRH_HIP_TRY(hipMemcpyAsync(sc.host, flags, 40, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    memcpy(h, sc.host, 40);
-    int primary[2];
-    for (int c = 0; c < 2; ++c) {
-        primary[c] = -1;
-        for (int k = 3; k >= 0; --k) if (h[5 * c + k]) { primary[c] = k; break; }
-        if (primary[c] < 0) continue;  // a constant column: any order
-        u32* out = sc.perm_tmp.as<u32>() + (size_t)c * n;
-        hipLaunchKernelGGL(gather_u64_kernel, dim3(gb), dim3(256), 0, s, planes[c] + (size_t)primary[c] * n, perms[c], sc.keys_in.as<u64>(), n);
-        TRH_HIP_TRY(rocprim::radix_sort_pairs(sc.tmp.p, tmp_bytes, sc.keys_in.as<u64>(), sc.keys_out.as<u64>(), perms[c], out, n, 0, 64, s));
-        hipLaunchKernelGGL(tie_check_kernel, dim3(gb), dim3(256), 0, s, planes[c], n, out, primary[c], flags + 5 * c + 4);
-    }
-    TRH_HIP_TRY(hipMemcpyAsync(sc.host, flags + 4, 24, hipMemcpyDeviceToHost, s));  // bad[0] ... bad[1]: words 4 and 9
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    const u32 bad[2] = {sc.host[0], sc.host[5]};
-    for (int c = 0; c < 2; ++c) {
-        if (primary[c] < 0) continue;
-        if (!bad[c]) TRH_HIP_TRY(hipMemcpyAsync(perms[c], sc.perm_tmp.as<u32>() + (size_t)c * n, n * 4, hipMemcpyDeviceToDevice, s));
-    }
-    for (int c = 0; c < 2; ++c)  // after the copies: the fallback reuses perm_tmp
-        if (primary[c] >= 0 && bad[c]) TRH_TRY(sort_perm_fallback(planes[c], n, perms[c], h + 5 * c, tmp_bytes, s));
+    hipLaunchKernelGGL(settle_perm_kernel, dim3(gb, cols), dim3(256), 0, s, perm0, perm1, side, n);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
 
-int exclusive_scan_u32(const u32* in, u32* out, size_t n, hipStream_t s) {
+// `batch` lookups at once; general: the all-limbs sort (the redo of a lookup whose fast sort met a tie between different values)
+template <class F>
+int lookup_permute_batch_t(const void* inputs, const void* tables, size_t n, size_t stride, u32 batch, void* out_inputs, void* out_tables, bool general, u32* bad_out /* batch, or null */,
+                           hipStream_t s) {
     Scratch& sc = scratch();
-    size_t tmp_bytes = 0;
-    TRH_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0u, n, rocprim::plus<u32>(), s));
-    TRH_TRY(sc.tmp.ensure(tmp_bytes + 256));
-    TRH_HIP_TRY(rocprim::exclusive_scan(sc.tmp.p, tmp_bytes, in, out, 0u, n, rocprim::plus<u32>(), s));
+    const u32 cols = 2 * batch;
+    const size_t cn = (size_t)cols * n, bn = (size_t)batch * n;
+    const unsigned gb = (unsigned)((n + 255) / 256), nblk = (unsigned)((n + TILE - 1) / TILE);
+    TRH_TRY(sc.planes.ensure(cn * 32)); TRH_TRY(sc.keys0.ensure(cn * 8)); TRH_TRY(sc.keys1.ensure(cn * 8)); TRH_TRY(sc.perm0.ensure(cn * 4)); TRH_TRY(sc.perm1.ensure(cn * 4));
+    TRH_TRY(sc.hist.ensure((size_t)cols * RADIX * nblk * 4)); TRH_TRY(sc.flags.ensure(bn * 4)); TRH_TRY(sc.keep.ensure(bn * 4)); TRH_TRY(sc.pos.ensure(bn * 4));
+    TRH_TRY(sc.tile_sums.ensure((size_t)batch * nblk * 4)); TRH_TRY(sc.rows_rep.ensure(bn * 4)); TRH_TRY(sc.rows_left.ensure(bn * 4));
+    // small per-column words: varies[cols][4] u64 | key_mask[cols] u64 | key_limb[cols] | side[cols] | sel[PASSES][cols] | bad[cols] | err[batch] | n_rep[batch] | n_left[batch]
+    const size_t small_bytes = (size_t)cols * (32 + 8 + 4 + 4 + 4 * PASSES + 4) + (size_t)batch * 12 + 64;
+    TRH_TRY(sc.small.ensure(small_bytes));
+    char* sm = (char*)sc.small.p;
+    u64* varies = (u64*)sm; sm += (size_t)cols * 32;
+    u64* key_mask = (u64*)sm; sm += (size_t)cols * 8;
+    int* key_limb = (int*)sm; sm += (size_t)cols * 4;
+    u32* side = (u32*)sm; sm += (size_t)cols * 4;
+    u32* sel = (u32*)sm; sm += (size_t)cols * 4 * PASSES;
+    u32* bad = (u32*)sm; sm += (size_t)cols * 4;   // bad[cols], err[batch] contiguous: one read-back
+    u32* err = (u32*)sm; sm += (size_t)batch * 4;
+    u32* n_rep = (u32*)sm; sm += (size_t)batch * 4;
+    u32* n_left = (u32*)sm;
+    TRH_HIP_TRY(hipMemsetAsync(sc.small.p, 0, small_bytes, s));
+
+    hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb, cols), dim3(256), 0, s, (const uint4*)inputs, (const uint4*)tables, stride, batch, n, sc.planes.as<u64>(), sc.perm0.as<u32>());
+    hipLaunchKernelGGL(plane_varies_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, varies);
+    TRH_TRY(sort_columns(sc, n, cols, general, varies, key_limb, key_mask, side, sel, s));
+    if (!general) hipLaunchKernelGGL(tie_check_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), key_limb, bad);
+    hipLaunchKernelGGL(gather_elems_kernel, dim3(gb, batch), dim3(256), 0, s, (const uint4*)inputs, stride, sc.perm0.as<u32>(), (uint4*)out_inputs, n);
+    hipLaunchKernelGGL(repeat_flags_kernel, dim3(gb, batch), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), sc.flags.as<u32>());
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, s, sc.keep.as<u32>(), bn, 1u);
+    hipLaunchKernelGGL(remove_from_table_kernel, dim3(gb, batch), dim3(256), 0, s, sc.planes.as<u64>(), sc.perm0.as<u32>(), sc.flags.as<u32>(), n, batch, sc.keep.as<u32>(), err);
+    // repeated input rows (ascending) and left-over table positions (ascending)
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nblk, batch), dim3(THREADS), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), n, sc.tile_sums.as<u32>());
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(batch), dim3(THREADS), 0, s, sc.tile_sums.as<u32>(), nblk, n_rep);
+    hipLaunchKernelGGL(compact_kernel, dim3(gb, batch), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.tile_sums.as<u32>(), nblk, sc.rows_rep.as<u32>(), n);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nblk, batch), dim3(THREADS), 0, s, sc.keep.as<u32>(), sc.pos.as<u32>(), n, sc.tile_sums.as<u32>());
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(batch), dim3(THREADS), 0, s, sc.tile_sums.as<u32>(), nblk, n_left);
+    hipLaunchKernelGGL(compact_kernel, dim3(gb, batch), dim3(256), 0, s, sc.keep.as<u32>(), sc.pos.as<u32>(), sc.tile_sums.as<u32>(), nblk, sc.rows_left.as<u32>(), n);
+    hipLaunchKernelGGL(place_table_kernel, dim3(gb, batch), dim3(256), 0, s, (const uint4*)out_inputs, sc.flags.as<u32>(), (const uint4*)tables, stride, sc.perm0.as<u32>() + bn, sc.rows_left.as<u32>(),
+                       sc.rows_rep.as<u32>(), n_rep, n_left, (uint4*)out_tables, n);
+    TRH_HIP_TRY(hipGetLastError());
+    // one read-back per batch: tie flags of the 2 * batch columns, then the missing-value flags of the lookups
+    const size_t words = (size_t)cols + batch;
+    if (words > sc.host_words) {
+        if (sc.host) (void)hipHostFree(sc.host);
+        sc.host = nullptr;
+        TRH_HIP_TRY(hipHostMalloc((void**)&sc.host, (words + 64) * 4, hipHostMallocDefault));
+        sc.host_words = words + 64;
+    }
+    TRH_HIP_TRY(hipMemcpyAsync(sc.host, bad, words * 4, hipMemcpyDeviceToHost, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));
+    for (u32 l = 0; l < batch; ++l) {
+        const bool tie = sc.host[l] || sc.host[batch + l];
+        if (bad_out) bad_out[l] = tie ? 1u : 0u;
+        // a tie leaves the order of its members open, so a "missing" verdict of this pass is not final either: the redo decides
+        if (!tie && sc.host[cols + l]) {
+            set_error("lookup_permute: an input value of lookup %u does not occur in its table (halo2: Error::ConstraintSystemFailure)", l);
+            return TRH_EINVAL;
+        }
+    }
     return TRH_OK;
 }
 
 template <class F>
-int lookup_permute_t(const void* input, const void* table, size_t n, void* out_input, void* out_table, hipStream_t s) {
-    Scratch& sc = scratch();
-    TRH_TRY(sc.planes_a.ensure(n * 32)); TRH_TRY(sc.planes_s.ensure(n * 32)); TRH_TRY(sc.perm_a.ensure(n * 4)); TRH_TRY(sc.perm_s.ensure(n * 4));
-    TRH_TRY(sc.first.ensure(n * 4)); TRH_TRY(sc.removed.ensure(n * 4)); TRH_TRY(sc.flags.ensure(n * 4)); TRH_TRY(sc.pos.ensure(n * 4 + 4));
-    TRH_TRY(sc.rows_rep.ensure(n * 4)); TRH_TRY(sc.rows_left.ensure(n * 4)); TRH_TRY(sc.err.ensure(64));
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)input, n, sc.planes_a.as<u64>(), sc.perm_a.as<u32>());
-    hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb), dim3(256), 0, s, (const uint4*)table, n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>());
-    TRH_TRY(sort_perm_pair(sc.planes_a.as<u64>(), sc.perm_a.as<u32>(), sc.planes_s.as<u64>(), sc.perm_s.as<u32>(), n, s));
-    hipLaunchKernelGGL(gather_elems_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)input, sc.perm_a.as<u32>(), (uint4*)out_input, n);
-    hipLaunchKernelGGL(run_flags_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), n, sc.perm_a.as<u32>(), sc.first.as<u32>());
-    TRH_HIP_TRY(hipMemsetAsync(sc.removed.p, 0, n * 4, s));
-    TRH_HIP_TRY(hipMemsetAsync(sc.err.p, 0, 4, s));
-    hipLaunchKernelGGL(remove_from_table_kernel, dim3(gb), dim3(256), 0, s, sc.planes_a.as<u64>(), sc.perm_a.as<u32>(), sc.first.as<u32>(), n, sc.planes_s.as<u64>(), sc.perm_s.as<u32>(),
-                       sc.removed.as<u32>(), sc.err.as<u32>());
-    // repeated input rows (ascending) and left-over table positions (ascending)
-    hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.first.as<u32>(), sc.flags.as<u32>(), n);
-    TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
-    hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_rep.as<u32>(), n);
-    TRH_TRY(host_words(sc));
-    u32* rec = sc.err.as<u32>() + 12;  // device record behind the error word and the sort flags
-    hipLaunchKernelGGL(collect_tail_kernel, dim3(1), dim3(1), 0, s, sc.pos.as<u32>(), sc.flags.as<u32>(), n, sc.err.as<u32>(), rec);
-    hipLaunchKernelGGL(invert_flags_kernel, dim3(gb), dim3(256), 0, s, sc.removed.as<u32>(), sc.flags.as<u32>(), n);
-    TRH_TRY(exclusive_scan_u32(sc.flags.as<u32>(), sc.pos.as<u32>(), n, s));
-    hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, s, sc.flags.as<u32>(), sc.pos.as<u32>(), sc.rows_left.as<u32>(), n);
-    TRH_HIP_TRY(hipMemcpyAsync(sc.host, rec, 12, hipMemcpyDeviceToHost, s));
-    TRH_HIP_TRY(hipStreamSynchronize(s));
-    if (sc.host[2]) { set_error("lookup_permute: an input value does not occur in the table (halo2: Error::ConstraintSystemFailure)"); return TRH_EINVAL; }
-    const u32 n_rep = sc.host[0] + sc.host[1];  // repeated rows == left-over table elements (both n - #distinct inputs)
-    hipLaunchKernelGGL(place_table_kernel, dim3(gb), dim3(256), 0, s, (const uint4*)out_input, sc.first.as<u32>(), (const uint4*)table, sc.perm_s.as<u32>(), sc.rows_left.as<u32>(),
-                       sc.rows_rep.as<u32>(), n_rep, (uint4*)out_table, n);
-    TRH_HIP_TRY(hipGetLastError());
+int lookup_permute_all_t(const void* inputs, const void* tables, size_t n, size_t stride, size_t batch, void* out_inputs, void* out_tables, hipStream_t s) {
+    // chunks of at most 32 lookups bound the scratch (2^18 rows: 32 lookups = 64 columns = 0.9 GiB)
+    std::vector<u32> bad;
+    for (size_t b0 = 0; b0 < batch; b0 += 32) {
+        const u32 nb = (u32)(batch - b0 < 32 ? batch - b0 : 32);
+        const char* in = (const char*)inputs + b0 * stride * 32;
+        const char* tb = (const char*)tables + b0 * stride * 32;
+        char* oi = (char*)out_inputs + b0 * stride * 32;
+        char* ot = (char*)out_tables + b0 * stride * 32;
+        bad.assign(nb, 0);
+        TRH_TRY((lookup_permute_batch_t<F>(in, tb, n, stride, nb, oi, ot, false, bad.data(), s)));
+        for (u32 l = 0; l < nb; ++l) {
+            if (!bad[l]) continue;  // rare: two different values share the limb the fast path sorted by
+            const int rc = lookup_permute_batch_t<F>(in + (size_t)l * stride * 32, tb + (size_t)l * stride * 32, n, stride, 1, oi + (size_t)l * stride * 32, ot + (size_t)l * stride * 32, true,
+                                                     nullptr, s);
+            if (rc != TRH_OK) {
+                if (rc == TRH_EINVAL) set_error("lookup_permute: an input value of lookup %zu does not occur in its table (halo2: Error::ConstraintSystemFailure)", b0 + l);
+                return rc;
+            }
+        }
+    }
     return TRH_OK;
 }
 
@@ -245,9 +495,7 @@ void lookup_release() {
     Ctx& c = ctx();
     if (!c.lookup_scratch) return;
     Scratch& sc = *(Scratch*)c.lookup_scratch;
-    for (DevBuf* b : {&sc.planes_a, &sc.planes_s, &sc.keys_in, &sc.keys_out, &sc.perm_a, &sc.perm_s, &sc.perm_tmp, &sc.first, &sc.removed, &sc.flags, &sc.pos, &sc.rows_rep, &sc.rows_left, &sc.tmp,
-                      &sc.err})
-        b->release();
+    for (DevBuf* b : {&sc.planes, &sc.keys0, &sc.keys1, &sc.perm0, &sc.perm1, &sc.hist, &sc.flags, &sc.keep, &sc.pos, &sc.tile_sums, &sc.rows_rep, &sc.rows_left, &sc.small}) b->release();
     if (sc.host) { (void)hipHostFree(sc.host); sc.host = nullptr; }
     delete &sc;
     c.lookup_scratch = nullptr;
@@ -257,17 +505,24 @@ void lookup_release() {
 
 using namespace trh;
 
-extern "C" int trh_lookup_permute_dev(int field, const void* input_dev, const void* table_dev, size_t usable_rows, void* out_input_dev, void* out_table_dev, void* stream) {
+extern "C" {
+
+int trh_lookup_permute_batch_dev(int field, const void* inputs_dev, const void* tables_dev, size_t usable_rows, size_t row_stride, size_t batch, void* out_inputs_dev,
+                                 void* out_tables_dev, void* stream) {
     TRH_TRY(require_init());
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
-    if (usable_rows && (!input_dev || !table_dev || !out_input_dev || !out_table_dev)) { set_error("lookup_permute: null pointer"); return TRH_EINVAL; }
-    if (out_input_dev == input_dev || out_table_dev == table_dev || out_input_dev == out_table_dev) { set_error("lookup_permute: outputs must not alias the inputs"); return TRH_EINVAL; }
-    if (usable_rows >= ((size_t)1 << 31)) { set_error("lookup_permute: too many rows"); return TRH_EINVAL; }
-    if (!usable_rows) return TRH_OK;
+    if (usable_rows && batch && (!inputs_dev || !tables_dev || !out_inputs_dev || !out_tables_dev)) { set_error("lookup_permute: null pointer"); return TRH_EINVAL; }
+    if (out_inputs_dev == inputs_dev || out_tables_dev == tables_dev || out_inputs_dev == out_tables_dev) { set_error("lookup_permute: outputs must not alias the inputs"); return TRH_EINVAL; }
+    if (usable_rows >= ((size_t)1 << 31) || row_stride < usable_rows) { set_error("lookup_permute: bad row count / stride"); return TRH_EINVAL; }
+    if (!usable_rows || !batch) return TRH_OK;
     TRH_ENTER(stream);
-    Range range("trh_lookup_permute_dev");
-    Ctx& c = ctx();
-    (void)c;
-    if (field == TRH_FP) return lookup_permute_t<FpParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
-    return lookup_permute_t<FqParams>(input_dev, table_dev, usable_rows, out_input_dev, out_table_dev, (hipStream_t)stream);
+    Range range("trh_lookup_permute_batch_dev");
+    if (field == TRH_FP) return lookup_permute_all_t<FpParams>(inputs_dev, tables_dev, usable_rows, row_stride, batch, out_inputs_dev, out_tables_dev, (hipStream_t)stream);
+    return lookup_permute_all_t<FqParams>(inputs_dev, tables_dev, usable_rows, row_stride, batch, out_inputs_dev, out_tables_dev, (hipStream_t)stream);
 }
+
+int trh_lookup_permute_dev(int field, const void* input_dev, const void* table_dev, size_t usable_rows, void* out_input_dev, void* out_table_dev, void* stream) {
+    return trh_lookup_permute_batch_dev(field, input_dev, table_dev, usable_rows, usable_rows, 1, out_input_dev, out_table_dev, stream);
+}
+
+}  // extern "C"

@@ -150,3 +150,18 @@ def lookup_permute(field: str, input_col, table_col, usable_rows: int | None = N
     api._check(api.lib().trh_lookup_permute_dev(api.FIELD_ID[field], api._devptr(input_col), api._devptr(table_col), n, api._devptr(a), api._devptr(s),
                                                torch.cuda.current_stream(input_col.device).cuda_stream))
     return a, s
+
+
+def lookup_permute_batch(field: str, inputs, tables, usable_rows: int | None = None):
+    """permute_expression_pair for every lookup of a proof at once: inputs / tables are device tensors (batch, rows, 4) (contiguous);
+    returns (permuted_inputs, permuted_tables) of the same shape, rows behind usable_rows zero.  One set of launches and one host
+    synchronisation for the batch; raises api.TrhError naming the first lookup with an input value missing from its table"""
+    import torch
+    batch, rows = inputs.shape[0], inputs.shape[1]
+    n = rows if usable_rows is None else usable_rows
+    assert tables.shape == inputs.shape and n <= rows and inputs.is_contiguous() and tables.is_contiguous()
+    a = torch.zeros_like(inputs)
+    s = torch.zeros_like(inputs)
+    api._check(api.lib().trh_lookup_permute_batch_dev(api.FIELD_ID[field], api._devptr(inputs), api._devptr(tables), n, rows, batch, api._devptr(a), api._devptr(s),
+                                                     torch.cuda.current_stream(inputs.device).cuda_stream))
+    return a, s

@@ -163,19 +163,19 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     distinct = torch.from_numpy(synth.field_elements(0x7AB1E, min(n, 1 << 16)).view(np.int64)).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x100C)
-    for li in range(N_LOOKUPS):
-        table = distinct[torch.arange(n, device=dev) % distinct.shape[0]].contiguous()
-        inp = distinct[torch.randint(0, distinct.shape[0], (n,), device=dev, generator=gen)].contiguous()
-        e0 = ev()
-        pa, ps = permutation.lookup_permute(field, inp, table)
-        e1 = ev()
-        torch.cuda.synchronize()
-        times["lookup_permute"] += e0.elapsed_time(e1)
-        counts["lookup_permute"] += 1
-        if hook is not None and li == 0:
-            hook("lookup_permute", dict(input=inp.cpu().numpy().view(np.uint64), table=table.cpu().numpy().view(np.uint64), field=field),
-                 (pa.cpu().numpy().view(np.uint64), ps.cpu().numpy().view(np.uint64)))
-            checked += 1
+    tabs = torch.stack([distinct[torch.arange(n, device=dev) % distinct.shape[0]] for _ in range(N_LOOKUPS)]).contiguous()
+    inps = torch.stack([distinct[torch.randint(0, distinct.shape[0], (n,), device=dev, generator=gen)] for _ in range(N_LOOKUPS)]).contiguous()
+    e0 = ev()
+    pas, pss = permutation.lookup_permute_batch(field, inps, tabs)   # the 31 lookups of the proof in one call
+    e1 = ev()
+    torch.cuda.synchronize()
+    times["lookup_permute"] += e0.elapsed_time(e1)
+    counts["lookup_permute"] += N_LOOKUPS
+    if hook is not None:
+        hook("lookup_permute", dict(input=inps[0].cpu().numpy().view(np.uint64), table=tabs[0].cpu().numpy().view(np.uint64), field=field),
+             (pas[0].cpu().numpy().view(np.uint64), pss[0].cpu().numpy().view(np.uint64)))
+        checked += 1
+    del tabs, inps, pas, pss
     del distinct
 
     # --- grand products: the 47 permutation product columns (4 columns each) and the 31 lookup products, all at once ---
