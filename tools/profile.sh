@@ -9,8 +9,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check"
+ARGS="--gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- python3 $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.csv" | head -20
+# the witness-shaped k = 18 replay: the chunked-sort / heavy-bucket paths of the MSM, the batched lookups, the multiopen folds
+rocprofv3 --kernel-trace --stats -d $OUT/stats_witness -o trace -- python3 $REPO/tools/replay_probe.py 32 witness > $OUT/stats_witness.log 2>&1

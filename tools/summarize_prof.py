@@ -37,7 +37,7 @@ def main():
                       "from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check`",
+             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-sweep`",
              "(1 warm-up + 3 timed 2^%d Pallas MSMs, then the 2^%d Fp NTT loop).  Durations in microseconds." % (msm_log_n, ntt_log_n), "",
              "| kernel | calls | total us | avg us | min us | max us | % | VGPR | SGPR | LDS B | scratch | grid | wg |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
@@ -47,6 +47,21 @@ def main():
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))
+
+    wpath = os.path.join(src, "stats_witness", "trace_results.db")
+    if os.path.exists(wpath):  # the witness-shaped replay: which kernels the skewed commitments really spend their time in
+        wdb = sqlite3.connect(wpath)
+        wrows = wdb.execute("select name, count(*), sum(duration), avg(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+        wtotal = sum(r[2] for r in wrows) or 1
+        wl = [f"# rocprofv3 --kernel-trace --stats: k = 18 create_proof replay over WITNESS-SHAPED columns ({tag})", "",
+              "Command: `rocprofv3 --kernel-trace --stats -- python3 tools/replay_probe.py 32 witness` (= python -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --no-keygen)",
+              "(flags / 32-bit words on the n / 4 live rows, zero padding, blinding rows: almost every pair of a commitment falls into a handful of buckets, so the",
+              "chunked bucket passes (msm_bucket_pass_kernel) and the heavy-bucket combine (msm_combine_heavy_kernel) carry the commitments).  Durations in microseconds.", "",
+              "| kernel | calls | total us | avg us | max us | % |", "|---|---|---|---|---|---|"]
+        for r in wrows[:40]:
+            wl.append(f"| {short(r[0])} | {r[1]} | {r[2]/1e3:.1f} | {r[3]/1e3:.1f} | {r[4]/1e3:.1f} | {100*r[2]/wtotal:.1f} |")
+        with open(os.path.join(out_dir, f"{tag}_witness_replay_kernel_stats.md"), "w") as fh:
+            fh.write("\n".join(wl) + "\n")
 
     traffic_path = os.path.join(out_dir, "traffic.json")
     traffic = {}
