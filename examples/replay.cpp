@@ -164,25 +164,28 @@ int main(int argc, char** argv) {
             std::vector<Limbs> vals(distinct), table(n), input(n);
             SplitMix lr{0x7ab1e};
             for (auto& v : vals) v = lr.element();
-            DeviceBuffer d_in(n * 32), d_tab(n * 32), d_pa(n * 32), d_ps(n * 32);
+            DeviceBuffer d_in((size_t)N_LOOKUPS * n * 32), d_tab((size_t)N_LOOKUPS * n * 32), d_pa((size_t)N_LOOKUPS * n * 32), d_ps((size_t)N_LOOKUPS * n * 32);
+            std::vector<Limbs> in0, tab0;
             for (int li = 0; li < N_LOOKUPS; ++li) {
                 for (size_t i = 0; i < n; ++i) { table[i] = vals[i % distinct]; input[i] = vals[lr.next() % distinct]; }
-                d_in.upload(input.data(), n * 32); d_tab.upload(table.data(), n * 32);
-                Timer tl;
-                lookup_permute(field, d_in.data(), d_tab.data(), n, d_pa.data(), d_ps.data());
-                ms_lookup += tl.stop();
-                if (li == 0) {  // the argument's defining constraints: A'[i] == S'[i] or A'[i] == A'[i-1]; A' is a permutation of A (sums agree)
-                    std::vector<Limbs> pa(n), ps(n);
-                    d_pa.download(pa.data(), n * 32); d_ps.download(ps.data(), n * 32);
-                    bool ok = true;
-                    Limbs sa{0, 0, 0, 0}, sb{0, 0, 0, 0}, st{0, 0, 0, 0}, su{0, 0, 0, 0};
-                    for (size_t i = 0; i < n; ++i) {
-                        ok = ok && (pa[i] == ps[i] || (i > 0 && pa[i] == pa[i - 1]));
-                        sa = host::add(field, sa, input[i]); sb = host::add(field, sb, pa[i]);
-                        st = host::add(field, st, table[i]); su = host::add(field, su, ps[i]);
-                    }
-                    expect(ok && sa == sb && st == su, "lookup permuted columns");
+                d_in.upload(input.data(), n * 32, (size_t)li * n * 32); d_tab.upload(table.data(), n * 32, (size_t)li * n * 32);
+                if (li == 0) { in0 = input; tab0 = table; }
+            }
+            lookup_permute_batch(field, d_in.data(), d_tab.data(), n, n, N_LOOKUPS, d_pa.data(), d_ps.data());  // untimed first call: the scratch of the sort is allocated once per process
+            Timer tl;
+            lookup_permute_batch(field, d_in.data(), d_tab.data(), n, n, N_LOOKUPS, d_pa.data(), d_ps.data());  // the 31 lookups of the proof in one call
+            ms_lookup += tl.stop();
+            {   // the argument's defining constraints on lookup 0: A'[i] == S'[i] or A'[i] == A'[i-1]; A' is a permutation of A (sums agree)
+                std::vector<Limbs> pa(n), ps(n);
+                d_pa.download(pa.data(), n * 32); d_ps.download(ps.data(), n * 32);
+                bool ok = true;
+                Limbs sa{0, 0, 0, 0}, sb{0, 0, 0, 0}, st{0, 0, 0, 0}, su{0, 0, 0, 0};
+                for (size_t i = 0; i < n; ++i) {
+                    ok = ok && (pa[i] == ps[i] || (i > 0 && pa[i] == pa[i - 1]));
+                    sa = host::add(field, sa, in0[i]); sb = host::add(field, sb, pa[i]);
+                    st = host::add(field, st, tab0[i]); su = host::add(field, su, ps[i]);
                 }
+                expect(ok && sa == sb && st == su, "lookup permuted columns");
             }
         }
         size_t last_b = 0;

@@ -400,6 +400,12 @@ inline void lookup_permute(Field f, const void* input_dev, const void* table_dev
     check(trh_lookup_permute_dev((int)f, input_dev, table_dev, usable_rows, permuted_input_dev, permuted_table_dev, stream), "permute_expression_pair");
 }
 
+// all lookups of a proof at once: column l of inputs / tables / outputs at element offset l * row_stride
+inline void lookup_permute_batch(Field f, const void* inputs_dev, const void* tables_dev, size_t usable_rows, size_t row_stride, size_t batch, void* permuted_inputs_dev,
+                                 void* permuted_tables_dev, void* stream = nullptr) {
+    check(trh_lookup_permute_batch_dev((int)f, inputs_dev, tables_dev, usable_rows, row_stride, batch, permuted_inputs_dev, permuted_tables_dev, stream), "permute_expression_pair (batch)");
+}
+
 // z[0] = z0, z[i + 1] = z[i] * num(row i) / den(row i): the product columns of the permutation argument
 // (plonk/permutation/prover.rs) and of the lookup argument (plonk/lookup/prover.rs commit_product)
 class GrandProduct {
