@@ -189,3 +189,38 @@ def multiopen_create_proof_fast(curve, k, g_l, w_l, u_l, rng, transcript, querie
     s_blind = rng()  # drawn before the opening's own randomness, as the big-int restatement does
     c, f = cpu_ref.ipa_create_proof(curve, k, g_l, w_l, u_l, lambda: lim(rng()), transcript, arr(p_poly), lim(p_blind), lim(x3), arr(s_poly), lim(s_blind))
     return f_.from_limbs(c), f_.from_limbs(f)
+
+
+# ---- gate fixtures (tests/golden/*_gates.json): JSON expression trees <-> the Python Expression mirror <-> the oracle's tuple form ----
+def expr_from_json(j):
+    from tiny_ram_halo2_amd import expr
+    tag = j[0]
+    if tag == "const":
+        return expr.Constant(int(j[1], 16))
+    if tag in ("advice", "fixed", "instance", "selector"):
+        cls = {"advice": expr.Advice, "fixed": expr.Fixed, "instance": expr.Instance, "selector": expr.Selector}[tag]
+        return cls(j[1], j[2])
+    if tag == "neg":
+        return expr.Negated(expr_from_json(j[1]))
+    if tag == "sum":
+        return expr.Sum(expr_from_json(j[1]), expr_from_json(j[2]))
+    if tag == "prod":
+        return expr.Product(expr_from_json(j[1]), expr_from_json(j[2]))
+    if tag == "scaled":
+        return expr.Scaled(expr_from_json(j[1]), int(j[2], 16))
+    raise ValueError(tag)
+
+
+def expr_to_tuple(e):
+    from tiny_ram_halo2_amd import expr
+    if isinstance(e, expr.Constant):
+        return ("const", e.value)
+    if isinstance(e, expr._Query):
+        return ("col", (e.kind, e.column), e.rotation)
+    if isinstance(e, expr.Negated):
+        return ("neg", expr_to_tuple(e.e))
+    if isinstance(e, expr.Sum):
+        return ("sum", expr_to_tuple(e.a), expr_to_tuple(e.b))
+    if isinstance(e, expr.Product):
+        return ("prod", expr_to_tuple(e.a), expr_to_tuple(e.b))
+    return ("scaled", expr_to_tuple(e.e), e.value)
