@@ -172,6 +172,7 @@ struct NttFusion {
     uint32_t post_period = 0;
 };
 bool ntt_can_fuse(uint32_t log_n);
+int ntt_lazy_shift();
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr);
 void ntt_release_tables();
 // msm.hip

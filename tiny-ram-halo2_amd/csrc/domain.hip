@@ -48,9 +48,10 @@ void build_domain(trh_domain* d) {
     d->extended_ifft_divisor = mem(div);
     d->into_coset[0] = mem(one); d->into_coset[1] = mem(zeta); d->into_coset[2] = mem(zeta2);
     d->from_coset[0] = mem(one); d->from_coset[1] = mem(zeta2); d->from_coset[2] = mem(zeta);
-    // lazy form f * 2^270 = montmul(f * 2^256, 2^14 * 2^256)
+    // lazy form of the passes the factors ride in, f * 2^(256 + shift) = montmul(f * 2^256, 2^shift * 2^256): shift = 14 (2^270, the
+    // unsigned 30-bit passes) or 5 (2^261, the signed 29-bit passes) -- ntt_lazy_shift()
     Fe<F> two14 = one;
-    for (int i = 0; i < 14; ++i) two14 = fe_dbl(two14);
+    for (int i = 0; i < ntt_lazy_shift(); ++i) two14 = fe_dbl(two14);
     d->z_into[0] = mem(fe_mul(one, two14)); d->z_into[1] = mem(fe_mul(zeta, two14)); d->z_into[2] = mem(fe_mul(zeta2, two14));
     d->z_idiv = mem(fe_mul(reg<F>(d->ifft_divisor), two14));
     const Fe<F> ediv = reg<F>(d->extended_ifft_divisor);  // extended_to_coeff: 2^-extended_k and the inverse coset shift in one factor

@@ -567,6 +567,101 @@ TRH_HD i32 opaque_two22() {
     return v;
 }
 
+// acc (+)= a * b on signed 32-bit operands as ONE v_mad_i64_i32.  Left to itself the compiler multiplies an operand it knows to be
+// non-negative with v_mad_u64_u32 and repairs the sign of the other one with a second multiply-add on the high word plus two moves
+// (seen in the NTT pass: 675 v_mov and 30 % more multiply-adds than the source has products).
+TRH_HD i64 fy_prod(i32 a, i32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 d;  // the carry-out operand goes to vcc (an allocated SGPR pair makes the compiler put an s_nop behind every statement)
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+#else
+    return (i64)a * b;
+#endif
+}
+TRH_HD void fy_mac(i64& acc, i32 a, i32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+    acc += (i64)a * b;
+#endif
+}
+// One ROW of the schoolbook product, c[k] (+)= a * b[k] for k = 0 .. 8, as one block of nine independent multiply-adds.  Single
+// statements would each be followed by an s_nop (the compiler's hazard recogniser is conservative around inline assembly on
+// gfx950: 1338 of them in an NTT pass); a block pays one.  INIT 0: all nine accumulate; 1: the last column starts from zero (rows
+// 1 .. 8 of a product: column i + 8 is first reached there); 2: all nine start from zero (row 0).
+template <int INIT> TRH_HD void fy_row(i64 (&acc)[18], int base, i32 a, const i32 (&b)[NLIMBS]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    i64 &c0 = acc[base], &c1 = acc[base + 1], &c2 = acc[base + 2], &c3 = acc[base + 3], &c4 = acc[base + 4], &c5 = acc[base + 5], &c6 = acc[base + 6], &c7 = acc[base + 7],
+        &c8 = acc[base + 8];
+    if constexpr (INIT == 2) {
+        asm("v_mad_i64_i32 %0, vcc, %9, %10, 0\n\tv_mad_i64_i32 %1, vcc, %9, %11, 0\n\tv_mad_i64_i32 %2, vcc, %9, %12, 0\n\t"
+            "v_mad_i64_i32 %3, vcc, %9, %13, 0\n\tv_mad_i64_i32 %4, vcc, %9, %14, 0\n\tv_mad_i64_i32 %5, vcc, %9, %15, 0\n\t"
+            "v_mad_i64_i32 %6, vcc, %9, %16, 0\n\tv_mad_i64_i32 %7, vcc, %9, %17, 0\n\tv_mad_i64_i32 %8, vcc, %9, %18, 0"
+            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(c7), "=&v"(c8)
+            : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
+            : "vcc");
+    } else if constexpr (INIT == 1) {
+        asm("v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %1, vcc, %9, %11, %1\n\tv_mad_i64_i32 %2, vcc, %9, %12, %2\n\t"
+            "v_mad_i64_i32 %3, vcc, %9, %13, %3\n\tv_mad_i64_i32 %4, vcc, %9, %14, %4\n\tv_mad_i64_i32 %5, vcc, %9, %15, %5\n\t"
+            "v_mad_i64_i32 %6, vcc, %9, %16, %6\n\tv_mad_i64_i32 %7, vcc, %9, %17, %7\n\tv_mad_i64_i32 %8, vcc, %9, %18, 0"
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "=&v"(c8)
+            : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
+            : "vcc");
+    } else {
+        asm("v_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %1, vcc, %9, %11, %1\n\tv_mad_i64_i32 %2, vcc, %9, %12, %2\n\t"
+            "v_mad_i64_i32 %3, vcc, %9, %13, %3\n\tv_mad_i64_i32 %4, vcc, %9, %14, %4\n\tv_mad_i64_i32 %5, vcc, %9, %15, %5\n\t"
+            "v_mad_i64_i32 %6, vcc, %9, %16, %6\n\tv_mad_i64_i32 %7, vcc, %9, %17, %7\n\tv_mad_i64_i32 %8, vcc, %9, %18, %8"
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "+v"(c8)
+            : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
+            : "vcc");
+    }
+#else
+    for (int k = 0; k < NLIMBS; ++k) {
+        const i64 p = (i64)a * b[k];
+        if (INIT == 2 || (INIT == 1 && k == NLIMBS - 1)) acc[base + k] = p; else acc[base + k] += p;
+    }
+#endif
+}
+// one reduction round: the five columns q touches
+TRH_HD void fy_round(i64& c1, i64& c2, i64& c3, i64& c4, i64& c8, i32 q, i32 p1, i32 p2, i32 p3, i32 p4, i32 p8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %1, vcc, %5, %7, %1\n\tv_mad_i64_i32 %2, vcc, %5, %8, %2\n\t"
+        "v_mad_i64_i32 %3, vcc, %5, %9, %3\n\tv_mad_i64_i32 %4, vcc, %5, %10, %4"
+        : "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c8)
+        : "v"(q), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p8)
+        : "vcc");
+#else
+    c1 += (i64)q * p1; c2 += (i64)q * p2; c3 += (i64)q * p3; c4 += (i64)q * p4; c8 += (i64)q * p8;
+#endif
+}
+// the 9 x 9 products of a * b into the 17 columns they touch (column 17 only ever holds carries of the reduction: zeroed here)
+template <class F> TRH_HD void fy_products(i64 (&acc)[18], const Fy<F>& a, const Fy<F>& b) {
+    fy_row<2>(acc, 0, a.l[0], b.l);
+#pragma unroll
+    for (int i = 1; i < NLIMBS; ++i) fy_row<1>(acc, i, a.l[i], b.l);
+    acc[17] = 0;
+}
+template <class F> TRH_HD void fy_products_add(i64 (&acc)[18], const Fy<F>& a, const Fy<F>& b) {
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) fy_row<0>(acc, i, a.l[i], b.l);
+}
+template <class F> TRH_HD void fy_squares(i64 (&acc)[18], const Fy<F>& a) {
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) {
+        // column 2 i gets its cross terms before the square except for i = 0 and i = 8 (columns 0 and 16 hold nothing else)
+        if (i == 0 || i == NLIMBS - 1) acc[2 * i] = fy_prod(a.l[i], a.l[i]);
+        else fy_mac(acc[2 * i], a.l[i], a.l[i]);
+        const i32 a2 = a.l[i] * 2;  // < 2^30 in magnitude (the top limb is small)
+#pragma unroll
+        for (int j = i + 1; j < NLIMBS; ++j) {
+            if (i == 0 || j == NLIMBS - 1) acc[i + j] = fy_prod(a2, a.l[j]);  // first entry of columns 1 .. 8 (i = 0) and 9 .. 15 (j = 8)
+            else fy_mac(acc[i + j], a2, a.l[j]);
+        }
+    }
+    acc[17] = 0;
+}
+
 // nine uniform 29-bit rounds on signed columns; result = value / 2^261 (mod m) - s1 - 2 s2, normalised.  The subtrahends ride in the
 // final carry chain (the difference that follows a product would otherwise be a second chain): SUB 0 none, 1 s1, 2 s1 and 2 s2
 template <class F, int SUB> TRH_HD Fy<F> fy_reduce_sub(i64 (&acc)[18], const Fy<F>* s1, const Fy<F>* s2) {
@@ -576,11 +671,8 @@ template <class F, int SUB> TRH_HD Fy<F> fy_reduce_sub(i64 (&acc)[18], const Fy<
     for (int i = 0; i < 9; ++i) {
         const i32 q = (i32)((0u - (u32)acc[i]) & (u32)YMASK);
         // column i + q is a multiple of 2^29: its quotient is ceil(acc[i] / 2^29) (arithmetic shift = floor)
-        acc[i + 1] += ((acc[i] + YMASK) >> YBITS) + (i64)q * P1;
-        acc[i + 2] += (i64)q * P2;
-        acc[i + 3] += (i64)q * P3;
-        acc[i + 4] += (i64)q * P4;
-        acc[i + 8] += (i64)q * two22;
+        acc[i + 1] += (acc[i] + YMASK) >> YBITS;
+        fy_round(acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 8], q, P1, P2, P3, P4, two22);
     }
     Fy<F> r;
     i64 c = 0;
@@ -601,66 +693,32 @@ template <class F> TRH_HD Fy<F> fy_reduce(i64 (&acc)[18]) { return fy_reduce_sub
 // a normalised or lazy, b normalised (or the other way round): |a_i b_j| < 2^59
 template <class F> TRH_HD Fy<F> fy_mul(const Fy<F>& a, const Fy<F>& b) {
     i64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i)
-#pragma unroll
-        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
+    fy_products(acc, a, b);
     return fy_reduce<F>(acc);
 }
 // a normalised
 template <class F> TRH_HD Fy<F> fy_sqr(const Fy<F>& a) {
     i64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        acc[2 * i] += (i64)a.l[i] * a.l[i];
-        const i32 a2 = a.l[i] * 2;  // < 2^30 in magnitude (the top limb is small)
-#pragma unroll
-        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (i64)a2 * a.l[j];
-    }
+    fy_squares(acc, a);
     return fy_reduce<F>(acc);
 }
 // a b + c d with ONE reduction.  Column bound: (a or b lazy, the other normalised) + (c, d normalised) <= 9 * 2^59 + 9 * 2^58 < 2^62.8
 template <class F> TRH_HD Fy<F> fy_mul2(const Fy<F>& a, const Fy<F>& b, const Fy<F>& c, const Fy<F>& d) {
     i64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i)
-#pragma unroll
-        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i)
-#pragma unroll
-        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)c.l[i] * d.l[j];
+    fy_products(acc, a, b);
+    fy_products_add(acc, c, d);
     return fy_reduce<F>(acc);
 }
 // a b - s (U2 - X, S2 - Y of the mixed addition): the subtraction rides in the product's carry chain
 template <class F> TRH_HD Fy<F> fy_mul_sub(const Fy<F>& a, const Fy<F>& b, const Fy<F>& s) {
     i64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i)
-#pragma unroll
-        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (i64)a.l[i] * b.l[j];
+    fy_products(acc, a, b);
     return fy_reduce_sub<F, 1>(acc, &s, nullptr);
 }
 // a^2 - s1 - 2 s2 (x3 = R^2 - PPP - 2 Q)
 template <class F> TRH_HD Fy<F> fy_sqr_sub_sub2(const Fy<F>& a, const Fy<F>& s1, const Fy<F>& s2) {
     i64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        acc[2 * i] += (i64)a.l[i] * a.l[i];
-        const i32 a2 = a.l[i] * 2;
-#pragma unroll
-        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (i64)a2 * a.l[j];
-    }
+    fy_squares(acc, a);
     return fy_reduce_sub<F, 2>(acc, &s1, &s2);
 }
 // carry propagation: any limbs (|l[k]| < 2^31 - 2^3) -> normalised
@@ -676,6 +734,8 @@ template <class F> TRH_HD Fy<F> fy_norm(const Fy<F>& a) {
     r.l[8] = a.l[8] + c;
     return r;
 }
+// a product of two non-negative values is non-negative and already normalised: the name documents that it may be stored as words
+template <class F> TRH_HD Fy<F> fy_norm_nonneg(const Fy<F>& a) { return a; }
 // limb-wise, no carries: the result only feeds ONE multiplication (as its lazy operand) or a fy_norm
 template <class F> TRH_HD Fy<F> fy_add_lazy(const Fy<F>& a, const Fy<F>& b) {
     Fy<F> r;

@@ -88,14 +88,14 @@ __global__ void __launch_bounds__(256) ntt_tables_kernel(const uint4* __restrict
         store_fe<F>(t_hi + 2 * (size_t)i, r);
     }
 }
-// the same tables in the lazy domain's Montgomery form (x 2^270), values < 2 m
-template <class F>
+// the same tables in the lazy domain's Montgomery form (x 2^270 unsigned / x 2^261 signed), values < 2 m
+template <class F, bool SIGNED>
 __global__ void __launch_bounds__(256) ntt_tables_lazy_kernel(const uint4* __restrict__ t, uint4* __restrict__ z, u32 cnt) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
-    const Fz<F> v = fz_from_fe(load_fe<F>(t + 2 * (size_t)i));
     u32 w[8];
-    fz_store(v, w);
+    if (SIGNED) fy_store(fy_from_fe(load_fe<F>(t + 2 * (size_t)i)), w);  // non-negative, below m (1 + 2^-7)
+    else fz_store(fz_from_fe(load_fe<F>(t + 2 * (size_t)i)), w);
     z[2 * (size_t)i] = make_uint4(w[0], w[1], w[2], w[3]);
     z[2 * (size_t)i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
@@ -513,6 +513,243 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint
     }
 }
 
+// ---- signed lazy-domain pass (round 2; the default) ---------------------------------------------------------------------------
+// The same schedule in the signed 29-bit domain of field.h (Fy, R'' = 2^261): a butterfly is one fy_mul whose multiplicand may be
+// LAZY (limb-wise sums / differences, no carries), ONE carry chain for the un-multiplied operand, and two limb-wise operations
+//     t = b w;   a <- norm(a);   (a, b) <- (a + t, a - t)          45 instructions beside the product instead of 63
+// -- the results stay lazy through the LDS exchange (nine int32 limbs as they are) until they are either multiplied (as they are) or
+// take the `a` role (normalised there).  Between passes the values travel as raw nine-limb residues in planar scratch buffers
+// (16 + 16 + 4 bytes per element): the next pass multiplies every element by its inter-pass twiddle first, and a product accepts the
+// lazy limbs directly, so there is no reduction, no packing and no unpacking at a pass boundary (78 instructions per element before).
+// Bounds (units of m): inputs |v| < 1.13 (canonical words, a product); round 0: < 2 after the first trivial stage, < 4 after the
+// second; every later stage adds a product in (-0.24, 1.24): |v| < 4 + 1.24 (s - 2) <= 12.7 for s <= 9, inside the 16 of the domain;
+// lazy limbs are at most N + L1 = 1.5 * 2^30 in magnitude, and 9 * 1.5 * 2^30 * 2^29 + the reduction terms stays below 2^63.
+template <class F>
+__device__ __forceinline__ Fy<F> load_fy(const uint4* __restrict__ p) {
+    uint4 a = p[0], b = p[1];
+    return fy_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+}
+template <class F>
+__device__ __forceinline__ Fy<F> lds_load_limbs_y(const uint4* pa, const uint4* pb, const u32* pc, int idx) {
+    const uint4 a = pa[idx], b = pb[idx];
+    Fy<F> r;
+    r.l[0] = (i32)a.x; r.l[1] = (i32)a.y; r.l[2] = (i32)a.z; r.l[3] = (i32)a.w;
+    r.l[4] = (i32)b.x; r.l[5] = (i32)b.y; r.l[6] = (i32)b.z; r.l[7] = (i32)b.w;
+    r.l[8] = (i32)pc[idx];
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_store_limbs_y(uint4* pa, uint4* pb, u32* pc, int idx, const Fy<F>& v) {
+    pa[idx] = make_uint4((u32)v.l[0], (u32)v.l[1], (u32)v.l[2], (u32)v.l[3]);
+    pb[idx] = make_uint4((u32)v.l[4], (u32)v.l[5], (u32)v.l[6], (u32)v.l[7]);
+    pc[idx] = (u32)v.l[8];
+}
+template <class F>
+__device__ __forceinline__ Fy<F> twiddle_y(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, u32 e, int lo_bits) {
+    const u32 el = e & ((1u << lo_bits) - 1u), eh = e >> lo_bits;
+    Fy<F> w = load_fy<F>(z_lo + 2 * (size_t)el);
+    if (eh) w = fy_norm_nonneg(fy_mul(w, load_fy<F>(z_hi + 2 * (size_t)eh)));
+    return w;
+}
+// inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), x 2^261 form
+template <class F>
+__global__ void __launch_bounds__(256) ntt_direct_table_y_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
+                                                                 int log_ns, int s, int tw_shift) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (log_ns + s))) return;
+    const u32 k = (u32)i & ((1u << log_ns) - 1u), r = (u32)(i >> log_ns);
+    const Fy<F> w = twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits);
+    u32 o[8];
+    fy_store(w, o);
+    d[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    d[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+template <class F, bool TWL>
+struct TileTwiddlesY {
+    uint4* a;
+    uint4* b;
+    u32* c;
+    __device__ __forceinline__ Fy<F> operator()(int idx) const {
+        if constexpr (TWL) return lds_load_limbs_y<F>(a, b, c, idx);
+        else { const uint4 x = a[idx], y = b[idx]; return fy_load<F>(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w); }
+    }
+    __device__ __forceinline__ void put(int idx, const Fy<F>& v) const {
+        if constexpr (TWL) lds_store_limbs_y<F>(a, b, c, idx, v);
+        else { u32 w[8]; fy_store(v, w); a[idx] = make_uint4(w[0], w[1], w[2], w[3]); b[idx] = make_uint4(w[4], w[5], w[6], w[7]); }
+    }
+};
+// stage V of round 0 (rows u, u | 2^V of the thread's registers): inputs of stage 0 are normalised
+template <class F, int LG, int V, class TW>
+__device__ __forceinline__ void round0_stage_y(Fy<F> (&x)[1 << LG], const TW& tw, int s) {
+    const int sh = s - 1 - V;
+#pragma unroll
+    for (int u = 0; u < (1 << LG); ++u) {
+        if (u & (1 << V)) continue;
+        const u32 ul = (u32)(u & ((1 << V) - 1));
+        Fy<F> t = x[u | (1 << V)];
+        if (ul) t = fy_mul(t, tw((int)(ul << sh)));      // lazy multiplicand
+        const Fy<F> a = V ? fy_norm(x[u]) : x[u];         // stage 0 sees the loaded values; later ones the previous stage's lazy sums
+        x[u] = fy_add_lazy(a, t);
+        x[u | (1 << V)] = fy_sub_lazy(a, t);
+    }
+}
+// stage V of a later round; the values come from the LDS exchange (lazy) or from the stage before (lazy)
+template <class F, int LG, int V, class TW>
+__device__ __forceinline__ void round_stage_y(Fy<F> (&x)[1 << LG], const TW& tw, u32 L, int stl, int s, bool partner_zero) {
+    const int sh = s - 1 - stl - V;
+#pragma unroll
+    for (int u = 0; u < (1 << LG); ++u) {
+        if (u & (1 << V)) continue;
+        if (partner_zero) {
+            x[u | (1 << V)] = x[u];  // a + w * 0 = a - w * 0
+        } else {
+            const u32 idx = (L + ((u32)(u & ((1 << V) - 1)) << stl)) << sh;
+            const Fy<F> t = fy_mul(x[u | (1 << V)], tw((int)idx));  // idx 0 holds the lazy one
+            const Fy<F> a = fy_norm(x[u]);
+            x[u] = fy_add_lazy(a, t);
+            x[u | (1 << V)] = fy_sub_lazy(a, t);
+        }
+    }
+}
+// normalised |v| < 16 m  ->  the canonical residue in [0, m) as eight words.  q = floor(v / 2^254); v - (q - [q >= 0]) m lies in [0, 2 m)
+// for every such v (m = 2^254 + t, t < 2^126), so one conditional subtraction finishes
+template <class F>
+__device__ __forceinline__ void fy_canonical_words(const Fy<F>& v, u32* w) {
+    const i32 q = v.l[8] >> 22;
+    const i32 mult = q - (q >= 0 ? 1 : 0);
+    Fy<F> r;
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        c += (i64)v.l[i] - (i64)mult * ymod_limb<F>(i);
+        r.l[i] = (i32)((u32)c & (u32)YMASK);
+        c >>= YBITS;
+    }
+    r.l[8] = (i32)(c + v.l[8] - (i64)mult * ymod_limb<F>(8));
+    // conditional subtraction of m
+    i32 t[NLIMBS], b = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 d = r.l[i] - ymod_limb<F>(i) + b;
+        t[i] = d & YMASK;
+        b = d >> YBITS;
+    }
+    t[8] = r.l[8] - ymod_limb<F>(8) + b;
+    const bool ge = t[8] >= 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS; ++i) r.l[i] = ge ? t[i] : r.l[i];
+    fy_store(r, w);
+}
+
+// in / out: eight-word elements (the caller's buffer: pass 0 input, last pass output) or raw nine-limb planes of the scratch
+// (raw_in / raw_out: [N x 16 B][N x 16 B][N x 4 B] per transform)
+template <class F, int LG, int TLOG, bool TWL, bool FUSE>
+__global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
+                                                               const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last, int raw_in, int raw_out,
+                                                               const uint4* __restrict__ direct, NttFusion fu) {
+    constexpr int G = 1 << LG, T = 1 << TLOG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = 1 << s;
+    const int log_c = TLOG - s;
+    const int C = 1 << log_c;
+    uint4* pa = (uint4*)smem;
+    uint4* pb = pa + T;
+    uint4* tw_lo = pb + T;
+    uint4* tw_hi = tw_lo + (R >> 1);
+    u32* pc = (u32*)(tw_hi + (R >> 1));
+    const TileTwiddlesY<F, TWL> tw{tw_lo, tw_hi, pc + T};
+
+    const size_t N = (size_t)1 << log_n;
+    const bool padded = FUSE && fu.in_dev;
+    const size_t in_len = padded ? (size_t)1 << fu.in_log : N;
+    // element strides of a transform: 2 N uint4 in word form, 36 N bytes = 2 N uint4 + N u32 in raw form
+    const uint4* in_a = padded ? (const uint4*)fu.in_dev + (size_t)blockIdx.y * in_len * 2 : raw_in ? (const uint4*)((const char*)in + (size_t)blockIdx.y * N * 36) : in + (size_t)blockIdx.y * N * 2;
+    uint4* out_a = raw_out ? (uint4*)((char*)out + (size_t)blockIdx.y * N * 36) : out + (size_t)blockIdx.y * N * 2;
+    const int tid = threadIdx.x;
+    const u32 c = tid & (C - 1), m = tid >> log_c;
+    const u32 j = (blockIdx.x << log_c) + c;
+    const u32 k = j & ((1u << log_ns) - 1u);
+    const size_t row_stride = N >> s;
+    const u32 live_rows = (u32)(in_len / row_stride ? in_len / row_stride : 1);
+    const bool bcast0 = padded && LG == 2 && s > LG && live_rows <= (u32)(R >> 2);
+    const bool bcast2 = bcast0 && s >= 2 * LG && live_rows <= (u32)(R >> 3);
+
+    Fy<F> x[G];
+    const int tw_shift = log_n - log_ns - s;
+    auto load_row = [&](const int v) -> Fy<F> {
+        const u32 r = m + (u32)v * (u32)(R >> LG);
+        const size_t idx = (size_t)j + (size_t)r * row_stride;
+        Fy<F> val = fy_zero<F>();
+        if (!(bcast0 && v) && idx < in_len) {
+            if (raw_in) {
+                const uint4 a = in_a[idx], b = in_a[N + idx];
+                val.l[0] = (i32)a.x; val.l[1] = (i32)a.y; val.l[2] = (i32)a.z; val.l[3] = (i32)a.w;
+                val.l[4] = (i32)b.x; val.l[5] = (i32)b.y; val.l[6] = (i32)b.z; val.l[7] = (i32)b.w;
+                val.l[8] = (i32)((const u32*)(in_a + 2 * N))[idx];
+            } else {
+                val = load_fy<F>(in_a + 2 * idx);
+            }
+            if (FUSE && fu.pre) val = fy_mul(val, load_fy<F>((const uint4*)fu.pre + 2 * (idx % fu.pre_period)));
+            if (log_ns > 0)  // every element of a later pass: the product is also what brings a raw residue back to |v| < 1.13 m
+                val = fy_mul(val, direct ? load_fy<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits));
+        }
+        return val;
+    };
+    if constexpr (LG == 2) {
+        x[0] = load_row(0); x[2] = load_row(1); x[1] = load_row(2); x[3] = load_row(3);
+    } else {
+        x[0] = load_row(0); x[4] = load_row(1); x[2] = load_row(2); x[6] = load_row(3);
+        x[1] = load_row(4); x[5] = load_row(5); x[3] = load_row(6); x[7] = load_row(7);
+    }
+    for (int i = tid; i < (R >> 1); i += (T >> LG)) tw.put(i, twiddle_y<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
+    __syncthreads();
+
+    u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;
+    u32 L = 0;
+    int stl = 0, vb = 0;
+    if (bcast0) {
+#pragma unroll
+        for (int u = 1; u < G; ++u) x[u] = x[0];
+    } else {
+        round0_stage_y<F, LG, 0>(x, tw, s);
+        if constexpr (LG > 1) round0_stage_y<F, LG, 1>(x, tw, s);
+        if constexpr (LG > 2) round0_stage_y<F, LG, 2>(x, tw, s);
+    }
+    for (int st = LG; st < s; st += LG) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) lds_store_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
+        __syncthreads();
+        stl = st + LG <= s ? st : s - LG;
+        vb = st - stl;
+        L = m & ((1u << stl) - 1u);
+        base = L | ((m >> stl) << (stl + LG));
+#pragma unroll
+        for (int u = 0; u < G; ++u) x[u] = lds_load_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
+        const bool partner_zero = bcast2 && st == LG;
+        if (0 >= vb) round_stage_y<F, LG, 0>(x, tw, L, stl, s, partner_zero);
+        if constexpr (LG > 1) { if (1 >= vb) round_stage_y<F, LG, 1>(x, tw, L, stl, s, false); }
+        if constexpr (LG > 2) { if (2 >= vb) round_stage_y<F, LG, 2>(x, tw, L, stl, s, false); }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const u32 rr = base + ((u32)u << stl);
+        const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
+        if (raw_out) {  // lazy limbs as they are: the next pass's product takes them
+            out_a[dst] = make_uint4((u32)x[u].l[0], (u32)x[u].l[1], (u32)x[u].l[2], (u32)x[u].l[3]);
+            out_a[N + dst] = make_uint4((u32)x[u].l[4], (u32)x[u].l[5], (u32)x[u].l[6], (u32)x[u].l[7]);
+            ((u32*)(out_a + 2 * N))[dst] = (u32)x[u].l[8];
+        } else {
+            Fy<F> y;
+            if (FUSE && fu.post && last) y = fy_mul(x[u], load_fy<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));
+            else y = fy_norm(x[u]);
+            u32 w[8];
+            fy_canonical_words(y, w);
+            out_a[2 * dst] = make_uint4(w[0], w[1], w[2], w[3]);
+            out_a[2 * dst + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t rows, size_t row_len, size_t active_len,
                                                                    const uint4* __restrict__ factors, u32 period) {
@@ -553,6 +790,11 @@ bool lazy_enabled() {
     static const int lazy = getenv("TRH_NTT_LAZY") ? atoi(getenv("TRH_NTT_LAZY")) : 1;
     return lazy != 0;
 }
+// the signed 29-bit lazy passes (ntt_passy_kernel) instead of the unsigned 30-bit ones (ntt_passz_kernel); TRH_NTT_SIGNED=0 for A/B
+bool signed_enabled() {
+    static const int sg = getenv("TRH_NTT_SIGNED") ? atoi(getenv("TRH_NTT_SIGNED")) : 1;
+    return sg != 0 && lazy_enabled();
+}
 
 template <class F>
 int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** out) {
@@ -584,8 +826,13 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     TRH_HIP_TRY(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
     const u32 cnt = 1u << (t->lo_bits > t->hi_bits ? t->lo_bits : t->hi_bits);
     hipLaunchKernelGGL((ntt_tables_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, s, d_pw, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits, t->hi_bits);
-    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
-    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
+    if (signed_enabled()) {
+        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, true>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
+        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, true>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
+    } else {
+        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, false>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
+        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, false>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
+    }
     // direct inter-pass tables for the lazy passes (pass p >= 1 reads Ns * R entries, coalesced): up to 1 GiB per pass
     static const int direct_on = getenv("TRH_NTT_DIRECT") ? atoi(getenv("TRH_NTT_DIRECT")) : 1;
     int sizes[8], P, tlog;
@@ -596,7 +843,10 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
             const size_t entries = (size_t)1 << (log_ns + sizes[p]);
             if (entries * 32 <= ((size_t)1 << 30)) {
                 rc = t->direct[p].ensure(entries * 32);
-                if (rc == TRH_OK)
+                if (rc == TRH_OK && signed_enabled())
+                    hipLaunchKernelGGL((ntt_direct_table_y_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
+                                       t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
+                else if (rc == TRH_OK)
                     hipLaunchKernelGGL((ntt_direct_table_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
                                        t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
             }
@@ -622,6 +872,48 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     plan_passes((int)log_n, sizes, &P, &tlog);
     const size_t N = (size_t)1 << log_n;
     uint4* a = (uint4*)a_dev;
+    bool all_lazy = lazy_enabled() && tlog == TILE_LOG && (int)log_n >= TILE_LOG && P >= 2;
+    for (int p = 0; p < P; ++p) all_lazy = all_lazy && sizes[p] >= 2 && sizes[p] <= MAX_PASS_LOG;
+    if (all_lazy && signed_enabled()) {
+        // signed-domain passes: caller's words -> raw nine-limb scratch -> ... -> caller's words (canonical)
+        const size_t max_tmp = (size_t)2 << 30;
+        size_t chunk = max_tmp / (N * 72);
+        if (chunk < 1) chunk = 1;
+        if (chunk > batch) chunk = batch;
+        TRH_TRY(c.ntt_tmp.ensure(2 * chunk * N * 36));
+        char* raw[2] = {(char*)c.ntt_tmp.p, (char*)c.ntt_tmp.p + chunk * N * 36};
+        for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+            const size_t nb = (b0 + chunk <= batch) ? chunk : batch - b0;
+            uint4* base = a + b0 * N * 2;
+            int log_ns = 0;
+            for (int p = 0; p < P; ++p) {
+                const int sp = sizes[p];
+                const dim3 grid((unsigned)(N >> TILE_LOG), (unsigned)nb);
+                const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
+                NttFusion kf;
+                if (fu && p == 0) {
+                    kf.pre = fu->pre; kf.pre_period = fu->pre_period;
+                    if (fu->in_dev) { kf.in_dev = (const char*)fu->in_dev + b0 * ((size_t)32 << fu->in_log); kf.in_log = fu->in_log; }
+                }
+                if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; }
+                const bool fused = kf.in_dev || kf.pre || kf.post;
+                const uint4* src = p == 0 ? base : (const uint4*)raw[(p - 1) & 1];
+                uint4* dst = p == P - 1 ? base : (uint4*)raw[p & 1];
+                const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
+#define TRH_LAUNCH_PASSY(TWL, FUSE, LDS)                                                                                                       \
+    hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
+                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf)
+                if (sp <= 8 && !fused) TRH_LAUNCH_PASSY(true, false, ldl);
+                else if (sp <= 8) TRH_LAUNCH_PASSY(true, true, ldl);
+                else if (!fused) TRH_LAUNCH_PASSY(false, false, ldz);
+                else TRH_LAUNCH_PASSY(false, true, ldz);
+#undef TRH_LAUNCH_PASSY
+                log_ns += sp;
+            }
+        }
+        TRH_HIP_TRY(hipGetLastError());
+        return TRH_OK;
+    }
     uint4* tmp = nullptr;
     size_t chunk = batch;
     if (P > 1) {
@@ -703,6 +995,10 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
         TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
 #undef TRH_PASSZ_ATTR
+#define TRH_PASSY_ATTR(FIELD, TWL, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passy_kernel<FIELD, 2, TILE_LOG, TWL, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
+        TRH_PASSY_ATTR(FpParams, true, false); TRH_PASSY_ATTR(FpParams, true, true); TRH_PASSY_ATTR(FpParams, false, false); TRH_PASSY_ATTR(FpParams, false, true);
+        TRH_PASSY_ATTR(FqParams, true, false); TRH_PASSY_ATTR(FqParams, true, true); TRH_PASSY_ATTR(FqParams, false, false); TRH_PASSY_ATTR(FqParams, false, true);
+#undef TRH_PASSY_ATTR
         ctx().attr_done |= ATTR_NTT;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu);
@@ -718,6 +1014,10 @@ int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, si
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
+
+// log2 of the factor between the lazy domain of the passes and the memory format's Montgomery radix 2^256: the pointwise factors
+// fused into the passes (EvaluationDomain, domain.hip) are multiplied by 2^this
+int ntt_lazy_shift() { return signed_enabled() ? 5 : 14; }
 
 void ntt_release_tables() {
     Ctx& c = ctx();
