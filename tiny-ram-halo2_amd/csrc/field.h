@@ -646,19 +646,142 @@ template <class F> TRH_HD void fy_products_add(i64 (&acc)[18], const Fy<F>& a, c
 #pragma unroll
     for (int i = 0; i < NLIMBS; ++i) fy_row<0>(acc, i, a.l[i], b.l);
 }
+// c[k] (+)= a * b[k] for k < L as one block (the rows of a square: L = 9 .. 1).  ALL: every column starts from zero (row 0); otherwise the
+// first L - 1 accumulate and the last one -- the first entry of its column -- starts from zero
+template <int L, bool ALL> TRH_HD void fy_short_row(i64* c, i32 a, const i32* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L == 9 && ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], 0\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], 0\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], 0\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], 0\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], 0\n\t"
+            "v_mad_i64_i32 %[c5], vcc, %[a], %[b5], 0\n\t"
+            "v_mad_i64_i32 %[c6], vcc, %[a], %[b6], 0\n\t"
+            "v_mad_i64_i32 %[c7], vcc, %[a], %[b7], 0\n\t"
+            "v_mad_i64_i32 %[c8], vcc, %[a], %[b8], 0"
+            : [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [c4] "=&v"(c[4]), [c5] "=&v"(c[5]), [c6] "=&v"(c[6]), [c7] "=&v"(c[7]), [c8] "=&v"(c[8])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]), [b7] "v"(b[7]), [b8] "v"(b[8])
+            : "vcc");
+    }
+    else if constexpr (L == 9 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], %[c3]\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], %[c4]\n\t"
+            "v_mad_i64_i32 %[c5], vcc, %[a], %[b5], %[c5]\n\t"
+            "v_mad_i64_i32 %[c6], vcc, %[a], %[b6], %[c6]\n\t"
+            "v_mad_i64_i32 %[c7], vcc, %[a], %[b7], %[c7]\n\t"
+            "v_mad_i64_i32 %[c8], vcc, %[a], %[b8], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [c8] "=&v"(c[8])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]), [b7] "v"(b[7]), [b8] "v"(b[8])
+            : "vcc");
+    }
+    else if constexpr (L == 8 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], %[c3]\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], %[c4]\n\t"
+            "v_mad_i64_i32 %[c5], vcc, %[a], %[b5], %[c5]\n\t"
+            "v_mad_i64_i32 %[c6], vcc, %[a], %[b6], %[c6]\n\t"
+            "v_mad_i64_i32 %[c7], vcc, %[a], %[b7], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "=&v"(c[7])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]), [b7] "v"(b[7])
+            : "vcc");
+    }
+    else if constexpr (L == 7 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], %[c3]\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], %[c4]\n\t"
+            "v_mad_i64_i32 %[c5], vcc, %[a], %[b5], %[c5]\n\t"
+            "v_mad_i64_i32 %[c6], vcc, %[a], %[b6], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "=&v"(c[6])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6])
+            : "vcc");
+    }
+    else if constexpr (L == 6 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], %[c3]\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], %[c4]\n\t"
+            "v_mad_i64_i32 %[c5], vcc, %[a], %[b5], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "=&v"(c[5])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5])
+            : "vcc");
+    }
+    else if constexpr (L == 5 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], %[c3]\n\t"
+            "v_mad_i64_i32 %[c4], vcc, %[a], %[b4], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "=&v"(c[4])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4])
+            : "vcc");
+    }
+    else if constexpr (L == 4 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], %[c2]\n\t"
+            "v_mad_i64_i32 %[c3], vcc, %[a], %[b3], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "=&v"(c[3])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3])
+            : "vcc");
+    }
+    else if constexpr (L == 3 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], %[c1]\n\t"
+            "v_mad_i64_i32 %[c2], vcc, %[a], %[b2], 0"
+            : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "=&v"(c[2])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2])
+            : "vcc");
+    }
+    else if constexpr (L == 2 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], %[c0]\n\t"
+            "v_mad_i64_i32 %[c1], vcc, %[a], %[b1], 0"
+            : [c0] "+v"(c[0]), [c1] "=&v"(c[1])
+            : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1])
+            : "vcc");
+    }
+    else if constexpr (L == 1 && !ALL) {
+        asm("v_mad_i64_i32 %[c0], vcc, %[a], %[b0], 0"
+            : [c0] "=&v"(c[0])
+            : [a] "v"(a), [b0] "v"(b[0])
+            : "vcc");
+    }
+#else
+    for (int k = 0; k < L; ++k) {
+        const i64 p = (i64)a * b[k];
+        if (ALL || k == L - 1) c[k] = p; else c[k] += p;
+    }
+#endif
+}
+// a^2: row i is a_i * (a_i, 2 a_{i+1}, ..., 2 a_8) into columns 2 i .. i + 8
 template <class F> TRH_HD void fy_squares(i64 (&acc)[18], const Fy<F>& a) {
+    i32 d[NLIMBS][NLIMBS];  // d[i] = (a_i, 2 a_{i+1}, ...): the doubled limbs are shared (< 2^30 in magnitude: a is normalised)
+    i32 a2[NLIMBS];
+#pragma unroll
+    for (int j = 0; j < NLIMBS; ++j) a2[j] = a.l[j] * 2;
 #pragma unroll
     for (int i = 0; i < NLIMBS; ++i) {
-        // column 2 i gets its cross terms before the square except for i = 0 and i = 8 (columns 0 and 16 hold nothing else)
-        if (i == 0 || i == NLIMBS - 1) acc[2 * i] = fy_prod(a.l[i], a.l[i]);
-        else fy_mac(acc[2 * i], a.l[i], a.l[i]);
-        const i32 a2 = a.l[i] * 2;  // < 2^30 in magnitude (the top limb is small)
+        d[i][0] = a.l[i];
 #pragma unroll
-        for (int j = i + 1; j < NLIMBS; ++j) {
-            if (i == 0 || j == NLIMBS - 1) acc[i + j] = fy_prod(a2, a.l[j]);  // first entry of columns 1 .. 8 (i = 0) and 9 .. 15 (j = 8)
-            else fy_mac(acc[i + j], a2, a.l[j]);
-        }
+        for (int j = i + 1; j < NLIMBS; ++j) d[i][j - i] = a2[j];
     }
+    fy_short_row<9, true>(&acc[0], a.l[0], d[0]);
+    fy_short_row<8, false>(&acc[2], a.l[1], d[1]);
+    fy_short_row<7, false>(&acc[4], a.l[2], d[2]);
+    fy_short_row<6, false>(&acc[6], a.l[3], d[3]);
+    fy_short_row<5, false>(&acc[8], a.l[4], d[4]);
+    fy_short_row<4, false>(&acc[10], a.l[5], d[5]);
+    fy_short_row<3, false>(&acc[12], a.l[6], d[6]);
+    fy_short_row<2, false>(&acc[14], a.l[7], d[7]);
+    fy_short_row<1, false>(&acc[16], a.l[8], d[8]);
     acc[17] = 0;
 }
 
