@@ -243,6 +243,29 @@ template <class F> TRH_HD void xyzzz_madd(XYZZz<F>& acc, const AffineZ<F>& p) {
     acc.zzz = fy_mul(acc.zzz, PPP);
 }
 
+// The generic case of acc += p -- neither operand is the identity -- as ONE straight line that updates acc in place.  Returns P = 0
+// (mod m), i.e. "same x": acc was p or -p and now holds garbage; the caller patches those lanes (R = 0 (mod m) tells p + p from
+// p - p).  Keeping the special cases out of this function keeps their register copies out of the accumulation loop: with the
+// branches inside (xyzzz_madd above) every merge point copied the 36 accumulator limbs, ~220 moves per mixed addition.
+template <class F> TRH_HD bool xyzzz_madd_main(XYZZz<F>& acc, const AffineZ<F>& p, Fy<F>& R) {
+    const Fy<F> P = fy_mul_sub(p.x, acc.zz, acc.x);
+    R = fy_mul_sub(p.y, acc.zzz, acc.y);
+    bool same_x = false;
+    if (fy_maybe_zero_mod(P)) {  // a real branch: the full comparison (~50 instructions) must not be flattened into the line
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");
+#endif
+        same_x = fy_is_zero_mod(P);
+    }
+    const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(acc.x, PP);
+    const Fy<F> x3 = fy_sqr_sub_sub2(R, PPP, Q);
+    acc.y = fy_mul2(fy_sub_lazy(Q, x3), R, fy_neg_lazy(acc.y), PPP);
+    acc.x = x3;
+    acc.zz = fy_mul(acc.zz, PP);
+    acc.zzz = fy_mul(acc.zzz, PPP);
+    return same_x;
+}
+
 // a + b, both lazy XYZZ
 template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& b) {
     if (xyzzz_is_identity(a)) return b;

@@ -509,7 +509,7 @@ template <class F> TRH_HD Fe<F> fz_to_fe(const Fz<F>& a) {
 //   * a * b + c * d shares ONE Montgomery reduction (fy_mul2: y3 = R (Q - x3) - Y PPP of the mixed addition).
 // A reduction is more than half of a multiplication (45 of 126 multiply-adds and all of the 64-bit carry work), which is what
 // this buys over the 30-bit unsigned domain above (still used by the NTT, whose butterflies have no such pairs).
-// fy_mul(a, b) = a b / 2^261 (mod m) in (-|a b| / 2^261, |a b| / 2^261 + m): |a|, |b| < 16 m gives (-2 m, 3 m).
+// fy_mul(a, b) = a b / 2^261 (mod m) in (-|a b| / 2^261 - m, |a b| / 2^261]: |a|, |b| < 16 m gives (-3 m, 2 m).
 // =========================================================================================
 constexpr u32 YBITS = 29;
 constexpr i32 YMASK = (1 << YBITS) - 1;
@@ -559,8 +559,8 @@ template <class F> TRH_HD bool fy_is_exact_zero(const Fy<F>& a) {
 }
 
 // 2^22 in a register the compiler cannot see through: `q * two22 + acc` stays ONE multiply-add (the top modulus limb is 2^22)
-TRH_HD i32 opaque_two22() {
-    i32 v = 1 << 22;
+TRH_HD i32 opaque_two22(bool negative = false) {
+    i32 v = negative ? -(1 << 22) : 1 << 22;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(v));
 #endif
@@ -786,16 +786,27 @@ template <class F> TRH_HD void fy_squares(i64 (&acc)[18], const Fy<F>& a) {
 }
 
 // nine uniform 29-bit rounds on signed columns; result = value / 2^261 (mod m) - s1 - 2 s2, normalised.  The subtrahends ride in the
-// final carry chain (the difference that follows a product would otherwise be a second chain): SUB 0 none, 1 s1, 2 s1 and 2 s2
-template <class F, int SUB> TRH_HD Fy<F> fy_reduce_sub(i64 (&acc)[18], const Fy<F>* s1, const Fy<F>* s2) {
+// final carry chain (the difference that follows a product would otherwise be a second chain): SUB 0 none, 1 s1, 2 s1 and 2 s2.
+// A round removes r = column mod 2^29 by adding -r m (m = 1 mod 2^29): the low limb of -r m cancels r, so the carry into the next
+// column is simply floor(column / 2^29) and the other limbs of m enter as r * (-m_k) -- three instructions (and, shift, add) next to the
+// five multiply-adds.  The result lies in (-v / 2^261 - m, v / 2^261]: fine for the signed domain.  NONNEG picks the mirror image
+// (q = -r mod 2^29, + q m, carry = ceil): result in [v / 2^261, v / 2^261 + m), i.e. non-negative for v >= 0 -- needed where the
+// result is stored as eight words (fy_store) -- at five instructions per round.
+template <class F, int SUB, bool NONNEG = false> TRH_HD Fy<F> fy_reduce_sub(i64 (&acc)[18], const Fy<F>* s1, const Fy<F>* s2) {
     constexpr i32 P1 = YModLimb<F, 1>::v, P2 = YModLimb<F, 2>::v, P3 = YModLimb<F, 3>::v, P4 = YModLimb<F, 4>::v;
-    const i32 two22 = opaque_two22();
+    const i32 two22 = opaque_two22(!NONNEG);  // +-2^22
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const i32 q = (i32)((0u - (u32)acc[i]) & (u32)YMASK);
-        // column i + q is a multiple of 2^29: its quotient is ceil(acc[i] / 2^29) (arithmetic shift = floor)
-        acc[i + 1] += (acc[i] + YMASK) >> YBITS;
-        fy_round(acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 8], q, P1, P2, P3, P4, two22);
+        if (NONNEG) {
+            const i32 q = (i32)((0u - (u32)acc[i]) & (u32)YMASK);
+            // column i + q is a multiple of 2^29: its quotient is ceil(acc[i] / 2^29) (arithmetic shift = floor)
+            acc[i + 1] += (acc[i] + YMASK) >> YBITS;
+            fy_round(acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 8], q, P1, P2, P3, P4, two22);
+        } else {
+            const i32 r = (i32)((u32)acc[i] & (u32)YMASK);
+            acc[i + 1] += acc[i] >> YBITS;
+            fy_round(acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 8], r, -P1, -P2, -P3, -P4, two22);
+        }
     }
     Fy<F> r;
     i64 c = 0;
@@ -818,6 +829,12 @@ template <class F> TRH_HD Fy<F> fy_mul(const Fy<F>& a, const Fy<F>& b) {
     i64 acc[18];
     fy_products(acc, a, b);
     return fy_reduce<F>(acc);
+}
+// the same with a non-negative result for non-negative operands (below a b / 2^261 + m): for values that are stored as words
+template <class F> TRH_HD Fy<F> fy_mul_nonneg(const Fy<F>& a, const Fy<F>& b) {
+    i64 acc[18];
+    fy_products(acc, a, b);
+    return fy_reduce_sub<F, 0, true>(acc, nullptr, nullptr);
 }
 // a normalised
 template <class F> TRH_HD Fy<F> fy_sqr(const Fy<F>& a) {
@@ -857,8 +874,6 @@ template <class F> TRH_HD Fy<F> fy_norm(const Fy<F>& a) {
     r.l[8] = a.l[8] + c;
     return r;
 }
-// a product of two non-negative values is non-negative and already normalised: the name documents that it may be stored as words
-template <class F> TRH_HD Fy<F> fy_norm_nonneg(const Fy<F>& a) { return a; }
 // limb-wise, no carries: the result only feeds ONE multiplication (as its lazy operand) or a fy_norm
 template <class F> TRH_HD Fy<F> fy_add_lazy(const Fy<F>& a, const Fy<F>& b) {
     Fy<F> r;
@@ -916,6 +931,8 @@ template <class F> TRH_HD Fy<F> fy_sub_sub2(const Fy<F>& a, const Fy<F>& b, cons
     r.l[8] = a.l[8] - b.l[8] - 2 * c2.l[8] + c;
     return r;
 }
+// the cheap half of the test below: false for all but 33 of the 2^29 low limbs
+template <class F> TRH_HD bool fy_maybe_zero_mod(const Fy<F>& a) { return (u32)(a.l[0] + 16) % (u32)(YMASK + 1) <= 32u; }
 // normalised value == 0 (mod m)?  |value| < 16 m, so it would be j m with |j| <= 16, whose low limb is j mod 2^29 (m = 1 mod 2^29)
 template <class F> TRH_HD bool fy_is_zero_mod(const Fy<F>& a) {
     const i32 l0 = a.l[0];
@@ -967,14 +984,14 @@ template <class F> TRH_HD Fy<F> fy_from_fe(const Fe<F>& a) {
     Fy<F> c;
     c.l[0] = YToLazyLimb<F, 0>::v; c.l[1] = YToLazyLimb<F, 1>::v; c.l[2] = YToLazyLimb<F, 2>::v; c.l[3] = YToLazyLimb<F, 3>::v; c.l[4] = YToLazyLimb<F, 4>::v;
     c.l[5] = YToLazyLimb<F, 5>::v; c.l[6] = YToLazyLimb<F, 6>::v; c.l[7] = YToLazyLimb<F, 7>::v; c.l[8] = YToLazyLimb<F, 8>::v;
-    return fy_mul(x, c);
+    return fy_mul_nonneg(x, c);
 }
 // normalised (|value| < 16 m) -> canonical Montgomery-R element: multiply by 2^256 mod m here, then bring (-m/8, 9 m / 8) into [0, m)
 template <class F> TRH_HD Fe<F> fy_to_fe(const Fy<F>& a) {
     Fy<F> c;
     c.l[0] = YMontOneLimb<F, 0>::v; c.l[1] = YMontOneLimb<F, 1>::v; c.l[2] = YMontOneLimb<F, 2>::v; c.l[3] = YMontOneLimb<F, 3>::v; c.l[4] = YMontOneLimb<F, 4>::v;
     c.l[5] = YMontOneLimb<F, 5>::v; c.l[6] = YMontOneLimb<F, 6>::v; c.l[7] = YMontOneLimb<F, 7>::v; c.l[8] = YMontOneLimb<F, 8>::v;
-    Fy<F> t = fy_mul(a, c);
+    Fy<F> t = fy_mul_nonneg(a, c);
     Fy<F> mm;
 #pragma unroll
     for (int i = 0; i < NLIMBS; ++i) mm.l[i] = ymod_limb<F>(i);

@@ -576,40 +576,73 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     XYZZzMem* my_first = first + (size_t)j * nseg + t;
     XYZZz<BF> acc = xyzzz_identity<BF>();
     bool is_first = true;
+    bool fresh = true;  // acc holds no point of the current bucket yet (its limbs are the identity's, or stale)
     // two bases in flight: the gather for entry pos + 2 is issued while entry pos is added (its index was read one step earlier),
-    // so neither the index read nor the 64-byte gather sits on the dependency chain of an iteration
+    // so neither the index read nor the 64-byte gather sits on the dependency chain of an iteration.  The look-ahead is clamped to
+    // the segment's last entry instead of being conditional: a conditional load makes every slot register a merge of old and new
+    // (nine 64-bit copies per step); the two repeated gathers per segment hit the L2.
     struct Slot { u32 e; uint4 a, b, c, d; };
     auto issue = [&](Slot& sl, u32 entry) {
         sl.e = entry;
         const uint4* bp = bases_z + (size_t)(entry & ~SIGN_BIT) * 4;
         sl.a = bp[0]; sl.b = bp[1]; sl.c = bp[2]; sl.d = bp[3];
     };
+    const u32 last_pos = stop - 1;
+    auto clamp = [&](u32 q) { return q < last_pos ? q : last_pos; };
     Slot s0, s1;
     issue(s0, lst[pos]);
-    if (pos + 1 < stop) issue(s1, lst[pos + 1]);
-    u32 e_ahead = pos + 2 < stop ? lst[pos + 2] : 0u;  // index of the entry two steps ahead
+    issue(s1, lst[clamp(pos + 1)]);
+    u32 e_ahead = lst[clamp(pos + 2)];  // index of the entry two steps ahead
     auto step = [&](Slot& sl) {
         if (pos == cur_end) {  // bucket finished: publish its run and start the next bucket
             store_raw(is_first ? my_first : direct + (size_t)j * nb1 + B, acc);
             is_first = false;
-            acc = xyzzz_identity<BF>();
+            fresh = true;
             do { ++B; cur_end = en[B]; } while (cur_end <= pos);
         }
         const u32 ce = sl.e;
         AffineZ<BF> cur;
         cur.x = fy_load<BF>(sl.a.x, sl.a.y, sl.a.z, sl.a.w, sl.b.x, sl.b.y, sl.b.z, sl.b.w);
         cur.y = fy_load<BF>(sl.c.x, sl.c.y, sl.c.z, sl.c.w, sl.d.x, sl.d.y, sl.d.z, sl.d.w);
-        if (pos + 2 < stop) {
-            issue(sl, e_ahead);
-            if (pos + 3 < stop) e_ahead = lst[pos + 3];
-        }
-        {   // negative digit: -P.  Limb-wise two's complement negation (branch-free; the identity (0, 0) stays (0, 0)); the lazy
-            // limbs in (-2^29, 0] are as good as normalised ones wherever y is used (field.h "Signed lazy domain")
+        // the identity is stored as (0, 0) and no point of these curves has y = 0 (odd prime order): y = 0 <=> identity
+        const bool p_identity = ((sl.c.x | sl.c.y | sl.c.z) | (sl.c.w | sl.d.x | sl.d.y) | (sl.d.z | sl.d.w)) == 0;
+        issue(sl, e_ahead);
+        e_ahead = lst[clamp(pos + 3)];
+        {   // negative digit: -P.  Limb-wise two's complement negation (branch-free; the lazy limbs in (-2^29, 0] are as good as
+            // normalised ones wherever y is used, field.h "Signed lazy domain")
             const i32 neg = -(i32)(ce >> 31);
 #pragma unroll
             for (int i = 0; i < NLIMBS; ++i) cur.y.l[i] = (cur.y.l[i] ^ neg) - neg;
         }
-        xyzzz_madd(acc, cur);
+        if (!p_identity) {
+            if (fresh) {  // first point of a bucket
+                acc.x = cur.x; acc.y = cur.y; acc.zz = fy_one<BF>(); acc.zzz = fy_one<BF>();
+                fresh = false;
+            } else {
+                Fy<BF> R;
+                const bool same_x = xyzzz_madd_main(acc, cur, R);
+                if (__any(same_x)) {  // wave-uniformly rare: acc was +-p.  The base is read again (keeping it live through the addition costs 18 registers)
+                    if (same_x) {
+                        if (fy_is_zero_mod(R)) {
+                            const uint4* bp = bases_z + (size_t)(ce & ~SIGN_BIT) * 4;
+                            const uint4 a = bp[0], b = bp[1], c = bp[2], d = bp[3];
+                            AffineZ<BF> again;
+                            again.x = fy_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+                            again.y = fy_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w);
+                            const i32 neg = -(i32)(ce >> 31);
+#pragma unroll
+                            for (int i = 0; i < NLIMBS; ++i) again.y.l[i] = (again.y.l[i] ^ neg) - neg;
+                            acc = xyzzz_dbl_affine(again);
+                        } else {
+                            acc = xyzzz_identity<BF>();
+                            fresh = true;
+                        }
+                    }
+                }
+            }
+        } else if (fresh) {
+            acc = xyzzz_identity<BF>();  // stale limbs of the previous bucket must not be published if nothing else arrives
+        }
         ++pos;
     };
     while (pos < stop) {

@@ -548,7 +548,7 @@ template <class F>
 __device__ __forceinline__ Fy<F> twiddle_y(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, u32 e, int lo_bits) {
     const u32 el = e & ((1u << lo_bits) - 1u), eh = e >> lo_bits;
     Fy<F> w = load_fy<F>(z_lo + 2 * (size_t)el);
-    if (eh) w = fy_norm_nonneg(fy_mul(w, load_fy<F>(z_hi + 2 * (size_t)eh)));
+    if (eh) w = fy_mul_nonneg(w, load_fy<F>(z_hi + 2 * (size_t)eh));  // stored as words: non-negative
     return w;
 }
 // inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), x 2^261 form

@@ -8,7 +8,8 @@ OUT=$REPO/gpurun_out/pmc_msm_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d $OUT/sq -o pmc -- python3 $REPO/tools/msm_probe.py $LOGN pallas 0 0 > $OUT/sq.log 2>&1
+COUNTERS=${TRH_PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES}
+rocprofv3 --kernel-trace --pmc $COUNTERS -d $OUT/sq -o pmc -- python3 $REPO/tools/msm_probe.py $LOGN pallas 0 0 > $OUT/sq.log 2>&1
 python3 - <<PY
 import sqlite3, glob
 for p in glob.glob("$OUT/sq/*.db"):
