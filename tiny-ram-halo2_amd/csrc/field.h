@@ -623,6 +623,42 @@ template <int INIT> TRH_HD void fy_row(i64 (&acc)[18], int base, i32 a, const i3
     }
 #endif
 }
+// c[9 + k] += m * s[k]: a subtrahend (m = -1, -2) enters the result columns as one more row of multiply-adds -- one instruction
+// per limb, where sign-extending s[k] and a 64-bit subtraction in the final carry chain took three
+template <int M> TRH_HD void fy_row_hi(i64 (&acc)[18], const i32 (&b)[NLIMBS]) {
+    static_assert(M == -1 || M == -2, "inline constants of the instruction");
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (M == -1) {
+        asm("v_mad_i64_i32 %0, vcc, %9, -1, %0\n\t"
+            "v_mad_i64_i32 %1, vcc, %10, -1, %1\n\t"
+            "v_mad_i64_i32 %2, vcc, %11, -1, %2\n\t"
+            "v_mad_i64_i32 %3, vcc, %12, -1, %3\n\t"
+            "v_mad_i64_i32 %4, vcc, %13, -1, %4\n\t"
+            "v_mad_i64_i32 %5, vcc, %14, -1, %5\n\t"
+            "v_mad_i64_i32 %6, vcc, %15, -1, %6\n\t"
+            "v_mad_i64_i32 %7, vcc, %16, -1, %7\n\t"
+            "v_mad_i64_i32 %8, vcc, %17, -1, %8"
+            : "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17])
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
+            : "vcc");
+    } else {
+        asm("v_mad_i64_i32 %0, vcc, %9, -2, %0\n\t"
+            "v_mad_i64_i32 %1, vcc, %10, -2, %1\n\t"
+            "v_mad_i64_i32 %2, vcc, %11, -2, %2\n\t"
+            "v_mad_i64_i32 %3, vcc, %12, -2, %3\n\t"
+            "v_mad_i64_i32 %4, vcc, %13, -2, %4\n\t"
+            "v_mad_i64_i32 %5, vcc, %14, -2, %5\n\t"
+            "v_mad_i64_i32 %6, vcc, %15, -2, %6\n\t"
+            "v_mad_i64_i32 %7, vcc, %16, -2, %7\n\t"
+            "v_mad_i64_i32 %8, vcc, %17, -2, %8"
+            : "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17])
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8])
+            : "vcc");
+    }
+#else
+    for (int k = 0; k < NLIMBS; ++k) acc[9 + k] += (i64)M * b[k];
+#endif
+}
 // one reduction round: the five columns q touches
 TRH_HD void fy_round(i64& c1, i64& c2, i64& c3, i64& c4, i64& c8, i32 q, i32 p1, i32 p2, i32 p3, i32 p4, i32 p8) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -808,13 +844,13 @@ template <class F, int SUB, bool NONNEG = false> TRH_HD Fy<F> fy_reduce_sub(i64 
             fy_round(acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4], acc[i + 8], r, -P1, -P2, -P3, -P4, two22);
         }
     }
+    if (SUB >= 1) fy_row_hi<-1>(acc, s1->l);
+    if (SUB == 2) fy_row_hi<-2>(acc, s2->l);
     Fy<F> r;
     i64 c = 0;
 #pragma unroll
     for (int k = 0; k < NLIMBS; ++k) {
         c += acc[9 + k];
-        if (SUB == 1) c -= s1->l[k];
-        if (SUB == 2) c -= s1->l[k] + 2 * s2->l[k];  // > -2^31: s1, s2 normalised
         if (k < NLIMBS - 1) {
             r.l[k] = (i32)((u32)c & (u32)YMASK);
             c >>= YBITS;

@@ -645,10 +645,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
         }
         ++pos;
     };
-    while (pos < stop) {
+    // pairs of steps without a condition between them (a conditional second step makes the loop's end state a merge of two
+    // register sets: 130 copies per pair), then the odd one
+    while (pos + 1 < stop) {
         step(s0);
-        if (pos < stop) step(s1);
+        step(s1);
     }
+    if (pos < stop) step(s0);
     if (is_first) store_raw(my_first, acc);
     else if (cur_end == stop) store_raw(direct + (size_t)j * nb1 + B, acc);
     else store_raw(last + (size_t)j * nseg + t, acc);
