@@ -613,11 +613,11 @@ const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
     if (!b->owned || b->n == 0) return nullptr;
     if (!b->d_z) {
         void* z = nullptr;
-        if (hipMalloc(&z, b->n * 64 + 64) != hipSuccess) return nullptr;  // fall back to per-call conversion
+        if (hipMalloc(&z, b->n * ZREC + ZREC) != hipSuccess) return nullptr;  // fall back to per-call conversion
         if (msm_convert_bases(b->curve, b->d_xy, z, b->n, s) != TRH_OK || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(z); return nullptr; }
         b->d_z = z;
     }
-    return (const char*)b->d_z + offset * 64;
+    return (const char*)b->d_z + offset * ZREC;
 }
 
 // the fixed-base table covers the whole set: used for full-range MSMs unless a window width is forced
@@ -660,8 +660,8 @@ int trh_bases_precompute(trh_bases_t b, int window_bits) {
     if (!msm_fixed_base_fits(b->n, cb)) { set_error("bases_precompute: window width %d with %zu bases is outside the fixed-base range (W * n <= 2^24, c <= 18)", cb, b->n); return TRH_EINVAL; }
     const int W = msm_fixed_base_windows(cb);
     void* t = nullptr;
-    hipError_t e = hipMalloc(&t, (size_t)W * b->n * 64 + 64);
-    if (e != hipSuccess) { set_error("bases_precompute: hipMalloc(%zu): %s", (size_t)W * b->n * 64, hipGetErrorString(e)); return TRH_ENOMEM; }
+    hipError_t e = hipMalloc(&t, (size_t)W * b->n * ZREC + ZREC);
+    if (e != hipSuccess) { set_error("bases_precompute: hipMalloc(%zu): %s", (size_t)W * b->n * ZREC, hipGetErrorString(e)); return TRH_ENOMEM; }
     int rc = msm_build_table(b->curve, b->d_xy, b->n, cb, t, 0);
     if (rc == TRH_OK && hipStreamSynchronize(0) != hipSuccess) { set_error("bases_precompute: table kernel failed"); rc = TRH_EHIP; }
     if (rc != TRH_OK) { (void)hipFree(t); return rc; }

@@ -516,18 +516,24 @@ __device__ __forceinline__ XYZZ<BF> load_xyzz(const XYZZMem* src) {
 //             covers, plus last[] / direct[] of the segment it starts in), converts to the
 //             canonical Montgomery form and writes the bucket for the reduction kernels.
 // ---------------------------------------------------------------------------------------
+// x, y in the signed domain -> the 128-byte record (ctx.h ZREC)
+template <class BF>
+__device__ __forceinline__ void store_zrec(uint4* q, const Fy<BF>& x, const Fy<BF>& y) {
+    q[0] = make_uint4((u32)x.l[0], (u32)x.l[1], (u32)x.l[2], (u32)x.l[3]); q[1] = make_uint4((u32)x.l[4], (u32)x.l[5], (u32)x.l[6], (u32)x.l[7]);
+    q[2] = make_uint4((u32)y.l[0], (u32)y.l[1], (u32)y.l[2], (u32)y.l[3]); q[3] = make_uint4((u32)y.l[4], (u32)y.l[5], (u32)y.l[6], (u32)y.l[7]);
+    // -y limb by limb: limbs in (-2^29, 0], as good as normalised ones wherever y is used (field.h "Signed lazy domain"); 0 stays 0
+    q[4] = make_uint4((u32)-y.l[0], (u32)-y.l[1], (u32)-y.l[2], (u32)-y.l[3]); q[5] = make_uint4((u32)-y.l[4], (u32)-y.l[5], (u32)-y.l[6], (u32)-y.l[7]);
+    q[6] = make_uint4((u32)x.l[8], (u32)y.l[8], (u32)-y.l[8], 0u);
+    q[7] = make_uint4(0u, 0u, 0u, 0u);
+}
 template <class BF>
 __global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* p = in + i * 4;
     uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    u32 wx[8], wy[8];
-    fy_store(fy_from_fe(fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)), wx);  // 0 -> 0: identity stays (0, 0)
-    fy_store(fy_from_fe(fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w)), wy);
-    uint4* q = out + i * 4;
-    q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
-    q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+    // 0 -> 0: the identity stays (0, 0)
+    store_zrec(out + i * (ZREC / 16), fy_from_fe(fe_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)), fy_from_fe(fe_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w)));
 }
 
 template <class BF>
@@ -581,11 +587,18 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     // so neither the index read nor the 64-byte gather sits on the dependency chain of an iteration.  The look-ahead is clamped to
     // the segment's last entry instead of being conditional: a conditional load makes every slot register a merge of old and new
     // (nine 64-bit copies per step); the two repeated gathers per segment hit the L2.
-    struct Slot { u32 e; uint4 a, b, c, d; };
+    struct Slot { u32 e; uint4 a, b, c, d, t; };
     auto issue = [&](Slot& sl, u32 entry) {
         sl.e = entry;
-        const uint4* bp = bases_z + (size_t)(entry & ~SIGN_BIT) * 4;
-        sl.a = bp[0]; sl.b = bp[1]; sl.c = bp[2]; sl.d = bp[3];
+        const uint4* bp = bases_z + (size_t)(entry & ~SIGN_BIT) * (ZREC / 16);
+        const uint4* yp = bp + 2 + ((entry >> 31) << 1);  // y, or -y for a negative digit
+        sl.a = bp[0]; sl.b = bp[1]; sl.c = yp[0]; sl.d = yp[1]; sl.t = bp[6];
+    };
+    auto unpack = [&](const Slot& sl, AffineZ<BF>& p) {
+        p.x.l[0] = (i32)sl.a.x; p.x.l[1] = (i32)sl.a.y; p.x.l[2] = (i32)sl.a.z; p.x.l[3] = (i32)sl.a.w;
+        p.x.l[4] = (i32)sl.b.x; p.x.l[5] = (i32)sl.b.y; p.x.l[6] = (i32)sl.b.z; p.x.l[7] = (i32)sl.b.w; p.x.l[8] = (i32)sl.t.x;
+        p.y.l[0] = (i32)sl.c.x; p.y.l[1] = (i32)sl.c.y; p.y.l[2] = (i32)sl.c.z; p.y.l[3] = (i32)sl.c.w;
+        p.y.l[4] = (i32)sl.d.x; p.y.l[5] = (i32)sl.d.y; p.y.l[6] = (i32)sl.d.z; p.y.l[7] = (i32)sl.d.w; p.y.l[8] = (i32)((sl.e >> 31) ? sl.t.z : sl.t.y);
     };
     const u32 last_pos = stop - 1;
     auto clamp = [&](u32 q) { return q < last_pos ? q : last_pos; };
@@ -602,18 +615,11 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
         }
         const u32 ce = sl.e;
         AffineZ<BF> cur;
-        cur.x = fy_load<BF>(sl.a.x, sl.a.y, sl.a.z, sl.a.w, sl.b.x, sl.b.y, sl.b.z, sl.b.w);
-        cur.y = fy_load<BF>(sl.c.x, sl.c.y, sl.c.z, sl.c.w, sl.d.x, sl.d.y, sl.d.z, sl.d.w);
+        unpack(sl, cur);
         // the identity is stored as (0, 0) and no point of these curves has y = 0 (odd prime order): y = 0 <=> identity
-        const bool p_identity = ((sl.c.x | sl.c.y | sl.c.z) | (sl.c.w | sl.d.x | sl.d.y) | (sl.d.z | sl.d.w)) == 0;
+        const bool p_identity = ((cur.y.l[0] | cur.y.l[1] | cur.y.l[2]) | (cur.y.l[3] | cur.y.l[4] | cur.y.l[5]) | (cur.y.l[6] | cur.y.l[7] | cur.y.l[8])) == 0;
         issue(sl, e_ahead);
         e_ahead = lst[clamp(pos + 3)];
-        {   // negative digit: -P.  Limb-wise two's complement negation (branch-free; the lazy limbs in (-2^29, 0] are as good as
-            // normalised ones wherever y is used, field.h "Signed lazy domain")
-            const i32 neg = -(i32)(ce >> 31);
-#pragma unroll
-            for (int i = 0; i < NLIMBS; ++i) cur.y.l[i] = (cur.y.l[i] ^ neg) - neg;
-        }
         if (!p_identity) {
             if (fresh) {  // first point of a bucket
                 acc.x = cur.x; acc.y = cur.y; acc.zz = fy_one<BF>(); acc.zzz = fy_one<BF>();
@@ -624,14 +630,10 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
                 if (__any(same_x)) {  // wave-uniformly rare: acc was +-p.  The base is read again (keeping it live through the addition costs 18 registers)
                     if (same_x) {
                         if (fy_is_zero_mod(R)) {
-                            const uint4* bp = bases_z + (size_t)(ce & ~SIGN_BIT) * 4;
-                            const uint4 a = bp[0], b = bp[1], c = bp[2], d = bp[3];
+                            Slot rs;
+                            issue(rs, ce);
                             AffineZ<BF> again;
-                            again.x = fy_load<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
-                            again.y = fy_load<BF>(c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w);
-                            const i32 neg = -(i32)(ce >> 31);
-#pragma unroll
-                            for (int i = 0; i < NLIMBS; ++i) again.y.l[i] = (again.y.l[i] ^ neg) - neg;
+                            unpack(rs, again);
                             acc = xyzzz_dbl_affine(again);
                         } else {
                             acc = xyzzz_identity<BF>();
@@ -845,12 +847,7 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
             for (int k = 1; k < c; ++k) acc = xyzz_dbl(acc);
             a = xyzz_to_affine(acc);
         }
-        u32 wx[8], wy[8];
-        fy_store(fy_from_fe(a.x), wx);
-        fy_store(fy_from_fe(a.y), wy);
-        uint4* q = out + ((size_t)j * n + i) * 4;
-        q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
-        q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+        store_zrec(out + ((size_t)j * n + i) * (ZREC / 16), fy_from_fe(a.x), fy_from_fe(a.y));
     }
 }
 
@@ -879,7 +876,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         for (size_t off = 0; off < n && rc == TRH_OK; off += len) {
             const size_t cur = off + len < n ? len : n - off;
             const bool last = off + cur == n;
-            rc = msm_enqueue_t<SF, BF>((const char*)bases_dev + off * 64, bases_z ? (const char*)bases_z + off * 64 : nullptr, (const char*)scalars_dev + off * 32, cur, 1, cur,
+            rc = msm_enqueue_t<SF, BF>((const char*)bases_dev + off * 64, bases_z ? (const char*)bases_z + off * ZREC : nullptr, (const char*)scalars_dev + off * 32, cur, 1, cur,
                                        mont, s, nullptr, last ? tails_dev : nullptr);
             if (rc != TRH_OK || last) break;
             rc = msm_finish_t<BF>(s, acc + 12, 1);  // blocks: the next tile reuses the sort scratch anyway
@@ -966,7 +963,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
     TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZzMem)));
     TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZzMem)));
-    if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * 64 + 64));
+    if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * ZREC + ZREC));
     const uint4* bz = fb ? (const uint4*)fb->table : bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
     TRH_TRY(m.window_sums.ensure(batch * Ws * sizeof(XYZZMem)));
     const size_t hs = batch * Ws * sizeof(XYZZMem);
