@@ -910,6 +910,20 @@ template <class F> TRH_HD Fy<F> fy_norm(const Fy<F>& a) {
     r.l[8] = a.l[8] + c;
     return r;
 }
+// normalised -> balanced limbs: l[0..7] in [-2^28, 2^28), same value.  A table constant in this form halves the column bound of a
+// product, so the OTHER operand may be any limbs that fit 32 bits (the NTT's butterflies then normalise half as often)
+template <class F> TRH_HD Fy<F> fy_balance(const Fy<F>& a) {
+    Fy<F> r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMBS - 1; ++i) {
+        const i32 v = a.l[i] + c;                  // [0, 2^29]
+        c = (v + (1 << (YBITS - 1))) >> YBITS;     // 1 when v >= 2^28
+        r.l[i] = v - (c << YBITS);
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
 // limb-wise, no carries: the result only feeds ONE multiplication (as its lazy operand) or a fy_norm
 template <class F> TRH_HD Fy<F> fy_add_lazy(const Fy<F>& a, const Fy<F>& b) {
     Fy<F> r;

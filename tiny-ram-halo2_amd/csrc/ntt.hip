@@ -551,18 +551,29 @@ __device__ __forceinline__ Fy<F> twiddle_y(const uint4* __restrict__ z_lo, const
     if (eh) w = fy_mul_nonneg(w, load_fy<F>(z_hi + 2 * (size_t)eh));  // stored as words: non-negative
     return w;
 }
-// inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), x 2^261 form
+// inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), x 2^261 form, as raw
+// BALANCED limbs in three planes ([M x 16 B][M x 16 B][M x 4 B], M = entries): the pass multiplies by them without unpacking, and
+// the balanced form lets the multiplicand be the previous pass's unnormalised output (see round_stage_y)
 template <class F>
 __global__ void __launch_bounds__(256) ntt_direct_table_y_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
                                                                  int log_ns, int s, int tw_shift) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((size_t)1 << (log_ns + s))) return;
+    const size_t M = (size_t)1 << (log_ns + s);
+    if (i >= M) return;
     const u32 k = (u32)i & ((1u << log_ns) - 1u), r = (u32)(i >> log_ns);
-    const Fy<F> w = twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits);
-    u32 o[8];
-    fy_store(w, o);
-    d[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
-    d[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    const Fy<F> w = fy_balance(twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits));
+    d[i] = make_uint4((u32)w.l[0], (u32)w.l[1], (u32)w.l[2], (u32)w.l[3]);
+    d[M + i] = make_uint4((u32)w.l[4], (u32)w.l[5], (u32)w.l[6], (u32)w.l[7]);
+    ((u32*)(d + 2 * M))[i] = (u32)w.l[8];
+}
+template <class F>
+__device__ __forceinline__ Fy<F> load_direct_y(const uint4* __restrict__ d, size_t M, size_t i) {
+    const uint4 a = d[i], b = d[M + i];
+    Fy<F> r;
+    r.l[0] = (i32)a.x; r.l[1] = (i32)a.y; r.l[2] = (i32)a.z; r.l[3] = (i32)a.w;
+    r.l[4] = (i32)b.x; r.l[5] = (i32)b.y; r.l[6] = (i32)b.z; r.l[7] = (i32)b.w;
+    r.l[8] = (i32)((const u32*)(d + 2 * M))[i];
+    return r;
 }
 template <class F, bool TWL>
 struct TileTwiddlesY {
@@ -574,12 +585,19 @@ struct TileTwiddlesY {
         else { const uint4 x = a[idx], y = b[idx]; return fy_load<F>(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w); }
     }
     __device__ __forceinline__ void put(int idx, const Fy<F>& v) const {
-        if constexpr (TWL) lds_store_limbs_y<F>(a, b, c, idx, v);
+        if constexpr (TWL) lds_store_limbs_y<F>(a, b, c, idx, fy_balance(v));  // balanced: see round_stage_y
         else { u32 w[8]; fy_store(v, w); a[idx] = make_uint4(w[0], w[1], w[2], w[3]); b[idx] = make_uint4(w[4], w[5], w[6], w[7]); }
     }
 };
-// stage V of round 0 (rows u, u | 2^V of the thread's registers): inputs of stage 0 are normalised
-template <class F, int LG, int V, class TW>
+// Limb growth and where the butterflies normalise.  A butterfly is x[u] = a + t, x[u'] = a - t with t = x[u'] w a fresh product
+// (normalised limbs) and a = x[u] carried over: limb-wise sums, so |limb of a| grows by 2^29 per stage ("level").  Values only
+// have to fit 32 bits (level <= 3) -- PROVIDED the twiddle is in the balanced form (BAL: |limb| <= 2^28, the LDS limb table and
+// the direct tables): a column of multiplicand x twiddle is then < 9 * 3 * 2^29 * 2^28 + reduction terms < 2^62.  With the packed
+// (unsigned, < 2^29) twiddles of 9-stage passes the multiplicand must stay below level 2, i.e. every a is normalised first.
+// BAL schedule for the four rows of a thread (two stages per round): loaded values have level 1; round 0 runs without any
+// normalisation (level 3 at its end); every later round normalises the carried operands of its FIRST stage only (rows 0 and 2:
+// level 3 -> 1, results level 2), its second stage carries level 2 -> 3.  Two carry chains per round and thread instead of four.
+template <class F, int LG, int V, bool BAL, class TW>
 __device__ __forceinline__ void round0_stage_y(Fy<F> (&x)[1 << LG], const TW& tw, int s) {
     const int sh = s - 1 - V;
 #pragma unroll
@@ -588,14 +606,15 @@ __device__ __forceinline__ void round0_stage_y(Fy<F> (&x)[1 << LG], const TW& tw
         const u32 ul = (u32)(u & ((1 << V) - 1));
         Fy<F> t = x[u | (1 << V)];
         if (ul) t = fy_mul(t, tw((int)(ul << sh)));      // lazy multiplicand
-        const Fy<F> a = V ? fy_norm(x[u]) : x[u];         // stage 0 sees the loaded values; later ones the previous stage's lazy sums
+        const Fy<F> a = (V && !(BAL && LG == 2)) ? fy_norm(x[u]) : x[u];  // stage 0 sees the loaded values; later ones the previous stage's lazy sums
         x[u] = fy_add_lazy(a, t);
         x[u | (1 << V)] = fy_sub_lazy(a, t);
     }
 }
-// stage V of a later round; the values come from the LDS exchange (lazy) or from the stage before (lazy)
-template <class F, int LG, int V, class TW>
-__device__ __forceinline__ void round_stage_y(Fy<F> (&x)[1 << LG], const TW& tw, u32 L, int stl, int s, bool partner_zero) {
+// stage V of a later round; the values come from the LDS exchange (lazy) or from the stage before (lazy).  first: the first stage
+// this round executes
+template <class F, int LG, int V, bool BAL, class TW>
+__device__ __forceinline__ void round_stage_y(Fy<F> (&x)[1 << LG], const TW& tw, u32 L, int stl, int s, bool partner_zero, bool first) {
     const int sh = s - 1 - stl - V;
 #pragma unroll
     for (int u = 0; u < (1 << LG); ++u) {
@@ -605,7 +624,7 @@ __device__ __forceinline__ void round_stage_y(Fy<F> (&x)[1 << LG], const TW& tw,
         } else {
             const u32 idx = (L + ((u32)(u & ((1 << V) - 1)) << stl)) << sh;
             const Fy<F> t = fy_mul(x[u | (1 << V)], tw((int)idx));  // idx 0 holds the lazy one
-            const Fy<F> a = fy_norm(x[u]);
+            const Fy<F> a = (!(BAL && LG == 2) || first) ? fy_norm(x[u]) : x[u];
             x[u] = fy_add_lazy(a, t);
             x[u | (1 << V)] = fy_sub_lazy(a, t);
         }
@@ -691,7 +710,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
             }
             if (FUSE && fu.pre) val = fy_mul(val, load_fy<F>((const uint4*)fu.pre + 2 * (idx % fu.pre_period)));
             if (log_ns > 0)  // every element of a later pass: the product is also what brings a raw residue back to |v| < 1.13 m
-                val = fy_mul(val, direct ? load_fy<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits));
+                val = fy_mul(val, direct ? load_direct_y<F>(direct, (size_t)1 << (log_ns + s), ((size_t)r << log_ns) + k) : fy_balance(twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits)));
         }
         return val;
     };
@@ -711,9 +730,9 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
 #pragma unroll
         for (int u = 1; u < G; ++u) x[u] = x[0];
     } else {
-        round0_stage_y<F, LG, 0>(x, tw, s);
-        if constexpr (LG > 1) round0_stage_y<F, LG, 1>(x, tw, s);
-        if constexpr (LG > 2) round0_stage_y<F, LG, 2>(x, tw, s);
+        round0_stage_y<F, LG, 0, TWL>(x, tw, s);
+        if constexpr (LG > 1) round0_stage_y<F, LG, 1, TWL>(x, tw, s);
+        if constexpr (LG > 2) round0_stage_y<F, LG, 2, TWL>(x, tw, s);
     }
     for (int st = LG; st < s; st += LG) {
 #pragma unroll
@@ -726,9 +745,9 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
 #pragma unroll
         for (int u = 0; u < G; ++u) x[u] = lds_load_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
         const bool partner_zero = bcast2 && st == LG;
-        if (0 >= vb) round_stage_y<F, LG, 0>(x, tw, L, stl, s, partner_zero);
-        if constexpr (LG > 1) { if (1 >= vb) round_stage_y<F, LG, 1>(x, tw, L, stl, s, false); }
-        if constexpr (LG > 2) { if (2 >= vb) round_stage_y<F, LG, 2>(x, tw, L, stl, s, false); }
+        if (0 >= vb) round_stage_y<F, LG, 0, TWL>(x, tw, L, stl, s, partner_zero, true);
+        if constexpr (LG > 1) { if (1 >= vb) round_stage_y<F, LG, 1, TWL>(x, tw, L, stl, s, false, vb == 1); }
+        if constexpr (LG > 2) { if (2 >= vb) round_stage_y<F, LG, 2, TWL>(x, tw, L, stl, s, false, vb == 2); }
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -740,7 +759,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
             ((u32*)(out_a + 2 * N))[dst] = (u32)x[u].l[8];
         } else {
             Fy<F> y;
-            if (FUSE && fu.post && last) y = fy_mul(x[u], load_fy<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));
+            if (FUSE && fu.post && last) y = fy_mul(fy_norm(x[u]), load_fy<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));  // packed factor: the multiplicand must be normalised
             else y = fy_norm(x[u]);
             u32 w[8];
             fy_canonical_words(y, w);
@@ -841,8 +860,9 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
         int log_ns = sizes[0];
         for (int p = 1; p < P && rc == TRH_OK; ++p) {
             const size_t entries = (size_t)1 << (log_ns + sizes[p]);
-            if (entries * 32 <= ((size_t)1 << 30)) {
-                rc = t->direct[p].ensure(entries * 32);
+            const size_t entry_bytes = signed_enabled() ? 36 : 32;  // raw limbs for the signed passes
+            if (entries * entry_bytes <= ((size_t)1 << 30) + ((size_t)1 << 27)) {
+                rc = t->direct[p].ensure(entries * entry_bytes);
                 if (rc == TRH_OK && signed_enabled())
                     hipLaunchKernelGGL((ntt_direct_table_y_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
                                        t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
