@@ -130,15 +130,16 @@ def msm_roofline(n, acc_ms, tm, traffic):
             # the kernel is limited by VALU issue, not by HBM (see `valu`): the counter traffic is what it actually pulls per launch
             "limiter": "valu-issue", "traffic_gbs": (traffic / (acc_ms * 1e-3) / 1e9) if traffic else None}
     valu = {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc_ms * 1e-3),
-            "mad_u64_u32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": 32.7e12,
+            "mad_i64_i32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": 32.7e12,
             "other_valu_per_s": OTHER_PER_MADD * madds / (acc_ms * 1e-3), "other_peak_per_s": 65e12,
             "issue_frac": (MADS_PER_MADD * madds / 32.7e12 + OTHER_PER_MADD * madds / 65e12) / (acc_ms * 1e-3)}
     return roof, valu
 
 
-# instruction mix of one lazy mixed addition (SQ_INSTS_VALU per wave and mixed add, profiles/): half-rate 32 x 32 multiply-adds, and the rest
-MADS_PER_MADD = 1188
-OTHER_PER_MADD = 1130
+# instruction mix of one mixed addition in the signed 29-bit domain: 1733 VALU instructions per wave and mixed add (SQ_INSTS_VALU,
+# profiles/*_msm_sq_counters.txt) of which 8 x 81 + 2 x 45 product, 9 x 45 reduction and 3 x 9 subtrahend multiply-adds (v_mad_i64_i32)
+MADS_PER_MADD = 738 + 405 + 27
+OTHER_PER_MADD = 1733 - MADS_PER_MADD
 
 
 def main():
@@ -332,7 +333,7 @@ def main():
         ach = 64.0 * (1 << ln) / (ms * 1e-3) / 1e9
         traffic = load_traffic(f"ntt_fp_2^{ln}")
         return {"metric": f"Fp NTT elems/s @ 2^{ln}", "value": world * (1 << ln) / (ms * 1e-3), "unit": "elems/s", "ms_per_transform": ms, "check": chk,
-                "roofline": {"bound": "hbm", "kernel": "ntt_passz_kernel (all passes of one transform)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "roofline": {"bound": "hbm", "kernel": "ntt_passy_kernel (all passes of one transform)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": 64 << ln, "limiter": "valu-issue",
                              "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}}
 
@@ -430,9 +431,9 @@ def main():
                        "window_bits": tm["window_bits"], "windows": tm["windows"],
                        "parallelism": f"range-shard x{world}, one process per GPU, RCCL all-gather of 96-byte partials" if world > 1 else "single GPU"},
             "roofline": roof,
-            # what actually bounds the kernel: VALU issue.  Per mixed add 8 fz_mul (126 v_mad_u64_u32 each) + 2 fz_sqr (90) =
-            # 1188 half-rate multiply-adds and ~1130 other ALU instructions (SQ_INSTS_VALU: 2317 per mixed add and wave); peaks are the
-            # measured issue rates of tools/microbench.hip (profiles/microbench_r01m.txt: v_mad_u64_u32 32.7 T/s, v_add_u32 65 T/s)
+            # what actually bounds the kernel: VALU issue.  Per mixed add 1170 v_mad_i64_i32 (8 products of 81, 2 squares of 45, 9 reductions
+            # of 45, 27 for the fused subtrahends) and ~560 other ALU instructions (SQ_INSTS_VALU: 1733 per mixed add and wave); peaks are the
+            # measured issue rates of tools/microbench.hip (profiles/microbench_*.txt: 32 x 32 multiply-add 32.7 T/s, v_add_u32 65 T/s)
             "valu": valu,
             "phases_ms": phase,
             "check": check,
