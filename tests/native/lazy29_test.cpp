@@ -119,6 +119,57 @@ static int run(const char* name) {
         if ((it % 16) == 0 || kind < 8) if (!same_point(z, c) || xyzzz_is_identity(z) != xyzz_is_identity(c)) { fail("point mismatch", it); break; }
     }
     if (!same_point(z, c)) fail("final point", 0);
+
+    // ---- the accumulation kernel's step (msm.hip: msm_accumulate_seg_kernel) restated on the host: the first point of a bucket is taken
+    // over, the generic case runs as one straight line (xyzzz_madd_main), the same-x cases are patched afterwards, identity bases skip
+    {
+        XYZZ<F> cc = xyzz_identity<F>();
+        XYZZz<F> acc = xyzzz_identity<F>();
+        bool fresh = true;
+        int last = -1;
+        for (int it = 0; it < 6000; ++it) {
+            const u64 r = next();
+            int i = (int)(r % NB);
+            bool neg = (r >> 20) & 1;
+            const u64 kind = (r >> 24) % 32;
+            if (kind == 0) { acc = xyzzz_identity<F>(); cc = xyzz_identity<F>(); fresh = true; last = -1; continue; }  // bucket boundary (the kernel leaves acc stale; fresh guards it)
+            if (kind == 1 && last >= 0 && !fresh) { i = last; }                  // may repeat the previous base: same x when the bucket holds just that point
+            if (kind == 2 && last >= 0) { acc = xyzzz_identity<F>(); cc = xyzz_identity<F>(); fresh = true; i = last; }  // restart, then base, then (often) +-base again
+            Affine<F> b = bases[i];
+            AffineZ<F> y = bz[i];
+            if (neg) { b = aff_neg(b); for (int k = 0; k < NLIMBS; ++k) y.y.l[k] = -y.y.l[k]; }
+            i32 yor = 0;
+            for (int k = 0; k < NLIMBS; ++k) yor |= y.y.l[k];
+            const bool p_identity = yor == 0;
+            if (!p_identity) {
+                if (fresh) { acc.x = y.x; acc.y = y.y; acc.zz = fy_one<F>(); acc.zzz = fy_one<F>(); fresh = false; }
+                else {
+                    Fy<F> R;
+                    if (xyzzz_madd_main(acc, y, R)) {
+                        if (fy_is_zero_mod(R)) acc = xyzzz_dbl_affine(y);
+                        else { acc = xyzzz_identity<F>(); fresh = true; }
+                    }
+                }
+            } else if (fresh) acc = xyzzz_identity<F>();
+            xyzz_madd(cc, b);
+            last = i;
+            if (!fresh && !in_bounds(acc)) { fail("kernel step: magnitude invariant", it); break; }
+            if (fresh != xyzz_is_identity(cc)) { fail("kernel step: fresh flag vs identity", it); break; }
+            if (!fresh && ((it % 8) == 0 || kind < 3) && !same_point(acc, cc)) { fail("kernel step: point mismatch", it); break; }
+        }
+    }
+    // ---- balanced constants and unnormalised multiplicands (the NTT's butterflies), non-negative products (stored tables) ----
+    for (int i = 0; i < 2000; ++i) {
+        const Fe<F> a = rand_fe<F>(), b = rand_fe<F>(), c2 = rand_fe<F>(), d = rand_fe<F>();
+        const Fy<F> ya = fy_from_fe(a), yb = fy_from_fe(b), yc = fy_from_fe(c2), yd = fy_from_fe(d);
+        const Fy<F> bal = fy_balance(yb);
+        for (int k = 0; k < 8; ++k) if (bal.l[k] < -(1 << 28) || bal.l[k] >= (1 << 28)) fail("balance range", i);
+        if (!same(fy_to_fe(bal), b)) fail("balance value", i);
+        const Fy<F> lvl3 = fy_sub_lazy(fy_add_lazy(ya, yc), yd);   // |limb| < 3 * 2^29, never normalised
+        if (!same(fy_to_fe(fy_mul(lvl3, bal)), fe_mul(fe_sub(fe_add(a, c2), d), b))) fail("level-3 multiplicand x balanced constant", i);
+        const Fy<F> nn = fy_mul_nonneg(ya, yb);
+        if (!normalised(nn, 24) || nn.l[8] < 0 || !same(fy_to_fe(nn), fe_mul(a, b))) fail("mul_nonneg", i);
+    }
     return bad;
 }
 
