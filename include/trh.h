@@ -113,7 +113,7 @@ size_t trh_bases_len(trh_bases_t b);
 int trh_bases_shards(trh_bases_t b);  /* devices the set is range-sharded over (trh_init_multi); 1 for a single-device set */
 void trh_bases_destroy(trh_bases_t b);
 /* Fixed-base tables for an owned set (Params.g / g_lagrange serve ~500 commitments per proof): stores
- * 2^(c j) * P_i for every window j (W x n x 64 B of HBM), after which a full-range MSM over the handle puts the
+ * 2^(c j) * P_i for every window j (W x n x 128 B of HBM), after which a full-range MSM over the handle puts the
  * digits of all windows into ONE bucket set -- one bucket reduction per MSM instead of W, wider windows, no
  * Horner pass over windows.  window_bits 0 = automatic (<= 17); requires W * n <= 2^24.  Results are the same
  * group elements; MSMs over a sub-range (offset != 0 or n < len) keep using the per-window path.           */
