@@ -10,7 +10,7 @@
 //                base-2^c digits (buckets 1..2^(c-1)), per-window bucket histogram
 //   2. offsets   exclusive scan of the histogram per window
 //   3. scatter   counting sort: point indices grouped by (window, bucket)
-//   4. accumulate bases converted once to the lazy Montgomery domain (R' = 2^270, no modular
+//   4. accumulate bases converted once to the signed lazy Montgomery domain (R'' = 2^261, 29-bit limbs, no modular
 //                reduction in add/sub); one thread per fixed-length SEGMENT of the sorted list, so
 //                every lane does the same number of XYZZ mixed adds (8M + 2S) whatever the bucket
 //                sizes; per-bucket pieces are combined by one thread per bucket
@@ -506,7 +506,8 @@ __device__ __forceinline__ XYZZ<BF> load_xyzz(const XYZZMem* src) {
 
 // ---------------------------------------------------------------------------------------
 // 4. balanced accumulation in the lazy domain.
-//   convert   bases (Montgomery R = 2^256) -> lazy domain (R' = 2^270), once per MSM
+//   convert   bases (Montgomery R = 2^256) -> 128-byte records of ready limbs in the signed lazy domain (R'' = 2^261; ctx.h ZREC),
+//             once per base set (owned handles keep them) or per MSM
 //   segments  thread (segment, window) walks seg_len consecutive entries of the bucket-sorted
 //             list: every lane does the same number of mixed adds whatever the bucket sizes.
 //             At a bucket boundary the raw accumulator (36 limbs) is stored -- the first run of a
@@ -584,7 +585,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     bool is_first = true;
     bool fresh = true;  // acc holds no point of the current bucket yet (its limbs are the identity's, or stale)
     // two bases in flight: the gather for entry pos + 2 is issued while entry pos is added (its index was read one step earlier),
-    // so neither the index read nor the 64-byte gather sits on the dependency chain of an iteration.  The look-ahead is clamped to
+    // so neither the index read nor the gather of the record sits on the dependency chain of an iteration.  The look-ahead is clamped to
     // the segment's last entry instead of being conditional: a conditional load makes every slot register a merge of old and new
     // (nine 64-bit copies per step); the two repeated gathers per segment hit the L2.
     struct Slot { u32 e; uint4 a, b, c, d, t; };
