@@ -106,6 +106,42 @@ def test_edge_values_and_operand_order():
         assert got == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n)
 
 
+def test_long_sums_force_inserted_reductions():
+    """the machine's values are lazy (csrc/expr.hip): a loaded column is bounded by 32 m, sums add up, and trh_expr_create inserts a
+    reduction where a sum could pass 250 m or a stored value 15 m.  Sums of 9 .. 40 raw columns at the extreme values m - 1 / 0 / 1,
+    alone (stored directly), negated, squared, multiplied with each other, folded -- all bit-exact against the oracle"""
+    field, log_n = "fp", 3
+    f = o.FIELDS[field]
+    n = 1 << log_n
+
+    def total(k, start=0):
+        e = expr.Advice(start % 6, 0)
+        for i in range(1, k):
+            e = e + expr.Advice((start + i) % 6, (i % 3) - 1)
+        return e
+
+    def alternating(k):
+        e = expr.Advice(0, 0)
+        for i in range(1, k):
+            e = (e - expr.Advice(i % 6, 0)) if i % 2 else (e + expr.Advice(i % 6, 1))
+        return e
+
+    gates = [total(9), total(17, 2), -total(40, 1), total(12) * total(13, 3), total(20) * total(20) , alternating(33),
+             (total(9) + 5) * (alternating(15) - 7) - total(8), total(40) * 3 + total(39)]
+    vals = [f.m - 1, f.m - 1, 0, 1, f.m - 2, (f.m - 1) // 2, f.m - 1, 1 << 253]
+    ints = {("advice", c): [vals[(r + c) % len(vals)] if c % 2 else f.m - 1 for r in range(n)] for c in range(6)}
+    dev = {k: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda() for k, col in ints.items()}
+    for y in (1, f.m - 1, 0x1234567):
+        prog = expr.compile_gates(field, gates, y)
+        assert from_dev(f, expr.GateEvaluator(prog).eval(dev, log_n)) == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n)
+    # one output per expression: every sum is STORED as it is (no multiplication behind it)
+    prog = expr.compile_outputs(field, gates[:3])
+    out = expr.GateEvaluator(prog, n_outputs=3).eval(dev, log_n)
+    for i in range(3):
+        want = [o.evaluate_expression(f, to_tuple(gates[i]), ints, r, n, 1) for r in range(n)]
+        assert from_dev(f, out[i]) == want, i
+
+
 def test_program_validation():
     I = expr._Insn
     one = np.zeros((1, 4), np.uint64)
