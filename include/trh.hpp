@@ -190,6 +190,14 @@ public:
     }
     void precompute() {
         for (Bases* b : {&g_, &g_lagrange_}) { try { b->precompute(0); } catch (const Error&) { /* outside the table range: per-window path */ } }
+        // the opening's base set g || w || u with its own table: every MSM of trh_ipa_create_proof then runs in fixed-base mode
+        try {
+            std::vector<Affine> gwu = g_.download();
+            gwu.push_back(u);
+            Bases b(curve, gwu);
+            b.precompute(0);
+            ipa_ = std::move(b);
+        } catch (const Error&) { /* the opening uses g || w and the per-window path */ }
     }
     Point commit(const std::vector<Limbs>& poly, const Limbs& blind) const { return commit_host(g_, poly, blind); }
     Point commit_lagrange(const std::vector<Limbs>& poly, const Limbs& blind) const { return commit_host(g_lagrange_, poly, blind); }
@@ -198,6 +206,7 @@ public:
     std::vector<Point> commit_lagrange_batch(const DeviceBuffer& polys, size_t batch, const std::vector<Limbs>& blinds, void* stream = nullptr) const { return commit_dev(g_lagrange_, polys, batch, blinds, stream); }
     const Bases& g() const { return g_; }
     const Bases& g_lagrange() const { return g_lagrange_; }
+    const Bases& ipa_bases() const { return ipa_.handle() ? ipa_ : g_; }  // g || w || u with tables when precompute() built it
 
     Curve curve;
     uint32_t k;
@@ -215,7 +224,7 @@ private:
         check(trh_commit_batch_dev(b.handle(), polys.data(), n, batch, (const uint64_t*)blinds.data(), stream, (uint64_t*)out.data()), "commit_batch");
         return out;
     }
-    Bases g_, g_lagrange_;
+    Bases g_, g_lagrange_, ipa_;
 };
 
 // ---- poly::EvaluationDomain -----------------------------------------------------------------------------------
@@ -378,7 +387,7 @@ inline std::pair<Limbs, Limbs> ipa_create_proof(const Params& params, const Devi
                                                 const Limbs& s_blind, const trh_transcript_t& transcript, trh_rng_scalar_fn rng, void* rng_ctx, void* stream = nullptr) {
     require(p_poly.size() >= params.n * 32 && s_poly.size() >= params.n * 32, "px.len() == params.n");
     Limbs c, f;
-    check(trh_ipa_create_proof(params.g().handle(), (const uint64_t*)&params.u, params.k, p_poly.data(), p_blind.data(), x3.data(), s_poly.data(), s_blind.data(), &transcript, rng,
+    check(trh_ipa_create_proof(params.ipa_bases().handle(), (const uint64_t*)&params.u, params.k, p_poly.data(), p_blind.data(), x3.data(), s_poly.data(), s_blind.data(), &transcript, rng,
                                rng_ctx, stream, c.data(), f.data()), "ipa create_proof");
     return {c, f};
 }

@@ -57,22 +57,35 @@ class IntTranscript(LimbTranscript):
         return c
 
 
-def _params(curve, k, seed):
+def _params(curve, k, seed, precompute=False):
     n = 1 << k
     g_l = cpu_ref.gen_bases_hashed(curve, seed, n)          # unstructured generators
     w_l = cpu_ref.gen_bases_hashed(curve, seed ^ 0x5151, 1)
     u_l = cpu_ref.gen_bases_hashed(curve, seed ^ 0x6262, 1)
-    return g_l, w_l, u_l, poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=False)
+    return g_l, w_l, u_l, poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=precompute)
 
 
 @pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("vesta", 14), ("pallas", 14), ("vesta", 16), ("pallas", 16), ("vesta", 18), ("pallas", 18)])
 def test_ipa_native_vs_cpp_oracle(curve, k):
     """the single-call prover against the literal C++ restatement (G' collapsed with scalar multiplications there, never
     materialised here): identical S, L_j, R_j, c, f; then the verifier equation on what the GPU produced"""
+    _ipa_case(curve, k, precompute=False)
+
+
+@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("pallas", 16), ("vesta", 18)])
+def test_ipa_native_fixed_base_tables_vs_cpp_oracle(curve, k):
+    """the same with Params that carry fixed-base tables: the opening then runs over ONE resident set g || w || u with its own table
+    (poly.Params.ipa_bases -> the n + 2 form of trh_ipa_create_proof) and every MSM of it in fixed-base mode"""
+    _ipa_case(curve, k, precompute=True)
+
+
+def _ipa_case(curve, k, precompute):
     cv = o.CURVES[curve]
     fs = cv.scalar
     n = 1 << k
-    g_l, w_l, u_l, params = _params(curve, k, 0x1FA0 + k)
+    g_l, w_l, u_l, params = _params(curve, k, 0x1FA0 + k, precompute)
+    if precompute:
+        assert len(params.ipa_bases()) == n + 2 and int(api.lib().trh_bases_precomputed_window_bits(params.ipa_bases().handle)) > 0
     p_l, s_l = synth.field_elements(0xA000 + k, n), synth.field_elements(0xB000 + k, n)
     rnd = random.Random(0x1FA + k)
     p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)

@@ -307,8 +307,13 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // scratch kept in the context: a hipMalloc / hipFree pair per vector costs more than several rounds
     DevBuf* sc = ctx().ipa;
     DevBuf &b = sc[0], &sp = sc[1], &pp = sc[2], &wgt = sc[3], &lrsc = sc[4], &gwu = sc[5], &gwuz = sc[6];
-    TRH_TRY(b.ensure(n * 32)); TRH_TRY(sp.ensure((n + 1) * 32)); TRH_TRY(pp.ensure(n * 32)); TRH_TRY(wgt.ensure(n * 32)); TRH_TRY(lrsc.ensure(2 * (n + 2) * 32));
-    TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * ZREC));
+    // A base set that holds g || w || u (n + 2 points) with fixed-base tables attached (trh_bases_precompute: Params are fixed for
+    // the life of a proving key) lets every MSM of the opening run in fixed-base mode: one bucket set instead of one per window,
+    // wide windows, no heavy top-window buckets and no Horner over windows on the host between two rounds.
+    const bool with_u = gw->n == n + 2;
+    const MsmFixedBase* fb = (with_u && gw->d_table) ? &gw->fb : nullptr;
+    TRH_TRY(b.ensure(n * 32)); TRH_TRY(sp.ensure((n + 2) * 32)); TRH_TRY(pp.ensure(n * 32)); TRH_TRY(wgt.ensure(n * 32)); TRH_TRY(lrsc.ensure(2 * (n + 2) * 32));
+    if (!with_u) { TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * ZREC)); }
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
     // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended
@@ -322,6 +327,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     FeMem sbm = stm(s_blind);
     TRH_HIP_TRY(hipMemcpy((char*)sp.p + n * 32, &sbm, 32, hipMemcpyHostToDevice));
     u64 pt[12];
+    if (fb) {  // the scalar of u is zero: the full-range (table) path
+        TRH_HIP_TRY(hipMemsetAsync((char*)sp.p + (n + 1) * 32, 0, 32, s));
+        TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 2, 1, n + 2, 1, s, fb));
+    } else
     TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
     TRH_TRY(msm_finish(curve, s, pt, 1));
     tr->write_point(tr->ctx, pt);
@@ -342,9 +351,16 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // g (n points) followed by w and u, so that [rand] W + [value z] U ride in the same MSM as the main sum
     FeMem one_m = stm(fe_one<SF>());
     TRH_TRY((powers_t<SF>(wgt.p, n, (const u64*)&one_m, s)));  // all ones
-    TRH_HIP_TRY(hipMemcpyAsync(gwu.p, gw->d_xy, (n + 1) * 64, hipMemcpyDeviceToDevice, s));
-    TRH_HIP_TRY(hipMemcpy((char*)gwu.p + (n + 1) * 64, u_xy, 64, hipMemcpyHostToDevice));
-    TRH_TRY(msm_convert_bases(curve, gwu.p, gwuz.p, n + 2, s));
+    const void* round_xy = gw->d_xy;
+    const void* round_z = nullptr;
+    if (!with_u) {
+        TRH_HIP_TRY(hipMemcpyAsync(gwu.p, gw->d_xy, (n + 1) * 64, hipMemcpyDeviceToDevice, s));
+        TRH_HIP_TRY(hipMemcpy((char*)gwu.p + (n + 1) * 64, u_xy, 64, hipMemcpyHostToDevice));
+        TRH_TRY(msm_convert_bases(curve, gwu.p, gwuz.p, n + 2, s));
+        round_xy = gwu.p; round_z = gwuz.p;
+    } else if (!fb) {
+        round_z = gw->d_z;  // the handle's converted copy when it has one; otherwise the MSM converts per call
+    }
     const size_t stride = n + 2;
 
     // the round MSMs are batches of two with half of the scalars zero: their time is the latency of the sort / reduction chain,
@@ -353,7 +369,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         int& slot; int saved;
         WindowGuard(int& s_, int v) : slot(s_), saved(s_) { if (!saved) slot = v; }
         ~WindowGuard() { slot = saved; }
-    } window_guard(ctx().window_override, (k >= 16 && k <= 18) ? (int)k - 8 : 0);  // k = 20: the table's 15 is better again (60 vs 68 ms)
+    } window_guard(ctx().window_override, (!fb && k >= 16 && k <= 18) ? (int)k - 8 : 0);  // k = 20: the table's 15 is better again (60 vs 68 ms)
 
     for (uint32_t j = 0; j < k; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
@@ -377,7 +393,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             TRH_HIP_TRY(hipMemcpyAsync((char*)lrsc.p + (side * stride + n) * 32, d_tail, 64, hipMemcpyDeviceToDevice, s));
         }
         u64 lrb[24], lr[2][12];
-        TRH_TRY(msm_enqueue(curve, gwu.p, gwuz.p, lrsc.p, n + 2, 2, stride, 1, s));
+        TRH_TRY(msm_enqueue(curve, round_xy, round_z, lrsc.p, n + 2, 2, stride, 1, s, fb));
         TRH_TRY(msm_finish(curve, s, lrb, 2));
         memcpy(lr[0], lrb, 96); memcpy(lr[1], lrb + 12, 96);
         tr->write_point(tr->ctx, lr[0]);
@@ -488,12 +504,17 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
     TRH_TRY(require_init());
     if (!g_w || !u_xy || !p_poly_dev || !p_blind || !x3 || !s_poly_dev || !s_blind || !transcript || !rng ||
         !transcript->write_point || !transcript->write_scalar || !transcript->squeeze_challenge_scalar) { set_error("ipa_create_proof: null pointer"); return TRH_EINVAL; }
-    if (k > 26 || g_w->n != ((size_t)1 << k) + 1) { set_error("ipa_create_proof: bases must hold g (2^k points) followed by w"); return TRH_EINVAL; }
+    if (k > 26 || (g_w->n != ((size_t)1 << k) + 1 && g_w->n != ((size_t)1 << k) + 2)) { set_error("ipa_create_proof: bases must hold g (2^k points) followed by w (and optionally u)"); return TRH_EINVAL; }
     if (!g_w->shards.empty()) { set_error("ipa_create_proof: needs a base set on one device (the rounds are sequential: SURVEY 8e)"); return TRH_EINVAL; }
     TRH_ENTER(stream);
     Range range("trh_ipa_create_proof");
     if (g_w->owner && g_w->owner->device != ctx().device) { set_error("ipa_create_proof: the base set lives on another device than the calling context"); return TRH_EINVAL; }
     if (ctx().msm.pending_curve >= 0) { set_error("ipa_create_proof: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
+    if (g_w->n == ((size_t)1 << k) + 2) {  // g || w || u: the resident u must be the caller's
+        uint64_t last[8];
+        TRH_HIP_TRY(hipMemcpy(last, (const char*)g_w->d_xy + (g_w->n - 1) * 64, 64, hipMemcpyDeviceToHost));
+        if (memcmp(last, u_xy, 64) != 0) { set_error("ipa_create_proof: the last point of a g || w || u base set differs from u"); return TRH_EINVAL; }
+    }
     if (g_w->curve == TRH_PALLAS)
         return ipa_create_proof_t<FqParams, FpParams>(TRH_PALLAS, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);
     return ipa_create_proof_t<FpParams, FqParams>(TRH_VESTA, g_w, u_xy, k, p_poly_dev, p_blind, x3, s_poly_dev, s_blind, transcript, rng, rng_ctx, (hipStream_t)stream, out_c, out_f);

@@ -49,7 +49,8 @@ def create_proof_native(params, rng, transcript, p_poly, p_blind: int, x3: int, 
     s_dev = torch.from_numpy(np.ascontiguousarray(s_poly, dtype=np.uint64).view(np.int64).copy()).to(p_poly.device)
     out_c, out_f = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
     u = np.ascontiguousarray(params.u, dtype=np.uint64).reshape(8)
-    api._check(api.lib().trh_ipa_create_proof(params._g.handle, api._p(u), k, api._devptr(p_poly), api._p(_mont(sf, p_blind)), api._p(_mont(sf, x3)),
+    bases = params.ipa_bases() if hasattr(params, "ipa_bases") else params._g
+    api._check(api.lib().trh_ipa_create_proof(bases.handle, api._p(u), k, api._devptr(p_poly), api._p(_mont(sf, p_blind)), api._p(_mont(sf, x3)),
                                               api._devptr(s_dev), api._p(_mont(sf, s_blind)), ctypes.byref(tr), rn, None, _stream(p_poly),
                                               api._p(out_c), api._p(out_f)))
     return _canon(sf, out_c), _canon(sf, out_f)

@@ -17,6 +17,8 @@ assertions as the Rust types:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import api
@@ -183,6 +185,27 @@ class Params:
                 b.precompute(0)
             except api.TrhError:
                 pass
+        self._ipa = None
+        self.ipa_bases()
+
+    def ipa_bases(self):
+        """g || w || u as ONE resident set with fixed-base tables: `trh_ipa_create_proof` then runs every MSM of the opening in
+        fixed-base mode (csrc/ipa.hip).  Built on first use (a download of g || w, an upload, the table kernel: once per Params);
+        falls back to the g || w set when u is unknown or the tables do not fit."""
+        cached = getattr(self, "_ipa", None)
+        if cached is not None:
+            return cached
+        self._ipa = self._g
+        u = getattr(self, "u", None)
+        if u is not None and int(api.lib().trh_bases_precomputed_window_bits(self._g.handle)) != 0:  # only for Params that use tables at all
+            gwu = np.concatenate([self._g.download(), np.ascontiguousarray(u, dtype=np.uint64).reshape(1, 8)])
+            b = api.Bases.from_host(self.curve, gwu)
+            try:
+                b.precompute(int(os.environ.get("TRH_IPA_TABLE_BITS", "0")))
+                self._ipa = b
+            except api.TrhError:
+                pass
+        return self._ipa
 
     @staticmethod
     def g_lagrange_from_g(curve: str, k: int, g_dev):

@@ -144,6 +144,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     t_pre = time.perf_counter()
     if precompute:
         params.precompute()
+        params.ipa_bases()  # the opening's resident set g || w || u with its own table
     torch.cuda.synchronize()
     precompute_ms = (time.perf_counter() - t_pre) * 1e3
 

@@ -17,6 +17,8 @@ params.curve, params.k, params.n = curve, k, n
 params._g = g
 params.w = g.download(n, 1)
 params.u = api.Bases.generate(curve, 4242, 1, 1).download()
+if len(sys.argv) <= 2 and os.environ.get("TRH_IPA_TABLES", "1") != "0":
+    g.precompute(0)  # Params use tables: ipa_bases() then builds g || w || u with its own table
 m = poly._MODULUS["fp"]
 p_dev = torch.from_numpy(synth.field_elements(0x1FA, n).view(np.int64)).cuda()
 s_h = synth.field_elements(0x5A, n)
