@@ -200,7 +200,7 @@ int trh_bases_fold_dev(int curve, void* g_lo_dev, const void* g_hi_dev, size_t h
  * challenge cross the boundary, through the caller's transcript (BLAKE2b on the Rust side) and
  * randomness callbacks.  g_w: resident bases g (2^k points) followed by w -- or g, w and u (2^k + 2 points; the last one must
  * equal u_xy): with fixed-base tables attached to that set (trh_bases_precompute, once per Params) every MSM of the opening runs
- * in fixed-base mode (k = 18: 20 -> 16 ms).  u_xy: Params.u;
+ * in fixed-base mode (k = 18: 20 -> 15.5 ms).  u_xy: Params.u;
  * p_poly_dev / s_poly_dev: 2^k coefficients in device memory (s_poly: the caller's random polynomial,
  * its constant term is adjusted here so that s(x3) = 0); scalars are Montgomery limbs.
  * Writes to the transcript exactly what the Rust prover writes: S, then L_j, R_j per round, then c, f.

@@ -171,6 +171,42 @@ __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __rest
     if (threadIdx.x == 0) st<F>(partial + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), sh[0]);
 }
 
+// The two tail scalars of both round MSMs without a trip to the host: [rand] W comes from the staged draws, [value z] U from the
+// inner products' partial sums (the host never needs `value`).  Block `side` writes row `side` of the scalar matrix.
+template <class F>
+__global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const uint4* __restrict__ consts /* rand_l, rand_r, z */,
+                                                              uint4* __restrict__ lrsc, size_t n, size_t stride) {
+    __shared__ Fe<F> sh[256];
+    const u32 side = blockIdx.x;
+    const uint4* p = partial + 2 * (size_t)side * count;
+    Fe<F> acc = fe_zero<F>();
+    for (u32 i = threadIdx.x; i < count; i += 256) acc = fe_add(acc, ld<F>(p + 2 * i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st<F>(lrsc + 2 * (side * stride + n), ld<F>(consts + 2 * side));
+        st<F>(lrsc + 2 * (side * stride + n + 1), fe_mul(sh[0], ld<F>(consts + 4)));
+    }
+}
+// the folds of a round in one launch: p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] (i < half) and the generators' weights
+// (x u where bit log2(half) of the index is set); consts = (u^-1, u)
+template <class F>
+__global__ void __launch_bounds__(256) ipa_round_update_kernel(uint4* __restrict__ p, uint4* __restrict__ b, uint4* __restrict__ wgt, size_t n, size_t half, u32 bit,
+                                                               const uint4* __restrict__ consts) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const Fe<F> u = ld<F>(consts + 2);
+    if ((idx >> bit) & 1u) st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), u));
+    if (idx < half) {
+        st<F>(p + 2 * idx, fe_add(ld<F>(p + 2 * idx), fe_mul(ld<F>(p + 2 * (half + idx)), ld<F>(consts))));
+        st<F>(b + 2 * idx, fe_add(ld<F>(b + 2 * idx), fe_mul(ld<F>(b + 2 * (half + idx)), u)));
+    }
+}
+
 template <class F>
 int inner_product_t(const void* a, const void* b, size_t n, hipStream_t s, u64* out) {
     Ctx& c = ctx();
@@ -371,6 +407,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         ~WindowGuard() { slot = saved; }
     } window_guard(ctx().window_override, (!fb && k >= 16 && k <= 18) ? (int)k - 8 : 0);  // k = 20: the table's 15 is better again (60 vs 68 ms)
 
+    // per round: the scalar rows, both inner products and the tail scalars are three launches behind one staged 96-byte constant
+    // block (no host synchronisation before the MSM: the host never needs value_l / value_r), the MSM, the transcript, then ONE
+    // launch for the three folds.  (The first version had 14 small operations and two synchronisations per round.)
+    FeMem zm = stm(z);
     for (uint32_t j = 0; j < k; ++j) {
         const size_t half = (size_t)1 << (k - j - 1);
         const u32 bit = k - j - 1;
@@ -378,19 +418,20 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         char* bh = (char*)b.p + half * 32;
         // scalars of L_j (row 0) and R_j (row 1) over the bases g ‖ w ‖ u
         hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit, stride);
-        TRH_HIP_TRY(hipGetLastError());
-        Fe<SF> val[2], rnd[2];
-        FeMem ips[2];
-        TRH_TRY((inner_product2_t<SF>(pph, b.p, pp.p, bh, half, s, (u64*)ips)));
-        val[0] = fe_load<SF>(ips[0]);
-        val[1] = fe_load<SF>(ips[1]);
+        Fe<SF> rnd[2];
         rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
-        for (int side = 0; side < 2; ++side) {
-            FeMem tail[2] = {stm(rnd[side]), stm(fe_mul(val[side], z))};  // [rand] W + [value z] U
-            void* d_tail;
-            TRH_TRY(stage_constant(tail, 64, s, &d_tail));  // through the pinned ring: no synchronisation
-            TRH_HIP_TRY(hipMemcpyAsync((char*)lrsc.p + (side * stride + n) * 32, d_tail, 64, hipMemcpyDeviceToDevice, s));
+        {
+            unsigned blocks = (unsigned)((half + 255) / 256);
+            if (blocks > 512) blocks = 512;
+            TRH_TRY(ctx().io.ensure((size_t)(2 * blocks + 2) * 32));
+            uint4* partial = ctx().io.as<uint4>();
+            hipLaunchKernelGGL((inner_product2_kernel<SF>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)pph, (const uint4*)b.p, (const uint4*)pp.p, (const uint4*)bh, half, partial);
+            FeMem cst[3] = {stm(rnd[0]), stm(rnd[1]), zm};
+            void* d_cst;
+            TRH_TRY(stage_constant(cst, sizeof(cst), s, &d_cst));  // through the pinned ring: no synchronisation
+            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, (const uint4*)d_cst, (uint4*)lrsc.p, n, stride);
+            TRH_HIP_TRY(hipGetLastError());
         }
         u64 lrb[24], lr[2][12];
         TRH_TRY(msm_enqueue(curve, round_xy, round_z, lrsc.p, n + 2, 2, stride, 1, s, fb));
@@ -402,13 +443,11 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const Fe<SF> u_j = fe_load<SF>(tmp);
         if (fe_is_zero(u_j)) { set_error("ipa_create_proof: round %u challenge is zero (the Rust prover's u_j.invert().unwrap() panics here)", j); return TRH_EINVAL; }
         const Fe<SF> u_inv = fe_inv(u_j);
-        TRH_TRY((axpy_t<SF>(pp.p, pph, half, stm(u_inv), s)));
-        TRH_TRY((axpy_t<SF>(b.p, bh, half, stm(u_j), s)));
         {
-            FeMem ujm = stm(u_j);
-            void* d_u;
-            TRH_TRY(stage_constant(&ujm, 32, s, &d_u));
-            hipLaunchKernelGGL((ipa_weights_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)wgt.p, n, bit, (const uint4*)d_u);
+            FeMem cst[2] = {stm(u_inv), stm(u_j)};
+            void* d_cst;
+            TRH_TRY(stage_constant(cst, sizeof(cst), s, &d_cst));
+            hipLaunchKernelGGL((ipa_round_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)pp.p, (uint4*)b.p, (uint4*)wgt.p, n, half, bit, (const uint4*)d_cst);
             TRH_HIP_TRY(hipGetLastError());
         }
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
