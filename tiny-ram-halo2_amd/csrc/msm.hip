@@ -322,7 +322,9 @@ constexpr int BIN_THREADS = 1024;
 constexpr int BIN_PER_MAX = 36;                        // entries per thread, kept in registers from the load to the last pass
 constexpr u32 BIN_CAP_MAX = BIN_THREADS * BIN_PER_MAX; // 36864 entries
 // (Tried: a stage of half a bin filled in two passes, two 512-thread workgroups per CU so that one loads while the other
-// scatters -- 72 entries per thread spill and the sort went from 1.61 to 2.29 ms at 2^24.)
+// scatters -- 72 entries per thread spill and the sort went from 1.61 to 2.29 ms at 2^24.  Round 2: a workgroup taking 8 consecutive
+// bins with the NEXT bin's 36 entries per thread in flight in a second register array while the current bin is sorted in the LDS:
+// 128 VGPRs + 132 B of scratch, sort 1.66 -> 1.73 ms -- the register arrays, not the unoverlapped loads, are what it costs.)
 __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts, const u32* __restrict__ bin_ends,
                                                                    u32* __restrict__ sorted, u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2, u32 nbins,
                                                                    int idx_bits, u32 nbk, const u32* __restrict__ oversize) {
