@@ -168,6 +168,43 @@ def test_ipa_proof_verifies(curve, k):
     assert not o.ipa_verify_proof(*args, x3, v, pts[0], xi, z, rounds, ch, c, (f + 1) % fs.m)
 
 
+def test_ipa_base_set_forms_agree():
+    """trh_ipa_create_proof over g || w (the MSMs convert g || w || u per proof), over a resident g || w || u WITHOUT tables and over
+    one WITH fixed-base tables: the same transcript; a g || w || u set whose last point is not u is refused"""
+    curve, k = "pallas", 7
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    rnd = random.Random(0x1FA5E7)
+    g_l = cpu_ref.gen_bases(curve, 23, 11, n, threads=4)
+    w_l = cpu_ref.gen_bases(curve, 515152, 1, 1, threads=1)
+    u_l = cpu_ref.gen_bases(curve, 626263, 1, 1, threads=1)
+    p_l, s_l = synth.field_elements(0x1FA1, n), synth.field_elements(0x1FA2, n)
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    draws = [rnd.randrange(fs.m) for _ in range(2 * k)]
+
+    def run(params):
+        it = iter(draws)
+        tr = RecordingTranscript(fs.m)
+        c, f = ipa.create_proof_native(params, lambda: next(it), tr, to_dev(p_l), p_blind, x3, s_l, s_blind)
+        return c, f, [p.tolist() for p in tr.points], tr.challenges
+
+    plain = poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=False)
+    assert len(plain.ipa_bases()) == n + 1
+    want = run(plain)
+    gwu = np.concatenate([g_l, w_l, u_l])
+    no_table = poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=False)
+    no_table._ipa = api.Bases.from_host(curve, gwu)
+    assert run(no_table) == want
+    tables = poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=True)
+    assert len(tables.ipa_bases()) == n + 2 and int(api.lib().trh_bases_precomputed_window_bits(tables.ipa_bases().handle)) > 0
+    assert run(tables) == want
+    wrong = poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=False)
+    wrong._ipa = api.Bases.from_host(curve, np.concatenate([g_l, w_l, w_l]))
+    with pytest.raises(api.TrhError):
+        run(wrong)
+
+
 @pytest.mark.parametrize("curve,k", [("vesta", 5)])
 def test_multiopen_create_proof_vs_oracle(curve, k):
     """poly::multiopen::create_proof on resident polynomials (x1 folds per point set, kate_division, x2 fold, commitment, evaluations,
