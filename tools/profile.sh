@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-sweep"
+ARGS="--gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-check --no-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- python3 $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1

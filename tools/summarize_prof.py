@@ -37,8 +37,8 @@ def main():
                       "from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-sweep`",
-             "(1 warm-up + 3 timed 2^%d Pallas MSMs, then the 2^%d Fp NTT loop).  Durations in microseconds." % (msm_log_n, ntt_log_n), "",
+             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-check --no-sweep`",
+             "(2 warm-up + 8 timed 2^%d Pallas MSMs, then the 2^%d Fp NTT loop).  Durations in microseconds." % (msm_log_n, ntt_log_n), "",
              "| kernel | calls | total us | avg us | min us | max us | % | VGPR | SGPR | LDS B | scratch | grid | wg |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
