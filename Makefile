@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 # build id = hash of the library's sources (trh_version() reports it)
 BUILD_ID := $(shell cat $(CSRC)/*.hip $(CSRC)/*.h include/trh.h | sha1sum | cut -c1-12)
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-result
-OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o
+OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o $(CSRC)/hostio.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/ctx.h $(CSRC)/hostcombine.h include/trh.h
 
 all: $(PKG)/libtrh.so oracle examples/replay tests/native/multi_ctx_test
@@ -23,7 +23,7 @@ $(PKG)/libtrh.so: $(OBJS)
 
 # native (C++17, no Python) driver over include/trh.hpp
 examples/replay: examples/replay.cpp include/trh.hpp include/trh.h $(PKG)/libtrh.so
-	g++ -O2 -std=c++17 -Wall -Iinclude $< -o $@ -L$(PKG) -ltrh -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+	g++ -O2 -std=c++17 -Wall -Iinclude $< -o $@ -L$(PKG) -ltrh -pthread -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
 # native test of the context layer (device group, per-thread contexts); run by tests/test_gpu_native.py
 tests/native/multi_ctx_test: tests/native/multi_ctx_test.cpp include/trh.h $(PKG)/libtrh.so

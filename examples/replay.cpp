@@ -5,7 +5,9 @@
 // sizes and counts as tiny-ram-halo2_amd/replay.py, each kind self-checked once with the host arithmetic of trh.hpp
 // or against a second libtrh path (the bit-exact parity against the oracle lives in tests/).
 //
-//   ./examples/replay [--word-bits 16|32] [--batch 64] [--columns random|witness]   -> one JSON line, exit code 0 iff every check passed
+//   ./examples/replay [--word-bits 16|32] [--batch 64] [--columns random|witness] [--mode resident|dropin|dropin-batched] [--max-columns N]
+//   -> one JSON line, exit code 0 iff every check passed.  `--mode dropin*`: the polynomials stay in host memory and cross PCIe inside
+//   the host-pointer entries (run_dropin below)
 // `--columns witness`: the value classes the reference's tables hold (flags / WORD_BITS-bit words on the n / 4 live rows, zero padding,
 // blinding rows; /root/reference/src/circuits/tables/exe.rs:538-741, tables/prog.rs:139-161) instead of uniformly random columns.
 // Besides the per-proof schedule the driver replays keygen_vk / keygen_pk (fixed and sigma columns, the l0 / l_blind / l_last cosets:
@@ -16,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 
 #include "trh.hpp"
 
@@ -110,18 +113,198 @@ Limbs eval_host(Field f, const Expr& e, const std::vector<std::vector<Limbs>>& c
     }
 }
 
+// c[i] = a[i] * f[i % period] over `threads` host threads: the pointwise steps EvaluationDomain does on the Rust host between
+// its best_fft calls (x n^-1 after the inverse transform, the zeta shift before the coset transform)
+void host_scale(Field f, Limbs* a, size_t n, const Limbs* factors, size_t period) {
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([=] { for (size_t i = n * t / T; i < n * (t + 1) / T; ++i) a[i] = host::mul(f, a[i], factors[i % period]); });
+    for (auto& t : th) t.join();
+}
+
+// --mode dropin / dropin-batched: every polynomial lives in HOST memory (separate allocations, as the Rust prover's Vec<F>s) and
+// crosses PCIe inside the libtrh calls; see tiny-ram-halo2_amd/replay.py::run_dropin for the two levels.  Here the compiled host
+// also does EvaluationDomain's pointwise steps itself (timed apart as host_pointwise_ms), so the values ARE the prover's and the two
+// levels can be checked against each other: same commitments, same coefficient forms, same extended cosets.
+int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_columns) {
+    init(0);
+    const uint32_t k = 2 + word_bits / 2;
+    const size_t n = (size_t)1 << k;
+    const Curve curve = Curve::Vesta;
+    const Field field = scalar_field(curve);
+    EvaluationDomain dom(field, QUOTIENT_J, k);
+    const uint32_t ek = dom.extended_k;
+    const size_t N = dom.extended_len();
+    Params params(curve, k, 0x1234567, 0x89abcdef, true);
+    int lag_total = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS;
+    if (max_columns > 0 && max_columns < lag_total) lag_total = max_columns;
+    if (batch > (size_t)lag_total) batch = lag_total;
+    std::vector<std::pair<Kind, bool>> kinds;
+    for (const ColumnClass& c : WITNESS_CLASSES) for (int i = 0; i < c.count; ++i) kinds.push_back({c.kind, c.blinded});
+    const Limbs omega_inv = dom.constant(1), ext_omega = dom.constant(2), ext_omega_inv = dom.constant(3), ifft_div = dom.constant(4), ext_div = dom.constant(5);
+    const Limbs zeta = dom.constant(6), zeta2 = dom.constant(7);
+    const Limbs into_coset[3] = {host::one(field), zeta, zeta2};
+    SplitMix rng{0xc01};
+    double ms_commit = 0, ms_intt = 0, ms_ext = 0, ms_commit_coeff = 0, ms_ext_inv = 0, ms_ipa = 0, ms_host = 0;
+    std::vector<std::vector<Limbs>> cols(batch, std::vector<Limbs>(n)), exts(batched ? batch : 2, std::vector<Limbs>(N));
+    std::vector<Limbs> blinds(batch);
+    DeviceBuffer scratch(batch * n * 32);
+    trh_io_stats_t io0;
+    check(trh_io_stats(&io0, 1), "io_stats");
+    // cross-check state: the first batch is replayed through BOTH levels
+    for (int done = 0; done < lag_total; done += (int)batch) {
+        const size_t b = std::min(batch, (size_t)(lag_total - done));
+        for (size_t c = 0; c < b; ++c) {
+            if (!witness) { for (size_t i = 0; i < n; ++i) cols[c][i] = rng.element(); continue; }
+            fill_witness_column(kinds[done + c].first, kinds[done + c].second, rng, word_bits, n, cols[c].data());
+            scratch.upload(cols[c].data(), n * 32);  // canonical small integers -> field elements (input preparation, not the replayed path)
+            check(trh_field_op_dev((int)field, 6, scratch.data(), nullptr, scratch.data(), n, nullptr), "to_mont");
+            scratch.download(cols[c].data(), n * 32);
+        }
+        for (size_t i = 0; i < b; ++i) blinds[i] = rng.element();
+        std::vector<Point> pts(b);
+        const bool cross = done == 0;
+        std::vector<std::vector<Limbs>> keep;  // the first three Lagrange columns, for the cross-check of the other level
+        if (cross) for (size_t c = 0; c < std::min<size_t>(3, b); ++c) keep.push_back(cols[c]);
+        if (!batched) {
+            for (size_t c = 0; c < b; ++c) {
+                double t0 = now_ms();
+                pts[c] = params.commit_lagrange(cols[c], blinds[c]);
+                ms_commit += now_ms() - t0;
+                t0 = now_ms();
+                best_fft(field, cols[c], omega_inv, k);
+                ms_intt += now_ms() - t0;
+                t0 = now_ms();
+                host_scale(field, cols[c].data(), n, &ifft_div, 1);
+                std::vector<Limbs>& e = exts[c & 1];
+                std::fill(e.begin() + n, e.end(), Limbs{0, 0, 0, 0});
+                std::copy(cols[c].begin(), cols[c].end(), e.begin());
+                host_scale(field, e.data(), n, into_coset, 3);
+                ms_host += now_ms() - t0;
+                t0 = now_ms();
+                best_fft(field, e, ext_omega, ek);
+                ms_ext += now_ms() - t0;
+                if (cross && c < keep.size()) {  // the batched level on the same column: identical point, coefficients and coset
+                    std::vector<Limbs> a = keep[c], x(N);
+                    std::vector<const std::vector<Limbs>*> in1{&a};
+                    std::vector<std::vector<Limbs>*> io1{&a}, out1{&x};
+                    const Point p2 = params.commit_lagrange_batch_host(in1, {blinds[c]})[0];
+                    expect(std::memcmp(&p2, &pts[c], sizeof(Point)) == 0, "literal commit_lagrange == trh_commit_batch_host");
+                    dom.lagrange_to_coeff_host(io1);
+                    expect(a == cols[c], "best_fft + host x n^-1 == trh_domain_lagrange_to_coeff_host");
+                    dom.coeff_to_extended_host(in1, out1);
+                    expect(x == e, "host zero-pad + zeta shift + best_fft == trh_domain_coeff_to_extended_host");
+                }
+            }
+        } else {
+            std::vector<const std::vector<Limbs>*> in;
+            std::vector<std::vector<Limbs>*> io, out;
+            for (size_t c = 0; c < b; ++c) { in.push_back(&cols[c]); io.push_back(&cols[c]); out.push_back(&exts[c]); }
+            double t0 = now_ms();
+            pts = params.commit_lagrange_batch_host(in, std::vector<Limbs>(blinds.begin(), blinds.begin() + b));
+            double t1 = now_ms();
+            dom.lagrange_to_coeff_host(io);
+            double t2 = now_ms();
+            dom.coeff_to_extended_host(in, out);
+            double t3 = now_ms();
+            ms_commit += t1 - t0; ms_intt += t2 - t1; ms_ext += t3 - t2;
+            if (cross) {  // the literal level on the first column
+                std::vector<Limbs> a = keep[0];
+                const Point p1 = params.commit_lagrange(a, blinds[0]);
+                expect(std::memcmp(&p1, &pts[0], sizeof(Point)) == 0, "trh_commit_batch_host == literal commit_lagrange");
+                best_fft(field, a, omega_inv, k);
+                host_scale(field, a.data(), n, &ifft_div, 1);
+                expect(a == cols[0], "trh_domain_lagrange_to_coeff_host == best_fft + host x n^-1");
+                std::vector<Limbs> e(N, Limbs{0, 0, 0, 0});
+                std::copy(a.begin(), a.end(), e.begin());
+                host_scale(field, e.data(), n, into_coset, 3);
+                best_fft(field, e, ext_omega, ek);
+                expect(e == exts[0], "trh_domain_coeff_to_extended_host == host zero-pad + zeta shift + best_fft");
+            }
+        }
+    }
+    // coefficient-basis commits (random vanishing polynomial + h pieces)
+    const size_t ncoef = 1 + N_H_PIECES;
+    std::vector<std::vector<Limbs>> cf(ncoef, std::vector<Limbs>(n));
+    for (auto& c : cf) for (auto& v : c) v = rng.element();
+    std::vector<Limbs> bl(ncoef);
+    for (auto& v : bl) v = rng.element();
+    {
+        const double t0 = now_ms();
+        if (!batched) for (size_t c = 0; c < ncoef; ++c) (void)params.commit(cf[c], bl[c]);
+        else { std::vector<const std::vector<Limbs>*> in; for (auto& c : cf) in.push_back(&c); (void)params.commit_batch_host(in, bl); }
+        ms_commit_coeff = now_ms() - t0;
+    }
+    // h(X): 2^extended_k values back from the host's gate evaluation
+    {
+        std::vector<Limbs> h(N);
+        for (auto& v : h) v = rng.element();
+        std::vector<Limbs> h2 = h;
+        const double t0 = now_ms();
+        if (!batched) best_fft(field, h, ext_omega_inv, ek); else dom.extended_to_coeff_host(h, false);
+        ms_ext_inv = now_ms() - t0;
+        // cross-check: literal + the host's pointwise tail == the domain form
+        const Limbs from_div[3] = {ext_div, host::mul(field, ext_div, zeta2), host::mul(field, ext_div, zeta)};
+        if (!batched) { host_scale(field, h.data(), N, from_div, 3); dom.extended_to_coeff_host(h2, false); }
+        else { best_fft(field, h2, ext_omega_inv, ek); host_scale(field, h2.data(), N, from_div, 3); }
+        expect(h == h2, "extended_to_coeff: best_fft + host tail == trh_domain_extended_to_coeff_host");
+    }
+    // the opening
+    {
+        std::vector<Limbs> p(n), sp(n);
+        for (auto& v : p) v = rng.element();
+        for (auto& v : sp) v = rng.element();
+        const double t0 = now_ms();
+        if (!batched) {  // commitment::create_proof on the host: S, then two best_multiexp per round over the folded generators (host bases)
+            (void)params.commit(sp, rng.element());
+            const std::vector<Affine> g = params.g().download();
+            for (uint32_t j = 0; j < k; ++j) {
+                const size_t half = (size_t)1 << (k - j - 1);
+                (void)best_multiexp(curve, std::vector<Limbs>(p.begin() + half, p.begin() + 2 * half), std::vector<Affine>(g.begin(), g.begin() + half));
+                (void)best_multiexp(curve, std::vector<Limbs>(p.begin(), p.begin() + half), std::vector<Affine>(g.begin() + half, g.begin() + 2 * half));
+            }
+        } else {
+            DeviceBuffer pd(n * 32), sd(n * 32);
+            pd.upload(p.data(), n * 32); sd.upload(sp.data(), n * 32);
+            Transcript tr;
+            trh_transcript_t tcb{&tr, tr_write_point, tr_write_scalar, tr_squeeze};
+            SplitMix prng{0x99};
+            (void)ipa_create_proof(params, pd, rng.element(), rng.element(), sd, rng.element(), tcb, rng_scalar, &prng);
+        }
+        ms_ipa = now_ms() - t0;
+    }
+    trh_io_stats_t io;
+    check(trh_io_stats(&io, 0), "io_stats");
+    const double total = ms_commit + ms_intt + ms_ext + ms_commit_coeff + ms_ext_inv + ms_ipa;
+    std::printf("{\"driver\": \"examples/replay.cpp\", \"mode\": \"%s\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"columns_replayed\": %d, \"checks_failed\": %d, "
+                "\"wall_ms_incl_pcie\": {\"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"commit\": %.3f, \"extended_to_coeff\": %.3f, \"ipa\": %.3f}, "
+                "\"wall_ms_incl_pcie_total\": %.3f, \"host_pointwise_ms\": %.3f, \"pcie\": {\"h2d_GB\": %.3f, \"d2h_GB\": %.3f, \"h2d_GBps_in_copies\": %.2f, \"d2h_GBps_in_copies\": %.2f, "
+                "\"GBps_over_call_time\": %.2f, \"link_peak_GBps_per_direction\": 57.0}}\n",
+                batched ? "dropin-batched" : "dropin-literal", word_bits, k, batch, witness ? "witness" : "random", lag_total, failures, ms_commit, ms_intt, ms_ext, ms_commit_coeff, ms_ext_inv, ms_ipa, total,
+                ms_host, io.h2d_bytes / 1e9, io.d2h_bytes / 1e9, io.h2d_bytes / std::max(io.h2d_seconds, 1e-9) / 1e9, io.d2h_bytes / std::max(io.d2h_seconds, 1e-9) / 1e9,
+                (io.h2d_bytes + io.d2h_bytes) / std::max(total * 1e-3, 1e-9) / 1e9);
+    trh_shutdown();
+    return failures ? 1 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     int word_bits = 32;
     size_t batch = 64;
     bool witness = false;
+    std::string mode = "resident";
+    int max_columns = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
         else if (std::string(argv[i]) == "--batch") batch = (size_t)std::atol(argv[i + 1]);
         else if (std::string(argv[i]) == "--columns") witness = std::string(argv[i + 1]) == "witness";
+        else if (std::string(argv[i]) == "--mode") mode = argv[i + 1];
+        else if (std::string(argv[i]) == "--max-columns") max_columns = std::atoi(argv[i + 1]);
     }
     try {
+        if (mode == "dropin" || mode == "dropin-batched") return run_dropin(word_bits, batch, witness, mode == "dropin-batched", max_columns);
         init(0);
         const uint32_t k = 2 + word_bits / 2;
         const size_t n = (size_t)1 << k;

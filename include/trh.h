@@ -77,6 +77,7 @@ const char* trh_version(void);       /* "trh <version> (gfx950, build <hash of t
  * the host.  Device-resident scalars (trh_msm_dev) are handed to the other GPUs with peer copies.                    */
 int trh_init_multi(const int* devices, int n_devices);
 int trh_group_size(void);
+int trh_group_peer_access(void);  /* 1: every pair of distinct group devices has peer access; 0: some pair has not (trh_last_error() after trh_init_multi names the first) */
 int trh_set_shard_min(size_t n_points);
 
 /* ---- explicit contexts (see "Threading and contexts" above) ------------------------------------------------------- */
@@ -88,7 +89,8 @@ int trh_ctx_device(trh_ctx_t ctx_or_null);       /* device index of the context 
 
 /* ---- halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------------
  * coeffs: n x 4 u64 (scalar field, Montgomery -- the memory image of `&[C::Scalar]`),
- * bases: n x 8 u64 affine, out: 12 u64.  Host pointers; data is copied to the device.     */
+ * bases: n x 8 u64 affine, out: 12 u64.  Host pointers: the pairs cross PCIe in ranges, range t + 1 while range t is
+ * computed (96 B per pair: bound by the link, 2^24 pairs in ~max(link, 17 ms)).             */
 int trh_best_multiexp_pallas(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
 int trh_best_multiexp_vesta(const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t out_xyz[12]);
 
@@ -97,6 +99,25 @@ int trh_best_multiexp_vesta(const uint64_t* coeffs, const uint64_t* bases, size_
  * primitive 2^log_n-th root of unity (what EvaluationDomain passes).  Host pointers.       */
 int trh_best_fft_fp(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
 int trh_best_fft_fq(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+
+/* the same for `count` host slices with one omega (one pointer per column): the uploads, transforms and downloads of
+ * consecutive columns overlap on three streams (the link carries both directions at once); results as `count` single calls */
+int trh_best_fft_batch_fp(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n);
+int trh_best_fft_batch_fq(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n);
+
+/* ---- host memory of the host-pointer entry points.  A pageable slice crosses PCIe through the library's pinned rings
+ * (csrc/hostio.hip).  A caller that keeps long-lived buffers (Params.g_lagrange, a polynomial arena) may page-lock them once --
+ * trh_host_register on memory it owns, or trh_host_alloc -- and the DMA engine then reads / writes them directly.
+ * trh_io_stats: bytes moved by the host-pointer entry points on the calling thread's context and the host seconds spent in
+ * the copies, per direction (overlapping copies each count their own time); reset != 0 clears the counters.              */
+int trh_host_register(void* host, size_t bytes);
+int trh_host_unregister(void* host);
+int trh_host_alloc(void** host, size_t bytes);
+int trh_host_free(void* host);
+typedef struct trh_io_stats {
+    double h2d_bytes, d2h_bytes, h2d_seconds, d2h_seconds;
+} trh_io_stats_t;
+int trh_io_stats(trh_io_stats_t* out, int reset);
 
 /* ---- device-resident base sets: poly::commitment::Params { g, g_lagrange, w } -------------
  * `Params::commit` / `commit_lagrange` run hundreds of MSMs over the same bases; upload once. */
@@ -141,6 +162,10 @@ int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev,
  * is read from its own small array, so the polynomials are not copied to make room for it.  blinds: batch x 4 u64, host. */
 int trh_commit_batch_dev(trh_bases_t bases, const void* polys_dev, size_t n, size_t batch, const uint64_t* blinds_host,
                          void* stream, uint64_t* out_xyz /* batch x 12 */);
+/* the same for polynomials in HOST memory (polys_host[b]: n scalars, Montgomery): the columns cross PCIe in chunks, chunk
+ * j + 1 while the batched MSM of chunk j runs */
+int trh_commit_batch_host(trh_bases_t bases, const uint64_t* const* polys_host, size_t n, size_t batch, const uint64_t* blinds_host,
+                          uint64_t* out_xyz /* batch x 12 */);
 /* window width override for tuning (0 = automatic) */
 int trh_msm_set_window_bits(int c); /* 0 or 2..18 */
 
@@ -178,6 +203,14 @@ int trh_domain_lagrange_to_coeff(trh_domain_t d, void* a_dev, size_t batch, void
 int trh_domain_coeff_to_extended(trh_domain_t d, const void* coeff_dev, void* ext_dev, size_t batch, void* stream);
 int trh_domain_extended_to_coeff(trh_domain_t d, void* a_dev, size_t batch, void* stream);            /* in place; caller truncates */
 int trh_domain_divide_by_vanishing_poly(trh_domain_t d, void* a_dev, size_t batch, void* stream);     /* in place */
+
+/* the same on HOST polynomials (one pointer per column; what the Rust EvaluationDomain's methods take), pipelined over PCIe:
+ * lagrange_to_coeff in place; coeff_to_extended reads 2^k coefficients and writes 2^extended_k values (only the non-zero
+ * coefficients go up); extended_to_coeff in place on one polynomial of 2^extended_k values, optionally preceded by
+ * divide_by_vanishing_poly (the two steps create_proof applies to h(X))                                                     */
+int trh_domain_lagrange_to_coeff_host(trh_domain_t d, uint64_t* const* a, size_t count);
+int trh_domain_coeff_to_extended_host(trh_domain_t d, const uint64_t* const* coeff, uint64_t* const* ext, size_t count);
+int trh_domain_extended_to_coeff_host(trh_domain_t d, uint64_t* a, int divide_by_vanishing_first);
 
 /* ---- IPA opening rounds: poly::commitment::prover::create_proof (device memory) ---------------
  * The two half-size MSMs of a round run through trh_msm_dev on the live G' buffer

@@ -128,6 +128,13 @@ inline void best_fft(Field f, std::vector<Limbs>& a, const Limbs& omega, uint32_
     check(fn((uint64_t*)a.data(), omega.data(), log_n), "best_fft");
 }
 
+// the same over a batch of host slices with one omega (pipelined over PCIe)
+inline void best_fft_batch(Field f, std::vector<std::vector<Limbs>*>& columns, const Limbs& omega, uint32_t log_n) {
+    std::vector<uint64_t*> ptrs;
+    for (auto* c : columns) { require(c->size() == (size_t)1 << log_n, "a.len() == 1 << log_n"); ptrs.push_back((uint64_t*)c->data()); }
+    check((f == Field::Fp ? trh_best_fft_batch_fp : trh_best_fft_batch_fq)(ptrs.data(), ptrs.size(), omega.data(), log_n), "best_fft_batch");
+}
+
 // ---- device memory -------------------------------------------------------------------------------------------
 class DeviceBuffer {
 public:
@@ -204,6 +211,9 @@ public:
     // `batch` polynomials of n coefficients back to back in device memory
     std::vector<Point> commit_batch(const DeviceBuffer& polys, size_t batch, const std::vector<Limbs>& blinds, void* stream = nullptr) const { return commit_dev(g_, polys, batch, blinds, stream); }
     std::vector<Point> commit_lagrange_batch(const DeviceBuffer& polys, size_t batch, const std::vector<Limbs>& blinds, void* stream = nullptr) const { return commit_dev(g_lagrange_, polys, batch, blinds, stream); }
+    // the same for polynomials in HOST memory, one vector per column (trh_commit_batch_host: chunked uploads under the MSMs)
+    std::vector<Point> commit_batch_host(const std::vector<const std::vector<Limbs>*>& polys, const std::vector<Limbs>& blinds) const { return commit_hosts(g_, polys, blinds); }
+    std::vector<Point> commit_lagrange_batch_host(const std::vector<const std::vector<Limbs>*>& polys, const std::vector<Limbs>& blinds) const { return commit_hosts(g_lagrange_, polys, blinds); }
     const Bases& g() const { return g_; }
     const Bases& g_lagrange() const { return g_lagrange_; }
     const Bases& ipa_bases() const { return ipa_.handle() ? ipa_ : g_; }  // g || w || u with tables when precompute() built it
@@ -217,6 +227,14 @@ private:
         require(poly.size() == n, "poly.len() == params.n");
         std::vector<Limbs> sc(poly); sc.push_back(blind);
         return b.msm(sc);
+    }
+    std::vector<Point> commit_hosts(const Bases& b, const std::vector<const std::vector<Limbs>*>& polys, const std::vector<Limbs>& blinds) const {
+        require(blinds.size() == polys.size(), "one blind per polynomial");
+        std::vector<const uint64_t*> ptrs;
+        for (const auto* p : polys) { require(p->size() == n, "poly.len() == params.n"); ptrs.push_back((const uint64_t*)p->data()); }
+        std::vector<Point> out(polys.size());
+        check(trh_commit_batch_host(b.handle(), ptrs.data(), n, ptrs.size(), (const uint64_t*)blinds.data(), (uint64_t*)out.data()), "commit_batch_host");
+        return out;
     }
     std::vector<Point> commit_dev(const Bases& b, const DeviceBuffer& polys, size_t batch, const std::vector<Limbs>& blinds, void* stream) const {
         require(blinds.size() == batch && polys.size() >= batch * n * 32, "batch x n coefficients and one blind per polynomial");
@@ -243,6 +261,26 @@ public:
     void coeff_to_extended(const void* coeff_dev, void* ext_dev, size_t batch, void* stream = nullptr) const { check(trh_domain_coeff_to_extended(d_, coeff_dev, ext_dev, batch, stream), "coeff_to_extended"); }
     void extended_to_coeff(void* a_dev, size_t batch, void* stream = nullptr) const { check(trh_domain_extended_to_coeff(d_, a_dev, batch, stream), "extended_to_coeff"); }
     void divide_by_vanishing_poly(void* a_dev, size_t batch, void* stream = nullptr) const { check(trh_domain_divide_by_vanishing_poly(d_, a_dev, batch, stream), "divide_by_vanishing_poly"); }
+
+    // host polynomials, one vector per column (pipelined over PCIe): lagrange_to_coeff in place; coeff_to_extended 2^k -> 2^extended_k;
+    // extended_to_coeff in place on one polynomial, optionally preceded by divide_by_vanishing_poly (the caller truncates)
+    void lagrange_to_coeff_host(std::vector<std::vector<Limbs>*>& cols) const {
+        std::vector<uint64_t*> ptrs;
+        for (auto* c : cols) { require(c->size() == n, "a.len() == 1 << k"); ptrs.push_back((uint64_t*)c->data()); }
+        check(trh_domain_lagrange_to_coeff_host(d_, ptrs.data(), ptrs.size()), "lagrange_to_coeff_host");
+    }
+    void coeff_to_extended_host(const std::vector<const std::vector<Limbs>*>& coeff, std::vector<std::vector<Limbs>*>& ext) const {
+        require(coeff.size() == ext.size(), "one output per input");
+        std::vector<const uint64_t*> in;
+        std::vector<uint64_t*> out;
+        for (const auto* c : coeff) { require(c->size() == n, "a.len() == 1 << k"); in.push_back((const uint64_t*)c->data()); }
+        for (auto* e : ext) { require(e->size() == extended_len(), "ext.len() == 1 << extended_k"); out.push_back((uint64_t*)e->data()); }
+        check(trh_domain_coeff_to_extended_host(d_, in.data(), out.data(), in.size()), "coeff_to_extended_host");
+    }
+    void extended_to_coeff_host(std::vector<Limbs>& a, bool divide_by_vanishing_first = false) const {
+        require(a.size() == extended_len(), "a.len() == 1 << extended_k");
+        check(trh_domain_extended_to_coeff_host(d_, (uint64_t*)a.data(), divide_by_vanishing_first ? 1 : 0), "extended_to_coeff_host");
+    }
 
     Field field;
     uint32_t k, extended_k = 0;

@@ -56,8 +56,14 @@ int main() {
     trh_bases_t sharded = nullptr;
     OK(trh_bases_generate(TRH_PALLAS, 0x1234567, 0x89abcdef, 0, n, &sharded));
     EXPECT(trh_bases_shards(sharded) == (int)devs.size(), "sharded set");
+    int dev_before = -1, dev_after = -1;
+    EXPECT(hipGetDevice(&dev_before) == hipSuccess, "hipGetDevice");
     OK(trh_msm(sharded, 0, sc.data(), n, 1, got));
     EXPECT(same_point(ref, got), "trh_msm over the range-sharded set == single device");
+    // the shard scopes are left in reverse order -- the caller's HIP device and active context are what they were
+    EXPECT(hipGetDevice(&dev_after) == hipSuccess && dev_after == dev_before, "current device unchanged by a sharded MSM");
+    EXPECT(trh_ctx_device(nullptr) == devs[0], "calling thread still on the default context");
+    EXPECT(trh_group_peer_access() == 1 || ndev >= 2, "peer access flag");
     {   // sub-range that cuts through the shard boundary
         uint64_t a[12], b[12];
         const size_t off = n / 3, len = n / 2;
@@ -176,6 +182,48 @@ int main() {
         // the default context is still usable from the main thread afterwards
         OK(trh_msm(single, 0, sc.data(), n, 1, got));
         EXPECT(same_point(ref, got), "default context after the worker threads");
+    }
+
+    // ---- column-sharded commitments: one thread + one context per "GPU", each with its OWN copy of the
+    // Params bases, each committing its contiguous share of 64 host columns through trh_commit_batch_host; the commitments equal
+    // the single-context ones column by column (the per-column steps of create_proof shard without a collective)
+    {
+        const size_t cn = (size_t)1 << 12, ncols = 64;
+        trh_bases_t pb = nullptr;
+        OK(trh_bases_generate(TRH_VESTA, 0x1234567 + 77, 0x89abcdef + 2, 0, cn + 1, &pb));
+        std::vector<std::vector<uint64_t>> cols(ncols);
+        std::vector<const uint64_t*> ptrs(ncols);
+        for (size_t i = 0; i < ncols; ++i) { cols[i] = scalars(cn, 0xC01 + i); ptrs[i] = cols[i].data(); }
+        const std::vector<uint64_t> blinds = scalars(ncols, 0xB11D);
+        std::vector<uint64_t> want(12 * ncols), gotc(12 * ncols, 0);
+        for (size_t i = 0; i < ncols; ++i) {
+            std::vector<uint64_t> scb(cols[i]);
+            scb.insert(scb.end(), blinds.begin() + 4 * i, blinds.begin() + 4 * i + 4);
+            OK(trh_msm(pb, 0, scb.data(), cn + 1, 1, want.data() + 12 * i));
+        }
+        OK(trh_commit_batch_host(pb, ptrs.data(), cn, ncols, blinds.data(), gotc.data()));
+        EXPECT(gotc == want, "trh_commit_batch_host == per-column trh_msm");
+        const size_t G = devs.size();
+        std::vector<int> bad(G, 0);
+        std::fill(gotc.begin(), gotc.end(), 0);
+        std::vector<std::thread> th;
+        for (size_t gi = 0; gi < G; ++gi)
+            th.emplace_back([&, gi] {
+                trh_ctx_t cx = nullptr;
+                if (trh_ctx_create(devs[gi], &cx) != TRH_OK || trh_ctx_set_current(cx) != TRH_OK) { ++bad[gi]; return; }
+                trh_bases_t mine = nullptr;
+                if (trh_bases_generate(TRH_VESTA, 0x1234567 + 77, 0x89abcdef + 2, 0, cn + 1, &mine) != TRH_OK) { ++bad[gi]; return; }
+                const size_t per = (ncols + G - 1) / G, lo = gi * per, hi = lo + per < ncols ? lo + per : ncols;
+                if (hi > lo && trh_commit_batch_host(mine, ptrs.data() + lo, cn, hi - lo, blinds.data() + 4 * lo, gotc.data() + 12 * lo) != TRH_OK) ++bad[gi];
+                trh_bases_destroy(mine);
+                (void)trh_ctx_set_current(nullptr);
+                trh_ctx_destroy(cx);
+            });
+        for (std::thread& t : th) t.join();
+        int badsum = 0;
+        for (int b : bad) badsum += b;
+        EXPECT(badsum == 0 && gotc == want, "column-sharded commitments: one thread + context + Params copy per device");
+        trh_bases_destroy(pb);
     }
 
     trh_bases_destroy(sharded);

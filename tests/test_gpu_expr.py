@@ -142,6 +142,34 @@ def test_long_sums_force_inserted_reductions():
         assert from_dev(f, out[i]) == want, i
 
 
+def test_products_of_wide_sums_stay_inside_the_limbs():
+    """a value B m has the top limb B 2^22, so the operands and the result of a multiplication have to stay below 512 m
+    and the operand of a squaring below 256 m; trh_expr_create now bounds MUL / SQR operands as well.  S = c0 + .. + c6 with every
+    column m - 1 (bound 224 m): (S S) S, its square, the square of S S (393 m), cubes and products of such products"""
+    field, log_n = "fp", 3
+    f = o.FIELDS[field]
+    n = 1 << log_n
+    S = expr.Advice(0, 0)
+    for i in range(1, 7):
+        S = S + expr.Advice(i, 0)
+    P = S * S
+    Q = P * S
+    T = expr.Advice(0, 1)
+    for i in range(1, 7):
+        T = T - expr.Advice(i, 0)          # about -6 (m - 1): the negative side of the signed domain
+    gates = [Q, Q * Q, P * P, (P * P) * (P * P), P * P * P, (S * T) * (T * T), (P + S) * (Q - T), ((S * S) * (T * T)) * (S + T), -(Q * Q) + P]
+    for fill in (f.m - 1, 1, (f.m - 1) // 2):
+        ints = {("advice", c): [fill if (r + c) % 5 else f.m - 1 for r in range(n)] for c in range(7)}
+        dev = {k: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda() for k, col in ints.items()}
+        for y in (1, 0x1234567):
+            prog = expr.compile_gates(field, gates, y)
+            assert from_dev(f, expr.GateEvaluator(prog).eval(dev, log_n)) == o.evaluate_gates(f, [to_tuple(g) for g in gates], ints, y, n)
+        prog = expr.compile_outputs(field, gates[:4])
+        out = expr.GateEvaluator(prog, n_outputs=4).eval(dev, log_n)
+        for i in range(4):
+            assert from_dev(f, out[i]) == [o.evaluate_expression(f, to_tuple(gates[i]), ints, r, n, 1) for r in range(n)], i
+
+
 def test_program_validation():
     I = expr._Insn
     one = np.zeros((1, 4), np.uint64)

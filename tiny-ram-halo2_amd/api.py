@@ -59,6 +59,10 @@ class Timing(ctypes.Structure):
                 ("window_bits", ctypes.c_int), ("windows", ctypes.c_int), ("accumulate_kernel_ms", ctypes.c_float)]
 
 
+class IoStats(ctypes.Structure):
+    _fields_ = [("h2d_bytes", ctypes.c_double), ("d2h_bytes", ctypes.c_double), ("h2d_seconds", ctypes.c_double), ("d2h_seconds", ctypes.c_double)]
+
+
 _SIGNATURES = {
     "trh_init": ([ctypes.c_int], ctypes.c_int),
     "trh_shutdown": ([], None),
@@ -67,6 +71,7 @@ _SIGNATURES = {
     "trh_version": ([], ctypes.c_char_p),
     "trh_init_multi": ([ctypes.POINTER(ctypes.c_int), ctypes.c_int], ctypes.c_int),
     "trh_group_size": ([], ctypes.c_int),
+    "trh_group_peer_access": ([], ctypes.c_int),
     "trh_set_shard_min": ([ctypes.c_size_t], ctypes.c_int),
     "trh_ctx_create": ([ctypes.c_int, ctypes.POINTER(_vp)], ctypes.c_int),
     "trh_ctx_destroy": ([_vp], None),
@@ -135,6 +140,17 @@ _SIGNATURES = {
     "trh_memcpy_h2d": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
     "trh_memcpy_d2h": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
     "trh_stream_synchronize": ([_vp], ctypes.c_int),
+    "trh_best_fft_batch_fp": ([ctypes.POINTER(_u64p), ctypes.c_size_t, _u64p, ctypes.c_uint32], ctypes.c_int),
+    "trh_best_fft_batch_fq": ([ctypes.POINTER(_u64p), ctypes.c_size_t, _u64p, ctypes.c_uint32], ctypes.c_int),
+    "trh_commit_batch_host": ([_vp, ctypes.POINTER(_u64p), ctypes.c_size_t, ctypes.c_size_t, _u64p, _u64p], ctypes.c_int),
+    "trh_domain_lagrange_to_coeff_host": ([_vp, ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
+    "trh_domain_coeff_to_extended_host": ([_vp, ctypes.POINTER(_u64p), ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
+    "trh_domain_extended_to_coeff_host": ([_vp, _u64p, ctypes.c_int], ctypes.c_int),
+    "trh_host_register": ([_vp, ctypes.c_size_t], ctypes.c_int),
+    "trh_host_unregister": ([_vp], ctypes.c_int),
+    "trh_host_alloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
+    "trh_host_free": ([_vp], ctypes.c_int),
+    "trh_io_stats": ([ctypes.POINTER(IoStats), ctypes.c_int], ctypes.c_int),
     "trh_set_timing": ([ctypes.c_int], ctypes.c_int),
     "trh_last_timing": ([ctypes.POINTER(Timing)], ctypes.c_int),
 }
@@ -238,6 +254,36 @@ def best_fft(field: str, a, omega, log_n: int) -> np.ndarray:
     """In-place semantics of the Rust function; returns the transformed copy."""
     a = _c(a, 4).copy()
     assert a.shape[0] == 1 << log_n  # reference: assert_eq!(a.len(), 1 << log_n)
+    w = _c(omega).reshape(4)
+    fn = lib().trh_best_fft_fp if field == "fp" else lib().trh_best_fft_fq
+    _check(fn(_p(a), _p(w), log_n))
+    return a
+
+
+def _ptr_array(arrays):
+    """host columns -> C array of pointers (the arrays must stay alive for the call)"""
+    return (_u64p * len(arrays))(*[_p(a) for a in arrays])
+
+
+def best_fft_batch(field: str, columns, omega, log_n: int):
+    """best_fft over a list of host columns (each (2^log_n, 4) uint64, C-contiguous), IN PLACE, pipelined over PCIe"""
+    for a in columns:
+        assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size == 4 << log_n  # reference: assert_eq!(a.len(), 1 << log_n)
+    w = _c(omega).reshape(4)
+    fn = lib().trh_best_fft_batch_fp if field == "fp" else lib().trh_best_fft_batch_fq
+    _check(fn(_ptr_array(columns), len(columns), _p(w), log_n))
+
+
+def io_stats(reset: bool = False) -> dict:
+    """bytes moved by the host-pointer entry points and the host seconds spent in the copies, per direction"""
+    st = IoStats()
+    _check(lib().trh_io_stats(ctypes.byref(st), 1 if reset else 0))
+    return {k: getattr(st, k) for k, _ in IoStats._fields_}
+
+
+def best_fft_inplace(field: str, a: np.ndarray, omega, log_n: int) -> np.ndarray:
+    """the Rust signature: transforms the caller's (2^log_n, 4) uint64 array in place"""
+    assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size == 4 << log_n  # reference: assert_eq!(a.len(), 1 << log_n)
     w = _c(omega).reshape(4)
     fn = lib().trh_best_fft_fp if field == "fp" else lib().trh_best_fft_fq
     _check(fn(_p(a), _p(w), log_n))
@@ -477,6 +523,17 @@ class Bases:
         bl = _c(blinds, 4)
         assert bl.shape[0] == batch
         _check(lib().trh_commit_batch_dev(self.handle, _devptr(polys_dev), n, batch, _p(bl), stream, _p(out)))
+        return out
+
+    def commit_batch_host(self, polys, blinds) -> np.ndarray:
+        """Params::commit(_lagrange) of a list of HOST polynomials ((n, 4) uint64 each): columns go up in chunks under the MSMs"""
+        n = polys[0].shape[0]
+        for a in polys:
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (n, 4)
+        out = np.zeros((len(polys), 12), dtype=np.uint64)
+        bl = _c(blinds, 4)
+        assert bl.shape[0] == len(polys)
+        _check(lib().trh_commit_batch_host(self.handle, _ptr_array(polys), n, len(polys), _p(bl), _p(out)))
         return out
 
     def destroy(self):

@@ -29,6 +29,7 @@ static std::mutex g_reg_mu;
 static Ctx* g_default = nullptr;            // trh_init / trh_init_multi
 static std::vector<Ctx*> g_group;           // trh_init_multi: g_group[0] == g_default
 static size_t g_shard_min = (size_t)1 << 20;  // smaller base sets stay on the default device
+static int g_peer_ok = 1;                     // every pair of distinct group devices has peer access enabled
 static thread_local Ctx* t_bound = nullptr;   // trh_ctx_set_current
 static thread_local Ctx* t_active = nullptr;  // innermost TRH_ENTER
 
@@ -146,6 +147,7 @@ static void destroy_ctx(Ctx* c) {
             ntt_release_tables();
             for (DevBuf& d : c->ipa) d.release();
             c->io.release();
+            stage_release(*c);
             c->factors.release();
             if (c->pinned_ring) { (void)hipHostFree(c->pinned_ring); c->pinned_ring = nullptr; c->pinned_slot = 0; }
             if (c->pinned_land) { (void)hipHostFree(c->pinned_land); c->pinned_land = nullptr; }
@@ -259,6 +261,64 @@ void bases_cache_clear() {
 int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, uint64_t first, size_t n, trh_bases_t* out);
 int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out);
 
+const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s);
+const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n);
+
+// a synchronous entry point leaves no MSM "in flight" behind, whatever went wrong between its enqueue and its finish
+// (otherwise every later call on the context would answer TRH_EBUSY)
+struct PendingGuard {
+    Ctx& c;
+    bool armed = true;
+    ~PendingGuard() {
+        if (!armed || c.msm.pending_curve < 0) return;
+        (void)hipStreamSynchronize(c.msm.pending_stream);
+        c.msm.pending_curve = -1;
+        c.msm.tile_sum_valid = false;
+    }
+};
+
+// One MSM with the scalars (and, for best_multiexp, the bases) in HOST memory.  The sum over pairs is cut into ranges: range
+// t + 1 crosses PCIe (stage_h2d on the upload stream, two device buffers) while range t is computed; the range points are added
+// on the host.  With the bases on the host the call is bound by the link (96 B per pair: 2^24 pairs = 1.6 GB = 28 ms at 57 GB/s
+// against 17 ms of arithmetic), so the ranges are small (2^20 pairs) and only the last one's arithmetic is exposed; with resident
+// bases (32 B per pair) it is bound by the arithmetic and the ranges are large (2^22), only the first upload is exposed.
+int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host, trh_bases* res, size_t offset, size_t n, int mont, uint64_t* out) {
+    Ctx& c = ctx();
+    TRH_TRY(stage_begin(c));
+    Stage& st = c.stage;
+    size_t tile = n ? n : 1;
+    if (bases_host) { if (n > ((size_t)1 << 21)) tile = (size_t)1 << 20; }
+    else if (n > ((size_t)3 << 21)) tile = (size_t)1 << 22;
+    if (const char* e = getenv("TRH_HOST_TILE_LOG")) { const int v = atoi(e); if (v >= 10 && v <= 26) tile = (size_t)1 << v; }
+    const size_t ntiles = n ? (n + tile - 1) / tile : 1;
+    tile = (n + ntiles - 1) / ntiles;
+    uint64_t acc[24];
+    memset(acc, 0, sizeof(acc));
+    for (size_t t = 0; t < ntiles; ++t) {
+        const size_t slot = t & 1, off = t * tile, cur = off + tile < n ? tile : n - off;
+        TRH_TRY(st.ring_in[slot].ensure(cur * 32 + 32));
+        TRH_TRY(stage_h2d(c, st.ring_in[slot].p, coeffs + 4 * off, cur * 32, st.us));
+        if (bases_host) {
+            TRH_TRY(st.ring_out[slot].ensure(cur * 64 + 64));
+            TRH_TRY(stage_h2d(c, st.ring_out[slot].p, bases_host + 8 * off, cur * 64, st.us));
+        }
+        TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
+        if (t > 0) {  // the previous range finished under this upload
+            TRH_TRY(msm_finish(curve, st.cs, acc + 12, 1));
+            TRH_TRY(point_sum_host(curve, acc, 2, acc));
+        }
+        TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
+        const void* bdev = bases_host ? st.ring_out[slot].p : (const void*)((const char*)res->d_xy + (offset + off) * 64);
+        const void* bz = bases_host ? nullptr : lazy_bases(res, offset + off, st.cs);
+        const MsmFixedBase* fb = (!bases_host && ntiles == 1) ? fixed_base(res, offset, n) : nullptr;
+        TRH_TRY(msm_enqueue(curve, bdev, bz, st.ring_in[slot].p, cur, 1, cur, mont, st.cs, fb));
+    }
+    TRH_TRY(msm_finish(curve, st.cs, acc + 12, 1));
+    if (ntiles > 1) TRH_TRY(point_sum_host(curve, acc, 2, acc));
+    memcpy(out, ntiles > 1 ? acc : acc + 12, 96);
+    return stage_end(c);
+}
+
 int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t* out) {
     TRH_TRY(require_init());
     Range range(curve == TRH_PALLAS ? "trh_best_multiexp_pallas" : "trh_best_multiexp_vesta");
@@ -302,35 +362,9 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
         return rc;
     }
     TRH_ENTER(0);
-    Ctx& c = ctx();
-    DevBuf bbuf;
-    TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
-    int rc = bbuf.ensure(n * 64 + 64);
-    if (rc != TRH_OK) return rc;
-    hipError_t e = hipSuccess;
-    if (n) {
-        e = hipMemcpy(c.msm.scalars.p, coeffs, n * 32, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(bbuf.p, bases, n * 64, hipMemcpyHostToDevice);
-    }
-    if (e != hipSuccess) { bbuf.release(); set_error("best_multiexp: upload failed: %s", hipGetErrorString(e)); return TRH_EHIP; }
-    rc = msm_enqueue(curve, bbuf.p, nullptr, c.msm.scalars.p, n, 1, n, 1, 0);
-    if (rc == TRH_OK) rc = msm_finish(curve, 0, out, 1);
-    bbuf.release();
-    return rc;
-}
-
-int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n) {
-    Range range(field == TRH_FP ? "trh_best_fft_fp" : "trh_best_fft_fq");
-    if (!a || !omega) { set_error("best_fft: null pointer"); return TRH_EINVAL; }
-    if (log_n > 27) { set_error("best_fft: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
-    TRH_ENTER(0);
-    Ctx& c = ctx();
-    const size_t bytes = (size_t)32 << log_n;
-    TRH_TRY(c.io.ensure(bytes));
-    TRH_HIP_TRY(hipMemcpy(c.io.p, a, bytes, hipMemcpyHostToDevice));
-    TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, 0));
-    TRH_HIP_TRY(hipMemcpy(a, c.io.p, bytes, hipMemcpyDeviceToHost));
-    return TRH_OK;
+    PendingGuard guard{ctx()};
+    if (ctx().msm.pending_curve >= 0) { guard.armed = false; set_error("best_multiexp: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
+    return msm_host_tiled(curve, coeffs, bases, nullptr, 0, n, 1, out);
 }
 
 // one resident set on the entered context's device: uploaded from the host, or generated (xy == null)
@@ -384,9 +418,6 @@ int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, 
     return TRH_OK;
 }
 
-const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s);
-const MsmFixedBase* fixed_base(trh_bases_t b, size_t offset, size_t n);
-
 int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out) {
     Range range("trh_msm[sharded]");
     const size_t G = B->shards.size();
@@ -402,8 +433,24 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
         en.outermost = false;  // order_ev was just recorded by hand
         ctx().last_stream = caller_stream; ctx().last_stream_valid = true;
     }
-    // lock the shard contexts in group order (every sharded call takes them in this order), enqueue everywhere, then collect
-    std::vector<std::unique_ptr<Enter>> held(G);
+    // lock the shard contexts in group order (every sharded call takes them in this order), enqueue everywhere, then collect.
+    // The scopes nest, so they are left in REVERSE order on every path (each ~Enter restores the active context and the HIP device
+    // it found: front-to-back destruction left the calling thread on shard G - 2's device); a shard whose MSM was
+    // enqueued but not collected (an error in between) gets its in-flight state cleared, or the context would answer TRH_EBUSY forever
+    struct HeldScopes {
+        std::vector<std::unique_ptr<Enter>> v;
+        explicit HeldScopes(size_t n) : v(n) {}
+        ~HeldScopes() {
+            while (!v.empty()) {
+                if (v.back() && v.back()->c && v.back()->c->msm.pending_curve >= 0) {
+                    (void)hipStreamSynchronize(v.back()->c->own_stream);
+                    v.back()->c->msm.pending_curve = -1;
+                }
+                v.pop_back();
+            }
+        }
+        std::unique_ptr<Enter>& operator[](size_t i) { return v[i]; }
+    } held(G);
     std::vector<uint64_t> partial(12 * G, 0);
     std::vector<char> active(G, 0);
     for (size_t g = 0; g < G; ++g) {
@@ -417,7 +464,7 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
         const size_t cnt = hi - lo, local = lo - B->shard_off[g];
         TRH_TRY(sc->msm.scalars.ensure(cnt * 32 + 32));
         const char* src = (const char*)scalars + (lo - offset) * 32;
-        if (scalars_on_host) TRH_HIP_TRY(hipMemcpyAsync(sc->msm.scalars.p, src, cnt * 32, hipMemcpyHostToDevice, sc->own_stream));
+        if (scalars_on_host) TRH_TRY(stage_h2d(*sc, sc->msm.scalars.p, src, cnt * 32, sc->own_stream));  // returns when the range left the caller's memory: the DMAs of the G devices overlap
         else if (src_device == sc->device) TRH_HIP_TRY(hipMemcpyAsync(sc->msm.scalars.p, src, cnt * 32, hipMemcpyDeviceToDevice, sc->own_stream));
         else TRH_HIP_TRY(hipMemcpyPeerAsync(sc->msm.scalars.p, sc->device, src, src_device, cnt * 32, sc->own_stream));
         TRH_TRY(msm_enqueue(B->curve, (const char*)sh->d_xy + local * 64, lazy_bases(sh, local, sc->own_stream), sc->msm.scalars.p, cnt, 1, cnt, mont, sc->own_stream,
@@ -433,7 +480,6 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
         TRH_TRY(msm_finish(B->curve, sc->own_stream, partial.data() + 12 * cntp, 1));
         ++cntp;
     }
-    held.clear();
     return point_sum_host(B->curve, partial.data(), cntp, out);
 }
 
@@ -500,15 +546,29 @@ int trh_init_multi(const int* devices, int n_devices) {
         }
         made.push_back(c);
     }
-    for (int i = 0; i < n_devices; ++i)  // peer access for the hand-over of device-resident scalars (best effort: the peer copy works without it)
+    // peer access for the hand-over of device-resident scalars.  Not fatal when it cannot be had (hipMemcpyPeerAsync then stages
+    // through the host), but not silent either: trh_group_peer_access() reports it and trh_last_error() names the first pair
+    g_peer_ok = 1;
+    for (int i = 0; i < n_devices; ++i)
         for (int j = 0; j < n_devices; ++j)
             if (devices[i] != devices[j]) {
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                hipError_t e = hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
+                if (e == hipSuccess && can) {
                     int cur = -1;
                     (void)hipGetDevice(&cur);
-                    if (hipSetDevice(devices[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
+                    e = hipSetDevice(devices[i]);
+                    if (e == hipSuccess) {
+                        e = hipDeviceEnablePeerAccess(devices[j], 0);
+                        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+                    }
                     if (cur >= 0) (void)hipSetDevice(cur);
+                }
+                if (e != hipSuccess || !can) {
+                    if (g_peer_ok) set_error("trh_init_multi: no peer access from device %d to device %d (%s); device-resident scalars will be staged through the host",
+                                             devices[i], devices[j], e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer says no");
+                    (void)hipGetLastError();
+                    g_peer_ok = 0;
                 }
             }
     g_group = made;
@@ -516,6 +576,7 @@ int trh_init_multi(const int* devices, int n_devices) {
     return TRH_OK;
 }
 int trh_group_size(void) { return (int)g_group.size(); }
+int trh_group_peer_access(void) { return g_peer_ok; }
 int trh_set_shard_min(size_t n_pairs) { g_shard_min = n_pairs ? n_pairs : 1; return TRH_OK; }
 
 void trh_shutdown(void) {
@@ -677,11 +738,46 @@ int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size
     TRH_ENTER(0);
     Range range("trh_msm");
     TRH_TRY(single_device(bases, "msm"));
+    PendingGuard guard{ctx()};
+    if (ctx().msm.pending_curve >= 0) { guard.armed = false; set_error("msm: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
+    return msm_host_tiled(bases->curve, scalars_host, nullptr, bases, offset, n, mont, out);
+}
+
+/* Params::commit / commit_lagrange for `batch` polynomials in HOST memory (one pointer per column, n scalars each): the columns
+ * cross PCIe in chunks, chunk j + 1 while the batched MSM of chunk j runs. */
+int trh_commit_batch_host(trh_bases_t bases, const uint64_t* const* polys_host, size_t n, size_t batch, const uint64_t* blinds_host, uint64_t* out) {
+    TRH_TRY(msm_args(bases, 0, polys_host, n + 1, batch, out));
+    if (!blinds_host) { set_error("commit_batch: null blinds"); return TRH_EINVAL; }
+    if (bases->n != n + 1) { set_error("commit_batch: the handle must hold n + 1 = %zu bases (g or g_lagrange followed by w), it holds %zu", n + 1, bases->n); return TRH_EINVAL; }
+    for (size_t i = 0; i < batch; ++i) if (!polys_host[i]) { set_error("commit_batch_host: column %zu is null", i); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_commit_batch_host");
+    TRH_TRY(single_device(bases, "commit_batch_host"));
     Ctx& c = ctx();
-    TRH_TRY(c.msm.scalars.ensure(n * 32 + 32));
-    if (n) TRH_HIP_TRY(hipMemcpy(c.msm.scalars.p, scalars_host, n * 32, hipMemcpyHostToDevice));
-    TRH_TRY(msm_enqueue(bases->curve, (const char*)bases->d_xy + offset * 64, lazy_bases(bases, offset, 0), c.msm.scalars.p, n, 1, n, mont, 0, fixed_base(bases, offset, n)));
-    return msm_finish(bases->curve, 0, out, 1);
+    PendingGuard guard{c};
+    if (c.msm.pending_curve >= 0) { guard.armed = false; set_error("commit_batch_host: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
+    TRH_TRY(stage_begin(c));
+    Stage& st = c.stage;
+    size_t chunk = 16;  // 2^18-row columns: 128 MiB and ~7 ms of MSM per chunk
+    while (chunk > 1 && chunk * n * 32 > ((size_t)256 << 20)) chunk >>= 1;
+    if (chunk > batch) chunk = batch;
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    for (size_t j = 0; j < nchunks; ++j) {
+        const size_t slot = j & 1, first = j * chunk, nb = first + chunk <= batch ? chunk : batch - first;
+        TRH_TRY(st.ring_in[slot].ensure(chunk * n * 32 + chunk * 32 + 32));
+        char* const tails = (char*)st.ring_in[slot].p + chunk * n * 32;
+        for (size_t i = 0; i < nb; ++i) TRH_TRY(stage_h2d(c, (char*)st.ring_in[slot].p + i * n * 32, polys_host[first + i], n * 32, st.us));
+        TRH_TRY(stage_h2d(c, tails, blinds_host + 4 * first, nb * 32, st.us));
+        TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
+        if (j > 0) TRH_TRY(msm_finish(bases->curve, st.cs, out + 12 * (first - chunk), chunk));
+        TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
+        TRH_TRY(msm_enqueue(bases->curve, bases->d_xy, lazy_bases(bases, 0, st.cs), st.ring_in[slot].p, n + 1, nb, n, 1, st.cs, fixed_base(bases, 0, n + 1), tails));
+    }
+    {
+        const size_t first = (nchunks - 1) * chunk;
+        TRH_TRY(msm_finish(bases->curve, st.cs, out + 12 * first, batch - first));
+    }
+    return stage_end(c);
 }
 
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream) {

@@ -11,6 +11,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -103,6 +104,26 @@ struct MsmScratch {
     bool ev_valid = false;
 };
 
+// Host <-> device staging of the host-pointer entry points (hostio.hip): pinned slot rings + three streams.  Measured on the
+// MI355X box (profiles/pcie_probe_r03.txt): the runtime's own pageable path pins the caller's pages at first sight -- 27 GB/s up,
+// 12.7 GB/s down for a buffer it has not seen, hipMemcpyAsync blocks -- while pinned copies run at 57 GB/s and both directions at
+// once at 2 x 48 GB/s.  The rings carry a pageable buffer in slots: a pool of host threads copies slot i + 1 while the DMA engine
+// moves slot i, uploads, kernels and downloads of a batch run on their own streams.
+struct Stage {
+    static constexpr int NS = 4;
+    size_t slot = 0;                 // bytes per slot
+    char* up = nullptr;              // NS slots of pinned memory, host -> device
+    char* down = nullptr;            // NS slots, device -> host
+    hipEvent_t up_ev[NS] = {nullptr, nullptr, nullptr, nullptr}, down_ev[NS] = {nullptr, nullptr, nullptr, nullptr};
+    bool up_used[NS] = {false, false, false, false};
+    unsigned up_next = 0;
+    hipStream_t us = nullptr, cs = nullptr, ds = nullptr;  // upload, compute, download
+    hipEvent_t ev_up[4] = {nullptr, nullptr, nullptr, nullptr}, ev_comp[4] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf ring_in[4], ring_out[4];  // device-side ring of the batch pipelines
+    // traffic of the host-pointer entry points on this context since trh_io_stats_reset (bytes, host seconds inside the copies)
+    double up_bytes = 0, down_bytes = 0, up_s = 0, down_s = 0;
+};
+
 struct Ctx {
     std::recursive_mutex mu;  // recursive: an entry point may call another one (and a transcript callback may call host-side helpers)
     bool inited = false;
@@ -113,6 +134,7 @@ struct Ctx {
     MsmScratch msm;
     DevBuf ntt_tmp;
     DevBuf io;  // staging for host-pointer NTT entry points
+    Stage stage;
     DevBuf pfft;  // curve-point FFT work array + twiddle scalars
     DevBuf scan, scan2;  // prefix-product block totals / batch-inversion running products
     DevBuf ipa[7];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy), kept across proofs
@@ -160,6 +182,27 @@ struct Range {
     ~Range();
 };
 
+// hostio.hip
+int stage_ensure(Ctx& c);
+void stage_release(Ctx& c);
+// src_host -> dst_dev on stream s through the upload ring; returns when the source has been read (the last DMA may still be in flight on s)
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
+// src_dev -> dst_host through the download ring, ordered behind the work queued on s; returns when dst_host is complete
+int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
+// Batch pipeline over `count` items (each a group of host buffers): upload (caller thread, stage.us) -> compute(item, in, out,
+// stage.cs) -> download (helper thread, stage.ds), over a ring of device buffers.  in_bytes / out_bytes: device bytes per item;
+// upload(item, dev_in) / download(item, dev_out) issue the stage_h2d / stage_d2h calls of one item.
+struct HostPipe {
+    size_t count = 0, in_bytes = 0, out_bytes = 0;
+    bool in_place = false;  // compute works in the input buffer (out == in)
+    std::function<int(size_t, void*)> upload;
+    std::function<int(size_t, void*, void*, hipStream_t)> compute;
+    std::function<int(size_t, const void*)> download;
+};
+int host_pipeline(Ctx& c, const HostPipe& p);
+int stage_begin(Ctx& c);  // the stage's streams wait for the context's previous work
+int stage_end(Ctx& c);    // drains the three streams
+int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n);
 // ntt.hip
 // pointwise steps of EvaluationDomain fused into the first / last pass of a transform (lazy passes only:
 // ntt_can_fuse).  Factor tables hold `period` elements in the lazy Montgomery form (x 2^270, < 2 m), device memory.

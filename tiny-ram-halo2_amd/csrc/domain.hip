@@ -228,4 +228,82 @@ int trh_domain_divide_by_vanishing_poly(trh_domain* d, void* a_dev, size_t batch
     return field_scale_periodic(d->field, a_dev, batch, N, N, tab(d, T_TINV), (u32)d->t_inv.size(), (hipStream_t)stream);
 }
 
+
+/* ---- the same operations on HOST polynomials (one pointer per column), pipelined over PCIe (hostio.hip): what the Rust host's
+ * EvaluationDomain calls become when create_proof keeps its polynomials in host memory ------------------------------------- */
+static size_t group_for(size_t bytes_per_column) {
+    size_t g = 1;
+    while (g < 64 && g * bytes_per_column < ((size_t)8 << 20)) g <<= 1;  // a pipeline item is worth a few MiB of link time
+    return g;
+}
+
+int trh_domain_lagrange_to_coeff_host(trh_domain* d, uint64_t* const* a, size_t count) {
+    TRH_TRY(check(d, a));
+    for (size_t i = 0; i < count; ++i) if (!a[i]) { set_error("domain: column %zu is null", i); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_domain_lagrange_to_coeff_host");
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)32 << d->k, group = group_for(bytes);
+    HostPipe p;
+    p.count = (count + group - 1) / group;
+    p.in_bytes = group * bytes;
+    p.in_place = true;
+    p.upload = [&](size_t it, void* din) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us));
+        return TRH_OK;
+    };
+    p.compute = [&](size_t it, void* din, void*, hipStream_t s) -> int {
+        return trh_domain_lagrange_to_coeff(d, din, count - it * group < group ? count - it * group : group, s);
+    };
+    p.download = [&](size_t it, const void* dout) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, a[j], (const char*)dout + (j - it * group) * bytes, bytes, c.stage.ds));
+        return TRH_OK;
+    };
+    return host_pipeline(c, p);
+}
+
+/* coeff[i]: 2^k coefficients (read), ext[i]: 2^extended_k values (written): only the 2^k non-zero coefficients go up */
+int trh_domain_coeff_to_extended_host(trh_domain* d, const uint64_t* const* coeff, uint64_t* const* ext, size_t count) {
+    TRH_TRY(check(d, coeff));
+    if (!ext) { set_error("domain: null pointer"); return TRH_EINVAL; }
+    for (size_t i = 0; i < count; ++i) if (!coeff[i] || !ext[i]) { set_error("domain: column %zu is null", i); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_domain_coeff_to_extended_host");
+    Ctx& c = ctx();
+    const size_t in_b = (size_t)32 << d->k, out_b = (size_t)32 << d->extended_k, group = group_for(out_b);
+    HostPipe p;
+    p.count = (count + group - 1) / group;
+    p.in_bytes = group * in_b;
+    p.out_bytes = group * out_b;
+    p.upload = [&](size_t it, void* din) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * in_b, coeff[j], in_b, c.stage.us));
+        return TRH_OK;
+    };
+    p.compute = [&](size_t it, void* din, void* dout, hipStream_t s) -> int {
+        return trh_domain_coeff_to_extended(d, din, dout, count - it * group < group ? count - it * group : group, s);
+    };
+    p.download = [&](size_t it, const void* dout) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, ext[j], (const char*)dout + (j - it * group) * out_b, out_b, c.stage.ds));
+        return TRH_OK;
+    };
+    return host_pipeline(c, p);
+}
+
+/* h(X): [divide_by_vanishing_poly,] extended_to_coeff on one host polynomial of 2^extended_k values, in place */
+int trh_domain_extended_to_coeff_host(trh_domain* d, uint64_t* a, int divide_by_vanishing_first) {
+    TRH_TRY(check(d, a));
+    TRH_ENTER(0);
+    Range range("trh_domain_extended_to_coeff_host");
+    Ctx& c = ctx();
+    TRH_TRY(stage_begin(c));
+    hipStream_t s = c.stage.cs;
+    const size_t bytes = (size_t)32 << d->extended_k;
+    TRH_TRY(c.io.ensure(bytes));
+    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s));
+    if (divide_by_vanishing_first) TRH_TRY(trh_domain_divide_by_vanishing_poly(d, c.io.p, 1, s));
+    TRH_TRY(trh_domain_extended_to_coeff(d, c.io.p, 1, s));
+    TRH_TRY(stage_d2h(c, a, c.io.p, bytes, s));
+    return stage_end(c);
+}
+
 }  // extern "C"

@@ -21,8 +21,9 @@
 // becomes the domain value (x 2^261) by reading its limbs five bits lower (x 32, value < 32 m: free); constants are multiplied by
 // 32 mod m on the host when the program is created; results leave through fy_to_fe (canonical Montgomery words, bit-exact).
 // Values are only bounded, not reduced: trh_expr_create walks the program with a magnitude bound per stack entry (in units of m)
-// and inserts a REDUCE (multiplication by the domain's one) wherever a sum could pass 250 m or a stored value 15 m -- never for
-// the reference's gate shapes.
+// and inserts a REDUCE (multiplication by the domain's one) wherever a sum could pass 250 m, a product 500 m (its top limb is
+// value / 2^232: 512 m fills the signed 32-bit limb), the operand of a squaring 250 m or a stored value 15 m -- never for the
+// reference's gate shapes.
 #include <stdlib.h>
 #include <string.h>
 
@@ -214,7 +215,7 @@ int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, cons
     // pass 1: stack depth at every instruction, maximum depth (the two top entries live in registers), and a magnitude bound (in
     // units of m) for every stack entry, local and the accumulator: the machine's values are lazy (expr.hip header); a REDUCE
     // goes in front of an instruction whose result could pass MAXV or whose stored value could pass what fy_to_fe accepts
-    constexpr double MAXV = 250.0, MAX_STORE = 15.0, LOADED = 32.0;
+    constexpr double MAXV = 250.0, MAX_STORE = 15.0, LOADED = 32.0, MAX_OPERAND = 500.0, MAX_SQR = 250.0;
     auto after_mul = [](double a, double b) { return a * b / 128.0 + 1.0; };  // |a b| / 2^261 + m, m / 2^261 < 2^-7
     std::vector<DevInsn> dev;
     dev.reserve(n_insn + 16);
@@ -243,6 +244,12 @@ int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, cons
                     if (bound[bound.size() - 1] >= bound[bound.size() - 2]) reduce_top(); else reduce_next();
                     if (bound[bound.size() - 1] + bound[bound.size() - 2] > MAXV) { if (bound[bound.size() - 1] >= bound[bound.size() - 2]) reduce_top(); else reduce_next(); }
                 }
+                // a product B m has the top limb B 2^22: operands and result have to stay below 512 m to fit the signed 32-bit limb.
+                // Every value on the stack is <= MAX_OPERAND by construction (sums <= MAXV, products checked here), so one reduction of
+                // the larger operand (-> below 5 m) is enough
+                if (u.op == TRH_EXPR_MUL && after_mul(bound[bound.size() - 1], bound[bound.size() - 2]) > MAX_OPERAND) {
+                    if (bound[bound.size() - 1] >= bound[bound.size() - 2]) reduce_top(); else reduce_next();
+                }
                 const double a = bound[bound.size() - 2], b = bound.back();
                 bound.pop_back();
                 bound.back() = u.op == TRH_EXPR_MUL ? after_mul(a, b) : a + b;
@@ -252,7 +259,10 @@ int trh_expr_create(int field, const trh_expr_insn_t* insns, size_t n_insn, cons
             }
             case TRH_EXPR_NEG: case TRH_EXPR_SQR:
                 if (depth < 1) return bad("unary operator on an empty stack");
-                if (u.op == TRH_EXPR_SQR) bound.back() = after_mul(bound.back(), bound.back());
+                if (u.op == TRH_EXPR_SQR) {  // fy_squares doubles the limbs of its operand: below 256 m, and the result below 512 m
+                    if (bound.back() > MAX_SQR) reduce_top();
+                    bound.back() = after_mul(bound.back(), bound.back());
+                }
                 break;
             case TRH_EXPR_MUL_CONST: case TRH_EXPR_ADD_CONST:
                 if (depth < 1) return bad("operator on an empty stack");

@@ -1,0 +1,396 @@
+// Host-pointer side of the C ABI: what the reference's Rust host gets when `create_proof` stays on the CPU and only
+// `best_multiexp` / `best_fft` / `Params::commit*` / `EvaluationDomain::*` cross into libtrh with slices in HOST memory
+// (north_star's integration; the call site is /root/reference/src/test_utils.rs:41-49, the slices are the `Vec<F>`s of
+// halo2_proofs 0.2.0 `Polynomial`s).  Every byte crosses PCIe here, so this file is about the link, not about arithmetic:
+//
+//   * staging (stage_h2d / stage_d2h): a pageable buffer travels through a ring of pinned slots; a small pool of host threads
+//     copies slot i + 1 while the DMA engine moves slot i.  Measured on the MI355X box (profiles/pcie_probe_r03.txt): the HIP
+//     runtime's own pageable path pins the caller's pages the first time it sees them (27 GB/s up, 12.7 GB/s down into
+//     untouched pages; the prover's columns are fresh allocations every time) and hipMemcpyAsync on pageable memory blocks; pinned
+//     copies run at 57 GB/s, both directions at once at 2 x 48 GB/s.  Memory the caller pinned itself (trh_host_register /
+//     trh_host_alloc) skips the ring.
+//   * batch pipelines (host_pipeline): uploads, kernels and downloads of consecutive columns run on three streams over a ring
+//     of device buffers; the calling thread uploads and launches, a helper thread drains the downloads -- the link is used in
+//     both directions at once and the kernels hide under it.
+//   * tiled MSMs (msm_host_tiled): an MSM over host scalars (and host bases) is a sum over ranges; range t + 1 is uploaded
+//     while range t is computed.
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <string>
+#include <thread>
+
+#include "ctx.h"
+
+namespace trh {
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- host threads that move bytes between pageable memory and the pinned rings -----------------------------------------------------
+// One pool per direction (the upload side runs on the calling thread, the download side of a pipeline on its helper thread: they
+// must not queue behind each other).  Heap-allocated and never destroyed: worker threads parked on a condition variable at
+// process exit are harmless, a destructor joining them from a static object is not.
+class CopyPool {
+  public:
+    explicit CopyPool(int threads) : T(threads) {
+        for (int i = 0; i < T; ++i) th.emplace_back([this, i] { worker(i); });
+        for (std::thread& t : th) t.detach();
+    }
+    // dst <- src, split over the pool and the calling thread; serialised per pool
+    void copy(char* dst, const char* src, size_t bytes) {
+        if (bytes < ((size_t)1 << 20) || T == 0) { memcpy(dst, src, bytes); return; }
+        std::lock_guard<std::mutex> call(call_mu);
+        const size_t parts = (size_t)T + 1;
+        const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per;
+            pending = T;
+            ++gen;
+        }
+        cv_work.notify_all();
+        memcpy(dst, src, per < bytes ? per : bytes);  // part 0 on the caller
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+
+  private:
+    void worker(int id) {
+        unsigned seen = 0;
+        for (;;) {
+            char* dst; const char* src; size_t bytes, per;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per;
+            }
+            const size_t lo = (size_t)(id + 1) * per;
+            if (lo < bytes) memcpy(dst + lo, src + lo, lo + per < bytes ? per : bytes - lo);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    const int T;
+    std::vector<std::thread> th;
+    std::mutex mu, call_mu;
+    std::condition_variable cv_work, cv_done;
+    char* job_dst = nullptr; const char* job_src = nullptr; size_t job_bytes = 0, job_per = 0;
+    unsigned gen = 0;
+    int pending = 0;
+};
+
+int copy_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("TRH_COPY_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        // one memcpy thread moves 24-36 GB/s on the box, five (four workers + the caller) 60-85: above the 57 GB/s of the link
+        return hw >= 16 ? 4 : hw >= 8 ? 2 : hw >= 4 ? 1 : 0;
+    }();
+    return n;
+}
+CopyPool& up_pool() { static CopyPool* p = new CopyPool(copy_threads()); return *p; }
+CopyPool& down_pool() { static CopyPool* p = new CopyPool(copy_threads()); return *p; }
+
+// is this host pointer already page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engine reads it directly.
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+int stage_ensure(Ctx& c) {
+    Stage& st = c.stage;
+    if (st.up) return TRH_OK;
+    size_t slot = (size_t)16 << 20;
+    if (const char* e = getenv("TRH_STAGE_SLOT_MB")) { const long v = atol(e); if (v >= 1 && v <= 256) slot = (size_t)v << 20; }
+    hipError_t e = hipHostMalloc((void**)&st.up, slot * Stage::NS, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st.down, slot * Stage::NS, hipHostMallocDefault);
+    for (int i = 0; i < Stage::NS && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&st.up_ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st.down_ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_up[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_comp[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st.us, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st.cs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st.ds, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("host staging: %s", hipGetErrorString(e));
+        stage_release(c);
+        return e == hipErrorOutOfMemory ? TRH_ENOMEM : TRH_EHIP;
+    }
+    st.slot = slot;
+    return TRH_OK;
+}
+
+void stage_release(Ctx& c) {
+    Stage& st = c.stage;
+    if (st.up) (void)hipHostFree(st.up);
+    if (st.down) (void)hipHostFree(st.down);
+    st.up = st.down = nullptr;
+    for (int i = 0; i < Stage::NS; ++i) {
+        if (st.up_ev[i]) (void)hipEventDestroy(st.up_ev[i]);
+        if (st.down_ev[i]) (void)hipEventDestroy(st.down_ev[i]);
+        if (st.ev_up[i]) (void)hipEventDestroy(st.ev_up[i]);
+        if (st.ev_comp[i]) (void)hipEventDestroy(st.ev_comp[i]);
+        st.up_ev[i] = st.down_ev[i] = st.ev_up[i] = st.ev_comp[i] = nullptr;
+        st.up_used[i] = false;
+        st.ring_in[i].release(); st.ring_out[i].release();
+    }
+    if (st.us) (void)hipStreamDestroy(st.us);
+    if (st.cs) (void)hipStreamDestroy(st.cs);
+    if (st.ds) (void)hipStreamDestroy(st.ds);
+    st.us = st.cs = st.ds = nullptr;
+    st.slot = 0;
+}
+
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    if (!bytes) return TRH_OK;
+    TRH_TRY(stage_ensure(c));
+    Stage& st = c.stage;
+    const double t0 = now_s();
+    if (is_pinned(src_host)) {
+        TRH_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+    } else {
+        // a transfer smaller than the ring still wants a few slots in flight: the copy into slot i + 1 hides under the DMA of slot i
+        size_t chunk = st.slot;
+        while (chunk > ((size_t)1 << 20) && bytes < chunk * 3) chunk >>= 1;
+        for (size_t off = 0; off < bytes; off += chunk) {
+            const size_t cur = bytes - off < chunk ? bytes - off : chunk;
+            const int sl = (int)(st.up_next++ % Stage::NS);
+            if (st.up_used[sl]) TRH_HIP_TRY(hipEventSynchronize(st.up_ev[sl]));
+            char* pin = st.up + (size_t)sl * st.slot;
+            up_pool().copy(pin, (const char*)src_host + off, cur);
+            TRH_HIP_TRY(hipMemcpyAsync((char*)dst_dev + off, pin, cur, hipMemcpyHostToDevice, s));
+            TRH_HIP_TRY(hipEventRecord(st.up_ev[sl], s));
+            st.up_used[sl] = true;
+        }
+    }
+    st.up_bytes += (double)bytes;
+    st.up_s += now_s() - t0;
+    return TRH_OK;
+}
+
+int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s) {
+    if (!bytes) return TRH_OK;
+    TRH_TRY(stage_ensure(c));
+    Stage& st = c.stage;
+    const double t0 = now_s();
+    if (is_pinned(dst_host)) {
+        TRH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        TRH_HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        size_t chunk = st.slot;
+        while (chunk > ((size_t)1 << 20) && bytes < chunk * 3) chunk >>= 1;
+        const size_t nchunks = (bytes + chunk - 1) / chunk;
+        size_t issued = 0;
+        for (size_t k = 0; k < nchunks; ++k) {
+            for (; issued < nchunks && issued < k + Stage::NS; ++issued) {  // keep the ring full
+                const size_t off = issued * chunk, cur = bytes - off < chunk ? bytes - off : chunk;
+                const int sl = (int)(issued % Stage::NS);
+                TRH_HIP_TRY(hipMemcpyAsync(st.down + (size_t)sl * st.slot, (const char*)src_dev + off, cur, hipMemcpyDeviceToHost, s));
+                TRH_HIP_TRY(hipEventRecord(st.down_ev[sl], s));
+            }
+            const size_t off = k * chunk, cur = bytes - off < chunk ? bytes - off : chunk;
+            const int sl = (int)(k % Stage::NS);
+            TRH_HIP_TRY(hipEventSynchronize(st.down_ev[sl]));
+            down_pool().copy((char*)dst_host + off, st.down + (size_t)sl * st.slot, cur);
+        }
+    }
+    st.down_bytes += (double)bytes;
+    st.down_s += now_s() - t0;
+    return TRH_OK;
+}
+
+// the three streams of the stage join the context's order: whatever ran last on the context's scratch finishes first
+int stage_begin(Ctx& c) {
+    TRH_TRY(stage_ensure(c));
+    Stage& st = c.stage;
+    if (c.last_stream_valid) {
+        TRH_HIP_TRY(hipStreamWaitEvent(st.us, c.order_ev, 0));
+        TRH_HIP_TRY(hipStreamWaitEvent(st.cs, c.order_ev, 0));
+        TRH_HIP_TRY(hipStreamWaitEvent(st.ds, c.order_ev, 0));
+    }
+    return TRH_OK;
+}
+int stage_end(Ctx& c) {
+    Stage& st = c.stage;
+    TRH_HIP_TRY(hipStreamSynchronize(st.us));
+    TRH_HIP_TRY(hipStreamSynchronize(st.cs));
+    TRH_HIP_TRY(hipStreamSynchronize(st.ds));
+    return TRH_OK;
+}
+
+int host_pipeline(Ctx& c, const HostPipe& p) {
+    if (!p.count) return TRH_OK;
+    TRH_TRY(stage_begin(c));
+    Stage& st = c.stage;
+    const size_t D = p.count < 3 ? p.count : 3;
+    for (size_t d = 0; d < D; ++d) {
+        TRH_TRY(st.ring_in[d].ensure(p.in_bytes));
+        if (!p.in_place) TRH_TRY(st.ring_out[d].ensure(p.out_bytes));
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0, downloaded = 0;
+    bool abort = false;
+    int helper_rc = TRH_OK;
+    std::string helper_err;
+    const int device = c.device;
+    std::thread helper([&] {
+        int rc = hipSetDevice(device) == hipSuccess ? TRH_OK : TRH_EHIP;
+        for (size_t i = 0; i < p.count; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return submitted > i || abort; });
+                if (submitted <= i) return;
+            }
+            const size_t slot = i % D;
+            if (rc == TRH_OK && hipStreamWaitEvent(st.ds, st.ev_comp[slot], 0) != hipSuccess) { set_error("host pipeline: hipStreamWaitEvent failed"); rc = TRH_EHIP; }
+            if (rc == TRH_OK) rc = p.download(i, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != TRH_OK && helper_rc == TRH_OK) { helper_rc = rc; helper_err = trh_last_error(); abort = true; }
+                downloaded = i + 1;
+            }
+            cv.notify_all();
+            if (rc != TRH_OK) return;
+        }
+    });
+    int rc = TRH_OK;
+    auto step = [&](size_t i) -> int {
+        const size_t slot = i % D;
+        if (i >= D) {  // the slot's buffers are free once item i - D is back on the host
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return downloaded + D > i || abort; });
+            if (abort) return helper_rc;
+        }
+        TRH_TRY(p.upload(i, st.ring_in[slot].p));
+        TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
+        TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
+        TRH_TRY(p.compute(i, st.ring_in[slot].p, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p, st.cs));
+        TRH_HIP_TRY(hipEventRecord(st.ev_comp[slot], st.cs));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            submitted = i + 1;
+        }
+        cv.notify_all();
+        return TRH_OK;
+    };
+    for (size_t i = 0; i < p.count && rc == TRH_OK; ++i) rc = step(i);
+    if (rc != TRH_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        abort = true;
+    }
+    cv.notify_all();
+    helper.join();
+    if (rc == TRH_OK && helper_rc != TRH_OK) { set_error("%s", helper_err.c_str()); rc = helper_rc; }
+    const int rc2 = stage_end(c);
+    return rc != TRH_OK ? rc : rc2;
+}
+
+// halo2_proofs::arithmetic::best_fft on a host slice: up, transform, down.  One transform cannot overlap its own transfers (its
+// first pass reads elements from the whole array, its last pass writes the whole array), so this is the sum of the three; the
+// batch form below overlaps them across columns.
+int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n) {
+    Range range(field == TRH_FP ? "trh_best_fft_fp" : "trh_best_fft_fq");
+    if (!a || !omega) { set_error("best_fft: null pointer"); return TRH_EINVAL; }
+    if (log_n > 27) { set_error("best_fft: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Ctx& c = ctx();
+    TRH_TRY(stage_begin(c));
+    hipStream_t s = c.stage.cs;
+    const size_t bytes = (size_t)32 << log_n;
+    TRH_TRY(c.io.ensure(bytes));
+    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s));
+    TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
+    TRH_TRY(stage_d2h(c, a, c.io.p, bytes, s));
+    return stage_end(c);
+}
+
+static int best_fft_batch_host(int field, uint64_t* const* a, size_t count, const uint64_t* omega, uint32_t log_n) {
+    Range range("trh_best_fft_batch");
+    if (!omega || (count && !a)) { set_error("best_fft_batch: null pointer"); return TRH_EINVAL; }
+    if (log_n > 27) { set_error("best_fft_batch: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
+    for (size_t i = 0; i < count; ++i) if (!a[i]) { set_error("best_fft_batch: column %zu is null", i); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)32 << log_n;
+    // small transforms travel in groups, so that a pipeline item is worth a few MiB of link time
+    size_t group = 1;
+    while (group < 64 && group * bytes < ((size_t)8 << 20)) group <<= 1;
+    HostPipe p;
+    p.count = (count + group - 1) / group;
+    p.in_bytes = group * bytes;
+    p.in_place = true;
+    p.upload = [&](size_t it, void* din) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us));
+        return TRH_OK;
+    };
+    p.compute = [&](size_t it, void* din, void*, hipStream_t s) -> int {
+        const size_t nb = count - it * group < group ? count - it * group : group;
+        return ntt_device(field, din, log_n, omega, nb, s);
+    };
+    p.download = [&](size_t it, const void* dout) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, a[j], (const char*)dout + (j - it * group) * bytes, bytes, c.stage.ds));
+        return TRH_OK;
+    };
+    return host_pipeline(c, p);
+}
+
+}  // namespace trh
+
+using namespace trh;
+
+extern "C" {
+
+int trh_best_fft_batch_fp(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n) { return best_fft_batch_host(TRH_FP, a, count, omega, log_n); }
+int trh_best_fft_batch_fq(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n) { return best_fft_batch_host(TRH_FQ, a, count, omega, log_n); }
+
+int trh_host_register(void* host, size_t bytes) {
+    TRH_TRY(require_init());
+    if (!host || !bytes) { set_error("host_register: bad arguments"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    TRH_HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return TRH_OK;
+}
+int trh_host_unregister(void* host) {
+    TRH_TRY(require_init());
+    TRH_ENTER(0);
+    TRH_HIP_TRY(hipHostUnregister(host));
+    return TRH_OK;
+}
+int trh_host_alloc(void** host, size_t bytes) {
+    TRH_TRY(require_init());
+    if (!host) { set_error("host_alloc: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    const hipError_t e = hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
+    return TRH_OK;
+}
+int trh_host_free(void* host) {
+    TRH_TRY(require_init());
+    TRH_ENTER(0);
+    TRH_HIP_TRY(hipHostFree(host));
+    return TRH_OK;
+}
+
+int trh_io_stats(trh_io_stats_t* out, int reset) {
+    if (!out) { set_error("io_stats: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Stage& st = ctx().stage;
+    out->h2d_bytes = st.up_bytes; out->d2h_bytes = st.down_bytes; out->h2d_seconds = st.up_s; out->d2h_seconds = st.down_s;
+    if (reset) st.up_bytes = st.down_bytes = st.up_s = st.down_s = 0;
+    return TRH_OK;
+}
+
+}  // extern "C"

@@ -1068,6 +1068,7 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
     if (m.pending_curve != BF::ID || m.pending_batch != batch || m.pending_stream != s) { set_error("msm_finish: no matching MSM enqueued on this context and stream"); return TRH_EINVAL; }
+    m.pending_curve = -1;  // whatever happens below, the context is free for the next MSM
     TRH_HIP_TRY(hipStreamSynchronize(s));
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     for (size_t bi = 0; bi < batch; ++bi) combine_windows_host<BF>(ws + bi * m.pending_windows, m.pending_windows, m.pending_c, out_xyz + 12 * bi);
@@ -1084,7 +1085,6 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     }
     c.last.window_bits = m.pending_c;
     c.last.windows = m.pending_windows;
-    m.pending_curve = -1;
     if (m.tile_sum_valid && !m.in_tile) {  // last tile of a tiled MSM: add the earlier tiles
         u64 two[24];
         memcpy(two, m.tile_sum, 96);

@@ -160,6 +160,30 @@ class EvaluationDomain:
         return a
 
 
+    # ---- the same operations on HOST polynomials (numpy (n, 4) uint64 arrays, as the Rust host holds its `Polynomial`s):
+    # csrc/hostio.hip pipelines the columns over PCIe ----
+    def lagrange_to_coeff_host(self, columns):
+        """in place on a list of host columns"""
+        for a in columns:
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (self.n, 4)
+        api._check(api.lib().trh_domain_lagrange_to_coeff_host(self.handle(), api._ptr_array(columns), len(columns)))
+        return columns
+
+    def coeff_to_extended_host(self, coeffs, out=None):
+        """list of (n, 4) host coefficient arrays -> list of (2^extended_k, 4) host arrays"""
+        for a in coeffs:
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (self.n, 4)
+        ext = out if out is not None else [np.empty((self.extended_len(), 4), dtype=np.uint64) for _ in coeffs]
+        api._check(api.lib().trh_domain_coeff_to_extended_host(self.handle(), api._ptr_array(coeffs), api._ptr_array(ext), len(coeffs)))
+        return ext
+
+    def extended_to_coeff_host(self, a, divide_by_vanishing_first: bool = False):
+        """in place on one (2^extended_k, 4) host array; returns the truncated view of n * quotient_poly_degree coefficients"""
+        assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (self.extended_len(), 4)
+        api._check(api.lib().trh_domain_extended_to_coeff_host(self.handle(), api._p(a), 1 if divide_by_vanishing_first else 0))
+        return a[: self.n * self.quotient_poly_degree]
+
+
 class Params:
     """commitment::Params with device-resident bases: g ‖ w and g_lagrange ‖ w (n + 1 points each)."""
 
@@ -244,6 +268,13 @@ class Params:
         batch = polys.shape[0]
         assert polys.shape[1] == self.n and polys.is_contiguous()
         return self._g_lagrange.commit_batch_dev(polys, self.n, batch, np.ascontiguousarray(blinds, dtype=np.uint64).reshape(batch, 4), stream=_stream(polys))
+
+    def commit_lagrange_batch_host(self, polys, blinds):
+        """polys: list of host (n, 4) columns; blinds: (batch, 4) -> (batch, 12) points (trh_commit_batch_host)"""
+        return self._g_lagrange.commit_batch_host(polys, blinds)
+
+    def commit_batch_host(self, polys, blinds):
+        return self._g.commit_batch_host(polys, blinds)
 
     def commit_batch(self, polys, blinds):
         """coefficient-form counterpart of commit_lagrange_batch"""

@@ -427,6 +427,205 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     return out
 
 
+def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=None, device: int = 0, verbose: bool = True, columns: str = "witness",
+               max_columns: int | None = None) -> dict:
+    """The same schedule with every polynomial in HOST memory, as the reference's Rust `create_proof` keeps them
+    (/root/reference/src/test_utils.rs:41-49): north_star's literal integration, priced with PCIe.
+
+    level "literal": the two-function seam.  Per column `Params::commit_lagrange` -> trh_msm (resident bases, host scalars),
+        `lagrange_to_coeff` -> trh_best_fft (2^k, both ways over the link), `coeff_to_extended` -> trh_best_fft on the zero-padded
+        2^extended_k host vector (64 MiB each way at k = 18); h(X) -> one trh_best_fft of 2^extended_k; the IPA's round MSMs ->
+        trh_best_multiexp over the host's folded generators.  One synchronous call at a time, as the Rust loops issue them.
+    level "batched": the Params / EvaluationDomain seam with column batches (trh_commit_batch_host,
+        trh_domain_lagrange_to_coeff_host, trh_domain_coeff_to_extended_host: only the 2^k coefficients go up, uploads /
+        kernels / downloads of consecutive columns overlap), h(X) through trh_domain_extended_to_coeff_host, the opening
+        through the single-call IPA with p(X), s(X) uploaded.
+    What stays on the Rust host in both (and is NOT timed here): the pointwise steps of EvaluationDomain in the literal level
+    (x n^-1, the zeta shift), the lookup / permutation products, h(X)'s gate evaluation, the transcript.  The values passed on
+    between steps are therefore not the prover's (timing does not depend on them); `hook` sees inputs and outputs of each call."""
+    assert level in ("literal", "batched") and columns in ("random", "witness")
+    import torch
+
+    k = 2 + word_bits // 2
+    sch = schedule(k)
+    n, ek = sch["n"], sch["extended_k"]
+    N = 1 << ek
+    curve, field = "vesta", "fp"
+    api.init(device)
+    dev = torch.device("cuda", device)
+    dom = poly.EvaluationDomain(field, QUOTIENT_J, k)
+    g = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n + 1)
+    gl = api.Bases.generate(curve, synth.BASE_S0 + 77, synth.BASE_D + 2, n + 1)
+    params = poly.Params.__new__(poly.Params)
+    params.curve, params.k, params.n = curve, k, n
+    params._g, params._g_lagrange = g, gl
+    g_host = g.download()
+    params.w = g_host[n:n + 1]
+    params.u = api.Bases.generate(curve, 4242, 1, 1).download()
+    params.precompute()
+    lag_total = sch["intt_n"] if max_columns is None else min(max_columns, sch["intt_n"])
+    kinds = [(kind, blinded) for count, kind, blinded in column_classes(word_bits) for _ in range(count)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def host_columns(first, b, seed=0xC01):
+        """b host columns (Montgomery limbs), each its own C-contiguous (n, 4) array -- separate allocations, as `Vec<F>`s are"""
+        if columns == "random":
+            return [np.ascontiguousarray(synth.field_elements(seed + first + i, n)) for i in range(b)]
+        can = np.empty((b, n, 4), dtype=np.uint64)
+        i = 0
+        while i < b:
+            j = i
+            while j < b and kinds[first + j] == kinds[first + i]:
+                j += 1
+            can[i:j] = witness_columns(kinds[first + i][0], kinds[first + i][1], seed + first + i, j - i, n, word_bits)
+            i = j
+        d = torch.from_numpy(can.view(np.int64)).to(dev)
+        api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["to_mont"], api._devptr(d), None, api._devptr(d), b * n, stream))
+        torch.cuda.synchronize()
+        h = d.cpu().numpy().view(np.uint64).reshape(b, n, 4)
+        return [np.ascontiguousarray(h[i]) for i in range(b)]
+
+    wall = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "commit": 0.0, "extended_to_coeff": 0.0, "ipa": 0.0}
+    counts = {kk: 0 for kk in wall}
+    checked = 0
+    w_inv, w_ext, w_ext_inv = dom._w["omega_inv"], dom._w["extended_omega"], dom._w["extended_omega_inv"]
+    api.io_stats(reset=True)
+    t_all = time.perf_counter()
+    done = 0
+    ext_bufs = None
+    while done < lag_total:
+        b = min(batch, lag_total - done)
+        cols = host_columns(done, b)
+        blinds = synth.field_elements(0x100C01 + done, b)
+        if level == "literal":
+            if ext_bufs is None:
+                ext_bufs = [np.zeros((N, 4), dtype=np.uint64) for _ in range(2)]
+            for i in range(b):
+                sc = np.concatenate([cols[i], blinds[i][None]])  # the Rust side passes poly || blind through a chained iterator; the copy is not timed
+                t0 = time.perf_counter()
+                pt = gl.msm(sc)
+                t1 = time.perf_counter()
+                wall["commit_lagrange"] += t1 - t0
+                if hook is not None and done == 0 and i < 3:
+                    hook("commit_lagrange", dict(scalars=sc, bases=gl), pt)
+                    checked += 1
+                a_in = cols[i].copy() if hook is not None and done == 0 and i < 3 else None
+                t0 = time.perf_counter()
+                api.best_fft_inplace(field, cols[i], w_inv, k)
+                t1 = time.perf_counter()
+                wall["lagrange_to_coeff"] += t1 - t0
+                if a_in is not None:
+                    hook("best_fft", dict(a=a_in, omega=w_inv, log_n=k, field=field), cols[i])
+                    checked += 1
+                ext = ext_bufs[i & 1]
+                ext[:n] = cols[i]  # zero-padding (and, on the Rust host, the zeta shift) is host work
+                ext[n:] = 0
+                e_in = ext[:n].copy() if a_in is not None else None
+                t0 = time.perf_counter()
+                api.best_fft_inplace(field, ext, w_ext, ek)
+                t1 = time.perf_counter()
+                wall["coeff_to_extended"] += t1 - t0
+                if e_in is not None and i == 0:
+                    hook("best_fft_padded", dict(a=e_in, omega=w_ext, log_n=ek, field=field), ext)
+                    checked += 1
+        else:
+            if ext_bufs is None or len(ext_bufs) < b:
+                ext_bufs = [np.zeros((N, 4), dtype=np.uint64) for _ in range(b)]
+            lag_in = [c.copy() for c in cols[:3]] if hook is not None and done == 0 else None
+            t0 = time.perf_counter()
+            pts = params.commit_lagrange_batch_host(cols, blinds)
+            t1 = time.perf_counter()
+            dom.lagrange_to_coeff_host(cols)
+            t2 = time.perf_counter()
+            dom.coeff_to_extended_host(cols, out=ext_bufs[:b])
+            t3 = time.perf_counter()
+            wall["commit_lagrange"] += t1 - t0
+            wall["lagrange_to_coeff"] += t2 - t1
+            wall["coeff_to_extended"] += t3 - t2
+            if lag_in is not None:
+                for i in range(len(lag_in)):
+                    hook("commit_lagrange", dict(scalars=np.concatenate([lag_in[i], blinds[i][None]]), bases=gl), pts[i])
+                    hook("lagrange_to_coeff", dict(a=lag_in[i], domain=(field, QUOTIENT_J, k)), cols[i])
+                    hook("coeff_to_extended", dict(a=cols[i], domain=(field, QUOTIENT_J, k)), ext_bufs[i])
+                    checked += 3
+        for kk in ("commit_lagrange", "lagrange_to_coeff", "coeff_to_extended"):
+            counts[kk] += b
+        done += b
+
+    # coefficient-basis commits: the vanishing argument's random polynomial and the h pieces
+    ncoef = 1 + N_H_PIECES
+    ccols = [np.ascontiguousarray(synth.field_elements(0xABC + i, n)) for i in range(ncoef)]
+    cbl = synth.field_elements(0xABD, ncoef)
+    t0 = time.perf_counter()
+    if level == "literal":
+        cpts = [g.msm(np.concatenate([ccols[i], cbl[i][None]])) for i in range(ncoef)]
+    else:
+        cpts = params.commit_batch_host(ccols, cbl)
+    wall["commit"] += time.perf_counter() - t0
+    counts["commit"] += ncoef
+    if hook is not None:
+        hook("commit", dict(scalars=np.concatenate([ccols[0], cbl[0][None]]), bases=g), cpts[0])
+        checked += 1
+
+    # h(X): the quotient's numerator comes back from the host's gate evaluation as 2^extended_k values
+    h_h = np.ascontiguousarray(synth.field_elements(0xEE, N))
+    h_in = h_h.copy() if hook is not None else None
+    t0 = time.perf_counter()
+    if level == "literal":
+        api.best_fft_inplace(field, h_h, w_ext_inv, ek)
+    else:
+        dom.extended_to_coeff_host(h_h, divide_by_vanishing_first=True)
+    wall["extended_to_coeff"] += time.perf_counter() - t0
+    counts["extended_to_coeff"] += 1
+    if hook is not None:
+        if level == "literal":
+            hook("best_fft", dict(a=h_in, omega=w_ext_inv, log_n=ek, field=field), h_h)
+        else:
+            hook("divide_and_extended_to_coeff", dict(a=h_in, domain=(field, QUOTIENT_J, k)), h_h[: n * (QUOTIENT_J - 1)])
+        checked += 1
+
+    # the opening
+    p_h = np.ascontiguousarray(synth.field_elements(0x9A, n))
+    s_h = np.ascontiguousarray(synth.field_elements(0x5A, n))
+    m = poly._MODULUS[field]
+    t0 = time.perf_counter()
+    if level == "literal":
+        # commitment::create_proof on the host: S = commit(s), then per round two best_multiexp over the halves of p' and of the
+        # host's folded generators G' (bases AND scalars cross the link), the (u, w) two-term MSMs, the folds on the host
+        g.msm(np.concatenate([s_h, cbl[0][None]]))
+        gp = np.ascontiguousarray(g_host[:n])
+        for j in range(k):
+            half = 1 << (k - j - 1)
+            lj = api.best_multiexp(curve, p_h[half:2 * half], gp[:half])
+            rj = api.best_multiexp(curve, p_h[:half], gp[half:2 * half])
+            if hook is not None and j in (0, k - 1):
+                hook("best_multiexp", dict(scalars=p_h[half:2 * half], bases=gp[:half], curve=curve), lj)
+                hook("best_multiexp", dict(scalars=p_h[:half], bases=gp[half:2 * half], curve=curve), rj)
+                checked += 2
+    else:
+        draws = iter(range(7, 10 ** 9, 13))
+        p_dev = torch.from_numpy(p_h.view(np.int64)).to(dev)
+        ipa.create_proof_native(params, lambda: next(draws), _FixedTranscript(m), p_dev, 0x1234, int.from_bytes(synth.field_elements(0xE7A, 1)[0].tobytes(), "little") % m, s_h, 0x77)
+    wall["ipa"] += time.perf_counter() - t0
+    counts["ipa"] += 1
+
+    total_s = time.perf_counter() - t_all
+    io = api.io_stats()
+    in_calls = sum(wall.values())
+    out = {"mode": "dropin-" + level, "word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts,
+           "wall_ms_incl_pcie": {kk: round(v * 1e3, 3) for kk, v in wall.items()}, "wall_ms_incl_pcie_total": round(in_calls * 1e3, 3),
+           "pcie": {"h2d_GB": round(io["h2d_bytes"] / 1e9, 3), "d2h_GB": round(io["d2h_bytes"] / 1e9, 3),
+                    "h2d_GBps_in_copies": round(io["h2d_bytes"] / max(io["h2d_seconds"], 1e-9) / 1e9, 2),
+                    "d2h_GBps_in_copies": round(io["d2h_bytes"] / max(io["d2h_seconds"], 1e-9) / 1e9, 2),
+                    "GBps_over_call_time": round((io["h2d_bytes"] + io["d2h_bytes"]) / max(in_calls, 1e-9) / 1e9, 2),
+                    "link_peak_GBps_per_direction": 57.0, "link_peak_source": "pinned hipMemcpyAsync on the box, profiles/pcie_probe_r03.txt (PCIe Gen5 x16: 63 GB/s spec)"},
+           "scope": "wall time inside libtrh's host-pointer calls for ONE create_proof (uploads + kernels + downloads); the Rust host's own work between the calls is not in it",
+           "columns_replayed": lag_total, "wall_s_including_host_input_generation": round(total_s, 3), "checked_against_oracle": checked}
+    if verbose:
+        print(json.dumps(out))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--word-bits", type=int, default=32)
@@ -434,7 +633,14 @@ def main():
     ap.add_argument("--no-precompute", action="store_true", help="commit over the plain per-window path (no fixed-base tables)")
     ap.add_argument("--columns", choices=("random", "witness"), default="random", help="uniformly random columns, or the value classes of the reference's witness")
     ap.add_argument("--no-keygen", action="store_true")
+    ap.add_argument("--mode", choices=("resident", "dropin", "dropin-batched"), default="resident",
+                    help="resident: polynomials live on the device (the restructured prover); dropin: every polynomial in host memory, one "
+                         "trh_msm / trh_best_fft call at a time (north_star's literal integration); dropin-batched: host memory, batched host-pointer entries")
+    ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes: replay only the first N Lagrange columns")
     a = ap.parse_args()
+    if a.mode != "resident":
+        run_dropin(a.word_bits, "literal" if a.mode == "dropin" else "batched", a.batch, columns=a.columns, max_columns=a.max_columns)
+        return
     run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen)
 
 
