@@ -76,13 +76,15 @@ def cpu_baseline_msm(curve: str, log_cap: int = 24):
     sc = synth.msm_scalars(log_n)
     reps, t = 0, time.perf_counter()
     while True:
-        cpu_ref.best_multiexp(curve, sc, bases, threads)
+        last = cpu_ref.best_multiexp(curve, sc, bases, threads)
         reps += 1
         dt = time.perf_counter() - t
         if dt >= 10.0 or reps >= 8:
             break
-    return {"value": n * reps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x 2^{log_n} Pallas best_multiexp (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}
+    # the oracle's point for exactly the headline inputs (scalars synth.msm_scalars(log_n), bases (s0 + i d) G): the caller compares
+    # the GPU result with it limb for limb, outside every timed region
+    return ({"value": n * reps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+             "sample": f"{reps} x 2^{log_n} Pallas best_multiexp (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}, log_n, cpu_ref.to_affine(curve, last))
 
 
 def cpu_baseline_ntt(field: str, log_n: int):
@@ -96,13 +98,13 @@ def cpu_baseline_ntt(field: str, log_n: int):
     w = np.array(f.limbs(f.omega(log_n)), np.uint64)
     reps, t = 0, time.perf_counter()
     while True:
-        cpu_ref.best_fft(field, a, w, log_n, threads)
+        last = cpu_ref.best_fft(field, a, w, log_n, threads)
         reps += 1
         dt = time.perf_counter() - t
         if dt >= 5.0 or reps >= 16:
             break
-    return {"value": (1 << log_n) * reps / dt, "unit": "elems/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x 2^{log_n} Fp best_fft (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}
+    return ({"value": (1 << log_n) * reps / dt, "unit": "elems/s", "cores": threads, "kind": "port",
+             "sample": f"{reps} x 2^{log_n} Fp best_fft (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}, last)
 
 
 def load_traffic(name: str):
@@ -129,10 +131,17 @@ def msm_roofline(n, acc_ms, tm, traffic):
             "traffic": traffic, "kernel_ms": acc_ms, "algorithmic_bytes": 96 * n,
             # the kernel is limited by VALU issue, not by HBM (see `valu`): the counter traffic is what it actually pulls per launch
             "limiter": "valu-issue", "traffic_gbs": (traffic / (acc_ms * 1e-3) / 1e9) if traffic else None}
+    # issue model (tools/issue_probe.hip, profiles/issue_probe_r03.txt): a v_mad_i64_i32 occupies its SIMD for 4 cycles; a 32-bit ALU
+    # instruction for 2 in a loop of its own, but for 3.3-3.9 (3.6 here) between multiply-adds at the 2-4 waves per SIMD this
+    # 160-VGPR kernel can have.  `issue_frac` prices the non-mad instructions that way; the two-rate figure (every non-mad at 2
+    # cycles) is kept as the bound on what >= 8 waves per SIMD could buy.
+    mad_peak = 32.7e12
+    other_mixed = mad_peak * 4.0 / 3.6
     valu = {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc_ms * 1e-3),
-            "mad_i64_i32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": 32.7e12,
-            "other_valu_per_s": OTHER_PER_MADD * madds / (acc_ms * 1e-3), "other_peak_per_s": 65e12,
-            "issue_frac": (MADS_PER_MADD * madds / 32.7e12 + OTHER_PER_MADD * madds / 65e12) / (acc_ms * 1e-3)}
+            "mad_i64_i32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": mad_peak,
+            "other_valu_per_s": OTHER_PER_MADD * madds / (acc_ms * 1e-3), "other_peak_per_s_mixed_stream": other_mixed, "other_peak_per_s_alone": 65e12,
+            "issue_frac": (MADS_PER_MADD * madds / mad_peak + OTHER_PER_MADD * madds / other_mixed) / (acc_ms * 1e-3),
+            "issue_frac_two_rate_model": (MADS_PER_MADD * madds / mad_peak + OTHER_PER_MADD * madds / 65e12) / (acc_ms * 1e-3)}
     return roof, valu
 
 
@@ -296,12 +305,32 @@ def main():
     wl = Workload(lo, n)
     result, elapsed, acc, phase, tm = time_msm(wl, args.steps, args.warmup)
     check = None if args.no_check else check_msm(wl, result)
+    # the same step over a NOT-owned view of the same bases: libtrh then converts the 64-byte points to its 128-byte records inside
+    # every MSM (msm_convert_bases_kernel) instead of once per resident handle -- the rate a caller without a long-lived handle gets
+    with_conv = None
+    if world == 1 and not args.no_sweep and n <= (1 << 25):
+        view = api.Bases.wrap_device(curve, api.lib().trh_bases_device_ptr(wl.bases.handle), n)
+        for _ in range(2):
+            r2 = view.msm_dev(wl.d_sc, n, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(args.steps // 2, 3)):
+            r2 = view.msm_dev(wl.d_sc, n, stream=stream)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / max(args.steps // 2, 3)
+        with_conv = {"value": n / el, "unit": "pairs/s", "ms_per_step": el * 1e3, "same_point": bool((r2 == result).all()),
+                     "what": "bases as plain 64-byte affine points in HBM, converted to the 128-byte records inside every MSM"}
+        if not with_conv["same_point"]:
+            failed.append("msm over the unconverted view")
+        view.destroy()
     wl.destroy()
 
     # ---- secondary: Fp NTT @ 2^22 (same process, outside the MSM timed region) ----
     # every rank transforms its own column (create_proof's NTTs are independent per column: replicas, no collective);
     # the value is the whole-job rate over the slowest rank's time
-    def time_ntt(ln, reps, warm, with_check):
+    forward_kept = {}
+
+    def time_ntt(ln, reps, warm, with_check, keep_forward=False):
         omega = pow(FP_ROOT, 1 << (32 - ln), P_MOD)
         mont = lambda v: synth.ints_to_limbs([v % P_MOD * ((1 << 256) % P_MOD) % P_MOD])[0]  # noqa: E731
         a = synth.ntt_input(ln)
@@ -310,6 +339,8 @@ def main():
         if with_check:  # inverse(forward(a)) * n^-1 == a, and the forward transform is not the identity
             api.ntt_dev("fp", d_a, ln, mont(omega), stream=stream)
             torch.cuda.synchronize()
+            if keep_forward:
+                forward_kept[ln] = d_a.cpu().numpy().view(np.uint64).copy()
             moved = not bool((d_a[:4096].cpu().numpy().view(np.uint64) == a[:4096]).all())
             api.ntt_dev("fp", d_a, ln, mont(pow(omega, -1, P_MOD)), stream=stream)
             api.field_scale_dev("fp", d_a, 1 << ln, mont(pow(1 << ln, -1, P_MOD)), stream=stream)
@@ -338,14 +369,20 @@ def main():
                              "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}}
 
     ln = args.ntt_log_n
-    ms, chk = time_ntt(ln, max(args.steps, 5) * 4, max(args.warmup, 2), not args.no_check)
+    ms, chk = time_ntt(ln, max(args.steps, 5) * 4, max(args.warmup, 2), not args.no_check, keep_forward=world == 1 and not args.no_cpu_baseline)
     ntt = None
     if rank == 0:
         ntt = ntt_entry(ln, ms, chk)
         ntt["mode"] = "one transform per GPU at a time (independent columns, no collective)" if world > 1 else "single GPU"
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            ntt["cpu_baseline"] = cpu_baseline_ntt("fp", ln)
+            ntt["cpu_baseline"], cpu_fwd = cpu_baseline_ntt("fp", ln)
+            if ln in forward_kept:  # the oracle's transform of the same input, limb for limb (outside the timed region)
+                ok = bool((forward_kept.pop(ln) == cpu_fwd).all())
+                if not ok:
+                    failed.append(f"ntt 2^{ln} vs oracle")
+                ntt["check"] = (f"oracle limb-for-limb ok (cpu_ref.best_fft, 2^{ln}) + " + str(chk)) if ok else "MISMATCH vs oracle"
+            del cpu_fwd
 
     # ---- extras outside the timed headline region ---------------------------------------------------------------------------
     sweep, strong, single = None, None, None
@@ -361,7 +398,8 @@ def main():
             per_launch = (1 << lg) if lg <= 25 else (1 << 25)
             roof2, valu2 = msm_roofline(per_launch, acc2, tm2, load_traffic(f"msm_accumulate_2^{lg}"))
             sweep.append({"op": "msm", "curve": curve, "log_n": lg, "value": (1 << lg) * steps / el2, "unit": "pairs/s", "ms": el2 / steps * 1e3, "check": chk2,
-                          "window_bits": tm2["window_bits"], "pairs_per_launch": per_launch, "roofline": roof2, "valu_issue_frac": valu2["issue_frac"]})
+                          "window_bits": tm2["window_bits"], "pairs_per_launch": per_launch, "roofline": roof2, "valu_issue_frac": valu2["issue_frac"],
+                          "scalars": "uniformly random" if lg <= 24 else f"a uniformly random 2^22 block repeated {1 << (lg - 22)} times (the host generator would outlast the benchmark); bases all distinct"})
         for lg in (20, 24):
             ms2, chk2 = time_ntt(lg, 20, 3, True)
             e = ntt_entry(lg, ms2, chk2)
@@ -426,14 +464,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"Pallas MSM, {shape}, random 254-bit scalars, distinct bases (s0+i*d)G, inputs resident in HBM", "curve": curve,
+            "config": {"workload": f"Pallas MSM, {shape}, random 254-bit scalars, distinct bases (s0+i*d)G, inputs resident in HBM: scalars as 32-byte Montgomery words, "
+                                   "bases in a resident handle, i.e. already converted to libtrh's 128-byte signed-limb records (once per handle, 1.0 ms at 2^24, "
+                                   "outside the timed step; `with_base_conversion` is the rate with that conversion inside every step)", "curve": curve,
                        "pairs_per_gpu": n, "pairs_total": n_total, "mode": f"{mode} scaling" + (" (--global-log-n)" if mode == "strong" else " (default)"),
                        "window_bits": tm["window_bits"], "windows": tm["windows"],
                        "parallelism": f"range-shard x{world}, one process per GPU, RCCL all-gather of 96-byte partials" if world > 1 else "single GPU"},
             "roofline": roof,
             # what actually bounds the kernel: VALU issue.  Per mixed add 1170 v_mad_i64_i32 (8 products of 81, 2 squares of 45, 9 reductions
             # of 45, 27 for the fused subtrahends) and ~560 other ALU instructions (SQ_INSTS_VALU: 1733 per mixed add and wave); peaks are the
-            # measured issue rates of tools/microbench.hip (profiles/microbench_*.txt: 32 x 32 multiply-add 32.7 T/s, v_add_u32 65 T/s)
+            # measured issue rates of tools/microbench.hip and tools/issue_probe.hip (32 x 32 multiply-add 32.7 T/s; other ALU instructions
+            # 65 T/s alone, ~36 T/s between multiply-adds at this occupancy)
             "valu": valu,
             "phases_ms": phase,
             "check": check,
@@ -445,8 +486,22 @@ def main():
             out["strong"] = strong
         if single is not None:
             out["single_process"] = single
+        if with_conv is not None:
+            out["with_base_conversion"] = with_conv
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_msm(curve)
+            out["cpu_baseline"], cpu_log_n, cpu_point = cpu_baseline_msm(curve, args.log_n)
+            # the oracle's point for the same inputs against the GPU's, limb for limb: the headline size when the CPU sample reached it
+            # (it does on the driver's box), otherwise the largest size the sample ran, recomputed on the GPU for the comparison
+            if cpu_log_n == args.log_n and mode == "weak":
+                gpu_point = result
+            else:
+                wo = Workload(0, 1 << cpu_log_n)
+                gpu_point = wo.local_msm()
+                wo.destroy()
+            ok = bool((np.asarray(gpu_point)[:8] == cpu_point).all())
+            if not ok:
+                failed.append(f"msm 2^{cpu_log_n} vs oracle")
+            out["check"] = (f"oracle limb-for-limb ok (cpu_ref.best_multiexp, 2^{cpu_log_n}) + " + str(check)) if ok else "MISMATCH vs oracle"
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

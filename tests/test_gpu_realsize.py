@@ -115,8 +115,10 @@ def _ipa_case(curve, k, precompute):
         assert not ipa_verify_fast(*args, (v + 1) % fs.m, *tail, c_dev, f_dev)
 
 
-@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 12)])
+@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 12), ("vesta", 18)])
 def test_multiopen_vs_cpp_oracle(curve, k):
+    """poly::multiopen::create_proof on resident polynomials, transcript-identical to the oracle's restatement; k = 18 over Vesta is
+    the reference's own configuration (/root/reference/src/test_utils.rs:20-21, 41-49)"""
     cv = o.CURVES[curve]
     fs = cv.scalar
     n = 1 << k
@@ -200,6 +202,22 @@ def test_msm_unstructured_bases_vs_best_multiexp(curve, n):
     assert (b.msm_dev(to_dev(sc), n)[:8] == want).all()
     assert (api.best_multiexp(curve, sc, bases)[:8] == want).all()
     b.destroy()
+
+
+def test_msm_2_24_unstructured_bases_vs_best_multiexp():
+    """north_star's target size: 2^24 Pallas pairs, random 254-bit scalars, UNSTRUCTURED bases (hashed discrete logs: no arithmetic
+    progression a closed form could hide behind), limb-for-limb against the oracle's best_multiexp -- through
+    the resident-bases entry with device scalars (the headline path) and through the tiled host-pointer drop-in"""
+    curve, n = "pallas", 1 << 24
+    threads = cpu_ref.hardware_threads()
+    sc = synth.msm_scalars(24)
+    bases = cpu_ref.gen_bases_hashed(curve, 0xBA5E24, n, threads)
+    want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, sc, bases, threads=threads))
+    assert want.any()
+    b = api.Bases.from_host(curve, bases)
+    assert (b.msm_dev(to_dev(sc), n)[:8] == want).all()
+    b.destroy()
+    assert (api.best_multiexp(curve, sc, bases)[:8] == want).all()
 
 
 def test_msm_2_26_as_8_logical_shards():

@@ -95,20 +95,23 @@ def test_replay_k10_matches_oracle(columns):
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504 and res["columns"] == columns
     assert res["counts"]["multiopen_folds"] == 4 and res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 9 if columns == "witness" else 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
 
 
 def test_replay_k18_matches_oracle():
     """BASELINE config 4 (WORD_BITS = 32: k = 18, extended_k = 21, /root/reference/src/test_utils.rs:20, src/circuits/mod.rs:367):
-    the same schedule over WITNESS-SHAPED columns with the first item of every primitive kind compared against the C++ oracle (oracle/cpu_ref.py:
+    the same schedule (keygen section included) over WITNESS-SHAPED columns with the first item of every primitive kind -- and one
+    commitment of every value class of the witness -- compared against the C++ oracle (oracle/cpu_ref.py:
     best_multiexp, EvaluationDomain over best_fft, eval_polynomial; the lookup permutation and the product column against the
     step-by-step big-int restatements)"""
-    seen = {}
+    seen, classes = {}, []
     ftab = {"fp": o.FIELDS["fp"], "fq": o.FIELDS["fq"]}
 
     def hook(kind, inp, out):
         seen[kind] = seen.get(kind, 0) + 1
-        if seen[kind] > 1 and kind in ("commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals"):
+        if kind == "commit_lagrange" and "column_class" in inp:
+            classes.append(inp["column_class"])
+        elif seen[kind] > 1 and kind in ("commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals"):
             return  # the first item of each kind
         if kind in ("commit_lagrange", "commit"):
             want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], inp["bases"].download(), threads=cpu_ref.hardware_threads()))
@@ -180,8 +183,12 @@ def test_replay_k18_matches_oracle():
             want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
 
-    res = replay.run(32, batch=32, hook=hook, verbose=False, columns="witness", keygen=False)
+    res = replay.run(32, batch=32, hook=hook, verbose=False, columns="witness", keygen=True)
     assert res["schedule"]["k"] == 18 and res["schedule"]["extended_k"] == 21 and res["schedule"]["msm_n_plus_1"] == 504
+    # one commitment per value class beyond the first three columns: unblinded flags are the first columns, then
+    # unblinded words, blinded flags / words / even-bits words, the sorted lookup columns and the full-size ones
+    assert classes == [("word", False), ("flag", True), ("word", True), ("even", True), ("sorted", True), ("full", True)]
+    assert res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497 and res["counts"]["ipa"] == 1
     assert set(seen) == {"lookup_permute", "product_column", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "divide_and_extended_to_coeff"}
 

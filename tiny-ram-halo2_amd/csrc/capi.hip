@@ -286,20 +286,32 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
     Ctx& c = ctx();
     TRH_TRY(stage_begin(c));
     Stage& st = c.stage;
-    size_t tile = n ? n : 1;
-    if (bases_host) { if (n > ((size_t)1 << 21)) tile = (size_t)1 << 20; }
-    else if (n > ((size_t)3 << 21)) tile = (size_t)1 << 22;
-    if (const char* e = getenv("TRH_HOST_TILE_LOG")) { const int v = atoi(e); if (v >= 10 && v <= 26) tile = (size_t)1 << v; }
-    const size_t ntiles = n ? (n + tile - 1) / tile : 1;
-    tile = (n + ntiles - 1) / ntiles;
+    // range boundaries
+    std::vector<size_t> cut(1, 0);
+    size_t forced = 0;
+    if (const char* e = getenv("TRH_HOST_TILE_LOG")) { const int v = atoi(e); if (v >= 10 && v <= 26) forced = (size_t)1 << v; }
+    if (forced || (bases_host && n > ((size_t)1 << 21))) {  // equal ranges
+        const size_t want = forced ? forced : (size_t)1 << 20, nt = (n + want - 1) / want, len = (n + nt - 1) / nt;
+        for (size_t o = len; o < n; o += len) cut.push_back(o);
+    } else if (!bases_host && n > ((size_t)3 << 21)) {
+        // growing ranges: 2^21, 2^22, then the rest -- the first upload is short, every later one hides under the range before it
+        // (32 B per pair cross the link ~2x faster than they are multiplied), and most pairs run as one large MSM at the full rate
+        cut.push_back((size_t)1 << 21);
+        cut.push_back((size_t)3 << 21);
+    }
+    cut.push_back(n);
+    const size_t ntiles = cut.size() - 1;
     uint64_t acc[24];
     memset(acc, 0, sizeof(acc));
+    for (size_t t = 0; t < ntiles; ++t) {  // both device buffers at their final size before anything is in flight (a growing DevBuf frees)
+        size_t longest = 0;
+        for (size_t u = t & 1; u < ntiles; u += 2) longest = cut[u + 1] - cut[u] > longest ? cut[u + 1] - cut[u] : longest;
+        if (t < 2) { TRH_TRY(st.ring_in[t].ensure(longest * 32 + 32)); if (bases_host) TRH_TRY(st.ring_out[t].ensure(longest * 64 + 64)); }
+    }
     for (size_t t = 0; t < ntiles; ++t) {
-        const size_t slot = t & 1, off = t * tile, cur = off + tile < n ? tile : n - off;
-        TRH_TRY(st.ring_in[slot].ensure(cur * 32 + 32));
+        const size_t slot = t & 1, off = cut[t], cur = cut[t + 1] - cut[t];
         TRH_TRY(stage_h2d(c, st.ring_in[slot].p, coeffs + 4 * off, cur * 32, st.us));
         if (bases_host) {
-            TRH_TRY(st.ring_out[slot].ensure(cur * 64 + 64));
             TRH_TRY(stage_h2d(c, st.ring_out[slot].p, bases_host + 8 * off, cur * 64, st.us));
         }
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));

@@ -114,8 +114,8 @@ struct Stage {
     size_t slot = 0;                 // bytes per slot
     char* up = nullptr;              // NS slots of pinned memory, host -> device
     char* down = nullptr;            // NS slots, device -> host
-    hipEvent_t up_ev[NS] = {nullptr, nullptr, nullptr, nullptr}, down_ev[NS] = {nullptr, nullptr, nullptr, nullptr};
-    bool up_used[NS] = {false, false, false, false};
+    hipEvent_t up_ev[NS] = {}, down_ev[NS] = {};
+    bool up_used[NS] = {};
     unsigned up_next = 0;
     hipStream_t us = nullptr, cs = nullptr, ds = nullptr;  // upload, compute, download
     hipEvent_t ev_up[4] = {nullptr, nullptr, nullptr, nullptr}, ev_comp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -191,13 +191,16 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
 int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
 // Batch pipeline over `count` items (each a group of host buffers): upload (caller thread, stage.us) -> compute(item, in, out,
 // stage.cs) -> download (helper thread, stage.ds), over a ring of device buffers.  in_bytes / out_bytes: device bytes per item;
-// upload(item, dev_in) / download(item, dev_out) issue the stage_h2d / stage_d2h calls of one item.
+// upload(item, dev_in) issues the stage_h2d calls of one item; segments(item, dev_out, list) names where its results go -- the helper
+// thread keeps the download ring full ACROSS items (the DMA of item i + 1 starts while the last slots of item i are copied out).
 struct HostPipe {
     size_t count = 0, in_bytes = 0, out_bytes = 0;
     bool in_place = false;  // compute works in the input buffer (out == in)
     std::function<int(size_t, void*)> upload;
     std::function<int(size_t, void*, void*, hipStream_t)> compute;
-    std::function<int(size_t, const void*)> download;
+    // the host destinations of one item: (dst_host, src_dev, bytes) segments, src inside the item's device output buffer
+    struct Seg { void* dst; const void* src; size_t bytes; };
+    std::function<void(size_t, const void*, std::vector<Seg>&)> segments;
 };
 int host_pipeline(Ctx& c, const HostPipe& p);
 int stage_begin(Ctx& c);  // the stage's streams wait for the context's previous work

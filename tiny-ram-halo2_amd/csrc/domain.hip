@@ -255,9 +255,8 @@ int trh_domain_lagrange_to_coeff_host(trh_domain* d, uint64_t* const* a, size_t 
     p.compute = [&](size_t it, void* din, void*, hipStream_t s) -> int {
         return trh_domain_lagrange_to_coeff(d, din, count - it * group < group ? count - it * group : group, s);
     };
-    p.download = [&](size_t it, const void* dout) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, a[j], (const char*)dout + (j - it * group) * bytes, bytes, c.stage.ds));
-        return TRH_OK;
+    p.segments = [&](size_t it, const void* dout, std::vector<HostPipe::Seg>& out) {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) out.push_back(HostPipe::Seg{a[j], (const char*)dout + (j - it * group) * bytes, bytes});
     };
     return host_pipeline(c, p);
 }
@@ -282,9 +281,8 @@ int trh_domain_coeff_to_extended_host(trh_domain* d, const uint64_t* const* coef
     p.compute = [&](size_t it, void* din, void* dout, hipStream_t s) -> int {
         return trh_domain_coeff_to_extended(d, din, dout, count - it * group < group ? count - it * group : group, s);
     };
-    p.download = [&](size_t it, const void* dout) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, ext[j], (const char*)dout + (j - it * group) * out_b, out_b, c.stage.ds));
-        return TRH_OK;
+    p.segments = [&](size_t it, const void* dout, std::vector<HostPipe::Seg>& out) {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) out.push_back(HostPipe::Seg{ext[j], (const char*)dout + (j - it * group) * out_b, out_b});
     };
     return host_pipeline(c, p);
 }

@@ -16,7 +16,9 @@
 //     while range t is computed.
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <deque>
 #include <condition_variable>
 #include <string>
 #include <thread>
@@ -49,10 +51,13 @@ class CopyPool {
             std::lock_guard<std::mutex> lk(mu);
             job_dst = dst; job_src = src; job_bytes = bytes; job_per = per;
             pending = T;
+            pending_atomic.store(T, std::memory_order_release);
             ++gen;
+            gen_atomic.store(gen, std::memory_order_release);
         }
         cv_work.notify_all();
         memcpy(dst, src, per < bytes ? per : bytes);  // part 0 on the caller
+        for (int spin = 0; spin < 20000 && pending_atomic.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
     }
@@ -63,6 +68,9 @@ class CopyPool {
         for (;;) {
             char* dst; const char* src; size_t bytes, per;
             {
+                // jobs arrive every few hundred microseconds while a transfer runs: spin briefly before sleeping (a condition-variable
+                // wake-up costs 30-50 us, a quarter of a slot's DMA time)
+                for (int spin = 0; spin < 20000 && gen_atomic.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return gen != seen; });
                 seen = gen;
@@ -72,6 +80,7 @@ class CopyPool {
             if (lo < bytes) memcpy(dst + lo, src + lo, lo + per < bytes ? per : bytes - lo);
             {
                 std::lock_guard<std::mutex> lk(mu);
+                pending_atomic.store(pending - 1, std::memory_order_release);
                 if (--pending == 0) cv_done.notify_one();
             }
         }
@@ -83,6 +92,8 @@ class CopyPool {
     char* job_dst = nullptr; const char* job_src = nullptr; size_t job_bytes = 0, job_per = 0;
     unsigned gen = 0;
     int pending = 0;
+    std::atomic<unsigned> gen_atomic{0};
+    std::atomic<int> pending_atomic{0};
 };
 
 int copy_threads() {
@@ -110,14 +121,16 @@ bool is_pinned(const void* p) {
 int stage_ensure(Ctx& c) {
     Stage& st = c.stage;
     if (st.up) return TRH_OK;
-    size_t slot = (size_t)16 << 20;
+    size_t slot = (size_t)16 << 20;  // x NS = 4 slots per direction; smaller slots lose to the per-slot hand-over (measured: 16 MiB 32 ms, 8 MiB 39 ms, 4 MiB 45 ms for the 1.6 GB of a 2^24 best_multiexp)
     if (const char* e = getenv("TRH_STAGE_SLOT_MB")) { const long v = atol(e); if (v >= 1 && v <= 256) slot = (size_t)v << 20; }
     hipError_t e = hipHostMalloc((void**)&st.up, slot * Stage::NS, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st.down, slot * Stage::NS, hipHostMallocDefault);
     for (int i = 0; i < Stage::NS && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&st.up_ev[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&st.down_ev[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_up[i], hipEventDisableTiming);
+    }
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&st.ev_up[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_comp[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st.us, hipStreamNonBlocking);
@@ -140,10 +153,13 @@ void stage_release(Ctx& c) {
     for (int i = 0; i < Stage::NS; ++i) {
         if (st.up_ev[i]) (void)hipEventDestroy(st.up_ev[i]);
         if (st.down_ev[i]) (void)hipEventDestroy(st.down_ev[i]);
+        st.up_ev[i] = st.down_ev[i] = nullptr;
+        st.up_used[i] = false;
+    }
+    for (int i = 0; i < 4; ++i) {
         if (st.ev_up[i]) (void)hipEventDestroy(st.ev_up[i]);
         if (st.ev_comp[i]) (void)hipEventDestroy(st.ev_comp[i]);
-        st.up_ev[i] = st.down_ev[i] = st.ev_up[i] = st.ev_comp[i] = nullptr;
-        st.up_used[i] = false;
+        st.ev_up[i] = st.ev_comp[i] = nullptr;
         st.ring_in[i].release(); st.ring_out[i].release();
     }
     if (st.us) (void)hipStreamDestroy(st.us);
@@ -163,7 +179,7 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
     } else {
         // a transfer smaller than the ring still wants a few slots in flight: the copy into slot i + 1 hides under the DMA of slot i
         size_t chunk = st.slot;
-        while (chunk > ((size_t)1 << 20) && bytes < chunk * 3) chunk >>= 1;
+        while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a short transfer still gets two slots in flight
         for (size_t off = 0; off < bytes; off += chunk) {
             const size_t cur = bytes - off < chunk ? bytes - off : chunk;
             const int sl = (int)(st.up_next++ % Stage::NS);
@@ -190,7 +206,7 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
         TRH_HIP_TRY(hipStreamSynchronize(s));
     } else {
         size_t chunk = st.slot;
-        while (chunk > ((size_t)1 << 20) && bytes < chunk * 3) chunk >>= 1;
+        while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a short transfer still gets two slots in flight
         const size_t nchunks = (bytes + chunk - 1) / chunk;
         size_t issued = 0;
         for (size_t k = 0; k < nchunks; ++k) {
@@ -248,23 +264,66 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
     const int device = c.device;
     std::thread helper([&] {
         int rc = hipSetDevice(device) == hipSuccess ? TRH_OK : TRH_EHIP;
-        for (size_t i = 0; i < p.count; ++i) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return submitted > i || abort; });
-                if (submitted <= i) return;
+        struct Chunk { int slot; char* dst; size_t bytes; size_t item; bool direct; };
+        std::deque<Chunk> inflight;
+        std::vector<HostPipe::Seg> segs;
+        std::vector<size_t> chunks_left(p.count, 0);
+        size_t next_item = 0, seg_idx = 0, seg_off = 0, issue_ctr = 0, items_done = 0;
+        bool have_segs = false;
+        const double t_begin = now_s();
+        double bytes_moved = 0;
+        auto fail = [&](int code) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (helper_rc == TRH_OK) { helper_rc = code; helper_err = trh_last_error(); }
+            abort = true;
+        };
+        if (rc != TRH_OK) { set_error("host pipeline: hipSetDevice failed"); fail(rc); cv.notify_all(); return; }
+        while (items_done < p.count) {
+            // keep the ring full: chunks of the next items as soon as their kernels are queued
+            while ((int)inflight.size() < Stage::NS && (have_segs || next_item < p.count)) {
+                if (!have_segs) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (inflight.empty()) cv.wait(lk, [&] { return submitted > next_item || abort; });
+                        if (abort && submitted <= next_item) return;
+                        if (submitted <= next_item) break;  // not launched yet: go drain what is in flight
+                    }
+                    const size_t slot = next_item % D;
+                    if (hipStreamWaitEvent(st.ds, st.ev_comp[slot], 0) != hipSuccess) { set_error("host pipeline: hipStreamWaitEvent failed"); fail(TRH_EHIP); cv.notify_all(); return; }
+                    segs.clear();
+                    p.segments(next_item, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p, segs);
+                    size_t nch = 0;
+                    for (const HostPipe::Seg& sg : segs) nch += is_pinned(sg.dst) ? 1 : (sg.bytes + st.slot - 1) / st.slot;
+                    chunks_left[next_item] = nch;
+                    have_segs = true; seg_idx = 0; seg_off = 0;
+                    if (nch == 0) { have_segs = false; ++items_done; { std::lock_guard<std::mutex> lk(mu); downloaded = next_item + 1; } cv.notify_all(); ++next_item; continue; }
+                }
+                const HostPipe::Seg& sg = segs[seg_idx];
+                const bool direct = is_pinned(sg.dst);
+                const size_t cur = direct ? sg.bytes : (sg.bytes - seg_off < st.slot ? sg.bytes - seg_off : st.slot);
+                const int sl = (int)(issue_ctr++ % Stage::NS);
+                char* land = direct ? (char*)sg.dst : st.down + (size_t)sl * st.slot;
+                hipError_t e = hipMemcpyAsync(land, (const char*)sg.src + seg_off, cur, hipMemcpyDeviceToHost, st.ds);
+                if (e == hipSuccess) e = hipEventRecord(st.down_ev[sl], st.ds);
+                if (e != hipSuccess) { set_error("host pipeline: download failed: %s", hipGetErrorString(e)); fail(TRH_EHIP); cv.notify_all(); return; }
+                inflight.push_back(Chunk{sl, (char*)sg.dst + seg_off, cur, next_item, direct});
+                seg_off += cur;
+                if (seg_off >= sg.bytes) { seg_off = 0; if (++seg_idx >= segs.size()) { have_segs = false; ++next_item; } }
             }
-            const size_t slot = i % D;
-            if (rc == TRH_OK && hipStreamWaitEvent(st.ds, st.ev_comp[slot], 0) != hipSuccess) { set_error("host pipeline: hipStreamWaitEvent failed"); rc = TRH_EHIP; }
-            if (rc == TRH_OK) rc = p.download(i, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (rc != TRH_OK && helper_rc == TRH_OK) { helper_rc = rc; helper_err = trh_last_error(); abort = true; }
-                downloaded = i + 1;
+            if (inflight.empty()) continue;
+            const Chunk ch = inflight.front();
+            if (hipEventSynchronize(st.down_ev[ch.slot]) != hipSuccess) { set_error("host pipeline: hipEventSynchronize failed"); fail(TRH_EHIP); cv.notify_all(); return; }
+            if (!ch.direct) down_pool().copy(ch.dst, st.down + (size_t)ch.slot * st.slot, ch.bytes);
+            bytes_moved += (double)ch.bytes;
+            inflight.pop_front();
+            if (--chunks_left[ch.item] == 0) {
+                ++items_done;
+                { std::lock_guard<std::mutex> lk(mu); downloaded = ch.item + 1; }
+                cv.notify_all();
             }
-            cv.notify_all();
-            if (rc != TRH_OK) return;
         }
+        st.down_bytes += bytes_moved;
+        st.down_s += now_s() - t_begin;
     });
     int rc = TRH_OK;
     auto step = [&](size_t i) -> int {
@@ -340,9 +399,8 @@ static int best_fft_batch_host(int field, uint64_t* const* a, size_t count, cons
         const size_t nb = count - it * group < group ? count - it * group : group;
         return ntt_device(field, din, log_n, omega, nb, s);
     };
-    p.download = [&](size_t it, const void* dout) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_d2h(c, a[j], (const char*)dout + (j - it * group) * bytes, bytes, c.stage.ds));
-        return TRH_OK;
+    p.segments = [&](size_t it, const void* dout, std::vector<HostPipe::Seg>& out) {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) out.push_back(HostPipe::Seg{a[j], (const char*)dout + (j - it * group) * bytes, bytes});
     };
     return host_pipeline(c, p);
 }

@@ -236,6 +236,14 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         torch.cuda.synchronize()
         return (d.cpu().numpy().view(np.uint64).reshape(b, n, 4) if hook is not None and first == 0 else None), d
 
+    # with a hook, one commitment of EVERY value class is handed over (the first column of each class): flags, words, even-bits words,
+    # sorted lookup columns and full-size values, blinded and not, take different paths through the MSM (chunked bucket passes, heavy
+    # buckets, the plain accumulation)
+    class_first = {}
+    if hook is not None and columns == "witness":
+        for idx, kb in enumerate(kinds):
+            class_first.setdefault(kb, idx)
+    class_first = set(class_first.values())
     while done < lag_total:
         b = min(batch, lag_total - done)
         cols_h, cols = make_columns(done, b)
@@ -243,6 +251,11 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         e0 = ev()
         pts = params.commit_lagrange_batch(cols, blinds)
         e1 = ev()
+        for i in range(b):
+            if done + i in class_first and not (done == 0 and i < 3):
+                torch.cuda.synchronize()
+                hook("commit_lagrange", dict(scalars=np.concatenate([cols[i].cpu().numpy().view(np.uint64), blinds[i][None]]), bases=gl, column_class=kinds[done + i]), pts[i])
+                checked += 1
         coeff = dom.lagrange_to_coeff(cols)
         e2 = ev()
         ext = dom.coeff_to_extended(coeff, out=ext_buf)
