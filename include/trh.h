@@ -204,6 +204,20 @@ int trh_domain_coeff_to_extended(trh_domain_t d, const void* coeff_dev, void* ex
 int trh_domain_extended_to_coeff(trh_domain_t d, void* a_dev, size_t batch, void* stream);            /* in place; caller truncates */
 int trh_domain_divide_by_vanishing_poly(trh_domain_t d, void* a_dev, size_t batch, void* stream);     /* in place */
 
+/* The extended domain as coset blocks: its 2^extended_k points zeta * extended_omega^i, i = q * 2^(extended_k - k) + r, are the
+ * 2^(extended_k - k) cosets (zeta extended_omega^r) * omega^q of the size-2^k subgroup.  coeff_to_extended_blocks writes, for each
+ * of `batch` polynomials, blocks r = 0 .. n_blocks - 1 (2^k values each, back to back): entry q of block r is entry
+ * q * 2^(extended_k - k) + r of coeff_to_extended's output.  A block is a size-2^k transform (two passes at k = 18 instead of the
+ * three of the zero-padded 2^21 one), Rotation(1) is q + 1 inside a block (trh_expr_eval_blocks_dev), and the quotient h(X) --
+ * degree < (j - 1) 2^k -- is determined by j - 1 = trh_domain_quotient_blocks() blocks (5 of 8 for the reference's circuit), so the
+ * prover needs only those of every column.  blocks_to_quotient: (j - 1) x 2^k values of the numerator on blocks 0 .. j - 2
+ * (overwritten) -> the (j - 1) x 2^k coefficients of h(X) = numerator / (X^(2^k) - 1) (divide_by_vanishing = 1; with 0 the input
+ * is taken as h's own values): what extended_to_coeff(divide_by_vanishing_poly(.)) returns, truncated to (j - 1) 2^k, whenever the
+ * vanishing polynomial divides the numerator (it does in create_proof).                                                          */
+uint32_t trh_domain_quotient_blocks(trh_domain_t d);
+int trh_domain_coeff_to_extended_blocks(trh_domain_t d, const void* coeff_dev, void* ext_dev, size_t batch, uint32_t n_blocks, void* stream);
+int trh_domain_blocks_to_quotient(trh_domain_t d, void* num_blocks_dev, void* h_coeff_dev, int divide_by_vanishing, void* stream);
+
 /* the same on HOST polynomials (one pointer per column; what the Rust EvaluationDomain's methods take), pipelined over PCIe:
  * lagrange_to_coeff in place; coeff_to_extended reads 2^k coefficients and writes 2^extended_k values (only the non-zero
  * coefficients go up); extended_to_coeff in place on one polynomial of 2^extended_k values, optionally preceded by
@@ -326,6 +340,9 @@ uint32_t trh_expr_lds_slots(trh_expr_t e); /* stack entries below the two regist
 int trh_expr_set_const(trh_expr_t e, uint32_t index, const uint64_t value[4]);
 /* columns_dev / outputs_dev: host arrays of device pointers (2^log_n x 4 u64 each); synchronises the stream */
 int trh_expr_eval_dev(trh_expr_t e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, void* stream);
+/* the same over columns in the coset-block layout of trh_domain_coeff_to_extended_blocks: n_blocks x 2^block_log rows per column,
+ * Rotation(r) reads row (q + r) mod 2^block_log of the same block */
+int trh_expr_eval_blocks_dev(trh_expr_t e, const void* const* columns_dev, void* const* outputs_dev, uint32_t block_log, uint32_t n_blocks, void* stream);
 
 /* ---- best_fft over curve points: Params::new's g -> g_lagrange -----------------------------
  * halo2_proofs::arithmetic::best_fft::<C::Curve>(a, omega, log_n): a'[i] = sum_j [omega^(i j)] a[j].

@@ -427,6 +427,15 @@ def test_quotient_identity_end_to_end(k):
     folded = (g0 * y + g1) % f.m
     h_x = ev(hc.reshape(1, -1, 4), x)[0]
     assert h_x * (pow(x, n, f.m) - 1) % f.m == folded
+    # the same chain over the coset-block layout with only the j - 1 blocks the quotient needs: rotations stay inside a block, the
+    # vanishing polynomial is a constant per block, the quotient comes back from j - 1 inverse size-n transforms -- the SAME h(X)
+    D = dom.quotient_poly_degree
+    extb = dom.coeff_to_extended_blocks(coeff, D)                                     # (4, D, n, 4)
+    resb = {("advice", 0): extb[0], ("advice", 1): extb[1], ("advice", 2): extb[2], ("selector", 0): extb[3]}
+    hb = expr.GateEvaluator(prog).eval_blocks(resb, k, D).contiguous()
+    hq = dom.blocks_to_quotient(hb)
+    torch.cuda.synchronize()
+    assert (hq.cpu().numpy().view(np.uint64) == hc_host[: D * n]).all()
 
 
 def test_permutation_argument_closes_on_a_real_permutation():

@@ -291,3 +291,53 @@ def test_multiopen_lincomb_and_kate_division(field):
         want.append(acc)
         acc = (acc + v) % f.m
     assert [f.from_limbs(r) for r in to_host(out)] == want
+
+
+@pytest.mark.parametrize("field,k,j", [("fp", 5, 6), ("fq", 9, 4), ("fp", 11, 6), ("fq", 12, 6), ("fp", 13, 3), ("fp", 18, 6)])
+def test_extended_domain_as_coset_blocks(field, k, j):
+    """trh_domain_coeff_to_extended_blocks / trh_domain_blocks_to_quotient against EvaluationDomain's own functions:
+    (1) block r, entry q == coeff_to_extended(a)[q 2^(extended_k - k) + r] -- all 2^(extended_k - k) blocks and the quotient's j - 1,
+        fused (k >= 11, incl. the reference's k = 18 / extended_k = 21) and unfused (small k) forms, batch of ragged size;
+    (2) for a numerator the vanishing polynomial divides -- N = h (X^n - 1) with a random h of (j - 1) n coefficients, evaluated on the
+        extended coset by the oracle -- blocks_to_quotient of its first j - 1 blocks == extended_to_coeff(divide_by_vanishing_poly(N))
+        == h, coefficient for coefficient."""
+    import cpu_ref
+    f = o.FIELDS[field]
+    dom = poly.EvaluationDomain(field, j, k)
+    cd = cpu_ref.EvaluationDomain(field, j, k)
+    n, ek = 1 << k, dom.extended_k
+    N, step, D = 1 << ek, 1 << (ek - k), j - 1
+    batch = 3
+    a = synth.field_elements(0xB10C + k, batch * n).reshape(batch, n, 4)
+    d_a = torch.from_numpy(a.view(np.int64)).cuda()
+    want = [np.asarray(cd.coeff_to_extended(a[i])).reshape(N, 4) for i in (0, batch - 1)]
+    for nb in (step, D):
+        got = dom.coeff_to_extended_blocks(d_a, nb)
+        torch.cuda.synchronize()
+        g = got.cpu().numpy().view(np.uint64).reshape(batch, nb, n, 4)
+        for wi, i in enumerate((0, batch - 1)):
+            for r in range(nb):
+                assert (g[i, r] == want[wi][r::step]).all(), (nb, i, r)
+    # (2) quotient from j - 1 blocks
+    h = synth.field_elements(0x40 + k, D * n)
+    lim = lambda v: np.array(f.limbs(v), np.uint64)  # noqa: E731
+    # h on the extended coset: zero-pad to 2^extended_k, zeta shift, best_fft (EvaluationDomain::coeff_to_extended on a longer polynomial)
+    padded = np.zeros((N, 4), dtype=np.uint64)
+    padded[: D * n] = h
+    zs = [1, cd.c.g_coset, cd.c.g_coset_inv]
+    fac = np.array([f.limbs(zs[i % 3]) for i in range(3)], dtype=np.uint64)
+    padded[: D * n] = cpu_ref.field_op(field, "mul", padded[: D * n], np.tile(fac, (D * n // 3 + 1, 1))[: D * n])
+    h_ext = cpu_ref.best_fft(field, padded, lim(cd.c.extended_omega), ek, cpu_ref.hardware_threads())
+    # numerator = h * t with t = X^n - 1 on the coset (period 2^(extended_k - k)): multiply by the inverses' inverses
+    t_vals = np.array([f.limbs(pow(v, -1, f.m)) for v in cd.c.t_evaluations], dtype=np.uint64)
+    num = cpu_ref.field_op(field, "mul", h_ext, np.tile(t_vals, (N // len(t_vals), 1)))
+    ref = np.asarray(cd.extended_to_coeff(cd.divide_by_vanishing_poly(num.copy()))).reshape(-1, 4)
+    assert (ref[: D * n] == h).all()                        # the oracle's own chain returns h
+    blocks = np.stack([num[r::step] for r in range(D)])     # the numerator on blocks 0 .. j - 2
+    d_num = torch.from_numpy(np.ascontiguousarray(blocks).view(np.int64)).cuda()
+    got_h = dom.blocks_to_quotient(d_num, divide_by_vanishing=True)
+    torch.cuda.synchronize()
+    assert (got_h.cpu().numpy().view(np.uint64) == h).all()
+    # without the division: h's own values in, h out
+    d_hv = torch.from_numpy(np.ascontiguousarray(np.stack([h_ext[r::step] for r in range(D)])).view(np.int64)).cuda()
+    assert (dom.blocks_to_quotient(d_hv, divide_by_vanishing=False).cpu().numpy().view(np.uint64) == h).all()

@@ -67,6 +67,21 @@ def test_replay_k10_matches_oracle(columns):
                 acc = (acc * x + f.from_limbs(r)) % f.m
             assert f.from_limbs(out) == acc
             return
+        if kind == "h_eval" and "n_blocks" in inp:  # coset-block layout: a rotation stays inside its block
+            f = o.FIELDS[inp["field"]]
+            nb, D_ = 1 << inp["block_log"], inp["n_blocks"]
+            got = out.cpu().numpy().view(np.uint64).reshape(D_, nb, 4)
+            gates = [to_tuple(g) for g in inp["gates"]]
+            for r, q in ((0, 0), (1, nb - 1), (D_ - 1, 4097 % nb), (2, nb // 2 + 3)):
+                cols = Lazy({key: t.reshape(D_, nb, 4)[r] for key, t in inp["resident"].items()}, f)
+                acc = 0
+                for g in gates:
+                    acc = (acc * inp["y"] + o.evaluate_expression(f, g, cols, q, nb, 1)) % f.m
+                assert f.from_limbs(got[r, q]) == acc, (r, q)
+            return
+        if kind in ("coeff_to_extended_blocks", "blocks_to_quotient"):
+            check_blocks(kind, inp, out)
+            return
         if kind == "h_eval":  # sampled rows of the gate evaluation against the oracle's Expression::evaluate restatement
             f = o.FIELDS[inp["field"]]
             n = 1 << inp["log_n"]
@@ -95,7 +110,27 @@ def test_replay_k10_matches_oracle(columns):
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504 and res["columns"] == columns
     assert res["counts"]["multiopen_folds"] == 4 and res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 9 if columns == "witness" else 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "evals": 3, "h_eval": 1, "commit": 1, "divide_and_extended_to_coeff": 1}
+    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 9 if columns == "witness" else 3, "lagrange_to_coeff": 3, "coeff_to_extended_blocks": 3, "evals": 3, "h_eval": 1, "commit": 1,
+                    "blocks_to_quotient": 1}
+    assert res["extended_domain"].startswith("5 of 8")
+
+
+def test_replay_k10_full_extended_domain_matches_oracle():
+    """the halo2 0.2.0 layout of the extended domain (all 2^extended_k points, natural order) stays available: --extended full"""
+    seen = {}
+
+    def hook(kind, inp, out):
+        seen[kind] = seen.get(kind, 0) + 1
+        if kind not in ("coeff_to_extended", "divide_and_extended_to_coeff") or seen[kind] > 1:
+            return
+        field, j, k = inp["domain"]
+        dom = cpu_ref.EvaluationDomain(field, j, k)
+        a = np.asarray(inp["a"]).reshape(-1, 4)
+        want = dom.coeff_to_extended(a) if kind == "coeff_to_extended" else dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
+        assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
+
+    res = replay.run(16, batch=32, hook=hook, verbose=False, columns="witness", keygen=False, extended="full")
+    assert res["extended_domain"] == "all 2^13 points" and seen["coeff_to_extended"] == 3 and seen["divide_and_extended_to_coeff"] == 1 and seen["h_eval"] == 1
 
 
 def test_replay_k18_matches_oracle():
@@ -154,23 +189,18 @@ def test_replay_k18_matches_oracle():
             return
         if kind == "h_eval":  # sampled rows against the oracle's Expression::evaluate restatement (only the rows the gates touch are converted)
             f = ftab[inp["field"]]
-            n = 1 << inp["log_n"]
-            got = out.cpu().numpy().view(np.uint64)
+            nb, D_ = 1 << inp["block_log"], inp["n_blocks"]   # coset-block layout: a rotation stays inside its block
+            got = out.cpu().numpy().view(np.uint64).reshape(D_, nb, 4)
             gates = [to_tuple(g) for g in inp["gates"]]
-
-            class Lazy(dict):
-                def __missing__(self, key):
-                    t = inp["resident"][key]
-                    col = LazyColumn(f, t)
-                    self[key] = col
-                    return col
-
-            cols = Lazy()
-            for row in (0, 1, n - 1, 4097 % n, n // 2 + 3):
+            for r, q in ((0, 0), (1, nb - 1), (D_ - 1, 4097 % nb), (2, nb // 2 + 3), (3, 1)):
+                cols = Lazy({key: t.reshape(D_, nb, 4)[r] for key, t in inp["resident"].items()}, f)
                 acc = 0
                 for g in gates:
-                    acc = (acc * inp["y"] + o.evaluate_expression(f, g, cols, row, n, inp["rot_step"])) % f.m
-                assert f.from_limbs(got[row]) == acc, row
+                    acc = (acc * inp["y"] + o.evaluate_expression(f, g, cols, q, nb, 1)) % f.m
+                assert f.from_limbs(got[r, q]) == acc, (r, q)
+            return
+        if kind in ("coeff_to_extended_blocks", "blocks_to_quotient"):
+            check_blocks(kind, inp, out)
             return
         field, j, k = inp["domain"]
         dom = cpu_ref.EvaluationDomain(field, j, k)
@@ -190,7 +220,47 @@ def test_replay_k18_matches_oracle():
     assert classes == [("word", False), ("flag", True), ("word", True), ("even", True), ("sorted", True), ("full", True)]
     assert res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497 and res["counts"]["ipa"] == 1
-    assert set(seen) == {"lookup_permute", "product_column", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended", "evals", "h_eval", "commit", "divide_and_extended_to_coeff"}
+    assert set(seen) == {"lookup_permute", "product_column", "commit_lagrange", "lagrange_to_coeff", "coeff_to_extended_blocks", "evals", "h_eval", "commit", "blocks_to_quotient"}
+
+
+class Lazy(dict):
+    """resident device columns read row by row (canonical ints): sampling a few rows of 2^18 .. 2^21 does not convert the columns"""
+
+    def __init__(self, tensors, f):
+        super().__init__()
+        self.tensors, self.f = tensors, f
+
+    def __missing__(self, key):
+        col = LazyColumn(self.f, self.tensors[key])
+        self[key] = col
+        return col
+
+
+def check_blocks(kind, inp, out):
+    """the coset-block forms against EvaluationDomain's own functions (C++ oracle): block r, entry q of coeff_to_extended_blocks ==
+    coeff_to_extended(a)[8 q + r]; blocks_to_quotient's polynomial, brought back to the extended coset by the oracle, takes the
+    values input x (X^n - 1)^-1 on every point of the blocks it was interpolated from (the interpolant of degree < 5 n is unique)"""
+    field, j, k = inp["domain"]
+    f = o.FIELDS[field]
+    dom = cpu_ref.EvaluationDomain(field, j, k)
+    n, N, D_ = 1 << k, 1 << dom.extended_k, inp["n_blocks"]
+    step = N // n
+    if kind == "coeff_to_extended_blocks":
+        want = np.asarray(dom.coeff_to_extended(np.asarray(inp["a"]).reshape(n, 4))).reshape(N, 4)
+        got = np.asarray(out).reshape(D_, n, 4)
+        for r in range(D_):
+            assert (got[r] == want[r::step]).all(), r
+        return
+    h = np.asarray(out).reshape(D_ * n, 4)
+    padded = np.zeros((N, 4), dtype=np.uint64)
+    zs = [1, dom.c.g_coset, dom.c.g_coset_inv]
+    fac = np.array([f.limbs(zs[i % 3]) for i in range(3)], dtype=np.uint64)
+    padded[: D_ * n] = cpu_ref.field_op(field, "mul", h, np.tile(fac, (D_ * n // 3 + 1, 1))[: D_ * n])
+    h_ext = cpu_ref.best_fft(field, padded, np.array(f.limbs(dom.c.extended_omega), np.uint64), dom.extended_k, cpu_ref.hardware_threads())
+    num = np.asarray(inp["a"]).reshape(D_, n, 4)
+    tinv = np.array([f.limbs(v) for v in dom.c.t_evaluations], dtype=np.uint64)
+    for r in range(D_):
+        assert (h_ext[r::step] == cpu_ref.field_op(field, "mul", num[r], np.tile(tinv[r % len(tinv)], (n, 1)))).all(), r
 
 
 def synth_ints(a):

@@ -143,6 +143,10 @@ _SIGNATURES = {
     "trh_best_fft_batch_fp": ([ctypes.POINTER(_u64p), ctypes.c_size_t, _u64p, ctypes.c_uint32], ctypes.c_int),
     "trh_best_fft_batch_fq": ([ctypes.POINTER(_u64p), ctypes.c_size_t, _u64p, ctypes.c_uint32], ctypes.c_int),
     "trh_commit_batch_host": ([_vp, ctypes.POINTER(_u64p), ctypes.c_size_t, ctypes.c_size_t, _u64p, _u64p], ctypes.c_int),
+    "trh_domain_quotient_blocks": ([_vp], ctypes.c_uint32),
+    "trh_domain_coeff_to_extended_blocks": ([_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_uint32, _vp], ctypes.c_int),
+    "trh_domain_blocks_to_quotient": ([_vp, _vp, _vp, ctypes.c_int, _vp], ctypes.c_int),
+    "trh_expr_eval_blocks_dev": ([_vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint32, _vp], ctypes.c_int),
     "trh_domain_lagrange_to_coeff_host": ([_vp, ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
     "trh_domain_coeff_to_extended_host": ([_vp, ctypes.POINTER(_u64p), ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
     "trh_domain_extended_to_coeff_host": ([_vp, _u64p, ctypes.c_int], ctypes.c_int),

@@ -216,7 +216,19 @@ struct NttFusion {
     uint32_t pre_period = 0;
     const void* post = nullptr;    // y[i] *= post[i % post_period] on the final store
     uint32_t post_period = 0;
+    // coset blocks (EvaluationDomain's extended domain as 2^(extended_k - k) cosets of size 2^k, domain.hip): transform t of the batch
+    // belongs to block t % blocks and -- with pre_blocks -- reads input row t / blocks (in_dev, 2^in_log = 2^log_n elements per row).
+    // Tables: [blocks][2^log_n] entries as raw balanced limbs in three planes (ntt_block_table layout, 36 B per entry).
+    const void* pre_blocks = nullptr;   // x[i] *= pre_blocks[t % blocks][i] on the loads of pass 0
+    const void* post_blocks = nullptr;  // y[i] *= post_blocks[t % blocks][i] on the final store
+    uint32_t blocks = 0;
 };
+// bytes of a [blocks][2^log_n] table of NttFusion::pre_blocks / post_blocks, and the kernel that fills one: entry (b, i) =
+// base_b^i * scale with base_b = g * w^b (canonical Montgomery inputs): the coset generators' powers
+size_t ntt_block_table_bytes(uint32_t blocks, uint32_t log_n);
+int ntt_block_table_build(int field, void* table_dev, uint32_t blocks, uint32_t log_n, const u64 g[4], const u64 w[4], const u64 scale[4], hipStream_t s);
+// out[t][i] = in[t / blocks][i] * table[t % blocks][i] (canonical words in and out): the unfused form for sizes below the lazy passes
+int ntt_block_scale(int field, const void* in_dev, void* out_dev, size_t transforms, uint32_t blocks, uint32_t log_n, const void* table_dev, bool in_per_block, hipStream_t s);
 bool ntt_can_fuse(uint32_t log_n);
 int ntt_lazy_shift();
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr);

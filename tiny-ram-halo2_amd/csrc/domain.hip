@@ -23,6 +23,13 @@ struct trh_domain {
     void* d_tables = nullptr;                  // device copy: into_coset[3], from_coset[3], divisors[2], t_inv[...], then the lazy-form block
     trh::FeMem z_into[3], z_idiv, z_from_div[3];  // lazy Montgomery form (x 2^270) for the steps fused into the NTT passes
     int device = -1;                           // the tables live on this device
+    // extended domain as coset blocks (trh_domain_coeff_to_extended_blocks): zeta * extended_omega^(r + q * 2^(extended_k - k)) =
+    // (zeta * extended_omega^r) * omega^q -- block r is the size-2^k transform of the coefficients scaled by (zeta extended_omega^r)^j
+    void* d_post_blocks = nullptr;   // [j - 1][2^k]: (zeta extended_omega^r)^-j * 2^-k, the way back from block r
+    void* d_vinv = nullptr;          // two (j - 1) x (j - 1) matrices (canonical Montgomery): inverse of V[r][i] = c_r^i, c_r = (zeta extended_omega^r)^(2^k),
+                                     // plain and with column r divided by (c_r - 1) (the vanishing polynomial's value on block r)
+    void* d_pre_sub = nullptr;       // the first pre_sub_blocks rows as a table of its own (the kernel addresses planes by the row count)
+    uint32_t pre_sub_blocks = 0;
 };
 
 namespace trh {
@@ -112,6 +119,82 @@ int upload_tables(trh_domain* d) {
 }
 const FeMem* tab(const trh_domain* d, int idx) { return (const FeMem*)d->d_tables + idx; }
 
+// out[i][e] = sum_r M[i][r] * P[r][e]: the (j - 1) x (j - 1) solve that turns the blocks' residues mod (X^n - c_r) into the n-coefficient
+// pieces of the quotient
+template <class F>
+__global__ void __launch_bounds__(256) block_combine_kernel(const uint4* __restrict__ p, uint4* __restrict__ out, const uint4* __restrict__ mat, u32 D, size_t n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fe<F> v[8];
+    for (u32 r = 0; r < D; ++r) { const uint4 lo = p[2 * (r * n + e)], hi = p[2 * (r * n + e) + 1]; v[r] = fe_load<F>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w); }
+    for (u32 i = 0; i < D; ++i) {
+        Fe<F> acc = fe_zero<F>();
+        for (u32 r = 0; r < D; ++r) {
+            const uint4 lo = mat[2 * (i * D + r)], hi = mat[2 * (i * D + r) + 1];
+            acc = fe_add(acc, fe_mul(v[r], fe_load<F>(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w)));
+        }
+        u32 w[8];
+        fe_store(acc, w);
+        out[2 * (i * n + e)] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[2 * (i * n + e) + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+// block tables and the interpolation matrices, built at first use
+template <class F>
+int build_blocks(trh_domain* d, hipStream_t s) {
+    if (d->d_post_blocks) return TRH_OK;
+    const uint32_t nblk = 1u << (d->extended_k - d->k), D = d->j - 1;
+    if (D > 8 || D > nblk) { set_error("domain blocks: quotient degree %u unsupported", D); return TRH_EINVAL; }
+    const Fe<F> one = fe_one<F>(), zeta = fe_load<F>(F::ZETA), ext_omega = reg<F>(d->extended_omega);
+    (void)nblk;
+    void *post = nullptr, *vinv = nullptr;
+    hipError_t e = hipMalloc(&post, ntt_block_table_bytes(D, d->k));
+    if (e == hipSuccess) e = hipMalloc(&vinv, (size_t)2 * D * D * 32);
+    if (e != hipSuccess) { if (post) (void)hipFree(post); set_error("domain blocks: %s", hipGetErrorString(e)); return TRH_ENOMEM; }
+    const FeMem zi = mem(fe_inv(zeta)), wi = d->extended_omega_inv;
+    int rc = ntt_block_table_build(d->field, post, D, d->k, (const u64*)&zi, (const u64*)&wi, (const u64*)&d->ifft_divisor, s);
+    // c_r = (zeta ext_omega^r)^n; V[r][i] = c_r^i; invert by Gauss-Jordan over the field (D <= 8)
+    std::vector<Fe<F>> c(D), a(D * D), inv(D * D);
+    Fe<F> base = zeta;
+    for (uint32_t r = 0; r < D; ++r) {
+        Fe<F> t = base;
+        for (uint32_t i = 0; i < d->k; ++i) t = fe_sqr(t);
+        c[r] = t;
+        base = fe_mul(base, ext_omega);
+    }
+    const Fe<F> zero = fe_zero<F>();
+    for (uint32_t r = 0; r < D; ++r) { Fe<F> pw = one; for (uint32_t i = 0; i < D; ++i) { a[r * D + i] = pw; pw = fe_mul(pw, c[r]); inv[r * D + i] = r == i ? one : zero; } }
+    auto is_zero = [](const Fe<F>& v) { u32 w[8]; fe_store(v, w); u32 o = 0; for (int i = 0; i < 8; ++i) o |= w[i]; return o == 0; };
+    for (uint32_t col = 0; col < D && rc == TRH_OK; ++col) {
+        uint32_t piv = col;
+        while (piv < D && is_zero(a[piv * D + col])) ++piv;
+        if (piv == D) { set_error("domain blocks: singular coset matrix"); rc = TRH_EINVAL; break; }
+        for (uint32_t i = 0; i < D; ++i) { std::swap(a[piv * D + i], a[col * D + i]); std::swap(inv[piv * D + i], inv[col * D + i]); }
+        const Fe<F> pinv = fe_inv(a[col * D + col]);
+        for (uint32_t i = 0; i < D; ++i) { a[col * D + i] = fe_mul(a[col * D + i], pinv); inv[col * D + i] = fe_mul(inv[col * D + i], pinv); }
+        for (uint32_t r = 0; r < D; ++r) {
+            if (r == col) continue;
+            const Fe<F> f = a[r * D + col];
+            for (uint32_t i = 0; i < D; ++i) { a[r * D + i] = fe_sub(a[r * D + i], fe_mul(f, a[col * D + i])); inv[r * D + i] = fe_sub(inv[r * D + i], fe_mul(f, inv[col * D + i])); }
+        }
+    }
+    if (rc == TRH_OK) {
+        // inv = V^-1: h_i = sum_r inv[i][r] P_r.  Second matrix: the numerator's blocks are divided by t(X) = X^n - 1 = c_r - 1 on block r
+        std::vector<FeMem> h(2 * D * D);
+        for (uint32_t i = 0; i < D; ++i)
+            for (uint32_t r = 0; r < D; ++r) {
+                h[i * D + r] = mem(inv[i * D + r]);
+                h[D * D + i * D + r] = mem(fe_mul(inv[i * D + r], fe_inv(fe_sub(c[r], one))));
+            }
+        if (hipMemcpy(vinv, h.data(), h.size() * 32, hipMemcpyHostToDevice) != hipSuccess) { set_error("domain blocks: matrix upload failed"); rc = TRH_EHIP; }
+    }
+    if (rc == TRH_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("domain blocks: table kernel failed"); rc = TRH_EHIP; }
+    if (rc != TRH_OK) { (void)hipFree(post); (void)hipFree(vinv); return rc; }
+    d->d_post_blocks = post; d->d_vinv = vinv;
+    return TRH_OK;
+}
+
 int check(const trh_domain* d, const void* a) {
     TRH_TRY(require_init());
     if (!d || !a) { set_error("domain: null pointer"); return TRH_EINVAL; }
@@ -148,6 +231,9 @@ int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain** out) {
 void trh_domain_destroy(trh_domain* d) {
     if (!d) return;
     if (d->d_tables) (void)hipFree(d->d_tables);
+    if (d->d_post_blocks) (void)hipFree(d->d_post_blocks);
+    if (d->d_vinv) (void)hipFree(d->d_vinv);
+    if (d->d_pre_sub) (void)hipFree(d->d_pre_sub);
     delete d;
 }
 uint32_t trh_domain_extended_k(trh_domain* d) { return d ? d->extended_k : 0; }
@@ -228,6 +314,74 @@ int trh_domain_divide_by_vanishing_poly(trh_domain* d, void* a_dev, size_t batch
     return field_scale_periodic(d->field, a_dev, batch, N, N, tab(d, T_TINV), (u32)d->t_inv.size(), (hipStream_t)stream);
 }
 
+
+/* ---- the extended domain as coset blocks ------------------------------------------------------------------------------------
+ * The 2^extended_k points zeta * extended_omega^i split by i = q * 2^(extended_k - k) + r into 2^(extended_k - k) cosets
+ * (zeta extended_omega^r) * omega^q of the size-2^k subgroup.  Block r of a polynomial a(X) of 2^k coefficients is the size-2^k
+ * transform of a_j (zeta extended_omega^r)^j: two passes of a 2^18 transform instead of three of a zero-padded 2^21 one, and
+ * the quotient h(X) of degree < (j - 1) 2^k only needs j - 1 of the blocks (5 of 8 for the reference's circuit: 5/8 of the
+ * transforms and of the gate evaluation).  In this layout Rotation(1) is q + 1 inside a block (trh_expr_eval_blocks_dev).
+ * ext_dev: batch x n_blocks x 2^k elements; block r of polynomial b at element ((b * n_blocks + r) << k); its entry q is entry
+ * q * 2^(extended_k - k) + r of EvaluationDomain::coeff_to_extended.                                                             */
+uint32_t trh_domain_quotient_blocks(trh_domain* d) { return d ? d->j - 1 : 0; }
+
+int trh_domain_coeff_to_extended_blocks(trh_domain* d, const void* coeff_dev, void* ext_dev, size_t batch, uint32_t n_blocks, void* stream) {
+    TRH_TRY(check(d, coeff_dev));
+    if (!ext_dev || n_blocks == 0 || n_blocks > (1u << (d->extended_k - d->k))) { set_error("domain blocks: n_blocks out of range"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_domain_coeff_to_extended_blocks");
+    Ctx& c = ctx();
+    (void)c;
+    hipStream_t s = (hipStream_t)stream;
+    TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
+    // (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: built once per block count (the kernel addresses the table's planes by it)
+    if (d->pre_sub_blocks != n_blocks) {
+        if (d->d_pre_sub) { TRH_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(d->d_pre_sub); d->d_pre_sub = nullptr; d->pre_sub_blocks = 0; }
+        TRH_HIP_TRY(hipMalloc(&d->d_pre_sub, ntt_block_table_bytes(n_blocks, d->k)));
+        const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
+        TRH_TRY(ntt_block_table_build(d->field, d->d_pre_sub, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s));
+        d->pre_sub_blocks = n_blocks;
+    }
+    if (ntt_can_fuse(d->k) && ntt_lazy_shift() == 5) {  // the scaling rides on the loads of pass 0
+        NttFusion fu;
+        fu.in_dev = coeff_dev; fu.in_log = d->k;
+        fu.pre_blocks = d->d_pre_sub; fu.blocks = n_blocks;
+        return ntt_device(d->field, ext_dev, d->k, (const u64*)&d->omega, batch * n_blocks, s, &fu);
+    }
+    // small domains: the same two steps unfused
+    TRH_TRY(ntt_block_scale(d->field, coeff_dev, ext_dev, batch * n_blocks, n_blocks, d->k, d->d_pre_sub, false, s));
+    return ntt_device(d->field, ext_dev, d->k, (const u64*)&d->omega, batch * n_blocks, s);
+}
+
+/* num_blocks_dev: the quotient's NUMERATOR (or, with divide_by_vanishing = 0, the quotient itself) on blocks 0 .. j - 2 of the
+ * extended domain ((j - 1) x 2^k elements, overwritten); h_coeff_dev: (j - 1) x 2^k coefficients of h(X), piece i = coefficients
+ * [i 2^k, (i + 1) 2^k) -- what extended_to_coeff(divide_by_vanishing_poly(.)) truncated to (j - 1) 2^k returns for a numerator that
+ * the vanishing polynomial divides (create_proof's h(X)).  Block r yields h mod (X^n - c_r) = sum_i c_r^i h_i(X), an inverse
+ * size-2^k coset transform per block and a (j - 1) x (j - 1) solve per coefficient.                                              */
+int trh_domain_blocks_to_quotient(trh_domain* d, void* num_blocks_dev, void* h_coeff_dev, int divide_by_vanishing, void* stream) {
+    TRH_TRY(check(d, num_blocks_dev));
+    if (!h_coeff_dev) { set_error("domain: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_domain_blocks_to_quotient");
+    hipStream_t s = (hipStream_t)stream;
+    TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
+    const uint32_t D = d->j - 1;
+    const size_t n = (size_t)1 << d->k;
+    if (ntt_can_fuse(d->k) && ntt_lazy_shift() == 5) {
+        NttFusion fu;
+        fu.post_blocks = d->d_post_blocks; fu.blocks = D;
+        TRH_TRY(ntt_device(d->field, num_blocks_dev, d->k, (const u64*)&d->omega_inv, D, s, &fu));
+    } else {
+        TRH_TRY(ntt_device(d->field, num_blocks_dev, d->k, (const u64*)&d->omega_inv, D, s));
+        TRH_TRY(ntt_block_scale(d->field, num_blocks_dev, num_blocks_dev, D, D, d->k, d->d_post_blocks, true, s));
+    }
+    const uint4* mat = (const uint4*)d->d_vinv + (divide_by_vanishing ? (size_t)2 * D * D : 0);
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    if (d->field == TRH_FP) hipLaunchKernelGGL((block_combine_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)num_blocks_dev, (uint4*)h_coeff_dev, mat, D, n);
+    else hipLaunchKernelGGL((block_combine_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)num_blocks_dev, (uint4*)h_coeff_dev, mat, D, n);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
 
 /* ---- the same operations on HOST polynomials (one pointer per column), pipelined over PCIe (hostio.hip): what the Rust host's
  * EvaluationDomain calls become when create_proof keeps its polynomials in host memory ------------------------------------- */

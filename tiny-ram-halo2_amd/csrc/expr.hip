@@ -111,11 +111,14 @@ __device__ __forceinline__ Fy<F> ldg_column(const uint4* p) {
 
 template <class F>
 __global__ void __launch_bounds__(THREADS) expr_eval_kernel(const DevInsn* __restrict__ prog, u32 n_insn, const uint4* const* __restrict__ ptrs, u32 n_columns,
-                                                            const uint4* __restrict__ consts, u32 log_n, u32 rot_step) {
+                                                            const uint4* __restrict__ consts, u32 log_n, u32 rot_step, u32 n_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const size_t N = (size_t)1 << log_n;
-    const size_t row = ((size_t)blockIdx.x * THREADS + threadIdx.x) & (N - 1);  // N < 256: the surplus lanes repeat rows, their stores are masked
-    const bool live = (size_t)blockIdx.x * THREADS + threadIdx.x < N;
+    // rows: one cyclic domain of 2^log_n rows (n_blocks = 0), or n_blocks cosets of 2^log_n rows each -- a rotation stays inside its block
+    const size_t N = (size_t)1 << log_n, total = n_blocks ? (size_t)n_blocks << log_n : N;
+    const size_t gid = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    const size_t row = gid < total ? gid : gid & (N - 1);  // surplus lanes of the last workgroup repeat rows, their stores are masked
+    const bool live = gid < total;
+    const size_t row_base = row & ~(N - 1);
     Fy<F> T = fy_zero<F>(), Nx = fy_zero<F>(), ACC = fy_zero<F>();
     for (u32 pc = 0; pc < n_insn; ++pc) {
         const RawInsn raw = ((const RawInsn*)prog)[pc];  // uniform: scalar loads
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(THREADS) expr_eval_kernel(const DevInsn* __res
             case TRH_EXPR_PUSH_COLUMN: {
                 if (in.slot != NO_SLOT) lds_put<F>(smem, in.slot, Nx);
                 Nx = T;
-                const size_t r = (row + (size_t)((long long)in.rot * (long long)rot_step)) & (N - 1);
+                const size_t r = row_base | ((row + (size_t)((long long)in.rot * (long long)rot_step)) & (N - 1));
                 T = ldg_column<F>(ptrs[in.a] + 2 * r);
                 break;
             }
@@ -367,7 +370,15 @@ int trh_expr_set_const(trh_expr* e, uint32_t index, const uint64_t value[4]) {
     return TRH_OK;
 }
 
+static int expr_eval(trh_expr* e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, uint32_t n_blocks, void* stream);
 int trh_expr_eval_dev(trh_expr* e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, void* stream) {
+    return expr_eval(e, columns_dev, outputs_dev, log_n, rot_step, 0, stream);
+}
+int trh_expr_eval_blocks_dev(trh_expr* e, const void* const* columns_dev, void* const* outputs_dev, uint32_t block_log, uint32_t n_blocks, void* stream) {
+    if (n_blocks == 0 || n_blocks > 64) { set_error("expr_eval_blocks: n_blocks out of range"); return TRH_EINVAL; }
+    return expr_eval(e, columns_dev, outputs_dev, block_log, 1, n_blocks, stream);
+}
+static int expr_eval(trh_expr* e, const void* const* columns_dev, void* const* outputs_dev, uint32_t log_n, uint32_t rot_step, uint32_t n_blocks, void* stream) {
     TRH_TRY(require_init());
     if (!e || !outputs_dev || (e->n_columns && !columns_dev)) { set_error("expr_eval: null pointer"); return TRH_EINVAL; }
     if (log_n > 30) { set_error("expr_eval: log_n %u too large", log_n); return TRH_EINVAL; }
@@ -385,15 +396,15 @@ int trh_expr_eval_dev(trh_expr* e, const void* const* columns_dev, void* const* 
     (void)c;
     hipStream_t s = (hipStream_t)stream;
     TRH_HIP_TRY(hipMemcpyAsync(e->d_ptrs, e->h_ptrs.data(), e->h_ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, s));
-    const size_t N = (size_t)1 << log_n;
+    const size_t N = n_blocks ? (size_t)n_blocks << log_n : (size_t)1 << log_n;
     const unsigned blocks = (unsigned)((N + THREADS - 1) / THREADS);
     const size_t lds = (size_t)e->lds_slots * THREADS * 36;
     if (e->field == TRH_FP)
         hipLaunchKernelGGL((expr_eval_kernel<FpParams>), dim3(blocks), dim3(THREADS), lds, s, (const DevInsn*)e->d_prog, e->n_insn, (const uint4* const*)e->d_ptrs, e->n_columns,
-                           (const uint4*)e->d_consts, log_n, rot_step);
+                           (const uint4*)e->d_consts, log_n, rot_step, n_blocks);
     else
         hipLaunchKernelGGL((expr_eval_kernel<FqParams>), dim3(blocks), dim3(THREADS), lds, s, (const DevInsn*)e->d_prog, e->n_insn, (const uint4* const*)e->d_ptrs, e->n_columns,
-                           (const uint4*)e->d_consts, log_n, rot_step);
+                           (const uint4*)e->d_consts, log_n, rot_step, n_blocks);
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipStreamSynchronize(s));  // h_ptrs is reused by the next call
     return TRH_OK;

@@ -682,7 +682,9 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     const bool padded = FUSE && fu.in_dev;
     const size_t in_len = padded ? (size_t)1 << fu.in_log : N;
     // element strides of a transform: 2 N uint4 in word form, 36 N bytes = 2 N uint4 + N u32 in raw form
-    const uint4* in_a = padded ? (const uint4*)fu.in_dev + (size_t)blockIdx.y * in_len * 2 : raw_in ? (const uint4*)((const char*)in + (size_t)blockIdx.y * N * 36) : in + (size_t)blockIdx.y * N * 2;
+    const u32 blk = (FUSE && fu.blocks) ? blockIdx.y % fu.blocks : 0u;           // coset block of this transform
+    const size_t in_row = (FUSE && fu.pre_blocks) ? blockIdx.y / fu.blocks : blockIdx.y;  // the blocks of one polynomial share its coefficients
+    const uint4* in_a = padded ? (const uint4*)fu.in_dev + in_row * in_len * 2 : raw_in ? (const uint4*)((const char*)in + (size_t)blockIdx.y * N * 36) : in + (size_t)blockIdx.y * N * 2;
     uint4* out_a = raw_out ? (uint4*)((char*)out + (size_t)blockIdx.y * N * 36) : out + (size_t)blockIdx.y * N * 2;
     const int tid = threadIdx.x;
     const u32 c = tid & (C - 1), m = tid >> log_c;
@@ -709,6 +711,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
                 val = load_fy<F>(in_a + 2 * idx);
             }
             if (FUSE && fu.pre) val = fy_mul(val, load_fy<F>((const uint4*)fu.pre + 2 * (idx % fu.pre_period)));
+            if (FUSE && fu.pre_blocks && !raw_in) val = fy_mul(val, load_direct_y<F>((const uint4*)fu.pre_blocks, (size_t)fu.blocks << log_n, ((size_t)blk << log_n) + idx));
             if (log_ns > 0)  // every element of a later pass: the product is also what brings a raw residue back to |v| < 1.13 m
                 val = fy_mul(val, direct ? load_direct_y<F>(direct, (size_t)1 << (log_ns + s), ((size_t)r << log_ns) + k) : fy_balance(twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits)));
         }
@@ -760,6 +763,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
         } else {
             Fy<F> y;
             if (FUSE && fu.post && last) y = fy_mul(fy_norm(x[u]), load_fy<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));  // packed factor: the multiplicand must be normalised
+            else if (FUSE && fu.post_blocks && last) y = fy_mul(x[u], load_direct_y<F>((const uint4*)fu.post_blocks, (size_t)fu.blocks << log_n, ((size_t)blk << log_n) + dst));  // balanced factor: lazy limbs as they are
             else y = fy_norm(x[u]);
             u32 w[8];
             fy_canonical_words(y, w);
@@ -778,6 +782,41 @@ __global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __rest
     uint4* p = a + 2 * (r * row_len + c);
     Fe<F> f = load_fe<F>(factors + 2 * (c % period));
     store_fe<F>(p, fe_mul(load_fe<F>(p), f));
+}
+
+// table[b][i] = (g w^b)^i * scale as raw balanced limbs of the x 2^261 form, three planes over M = blocks << log_n entries
+template <class F>
+__global__ void __launch_bounds__(256) ntt_block_table_kernel(uint4* __restrict__ d, u32 blocks, int log_n, const uint4* __restrict__ consts /* g, w, scale */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = (size_t)blocks << log_n;
+    if (i >= M) return;
+    const u32 b = (u32)(i >> log_n), e = (u32)i & ((1u << log_n) - 1u);
+    Fe<F> base = load_fe<F>(consts);
+    const Fe<F> w = load_fe<F>(consts + 2);
+    for (u32 t = 0; t < b; ++t) base = fe_mul(base, w);  // b < 64
+    Fe<F> r = load_fe<F>(consts + 4);
+    for (int bit = 0; bit < log_n; ++bit) {
+        if ((e >> bit) & 1u) r = fe_mul(r, base);
+        base = fe_sqr(base);
+    }
+    const Fy<F> v = fy_balance(fy_from_fe(r));
+    d[i] = make_uint4((u32)v.l[0], (u32)v.l[1], (u32)v.l[2], (u32)v.l[3]);
+    d[M + i] = make_uint4((u32)v.l[4], (u32)v.l[5], (u32)v.l[6], (u32)v.l[7]);
+    ((u32*)(d + 2 * M))[i] = (u32)v.l[8];
+}
+// out[t][i] = in[in_per_block ? t : t / blocks][i] * table[t % blocks][i], canonical words
+template <class F>
+__global__ void __launch_bounds__(256) ntt_block_scale_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t transforms, u32 blocks, int log_n,
+                                                              const uint4* __restrict__ table, int in_per_block) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (transforms << log_n)) return;
+    const size_t t = i >> log_n, e = i & (((size_t)1 << log_n) - 1);
+    const size_t src = ((in_per_block ? t : t / blocks) << log_n) + e;
+    const Fy<F> y = fy_mul(load_fy<F>(in + 2 * src), load_direct_y<F>(table, (size_t)blocks << log_n, ((t % blocks) << log_n) + e));
+    u32 w[8];
+    fy_canonical_words(y, w);
+    out[2 * i] = make_uint4(w[0], w[1], w[2], w[3]);
+    out[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
@@ -899,6 +938,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
         const size_t max_tmp = (size_t)2 << 30;
         size_t chunk = max_tmp / (N * 72);
         if (chunk < 1) chunk = 1;
+        if (fu && fu->blocks) chunk = chunk < fu->blocks ? fu->blocks : chunk - chunk % fu->blocks;  // whole polynomials per launch: block = index % blocks
         if (chunk > batch) chunk = batch;
         TRH_TRY(c.ntt_tmp.ensure(2 * chunk * N * 36));
         char* raw[2] = {(char*)c.ntt_tmp.p, (char*)c.ntt_tmp.p + chunk * N * 36};
@@ -913,10 +953,13 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 NttFusion kf;
                 if (fu && p == 0) {
                     kf.pre = fu->pre; kf.pre_period = fu->pre_period;
-                    if (fu->in_dev) { kf.in_dev = (const char*)fu->in_dev + b0 * ((size_t)32 << fu->in_log); kf.in_log = fu->in_log; }
+                    const size_t row0 = fu->pre_blocks ? b0 / fu->blocks : b0;
+                    if (fu->in_dev) { kf.in_dev = (const char*)fu->in_dev + row0 * ((size_t)32 << fu->in_log); kf.in_log = fu->in_log; }
+                    kf.pre_blocks = fu->pre_blocks;
                 }
-                if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; }
-                const bool fused = kf.in_dev || kf.pre || kf.post;
+                if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; kf.post_blocks = fu->post_blocks; }
+                if (fu) kf.blocks = fu->blocks;
+                const bool fused = kf.in_dev || kf.pre || kf.post || kf.pre_blocks || kf.post_blocks;
                 const uint4* src = p == 0 ? base : (const uint4*)raw[(p - 1) & 1];
                 uint4* dst = p == P - 1 ? base : (uint4*)raw[p & 1];
                 const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
@@ -1031,6 +1074,35 @@ int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, si
     const unsigned gb = (unsigned)((n + 255) / 256);
     if (field == TRH_FP) hipLaunchKernelGGL((field_scale_periodic_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, rows, row_len, active_len, (const uint4*)factors_dev, period);
     else hipLaunchKernelGGL((field_scale_periodic_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (uint4*)a_dev, rows, row_len, active_len, (const uint4*)factors_dev, period);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+size_t ntt_block_table_bytes(uint32_t blocks, uint32_t log_n) { return ((size_t)blocks << log_n) * 36; }
+
+int ntt_block_table_build(int field, void* table_dev, uint32_t blocks, uint32_t log_n, const u64 g[4], const u64 w[4], const u64 scale[4], hipStream_t s) {
+    if (blocks == 0 || blocks > 64 || log_n > 27) { set_error("ntt_block_table: bad shape"); return TRH_EINVAL; }
+    Ctx& c = ctx();
+    TRH_TRY(c.factors.ensure(16 * 64 * 32));
+    char* slot = (char*)c.factors.p + (size_t)(c.factor_slot++ & 15) * 64 * 32;
+    u64 h[12];
+    memcpy(h, g, 32); memcpy(h + 4, w, 32); memcpy(h + 8, scale, 32);
+    TRH_HIP_TRY(hipMemcpyAsync(slot, h, 96, hipMemcpyHostToDevice, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // h is a stack buffer
+    const size_t M = (size_t)blocks << log_n;
+    const unsigned gb = (unsigned)((M + 255) / 256);
+    if (field == TRH_FP) hipLaunchKernelGGL((ntt_block_table_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (uint4*)table_dev, blocks, (int)log_n, (const uint4*)slot);
+    else hipLaunchKernelGGL((ntt_block_table_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (uint4*)table_dev, blocks, (int)log_n, (const uint4*)slot);
+    TRH_HIP_TRY(hipGetLastError());
+    return TRH_OK;
+}
+
+int ntt_block_scale(int field, const void* in_dev, void* out_dev, size_t transforms, uint32_t blocks, uint32_t log_n, const void* table_dev, bool in_per_block, hipStream_t s) {
+    const size_t total = transforms << log_n;
+    if (!total) return TRH_OK;
+    const unsigned gb = (unsigned)((total + 255) / 256);
+    if (field == TRH_FP) hipLaunchKernelGGL((ntt_block_scale_kernel<FpParams>), dim3(gb), dim3(256), 0, s, (const uint4*)in_dev, (uint4*)out_dev, transforms, blocks, (int)log_n, (const uint4*)table_dev, in_per_block ? 1 : 0);
+    else hipLaunchKernelGGL((ntt_block_scale_kernel<FqParams>), dim3(gb), dim3(256), 0, s, (const uint4*)in_dev, (uint4*)out_dev, transforms, blocks, (int)log_n, (const uint4*)table_dev, in_per_block ? 1 : 0);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }

@@ -281,6 +281,27 @@ class GateEvaluator:
         api._check(api.lib().trh_expr_eval_dev(self.handle, ptrs, outs, log_n, rot_step, stream))
         return o3[0] if self.n_outputs == 1 else o3
 
+    def eval_blocks(self, columns: dict, block_log: int, n_blocks: int, out=None, stream=None):
+        """the same over columns in the coset-block layout of EvaluationDomain.coeff_to_extended_blocks: (n_blocks, 2^block_log, 4)
+        per column; Rotation(r) reads row q + r of the same block.  Returns (n_blocks, 2^block_log, 4) (a leading output axis when
+        the program has several outputs)"""
+        import torch
+        first = next(iter(columns.values()))
+        rows = n_blocks << block_log
+        ptrs = (ctypes.c_void_p * max(1, len(self.program.columns)))()
+        for i, key in enumerate(self.program.columns):
+            t = columns[key]
+            assert t.numel() == rows * 4 and t.is_contiguous(), key
+            ptrs[i] = t.data_ptr()
+        if out is None:
+            out = torch.empty((self.n_outputs, n_blocks, 1 << block_log, 4), dtype=first.dtype, device=first.device)
+        o4 = out.reshape(self.n_outputs, n_blocks, 1 << block_log, 4)
+        outs = (ctypes.c_void_p * self.n_outputs)(*[o4[i].data_ptr() for i in range(self.n_outputs)])
+        if stream is None:
+            stream = torch.cuda.current_stream(first.device).cuda_stream
+        api._check(api.lib().trh_expr_eval_blocks_dev(self.handle, ptrs, outs, block_log, n_blocks, stream))
+        return o4[0] if self.n_outputs == 1 else o4
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

@@ -160,6 +160,33 @@ class EvaluationDomain:
         return a
 
 
+    # ---- the extended domain as coset blocks (csrc/domain.hip): entry q of block r is entry q * 2^(extended_k - k) + r of
+    # coeff_to_extended's output; the quotient h(X) needs quotient_poly_degree blocks of every column ----
+    def coeff_to_extended_blocks(self, a, n_blocks: int | None = None, out=None):
+        """(..., n, 4) coefficients -> (..., n_blocks, n, 4) coset evaluations (default: the quotient_poly_degree blocks h(X) needs)"""
+        import torch
+        nb = self.quotient_poly_degree if n_blocks is None else n_blocks
+        assert a.shape[-2] == self.n and 1 <= nb <= (1 << (self.extended_k - self.k))
+        a = a.contiguous()
+        shape = a.shape[:-2] + (nb, self.n, 4)
+        if out is not None:
+            assert out.is_contiguous() and out.numel() >= int(np.prod(shape))
+            ext = out.reshape(-1)[: int(np.prod(shape))].reshape(shape)
+        else:
+            ext = torch.empty(shape, dtype=a.dtype, device=a.device)
+        api._check(api.lib().trh_domain_coeff_to_extended_blocks(self.handle(), api._devptr(a), api._devptr(ext), self._batch(a), nb, _stream(a)))
+        return ext
+
+    def blocks_to_quotient(self, num_blocks, divide_by_vanishing: bool = True):
+        """(quotient_poly_degree, n, 4) values of the quotient's numerator on blocks 0 .. (overwritten) -> (quotient_poly_degree * n, 4)
+        coefficients of h(X): extended_to_coeff(divide_by_vanishing_poly(.)) for a numerator the vanishing polynomial divides"""
+        import torch
+        d = self.quotient_poly_degree
+        assert num_blocks.is_contiguous() and num_blocks.numel() == d * self.n * 4
+        out = torch.empty((d * self.n, 4), dtype=num_blocks.dtype, device=num_blocks.device)
+        api._check(api.lib().trh_domain_blocks_to_quotient(self.handle(), api._devptr(num_blocks), api._devptr(out), 1 if divide_by_vanishing else 0, _stream(num_blocks)))
+        return out
+
     # ---- the same operations on HOST polynomials (numpy (n, 4) uint64 arrays, as the Rust host holds its `Polynomial`s):
     # csrc/hostio.hip pipelines the columns over PCIe ----
     def lagrange_to_coeff_host(self, columns):

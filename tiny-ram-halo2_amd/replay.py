@@ -115,11 +115,15 @@ class _FixedTranscript:
 
 
 def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True, columns: str = "random",
-        keygen: bool = True) -> dict:
+        keygen: bool = True, extended: str = "blocks") -> dict:
     import torch
 
     from . import multiopen
-    assert columns in ("random", "witness")
+    assert columns in ("random", "witness") and extended in ("blocks", "full")
+    # extended = "blocks": the extended domain as cosets of the size-2^k subgroup, only the QUOTIENT_J - 1 = 5 of 8 the quotient needs
+    # (csrc/domain.hip); "full": EvaluationDomain::coeff_to_extended as halo2 0.2.0 has it (all 2^extended_k points, natural order)
+    blocks = extended == "blocks"
+    D = QUOTIENT_J - 1
 
     k = 2 + word_bits // 2
     sch = schedule(k)
@@ -205,7 +209,8 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     del zs, evs, sets, pcs, wit, om
 
     x_eval = synth.field_elements(0xE7A, 1)[0]
-    ext_buf = torch.empty((min(batch, sch["intt_n"]), 1 << ek, 4), dtype=torch.int64, device=dev)  # the batch's extended cosets, reused
+    ext_rows = D * n if blocks else 1 << ek
+    ext_buf = torch.empty((min(batch, sch["intt_n"]), ext_rows, 4), dtype=torch.int64, device=dev)  # the batch's extended cosets, reused
     # --- Lagrange-basis columns: instance, advice, lookup permuted x2 + z, permutation z ---
     lag_total = sch["intt_n"]
     done = 0
@@ -258,7 +263,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
                 checked += 1
         coeff = dom.lagrange_to_coeff(cols)
         e2 = ev()
-        ext = dom.coeff_to_extended(coeff, out=ext_buf)
+        ext = dom.coeff_to_extended_blocks(coeff, D, out=ext_buf) if blocks else dom.coeff_to_extended(coeff, out=ext_buf)
         e3 = ev()
         # the evaluations at the challenge x that precede the multiopen argument (eval_polynomial per queried column;
         # the real prover does them after x is squeezed, with the coefficient forms kept resident: same work)
@@ -278,7 +283,8 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
             for i in range(min(b, 3)):
                 hook("commit_lagrange", dict(scalars=np.concatenate([cols_h[i], blinds[i][None]]), bases=gl), pts[i])
                 hook("lagrange_to_coeff", dict(a=cols_h[i], domain=(field, QUOTIENT_J, k)), coeff[i].cpu().numpy().view(np.uint64))
-                hook("coeff_to_extended", dict(a=coeff[i].cpu().numpy().view(np.uint64), domain=(field, QUOTIENT_J, k)), ext[i].cpu().numpy().view(np.uint64))
+                hook("coeff_to_extended_blocks" if blocks else "coeff_to_extended", dict(a=coeff[i].cpu().numpy().view(np.uint64), domain=(field, QUOTIENT_J, k), n_blocks=D),
+                     ext[i].cpu().numpy().view(np.uint64))
                 hook("evals", dict(a=coeff[i].cpu().numpy().view(np.uint64), x=x_eval, field=field), evals[i])
                 checked += 4
         if done + b >= lag_total:
@@ -298,13 +304,16 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         res[key] = ext_keep[i % nres]
     gev = expr.GateEvaluator(prog)
     e0 = ev()
-    h_num = gev.eval(res, ek, 1 << (ek - k))
+    h_num = gev.eval_blocks(res, k, D) if blocks else gev.eval(res, ek, 1 << (ek - k))
     e1 = ev()
     torch.cuda.synchronize()
     times["h_eval"] += e0.elapsed_time(e1)
     counts["h_eval"] += 1
     if hook is not None:
-        hook("h_eval", dict(gates=gates, resident=res, log_n=ek, rot_step=1 << (ek - k), y=0x5EED, field=field), h_num)
+        if blocks:
+            hook("h_eval", dict(gates=gates, resident=res, block_log=k, n_blocks=D, y=0x5EED, field=field), h_num)
+        else:
+            hook("h_eval", dict(gates=gates, resident=res, log_n=ek, rot_step=1 << (ek - k), y=0x5EED, field=field), h_num)
         checked += 1
     del ext_keep, ext_buf, res, h_num
 
@@ -325,17 +334,20 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         checked += 1
 
     # --- h(X): one extended iNTT ---
-    h_h = synth.field_elements(0xEE, 1 << ek)
-    h = torch.from_numpy(h_h.view(np.int64)).to(dev).reshape(1, 1 << ek, 4)
+    h_h = synth.field_elements(0xEE, ext_rows)
+    h = torch.from_numpy(h_h.view(np.int64)).to(dev).reshape(1, ext_rows, 4)
     e0 = ev()
-    dom.divide_by_vanishing_poly(h)
-    hc = dom.extended_to_coeff(h)
+    if blocks:
+        hc = dom.blocks_to_quotient(h, divide_by_vanishing=True).reshape(1, D * n, 4)
+    else:
+        dom.divide_by_vanishing_poly(h)
+        hc = dom.extended_to_coeff(h)
     e1 = ev()
     torch.cuda.synchronize()
     times["extended_to_coeff"] += e0.elapsed_time(e1)
     counts["extended_to_coeff"] += 1
     if hook is not None:
-        hook("divide_and_extended_to_coeff", dict(a=h_h, domain=(field, QUOTIENT_J, k)), hc[0].cpu().numpy().view(np.uint64))
+        hook("blocks_to_quotient" if blocks else "divide_and_extended_to_coeff", dict(a=h_h, domain=(field, QUOTIENT_J, k), n_blocks=D), hc[0].cpu().numpy().view(np.uint64))
         checked += 1
 
     # --- poly::multiopen::create_proof over everything the prover opened: every column at x; the rotated advice queries and the
@@ -401,7 +413,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     keygen_ms = None
     if keygen:
         kg = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0}
-        kext = torch.empty((min(batch, N_FIXED + N_SIGMA), 1 << ek, 4), dtype=torch.int64, device=dev)
+        kext = torch.empty((min(batch, N_FIXED + N_SIGMA), ext_rows, 4), dtype=torch.int64, device=dev)
         todo = [(N_FIXED, "flag" if columns == "witness" else "full"), (N_SIGMA, "full"), (3, "flag" if columns == "witness" else "full")]
         for count, kind in todo:
             first = 0
@@ -417,7 +429,10 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
                 t1 = ev()
                 cf = dom.lagrange_to_coeff(d)
                 t2 = ev()
-                dom.coeff_to_extended(cf, out=kext)
+                if blocks:
+                    dom.coeff_to_extended_blocks(cf, D, out=kext)
+                else:
+                    dom.coeff_to_extended(cf, out=kext)
                 t3 = ev()
                 torch.cuda.synchronize()
                 kg["commit_lagrange"] += t0.elapsed_time(t1)
@@ -430,7 +445,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         del kext
 
     wall = time.perf_counter() - t_wall
-    out = {"word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
+    out = {"word_bits": word_bits, "columns": columns, "extended_domain": f"{D} of {1 << (ek - k)} coset blocks of 2^{k}" if blocks else f"all 2^{ek} points", "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
            "gpu_ms_total": round(sum(times.values()), 3),
            "scope": "GPU time of the offloaded arithmetic of ONE create_proof incl. the multiopen folds / divisions; witness generation, the transcript and PCIe are not in it",
            "keygen_gpu_ms": keygen_ms, "fixed_base_tables": bool(precompute), "setup_precompute_ms": round(precompute_ms, 3),
@@ -649,12 +664,13 @@ def main():
     ap.add_argument("--mode", choices=("resident", "dropin", "dropin-batched"), default="resident",
                     help="resident: polynomials live on the device (the restructured prover); dropin: every polynomial in host memory, one "
                          "trh_msm / trh_best_fft call at a time (north_star's literal integration); dropin-batched: host memory, batched host-pointer entries")
+    ap.add_argument("--extended", choices=("blocks", "full"), default="blocks", help="resident mode: the extended domain as the 5 coset blocks the quotient needs, or all 2^extended_k points")
     ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes: replay only the first N Lagrange columns")
     a = ap.parse_args()
     if a.mode != "resident":
         run_dropin(a.word_bits, "literal" if a.mode == "dropin" else "batched", a.batch, columns=a.columns, max_columns=a.max_columns)
         return
-    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen)
+    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended)
 
 
 if __name__ == "__main__":
