@@ -97,6 +97,8 @@ std::vector<Expr> synthetic_gates(Field f, uint32_t n_advice, uint32_t n_fixed, 
 }
 
 // host evaluation of one row (the check of the device evaluator)
+// n: rows of one cyclic domain (a power of two); rows beyond n belong to further blocks of n rows each (the coset-block layout):
+// a rotation stays inside its block
 Limbs eval_host(Field f, const Expr& e, const std::vector<std::vector<Limbs>>& cols, const Program& p, size_t row, size_t n, size_t rot_step) {
     switch (e->kind) {
         case Expression::Constant: return e->value;
@@ -107,7 +109,7 @@ Limbs eval_host(Field f, const Expr& e, const std::vector<std::vector<Limbs>>& c
         default: {
             size_t slot = 0;
             while (!(p.columns[slot].first == e->kind && p.columns[slot].second == e->column)) ++slot;
-            const size_t r = (row + (size_t)((long long)e->rotation * (long long)rot_step)) & (n - 1);
+            const size_t r = (row & ~(n - 1)) | ((row + (size_t)((long long)e->rotation * (long long)rot_step)) & (n - 1));
             return cols[slot][r];
         }
     }
@@ -323,7 +325,10 @@ int main(int argc, char** argv) {
 
         const int lag_total = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS;
         if (batch > (size_t)lag_total) batch = lag_total;
-        DeviceBuffer cols(batch * n * 32), ext(batch * N * 32), h_num(N * 32);
+        // the extended domain as the QUOTIENT_J - 1 = 5 coset blocks (of 8) the quotient needs: D * n rows per column (trh.h)
+        const uint32_t D = dom.quotient_blocks();
+        const size_t EN = (size_t)D * n;
+        DeviceBuffer cols(batch * n * 32), ext(batch * EN * 32), h_num(EN * 32);
         std::vector<Limbs> host_cols(batch * n), blinds(batch);
         SplitMix rng{0xc01};
         // the coefficient forms stay resident for the multiopen argument (497 + 6 polynomials)
@@ -400,7 +405,7 @@ int main(int argc, char** argv) {
                 for (size_t c = 0; c < b; ++c) lincomb(field, cols.at(c * n * 32), n, unit, coeff_all.at(((size_t)done + c) * n * 32));
             }
             Timer t3;
-            dom.coeff_to_extended(cols.data(), ext.data(), b);
+            dom.coeff_to_extended_blocks(cols.data(), ext.data(), b, D);
             ms_ext += t3.stop();
             Timer t4;
             std::vector<Limbs> evals;
@@ -420,18 +425,18 @@ int main(int argc, char** argv) {
         const Limbs y = host::from_u64(field, 0x5eed);
         GateEvaluator gev(compile_gates(field, gates, y));
         std::vector<const void*> res(gev.program.columns.size());
-        for (size_t i = 0; i < res.size(); ++i) res[i] = ext.at((i % nres) * N * 32);
+        for (size_t i = 0; i < res.size(); ++i) res[i] = ext.at((i % nres) * EN * 32);
         Timer t5;
-        gev.eval(res, h_num.data(), ek, 1u << (ek - k));
+        gev.eval_blocks(res, h_num.data(), k, D);
         ms_h = t5.stop();
-        {   // three rows against the host evaluation
-            std::vector<std::vector<Limbs>> hc(res.size(), std::vector<Limbs>(N));
-            for (size_t i = 0; i < res.size(); ++i) check(trh_memcpy_d2h(hc[i].data(), res[i], N * 32), "d2h");
-            std::vector<Limbs> got(N);
-            h_num.download(got.data(), N * 32);
-            for (size_t row : {(size_t)0, N - 1, (size_t)4097 % N}) {
+        {   // three rows against the host evaluation (rotations stay inside their block)
+            std::vector<std::vector<Limbs>> hc(res.size(), std::vector<Limbs>(EN));
+            for (size_t i = 0; i < res.size(); ++i) check(trh_memcpy_d2h(hc[i].data(), res[i], EN * 32), "d2h");
+            std::vector<Limbs> got(EN);
+            h_num.download(got.data(), EN * 32);
+            for (size_t row : {(size_t)0, EN - 1, (size_t)2 * n + 4097 % n}) {
                 Limbs acc{0, 0, 0, 0};
-                for (const Expr& g : gates) acc = host::add(field, host::mul(field, acc, y), eval_host(field, g, hc, gev.program, row, N, (size_t)1 << (ek - k)));
+                for (const Expr& g : gates) acc = host::add(field, host::mul(field, acc, y), eval_host(field, g, hc, gev.program, row, n, 1));
                 expect(acc == got[row], "h(X) numerator row");
             }
         }
@@ -463,7 +468,7 @@ int main(int argc, char** argv) {
             std::vector<const void*> pc;
             for (const auto& c : gp.columns()) {
                 if (c.first == Expression::Fixed) pc.push_back(omegas.data());
-                else pc.push_back(c.second < 4 ? ext.at(c.second * N * 32) /* any n values serve as the witness */ : sig.at((c.second - 4) * n * 32));
+                else pc.push_back(c.second < 4 ? ext.at(c.second * EN * 32) /* any n values serve as the witness */ : sig.at((c.second - 4) * n * 32));
             }
             Timer tp;
             gp.compute(pc, zcol.data());
@@ -492,20 +497,33 @@ int main(int argc, char** argv) {
         ms_commit_coeff = t6.stop();
 
         // extended iNTT of h(X): divide_by_vanishing_poly + extended_to_coeff; round trip check on one column
+        DeviceBuffer h_coeff(EN * 32);
         Timer t7;
-        dom.divide_by_vanishing_poly(h_num.data(), 1);
-        dom.extended_to_coeff(h_num.data(), 1);
+        dom.blocks_to_quotient(h_num.data(), h_coeff.data(), true);
         ms_ext_inv = t7.stop();
-        {
+        {   // both layouts of the extended domain return a polynomial they were given: all 2^extended_k points ...
             DeviceBuffer one_col(n * 32), one_ext(N * 32);
             one_col.upload(first_coeff.data(), n * 32);
             dom.coeff_to_extended(one_col.data(), one_ext.data(), 1);
+            std::vector<Limbs> full(N);
+            one_ext.download(full.data(), N * 32);
             dom.extended_to_coeff(one_ext.data(), 1);
             std::vector<Limbs> back(N);
             one_ext.download(back.data(), N * 32);
             bool ok = true;
             for (size_t i = 0; i < N; ++i) ok = ok && (i < n ? back[i] == first_coeff[i] : back[i] == Limbs{0, 0, 0, 0});
             expect(ok, "extended_to_coeff(coeff_to_extended(a)) == a || 0");
+            // ... and the coset blocks: block r entry q is entry q * 2^(extended_k - k) + r of the full form, and the D blocks give a back
+            DeviceBuffer blk(EN * 32), hq(EN * 32);
+            dom.coeff_to_extended_blocks(one_col.data(), blk.data(), 1, D);
+            std::vector<Limbs> bh(EN);
+            blk.download(bh.data(), EN * 32);
+            const size_t step = N / n;
+            for (size_t r = 0; r < D; ++r) for (size_t q = 0; q < n; q += 997) ok = ok && bh[r * n + q] == full[q * step + r];
+            dom.blocks_to_quotient(blk.data(), hq.data(), false);
+            hq.download(bh.data(), EN * 32);
+            for (size_t i = 0; i < EN; ++i) ok = ok && (i < n ? bh[i] == first_coeff[i] : bh[i] == Limbs{0, 0, 0, 0});
+            expect(ok, "coset blocks: entries match the full extended domain, blocks_to_quotient(coeff_to_extended_blocks(a)) == a || 0");
         }
 
         // poly::multiopen::create_proof, polynomial side: four point sets ({x}, {x, wx}, {x, w^-1 x}, {x, wx, w^last x}) over the resident
@@ -589,7 +607,7 @@ int main(int argc, char** argv) {
                     Timer tk;
                     if (g.commit) params.commit_lagrange_batch(cols, b, std::vector<Limbs>(blinds.begin(), blinds.begin() + b));
                     dom.lagrange_to_coeff(cols.data(), b);
-                    dom.coeff_to_extended(cols.data(), ext.data(), b);
+                    dom.coeff_to_extended_blocks(cols.data(), ext.data(), b, D);
                     ms_keygen += tk.stop();
                 }
             }
@@ -608,7 +626,7 @@ int main(int argc, char** argv) {
         expect(tr.points == 1 + 2 * (int)k && tr.scalars == 2, "IPA transcript: S, L_j / R_j per round, then c and f");
 
         const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_multiopen + ms_ipa;
-        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"keygen_ms\": %.3f, "
+        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"extended_domain\": \"5 of 8 coset blocks\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"keygen_ms\": %.3f, "
                     "\"ms\": {\"lookup_permute\": %.3f, \"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
                     "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f}\n",
                     word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total);

@@ -138,7 +138,7 @@ void trh_bases_destroy(trh_bases_t b);
  * digits of all windows into ONE bucket set -- one bucket reduction per MSM instead of W, wider windows, no
  * Horner pass over windows.  window_bits 0 = automatic (<= 17); requires W * n <= 2^24.  Results are the same
  * group elements; MSMs over a sub-range (offset != 0 or n < len) keep using the per-window path.           */
-int trh_bases_precompute(trh_bases_t b, int window_bits);
+int trh_bases_precompute(trh_bases_t b, int window_bits);   /* must not run while an MSM over `b` is in flight on another context; the same holds for trh_bases_destroy */
 int trh_bases_precomputed_window_bits(trh_bases_t b); /* 0 when no table is attached */
 
 /* MSM over bases[offset .. offset+n) with host scalars (Params::commit / commit_lagrange) */

@@ -262,6 +262,15 @@ public:
     void extended_to_coeff(void* a_dev, size_t batch, void* stream = nullptr) const { check(trh_domain_extended_to_coeff(d_, a_dev, batch, stream), "extended_to_coeff"); }
     void divide_by_vanishing_poly(void* a_dev, size_t batch, void* stream = nullptr) const { check(trh_domain_divide_by_vanishing_poly(d_, a_dev, batch, stream), "divide_by_vanishing_poly"); }
 
+    // the extended domain as coset blocks (trh.h): n_blocks x 2^k values per polynomial, block r entry q = coeff_to_extended's entry
+    // q * 2^(extended_k - k) + r; the quotient needs quotient_blocks() = j - 1 of them
+    uint32_t quotient_blocks() const { return trh_domain_quotient_blocks(d_); }
+    void coeff_to_extended_blocks(const void* coeff_dev, void* ext_dev, size_t batch, uint32_t n_blocks, void* stream = nullptr) const {
+        check(trh_domain_coeff_to_extended_blocks(d_, coeff_dev, ext_dev, batch, n_blocks, stream), "coeff_to_extended_blocks");
+    }
+    void blocks_to_quotient(void* num_blocks_dev, void* h_coeff_dev, bool divide_by_vanishing = true, void* stream = nullptr) const {
+        check(trh_domain_blocks_to_quotient(d_, num_blocks_dev, h_coeff_dev, divide_by_vanishing ? 1 : 0, stream), "blocks_to_quotient");
+    }
     // host polynomials, one vector per column (pipelined over PCIe): lagrange_to_coeff in place; coeff_to_extended 2^k -> 2^extended_k;
     // extended_to_coeff in place on one polynomial, optionally preceded by divide_by_vanishing_poly (the caller truncates)
     void lagrange_to_coeff_host(std::vector<std::vector<Limbs>*>& cols) const {
@@ -408,6 +417,12 @@ public:
         require(columns.size() == program.columns.size(), "one device column per program column");
         void* outs[1] = {out_dev};
         check(trh_expr_eval_dev(e_, columns.data(), outs, log_n, rot_step, stream), "expr_eval");
+    }
+    // columns in the coset-block layout: n_blocks x 2^block_log rows each, Rotation(r) stays inside its block
+    void eval_blocks(const std::vector<const void*>& columns, void* out_dev, uint32_t block_log, uint32_t n_blocks, void* stream = nullptr) const {
+        require(columns.size() == program.columns.size(), "one device column per program column");
+        void* outs[1] = {out_dev};
+        check(trh_expr_eval_blocks_dev(e_, columns.data(), outs, block_log, n_blocks, stream), "expr_eval_blocks");
     }
     void eval_outputs(const std::vector<const void*>& columns, const std::vector<void*>& outs, uint32_t log_n, uint32_t rot_step, void* stream = nullptr) const {
         require(columns.size() == program.columns.size() && outs.size() == n_outputs, "one device pointer per program column / output");

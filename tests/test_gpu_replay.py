@@ -110,8 +110,9 @@ def test_replay_k10_matches_oracle(columns):
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504 and res["columns"] == columns
     assert res["counts"]["multiopen_folds"] == 4 and res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
-    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 9 if columns == "witness" else 3, "lagrange_to_coeff": 3, "coeff_to_extended_blocks": 3, "evals": 3, "h_eval": 1, "commit": 1,
+    assert seen == {"lookup_permute": 1, "product_column": 1, "commit_lagrange": 9 if columns == "witness" else 3, "lagrange_to_coeff": 3, "coeff_to_extended_blocks": 3, "evals": 3, "h_eval": 2, "commit": 1,
                     "blocks_to_quotient": 1}
+    assert res["h_eval_real_gates"]["gates"] == 142 and res["h_eval_real_gates"]["by_site"]["exe.rs temp-var / trace gates"] == 90 and res["h_eval_real_gates_ms"] > 0
     assert res["extended_domain"].startswith("5 of 8")
 
 
@@ -130,7 +131,7 @@ def test_replay_k10_full_extended_domain_matches_oracle():
         assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
 
     res = replay.run(16, batch=32, hook=hook, verbose=False, columns="witness", keygen=False, extended="full")
-    assert res["extended_domain"] == "all 2^13 points" and seen["coeff_to_extended"] == 3 and seen["divide_and_extended_to_coeff"] == 1 and seen["h_eval"] == 1
+    assert res["extended_domain"] == "all 2^13 points" and seen["coeff_to_extended"] == 3 and seen["divide_and_extended_to_coeff"] == 1 and seen["h_eval"] == 2
 
 
 def test_replay_k18_matches_oracle():

@@ -684,6 +684,7 @@ namespace {
 // owned base sets are immutable: convert them to the lazy Montgomery domain once and keep the copy
 const void* lazy_bases(trh_bases_t b, size_t offset, hipStream_t s) {
     if (!b->owned || b->n == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(b->mu);
     if (!b->d_z) {
         void* z = nullptr;
         if (hipMalloc(&z, b->n * ZREC + ZREC) != hipSuccess) return nullptr;  // fall back to per-call conversion
@@ -722,6 +723,7 @@ int trh_bases_precompute(trh_bases_t b, int window_bits) {
     if (!b->shards.empty()) { set_error("bases_precompute: range-sharded sets keep the per-window path"); return TRH_EINVAL; }
     TRH_ENTER_CTX(0, b->owner);
     Range range("trh_bases_precompute");
+    std::lock_guard<std::mutex> lk(b->mu);  // (an MSM that is already running over the old table from another context is the caller's to exclude: trh.h)
     if (b->d_table) { (void)hipFree(b->d_table); b->d_table = nullptr; b->fb = MsmFixedBase{nullptr, 0, 0}; }
     if (b->n == 0) return TRH_OK;
     int cb = window_bits;

@@ -268,6 +268,9 @@ struct trh_bases {
     void* d_table = nullptr;  // trh_bases_precompute: W x n shifted copies (see MsmFixedBase)
     trh::MsmFixedBase fb{nullptr, 0, 0};
     trh::Ctx* owner = nullptr;  // the context (device) the memory lives on
+    // handles are shared by every context of their device: the lazily built copies (d_z, d_table) are created / replaced under this lock
+    // (two threads on two contexts running their first MSM over the same set would otherwise both convert, and one copy would leak)
+    std::mutex mu;
     // range-sharded set (trh_init_multi): shard g holds bases [shard_off[g], shard_off[g + 1]) on its own context's device;
     // d_xy is null and the per-shard handles carry the device memory
     std::vector<trh_bases*> shards;

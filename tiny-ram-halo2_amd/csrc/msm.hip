@@ -117,7 +117,9 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
     const u32 lo = t * per < nb1 ? t * per : nb1, hi = (lo + per < nb1) ? lo + per : nb1;
     u32 sum = 0, biggest = 0;
     for (u32 b = lo; b < hi; ++b) { const u32 v = cnt[b]; sum += v; biggest = v > biggest ? v : biggest; }
-    if (oversize && biggest > bin_cap) atomicMax(oversize, biggest);  // a bin that does not fit the LDS of msm_bin_sort_kernel: chunked passes instead
+    // a bin that does not fit the LDS of msm_bin_sort_kernel: this WINDOW takes the chunked passes instead (one flag per batch item and
+    // window: the short top window of 254-bit scalars has bins twice the average, the other windows keep the LDS sort)
+    if (oversize && biggest > bin_cap) atomicMax(oversize + z * gridDim.x + blockIdx.x, biggest);
     part[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(BS_THREADS) msm_bucket_pass_kernel(const u32* 
         parted += z * Wz * n; sorted += z * Wz * n; bin_starts += z * Wz * nbins; bin_ends += z * Wz * nbins;
         bucket_cnt += z * Wz * (nbk + 1);
     }
-    if (oversize && *oversize == 0u) return;  // every bin was sorted in LDS by msm_bin_sort_kernel
+    if (oversize && oversize[z * gridDim.y + blockIdx.y] == 0u) return;  // every bin of this window was sorted in LDS by msm_bin_sort_kernel
     __shared__ u32 cnt[128], tbase[128], gbase[128];
     __shared__ u32 stage[SCATTER ? BS_CHUNK : 1];
     const int j = blockIdx.y;
@@ -328,7 +330,7 @@ constexpr u32 BIN_CAP_MAX = BIN_THREADS * BIN_PER_MAX; // 36864 entries
 __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts, const u32* __restrict__ bin_ends,
                                                                    u32* __restrict__ sorted, u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2, u32 nbins,
                                                                    int idx_bits, u32 nbk, const u32* __restrict__ oversize) {
-    if (*oversize != 0u) return;
+    if (oversize[(size_t)blockIdx.z * gridDim.y + blockIdx.y] != 0u) return;
     extern __shared__ u32 bstage[];
     __shared__ u32 cnt[128], tbase[128], wave0_total;
     const size_t z = blockIdx.z, Wz = gridDim.y;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __
 constexpr int RANGE_BLOCK = 1024;
 __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(const u32* __restrict__ bucket_cnt, u32* __restrict__ block_sums, u32 nbk,
                                                                             const u32* __restrict__ oversize) {
-    if (oversize && *oversize == 0u) return;
+    if (oversize && oversize[(size_t)blockIdx.z * gridDim.y + blockIdx.y] == 0u) return;
     __shared__ u32 part[RANGE_BLOCK / 64];
     const size_t z = blockIdx.z, Wz = gridDim.y;
     const u32 nb1 = nbk + 1, b = blockIdx.x * RANGE_BLOCK + threadIdx.x;
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_block_sums_kernel(cons
 }
 __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_ranges_kernel(u32* __restrict__ bucket_cnt, const u32* __restrict__ block_sums, u32* __restrict__ starts,
                                                                         u32* __restrict__ ends, u32 nbk, const u32* __restrict__ oversize) {
-    if (oversize && *oversize == 0u) return;
+    if (oversize && oversize[(size_t)blockIdx.z * gridDim.y + blockIdx.y] == 0u) return;
     __shared__ u32 part[RANGE_BLOCK];
     __shared__ u32 before;
     const size_t z = blockIdx.z, Wz = gridDim.y;
@@ -803,7 +805,9 @@ __global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __r
     for (u32 k = threadIdx.x; k < count; k += 256) v = xyzzz_add(v, load_raw<BF>(&partials[(size_t)j * count + k]));
     sh[threadIdx.x] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    int top = 128;  // only the levels that hold partials (16 of them for a lone 2^20 MSM: four levels instead of eight barriers + additions)
+    while (top > 1 && (u32)top >= count) top >>= 1;
+    for (int s = top; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
@@ -947,7 +951,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
-    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + 4));  // + the oversize-bin flag of the LDS bin sort
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + chunk * Ws * 4));  // + the oversize-bin flags of the LDS bin sort (per item and window)
     u32* const oversize = L.counts.as<u32>() + chunk * Ws * nbins;
     // LDS bin sort when the bins are big enough to fill a 1024-thread workgroup and fit with 6 % + 512 entries of slack
     // (uniform digits: the largest of 8192 bins of 2^15 entries is 4.5 sigma = 800 entries above the mean)
@@ -999,7 +1003,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                            L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
                            tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-        if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, 4, s));
+        if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap);
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits);

@@ -1011,7 +1011,9 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; }
             const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
             const bool fused = kf.in_dev || kf.pre || kf.post;
-            const bool lazy_pass = lazy && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= MAX_PASS_LOG;
+            // (the tables are in the signed 2^261 form whenever the signed passes are on: the unsigned lazy kernel must not read them --
+            //  a mixed TRH_NTT_PLAN such as "10,4" then runs its passes canonically)
+            const bool lazy_pass = lazy && !signed_enabled() && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= MAX_PASS_LOG;
             const size_t ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
 #define TRH_LAUNCH_PASSZ(TWL, FUSE, LDS)                                                                                                       \
     hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
