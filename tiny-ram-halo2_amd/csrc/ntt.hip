@@ -665,8 +665,11 @@ __device__ __forceinline__ void fy_canonical_words(const Fy<F>& v, u32* w) {
 template <class F, int LG, int TLOG, bool TWL, bool FUSE>
 __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
                                                                const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last, int raw_in, int raw_out,
-                                                               const uint4* __restrict__ direct, NttFusion fu) {
+                                                               const uint4* __restrict__ direct, NttFusion fu, int batch_major) {
     constexpr int G = 1 << LG, T = 1 << TLOG;
+    // grid order: tile-major (x = tile, y = transform) or batch-major (x = transform, y = tile: consecutive workgroups run the SAME
+    // tile of consecutive transforms, so the rows of the shared inter-pass twiddle table they read stay in L2)
+    const u32 bx = batch_major ? blockIdx.y : blockIdx.x, by = batch_major ? blockIdx.x : blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
     const int log_c = TLOG - s;
@@ -682,13 +685,13 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     const bool padded = FUSE && fu.in_dev;
     const size_t in_len = padded ? (size_t)1 << fu.in_log : N;
     // element strides of a transform: 2 N uint4 in word form, 36 N bytes = 2 N uint4 + N u32 in raw form
-    const u32 blk = (FUSE && fu.blocks) ? blockIdx.y % fu.blocks : 0u;           // coset block of this transform
-    const size_t in_row = (FUSE && fu.pre_blocks) ? blockIdx.y / fu.blocks : blockIdx.y;  // the blocks of one polynomial share its coefficients
-    const uint4* in_a = padded ? (const uint4*)fu.in_dev + in_row * in_len * 2 : raw_in ? (const uint4*)((const char*)in + (size_t)blockIdx.y * N * 36) : in + (size_t)blockIdx.y * N * 2;
-    uint4* out_a = raw_out ? (uint4*)((char*)out + (size_t)blockIdx.y * N * 36) : out + (size_t)blockIdx.y * N * 2;
+    const u32 blk = (FUSE && fu.blocks) ? by % fu.blocks : 0u;           // coset block of this transform
+    const size_t in_row = (FUSE && fu.pre_blocks) ? by / fu.blocks : by;  // the blocks of one polynomial share its coefficients
+    const uint4* in_a = padded ? (const uint4*)fu.in_dev + in_row * in_len * 2 : raw_in ? (const uint4*)((const char*)in + (size_t)by * N * 36) : in + (size_t)by * N * 2;
+    uint4* out_a = raw_out ? (uint4*)((char*)out + (size_t)by * N * 36) : out + (size_t)by * N * 2;
     const int tid = threadIdx.x;
     const u32 c = tid & (C - 1), m = tid >> log_c;
-    const u32 j = (blockIdx.x << log_c) + c;
+    const u32 j = (bx << log_c) + c;
     const u32 k = j & ((1u << log_ns) - 1u);
     const size_t row_stride = N >> s;
     const u32 live_rows = (u32)(in_len / row_stride ? in_len / row_stride : 1);
@@ -948,7 +951,9 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             int log_ns = 0;
             for (int p = 0; p < P; ++p) {
                 const int sp = sizes[p];
-                const dim3 grid((unsigned)(N >> TILE_LOG), (unsigned)nb);
+                static const int grid_knob = getenv("TRH_NTT_GRID") ? atoi(getenv("TRH_NTT_GRID")) : -1;  // 0 tile-major, 1 batch-major, default: automatic
+                const int batch_major = grid_knob >= 0 ? (grid_knob && (N >> TILE_LOG) <= 65535) : (nb >= 8 && p > 0 && (N >> TILE_LOG) <= 65535);
+                const dim3 grid = batch_major ? dim3((unsigned)nb, (unsigned)(N >> TILE_LOG)) : dim3((unsigned)(N >> TILE_LOG), (unsigned)nb);
                 const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
                 NttFusion kf;
                 if (fu && p == 0) {
@@ -965,7 +970,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
 #define TRH_LAUNCH_PASSY(TWL, FUSE, LDS)                                                                                                       \
     hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
-                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf)
+                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major)
                 if (sp <= 8 && !fused) TRH_LAUNCH_PASSY(true, false, ldl);
                 else if (sp <= 8) TRH_LAUNCH_PASSY(true, true, ldl);
                 else if (!fused) TRH_LAUNCH_PASSY(false, false, ldz);

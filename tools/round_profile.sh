@@ -22,11 +22,28 @@ if [ "$MODE" = collect ]; then
     python3 -m tiny_ram_halo2_amd.replay --word-bits 16 2>/dev/null | tail -1 > gpurun_out/replay_k10_$TAG.json
     LD_LIBRARY_PATH=tiny-ram-halo2_amd ./examples/replay --word-bits 32 2>/dev/null | tail -1 > gpurun_out/native_replay_$TAG.json
     [ -x tools/microbench ] && ./tools/microbench > gpurun_out/microbench_$TAG.txt 2>&1
+    # round 3: the host-pointer (drop-in) path, the issue-rate question, the 2^20 MSM
+    for m in dropin dropin-batched; do
+        python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --mode $m 2>/dev/null | tail -1 > gpurun_out/replay_${m}_$TAG.json
+        python3 -m tiny_ram_halo2_amd.replay --word-bits 16 --columns witness --mode $m 2>/dev/null | tail -1 > gpurun_out/replay_${m}_k10_$TAG.json
+        LD_LIBRARY_PATH=tiny-ram-halo2_amd ./examples/replay --word-bits 32 --columns witness --mode $m 2>/dev/null | tail -1 > gpurun_out/native_replay_${m}_$TAG.json
+    done
+    python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --extended full 2>/dev/null | tail -1 > gpurun_out/replay_witness_full_domain_$TAG.json
+    python3 tools/dropin_probe.py 24 22 2>/dev/null | tail -1 > gpurun_out/dropin_probe_$TAG.json
+    [ -x tools/pcie_probe ] && ./tools/pcie_probe 512 > gpurun_out/pcie_probe_$TAG.txt 2>&1
+    [ -x tools/issue_probe ] && ./tools/issue_probe > gpurun_out/issue_probe_$TAG.txt 2>&1
+    bash tools/pmc_valu.sh $TAG 24 > gpurun_out/msm_valu_counters_$TAG.txt 2>&1
+    bash tools/prof_cmd.sh msm20_$TAG tools/msm_probe.py 20 pallas 0 0 > gpurun_out/msm_2_20_kernel_stats_$TAG.txt 2>&1
     head -c 160 gpurun_out/bench_$TAG.json; echo
 else
     python3 tools/summarize_prof.py gpurun_out/prof_$TAG "$TAG" | tail -2
     for f in bench replay replay_witness replay_k10 native_replay native_replay_witness; do cp gpurun_out/${f}_$TAG.json profiles/; done
     for f in msm_sq_counters ntt_sq_counters; do grep -v "^\[" gpurun_out/${f}_$TAG.txt > profiles/${TAG}_$f.txt; done
     [ -f gpurun_out/microbench_$TAG.txt ] && cp gpurun_out/microbench_$TAG.txt profiles/
+    for m in dropin dropin-batched; do for f in replay_${m} replay_${m}_k10 native_replay_${m}; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done; done
+    for f in replay_witness_full_domain dropin_probe; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done
+    for f in pcie_probe issue_probe; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/; done
+    [ -s gpurun_out/msm_valu_counters_$TAG.txt ] && grep -v "^\[" gpurun_out/msm_valu_counters_$TAG.txt > profiles/${TAG}_msm_valu_counters.txt
+    [ -s gpurun_out/msm_2_20_kernel_stats_$TAG.txt ] && cp gpurun_out/msm_2_20_kernel_stats_$TAG.txt profiles/${TAG}_msm_2_20_kernel_stats.txt
     ls profiles
 fi
