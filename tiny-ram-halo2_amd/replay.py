@@ -114,8 +114,64 @@ class _FixedTranscript:
         return (w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192) % self.m
 
 
+def _column_loop_two_contexts(params, dom, batches, blinds, ext_buf, D, blocks, x_eval, field, n, dev, overlapped: bool) -> float:
+    """The per-column phase of create_proof (commit_lagrange, lagrange_to_coeff, coeff_to_extended, the evaluations) over resident
+    column batches, either one step after the other or with the transforms of batch i - 1 on a SECOND libtrh context (own scratch, own
+    stream, a second host thread) while the first commits batch i: the batched MSM's latency-bound sort / bucket-reduction tails fill
+    with transform work.  Returns the wall time in ms (device synchronised on both sides)."""
+    import threading
+
+    import torch
+    ctx2 = api.Context(dev.index)
+    s2 = torch.cuda.Stream(device=dev)
+    err = []
+
+    def transforms(cols):
+        try:
+            ctx2.bind()
+            with torch.cuda.stream(s2):
+                coeff = dom.lagrange_to_coeff(cols)
+                if blocks:
+                    dom.coeff_to_extended_blocks(coeff, D, out=ext_buf)
+                else:
+                    dom.coeff_to_extended(coeff, out=ext_buf)
+                api.poly_eval_batch_dev(field, coeff, n, cols.shape[0], x_eval, stream=s2.cuda_stream)
+                s2.synchronize()
+        except Exception as e:  # surfaced by the caller
+            err.append(e)
+        finally:
+            api.Context.unbind()
+
+    try:
+        warm = batches[0].clone()
+        transforms(warm)  # the second context builds its twiddle tables once
+        del warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prev = None
+        for cols, bl in zip(batches, blinds):
+            th = None
+            if prev is not None and overlapped:
+                th = threading.Thread(target=transforms, args=(prev,))
+                th.start()
+            elif prev is not None:
+                transforms(prev)
+            params.commit_lagrange_batch(cols, bl)
+            if th is not None:
+                th.join()
+            prev = cols
+        transforms(prev)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        ctx2.destroy()
+    if err:
+        raise err[0]
+    return ms
+
+
 def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True, columns: str = "random",
-        keygen: bool = True, extended: str = "blocks") -> dict:
+        keygen: bool = True, extended: str = "blocks", overlap: bool = False) -> dict:
     import torch
 
     from . import multiopen
@@ -292,6 +348,23 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         coeff_all[done:done + b].copy_(coeff)
         del coeff, cols
         done += b
+
+    # the same per-column phase with the transforms on a second context / stream / host thread (reported beside the step-by-step sum)
+    loop_ms = None
+    if overlap:
+        keep_ext = ext_keep.clone()
+        batches, bls, d0 = [], [], 0
+        while d0 < lag_total:
+            b = min(batch, lag_total - d0)
+            batches.append(make_columns(d0, b)[1])
+            bls.append(synth.field_elements(seed + 0x100000 + d0, b))
+            d0 += b
+        copies = [t.clone() for t in batches]
+        loop_ms = {"step_by_step": round(_column_loop_two_contexts(params, dom, copies, bls, ext_buf, D, blocks, x_eval, field, n, dev, False), 3)}
+        del copies
+        loop_ms["two_contexts_overlapped"] = round(_column_loop_two_contexts(params, dom, batches, bls, ext_buf, D, blocks, x_eval, field, n, dev, True), 3)
+        del batches
+        ext_keep = keep_ext
 
     # --- h(X) numerator: gate expressions over the extended cosets, folded with the challenge y.  The real gate set is the
     # reference's circuit definition (src/circuits/tables/exe.rs:147-498 etc.), which cannot be extracted without the Rust
@@ -476,6 +549,8 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     wall = time.perf_counter() - t_wall
     out = {"word_bits": word_bits, "columns": columns, "extended_domain": f"{D} of {1 << (ek - k)} coset blocks of 2^{k}" if blocks else f"all 2^{ek} points", "schedule": sch, "counts": counts, "gpu_ms": {kk: round(v, 3) for kk, v in times.items()},
            "gpu_ms_total": round(sum(times.values()), 3),
+           "column_loop_ms": loop_ms,
+           "gpu_ms_total_two_contexts": round(sum(times.values()) - (loop_ms["step_by_step"] - loop_ms["two_contexts_overlapped"]), 3) if loop_ms else None,
            "h_eval_synthetic_gates": N_SYNTH_GATES, "h_eval_real_gates_ms": real["ms"] if real else None, "h_eval_real_gates": real,
            "gpu_ms_total_with_real_gates": round(sum(times.values()) - times["h_eval"] + real["ms"], 3) if real else None,
            "scope": "GPU time of the offloaded arithmetic of ONE create_proof incl. the multiopen folds / divisions; witness generation, the transcript and PCIe are not in it",
@@ -696,12 +771,13 @@ def main():
                     help="resident: polynomials live on the device (the restructured prover); dropin: every polynomial in host memory, one "
                          "trh_msm / trh_best_fft call at a time (north_star's literal integration); dropin-batched: host memory, batched host-pointer entries")
     ap.add_argument("--extended", choices=("blocks", "full"), default="blocks", help="resident mode: the extended domain as the 5 coset blocks the quotient needs, or all 2^extended_k points")
+    ap.add_argument("--overlap", action="store_true", help="resident mode: also time the per-column phase with the transforms on a second context / stream / host thread")
     ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes: replay only the first N Lagrange columns")
     a = ap.parse_args()
     if a.mode != "resident":
         run_dropin(a.word_bits, "literal" if a.mode == "dropin" else "batched", a.batch, columns=a.columns, max_columns=a.max_columns)
         return
-    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended)
+    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended, overlap=a.overlap)
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ if [ "$MODE" = collect ]; then
     bash tools/profile.sh "$TAG" > gpurun_out/profile_$TAG.log 2>&1
     python3 bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
     python3 -m tiny_ram_halo2_amd.replay --word-bits 32 2>/dev/null | tail -1 > gpurun_out/replay_$TAG.json
-    python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness 2>/dev/null | tail -1 > gpurun_out/replay_witness_$TAG.json
+    python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --overlap 2>/dev/null | tail -1 > gpurun_out/replay_witness_$TAG.json
     LD_LIBRARY_PATH=tiny-ram-halo2_amd ./examples/replay --word-bits 32 --columns witness 2>/dev/null | tail -1 > gpurun_out/native_replay_witness_$TAG.json
     bash tools/pmc_msm.sh $TAG 24 > gpurun_out/msm_sq_counters_$TAG.txt 2>&1
     bash tools/pmc_ntt.sh $TAG > gpurun_out/ntt_sq_counters_$TAG.txt 2>&1
