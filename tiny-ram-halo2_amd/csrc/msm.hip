@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
 // ---------------------------------------------------------------------------------------
 // 2. exclusive scan per window of cnt[0..len) -> starts; cnt becomes the running cursor
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1, u32* __restrict__ oversize, u32 bin_cap) {
+__global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ counts, u32* __restrict__ starts, u32 nb1, u32* __restrict__ oversize, u32 bin_cap,
+                                                           u32* __restrict__ totals /* or null: entries of this (item, row) */) {
     const size_t z = blockIdx.z;  // batch item
     counts += z * (size_t)gridDim.x * nb1; starts += z * (size_t)gridDim.x * nb1;
     __shared__ u32 part[1024];
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
         part[t] += v;
         __syncthreads();
     }
+    if (totals && t == 1023) totals[z * gridDim.x + blockIdx.x] = part[1023];
     u32 run = part[t] - sum;
     for (u32 b = lo; b < hi; ++b) {
         u32 cv = cnt[b];
@@ -616,7 +618,20 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
             store_raw(is_first ? my_first : direct + (size_t)j * nb1 + B, acc);
             is_first = false;
             fresh = true;
-            do { ++B; cur_end = en[B]; } while (cur_end <= pos);
+            // next bucket that holds an entry: almost always the very next one; sparse lists (the few blinding rows of a witness column
+            // scattered over 2^15 buckets) would otherwise walk thousands of empty buckets one dependent load at a time -- 1.3 ms of a
+            // 4 ms batch of flag columns -- so after a few steps the search turns binary (en is non-decreasing)
+            int walked = 0;
+            do { ++B; cur_end = en[B]; } while (cur_end <= pos && ++walked < 4);
+            if (cur_end <= pos) {
+                u32 lo = B + 1, hi = nbk;  // smallest b with en[b] > pos; it exists because pos < total = en[nbk]
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (en[mid] > pos) hi = mid; else lo = mid + 1;
+                }
+                B = lo;
+                cur_end = en[B];
+            }
         }
         const u32 ce = sl.e;
         AffineZ<BF> cur;
@@ -939,20 +954,28 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const u32 slice = nbk / tpw;
     const u32 rblocks = (tpw + 255) / 256;
     // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 128 entries each
-    u32 seg_len = 128;
-    while (seg_len > 16 && (size_t)W * n * chunk / seg_len < ((size_t)1 << 19)) seg_len >>= 1;  // W * n == Ws * ns
-    if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len = (u32)v; }  // tuning knob
-    const u32 nseg = (u32)((ns + seg_len - 1) / seg_len);
+    u32 seg_len0 = 128;
+    while (seg_len0 > 16 && (size_t)W * n * chunk / seg_len0 < ((size_t)1 << 19)) seg_len0 >>= 1;  // W * n == Ws * ns
+    if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len0 = (u32)v; }  // tuning knob
+    const u32 nseg0 = (u32)((ns + seg_len0 - 1) / seg_len0);
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
-    const size_t max_heavy = (size_t)Ws * nseg / HEAVY_PIECES + 1;
-    const u32 heavy_stride = (u32)(max_heavy + 1);
-    const unsigned heavy_blocks = (unsigned)(max_heavy < 256 ? max_heavy : 256);
+    const size_t max_heavy = (size_t)Ws * nseg0 / HEAVY_PIECES + 1;
+    const u32 heavy_stride0 = (u32)(max_heavy + 1);
+    const unsigned heavy_blocks0 = (unsigned)(max_heavy < 256 ? max_heavy : 256);
 
     TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
-    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + chunk * Ws * 4));  // + the oversize-bin flags of the LDS bin sort (per item and window)
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + 2 * chunk * Ws * 4));  // + the oversize-bin flags of the LDS bin sort and the entry totals (per item and window)
     u32* const oversize = L.counts.as<u32>() + chunk * Ws * nbins;
+    u32* const totals = oversize + chunk * Ws;
+    // Batched commitments of WITNESS columns (flags, small words: a few 10^4 entries per column, most of them in a handful of buckets)
+    // leave the sorted lists almost empty, and fixed 128-entry segments then mean a few hundred threads each walking a serial chain of 128
+    // mixed additions (3 ms per batch of 64 flag columns at k = 18, the chip idle).  For batches the entry counts are read back after the
+    // histogram scan (one synchronisation per chunk, ~20 us) and the segment length is sized to the entries that exist.
+    static const int adaptive_knob = getenv("TRH_ADAPTIVE_SEG") ? atoi(getenv("TRH_ADAPTIVE_SEG")) : 1;
+    const bool adaptive = adaptive_knob && batch >= 8 && !getenv("TRH_SEG_LEN");
+    if (adaptive && !c.pinned_land) TRH_HIP_TRY(hipHostMalloc(&c.pinned_land, 4096, hipHostMallocDefault));
     // LDS bin sort when the bins are big enough to fill a 1024-thread workgroup and fit with 6 % + 512 entries of slack
     // (uniform digits: the largest of 8192 bins of 2^15 entries is 4.5 sigma = 800 entries above the mean)
     const size_t avg_bin = ns / nbins;
@@ -963,11 +986,11 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4));
     TRH_TRY(L.ends.ensure(chunk * Ws * nb1 * 4));
     const unsigned range_blocks = (nb1 + RANGE_BLOCK - 1) / RANGE_BLOCK;  // <= 2^17 / 1024 + 1 = 129 < RANGE_BLOCK threads
-    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg > range_blocks ? nseg : range_blocks) * 4 + 16));
-    TRH_TRY(L.first.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
-    TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
+    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg0 > range_blocks ? nseg0 : range_blocks) * 4 + 16));
+    TRH_TRY(L.first.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
+    TRH_TRY(L.last.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
     TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
-    TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
+    TRH_TRY(L.heavy.ensure(chunk * heavy_stride0 * 4));
     TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZzMem)));
     TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZzMem)));
     if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * ZREC + ZREC));
@@ -996,7 +1019,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
         TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * Ws * nbins * 4, s));
-        TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         unsigned gb = (unsigned)((n + 255) / 256);
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
@@ -1004,7 +1026,30 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                            tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
         if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap);
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap,
+                           adaptive ? totals : nullptr);
+        u32 seg_len = seg_len0, nseg = nseg0, heavy_stride = heavy_stride0;
+        unsigned heavy_blocks = heavy_blocks0;
+        if (adaptive && (size_t)nb * Ws * 4 <= 4096) {
+            u32* ht = (u32*)c.pinned_land;
+            TRH_HIP_TRY(hipMemcpyAsync(ht, totals, (size_t)nb * Ws * 4, hipMemcpyDeviceToHost, s));
+            TRH_HIP_TRY(hipStreamSynchronize(s));
+            size_t sum = 0;
+            u32 most = 0;
+            for (size_t q = 0; q < (size_t)nb * Ws; ++q) { sum += ht[q]; most = ht[q] > most ? ht[q] : most; }
+            seg_len = 128;
+            while (seg_len > 16 && sum / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+            nseg = (most + seg_len - 1) / seg_len;  // segments beyond the longest list would find nothing
+            if (nseg == 0) nseg = 1;
+            const size_t mh = (size_t)Ws * nseg / HEAVY_PIECES + 1;
+            heavy_stride = (u32)(mh + 1);
+            heavy_blocks = (unsigned)(mh < 256 ? mh : 256);
+            TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg > range_blocks ? nseg : range_blocks) * 4 + 16));
+            TRH_TRY(L.first.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
+            TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
+            TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
+        }
+        TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits);
         {
