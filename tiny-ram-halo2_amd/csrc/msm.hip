@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const u32* __res
     }
 }
 
-// G lanes per bucket (1 or 4): a small MSM with few, long buckets (the IPA rounds: 512 buckets of 512 entries in segments
+// G lanes per bucket (1, 4 or 16): a small MSM with few, long buckets (the IPA rounds: 512 buckets of 512 entries in segments
 // of 16) would otherwise add its 32 pieces one after the other in one thread -- a 0.15 ms latency chain per MSM; the lanes of
 // a group take the pieces round-robin and a shuffle tree adds the group's partial sums
 template <class BF, int G>
@@ -1037,8 +1037,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             size_t sum = 0;
             u32 most = 0;
             for (size_t q = 0; q < (size_t)nb * Ws; ++q) { sum += ht[q]; most = ht[q] > most ? ht[q] : most; }
+            static const int target_log = getenv("TRH_ADAPTIVE_TARGET_LOG") ? atoi(getenv("TRH_ADAPTIVE_TARGET_LOG")) : 16;  // swept 15 .. 19 over the four sparse column classes at k = 18: 12.4 .. 13.8 ms per four batches, 15.5 without
             seg_len = 128;
-            while (seg_len > 16 && sum / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+            while (seg_len > 16 && sum / seg_len < ((size_t)1 << target_log)) seg_len >>= 1;
             nseg = (most + seg_len - 1) / seg_len;  // segments beyond the longest list would find nothing
             if (nseg == 0) nseg = 1;
             const size_t mh = (size_t)Ws * nseg / HEAVY_PIECES + 1;
@@ -1082,6 +1083,10 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                        L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride)
             // measured on the IPA opening at k = 18 (32 pieces per bucket): 24.0 ms with one lane per bucket, 23.0 with 4, 26.1 with 16
             // (idle lanes of the wider groups still occupy the SIMD)
+            // sparse lists cut into short segments (adaptive): the few buckets that hold anything hold many pieces (an even-bits word column:
+            // 256 buckets of 512 entries = 32 pieces each, added one after the other by one thread: 1.6 ms per batch) while most groups find an
+            // empty bucket and leave at once -- a quarter wave per bucket
+            // (16 lanes per bucket for these: 2^15 buckets x 64 columns x 16 lanes of mostly empty groups cost more than the chains: 3.4 -> 5.4 ms)
             if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
             else TRH_LAUNCH_COMBINE(1);
 #undef TRH_LAUNCH_COMBINE
