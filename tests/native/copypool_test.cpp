@@ -1,0 +1,35 @@
+// The copy pool of the host-pointer staging path (csrc/copypool.h) on its own: concurrent callers on two pools (the upload side and a
+// pipeline's download helper), sizes around the slicing boundaries, content checked byte for byte.  Built with -fsanitize=thread (and
+// address) by tests/test_hostcombine.py: the hand-over through the generation counter / pending count must be race-free.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../tiny-ram-halo2_amd/csrc/copypool.h"
+
+int main() {
+    trh::CopyPool* up = new trh::CopyPool(3);
+    trh::CopyPool* down = new trh::CopyPool(2);
+    trh::CopyPool* none = new trh::CopyPool(0);
+    int bad = 0;
+    auto run = [&](trh::CopyPool* pool, unsigned seed, int* fails) {
+        const size_t sizes[] = {0, 1, 4095, 4096, (1u << 20) - 1, 1u << 20, (1u << 20) + 1, (3u << 20) + 12345, 8u << 20, (8u << 20) + 4097};
+        for (int rep = 0; rep < 6; ++rep)
+            for (size_t sz : sizes) {
+                std::vector<unsigned char> src(sz + 64), dst(sz + 64, 0xEE);
+                for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)((i * 2654435761u + seed + rep) >> 13);
+                pool->copy((char*)dst.data() + 32, (const char*)src.data() + 32, sz);
+                if (sz && memcmp(dst.data() + 32, src.data() + 32, sz) != 0) ++*fails;
+                for (int g = 0; g < 32; ++g) if (dst[g] != 0xEE || dst[32 + sz + g] != 0xEE) { ++*fails; break; }  // nothing outside the range
+            }
+    };
+    int f[4] = {0, 0, 0, 0};
+    std::thread a(run, up, 1u, &f[0]), b(run, up, 2u, &f[1]), c(run, down, 3u, &f[2]);  // two callers share one pool, a third uses the other
+    run(none, 4u, &f[3]);
+    a.join(); b.join(); c.join();
+    for (int v : f) bad += v;
+    std::printf(bad ? "copypool: FAILED (%d)\n" : "copypool: ok\n", bad);
+    return bad ? 1 : 0;
+}

@@ -52,3 +52,18 @@ def test_host_side_under_sanitizers():
             r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
             assert r.returncode == 0 and banner in r.stdout, r.stdout + r.stderr
             assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr
+
+
+def test_copy_pool_under_thread_sanitizer():
+    """the host threads of the host-pointer staging path (csrc/copypool.h: spin-then-sleep workers handed slices through a generation
+    counter): two callers sharing one pool and a third on another, byte-exact copies, no report from -fsanitize=thread; then the same
+    under address + undefined"""
+    src = os.path.join(ROOT, "tests", "native", "copypool_test.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, san in (("tsan", "-fsanitize=thread"), ("asan", "-fsanitize=address,undefined")):
+            exe = os.path.join(tmp, "copypool_" + tag)
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-w", san, "-fno-omit-frame-pointer", src, "-o", exe, "-pthread"])
+            # the pools are never destroyed by design (workers parked on a condition variable at exit): no leak check
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+            assert r.returncode == 0 and "copypool: ok" in r.stdout, r.stdout + r.stderr
+            assert "WARNING: ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
