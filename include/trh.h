@@ -225,6 +225,11 @@ int trh_domain_blocks_to_quotient(trh_domain_t d, void* num_blocks_dev, void* h_
 int trh_domain_lagrange_to_coeff_host(trh_domain_t d, uint64_t* const* a, size_t count);
 int trh_domain_coeff_to_extended_host(trh_domain_t d, const uint64_t* const* coeff, uint64_t* const* ext, size_t count);
 int trh_domain_extended_to_coeff_host(trh_domain_t d, uint64_t* a, int divide_by_vanishing_first);
+/* the coset-block forms on host polynomials, for a host-side h(X) evaluation that has adopted the block layout: n_blocks x 2^k values
+ * per column come down instead of 2^extended_k (5/8 of the bytes when n_blocks = trh_domain_quotient_blocks()), the quotient's numerator
+ * goes up as (j - 1) x 2^k values and h(X)'s (j - 1) x 2^k coefficients come back                                                     */
+int trh_domain_coeff_to_extended_blocks_host(trh_domain_t d, const uint64_t* const* coeff, uint64_t* const* ext, size_t count, uint32_t n_blocks);
+int trh_domain_blocks_to_quotient_host(trh_domain_t d, const uint64_t* num_blocks, uint64_t* h_coeff, int divide_by_vanishing);
 
 /* ---- IPA opening rounds: poly::commitment::prover::create_proof (device memory) ---------------
  * The two half-size MSMs of a round run through trh_msm_dev on the live G' buffer

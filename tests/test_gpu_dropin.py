@@ -26,7 +26,7 @@ def _affine(curve, jac):
     return np.asarray(jac, dtype=np.uint64)[:8]
 
 
-@pytest.mark.parametrize("level", ["literal", "batched"])
+@pytest.mark.parametrize("level", ["literal", "batched", "batched-blocks"])
 def test_dropin_replay_k10_matches_oracle(level):
     """BASELINE config 1's circuit size through the host-pointer entries: every hooked call against the oracle"""
     seen = {}
@@ -49,6 +49,10 @@ def test_dropin_replay_k10_matches_oracle(level):
             full[: inp["a"].shape[0]] = inp["a"]
             assert (np.asarray(out) == cpu_ref.best_fft(inp["field"], full, inp["omega"], inp["log_n"], threads=8)).all()
             return
+        if kind in ("coeff_to_extended_blocks", "blocks_to_quotient"):
+            from test_gpu_replay import check_blocks
+            check_blocks(kind, inp, out)
+            return
         field, j, k = inp["domain"]
         f = o.FIELDS[field]
         dom = o.EvaluationDomain(f, j, k)
@@ -69,8 +73,11 @@ def test_dropin_replay_k10_matches_oracle(level):
         # the literal level moves every padded vector both ways: 497 x (n + 1 + n + 8 n) x 32 B up
         n = 1 << 10
         assert res["pcie"]["h2d_GB"] * 1e9 >= 497 * (10 * n + 1) * 32
-    else:
+    elif level == "batched":
         assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended": 3, "commit": 1, "divide_and_extended_to_coeff": 1}
+    else:
+        assert seen == {"commit_lagrange": 3, "lagrange_to_coeff": 3, "coeff_to_extended_blocks": 3, "commit": 1, "blocks_to_quotient": 1}
+        assert res["mode"] == "dropin-batched-blocks"
 
 
 @pytest.mark.parametrize("curve", ["pallas", "vesta"])

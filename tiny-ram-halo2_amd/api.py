@@ -150,6 +150,8 @@ _SIGNATURES = {
     "trh_domain_lagrange_to_coeff_host": ([_vp, ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
     "trh_domain_coeff_to_extended_host": ([_vp, ctypes.POINTER(_u64p), ctypes.POINTER(_u64p), ctypes.c_size_t], ctypes.c_int),
     "trh_domain_extended_to_coeff_host": ([_vp, _u64p, ctypes.c_int], ctypes.c_int),
+    "trh_domain_coeff_to_extended_blocks_host": ([_vp, ctypes.POINTER(_u64p), ctypes.POINTER(_u64p), ctypes.c_size_t, ctypes.c_uint32], ctypes.c_int),
+    "trh_domain_blocks_to_quotient_host": ([_vp, _u64p, _u64p, ctypes.c_int], ctypes.c_int),
     "trh_host_register": ([_vp, ctypes.c_size_t], ctypes.c_int),
     "trh_host_unregister": ([_vp], ctypes.c_int),
     "trh_host_alloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),

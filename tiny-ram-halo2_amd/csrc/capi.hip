@@ -780,7 +780,7 @@ int trh_commit_batch_host(trh_bases_t bases, const uint64_t* const* polys_host, 
         const size_t slot = j & 1, first = j * chunk, nb = first + chunk <= batch ? chunk : batch - first;
         TRH_TRY(st.ring_in[slot].ensure(chunk * n * 32 + chunk * 32 + 32));
         char* const tails = (char*)st.ring_in[slot].p + chunk * n * 32;
-        for (size_t i = 0; i < nb; ++i) TRH_TRY(stage_h2d(c, (char*)st.ring_in[slot].p + i * n * 32, polys_host[first + i], n * 32, st.us));
+        for (size_t i = 0; i < nb; ++i) TRH_TRY(stage_h2d(c, (char*)st.ring_in[slot].p + i * n * 32, polys_host[first + i], n * 32, st.us, true));
         TRH_TRY(stage_h2d(c, tails, blinds_host + 4 * first, nb * 32, st.us));
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
         if (j > 0) TRH_TRY(msm_finish(bases->curve, st.cs, out + 12 * (first - chunk), chunk));

@@ -186,7 +186,8 @@ struct Range {
 int stage_ensure(Ctx& c);
 void stage_release(Ctx& c);
 // src_host -> dst_dev on stream s through the upload ring; returns when the source has been read (the last DMA may still be in flight on s)
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
+// (part_of_batch: more uploads follow at once -- a transfer that fits one slot is then not split, the next call's copy overlaps its DMA)
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch = false);
 // src_dev -> dst_host through the download ring, ordered behind the work queued on s; returns when dst_host is complete
 int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
 // Batch pipeline over `count` items (each a group of host buffers): upload (caller thread, stage.us) -> compute(item, in, out,

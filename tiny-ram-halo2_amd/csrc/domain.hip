@@ -387,7 +387,7 @@ int trh_domain_blocks_to_quotient(trh_domain* d, void* num_blocks_dev, void* h_c
  * EvaluationDomain calls become when create_proof keeps its polynomials in host memory ------------------------------------- */
 static size_t group_for(size_t bytes_per_column) {
     size_t g = 1;
-    while (g < 64 && g * bytes_per_column < ((size_t)8 << 20)) g <<= 1;  // a pipeline item is worth a few MiB of link time
+    while (g < 64 && g * bytes_per_column < ((size_t)32 << 20)) g <<= 1;  // a pipeline item is worth ~0.5 ms of link time (per-item hand-overs cost ~0.1 ms)
     return g;
 }
 
@@ -403,7 +403,7 @@ int trh_domain_lagrange_to_coeff_host(trh_domain* d, uint64_t* const* a, size_t 
     p.in_bytes = group * bytes;
     p.in_place = true;
     p.upload = [&](size_t it, void* din) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us));
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us, true));
         return TRH_OK;
     };
     p.compute = [&](size_t it, void* din, void*, hipStream_t s) -> int {
@@ -429,7 +429,7 @@ int trh_domain_coeff_to_extended_host(trh_domain* d, const uint64_t* const* coef
     p.in_bytes = group * in_b;
     p.out_bytes = group * out_b;
     p.upload = [&](size_t it, void* din) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * in_b, coeff[j], in_b, c.stage.us));
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * in_b, coeff[j], in_b, c.stage.us, true));
         return TRH_OK;
     };
     p.compute = [&](size_t it, void* din, void* dout, hipStream_t s) -> int {
@@ -439,6 +439,50 @@ int trh_domain_coeff_to_extended_host(trh_domain* d, const uint64_t* const* coef
         for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) out.push_back(HostPipe::Seg{ext[j], (const char*)dout + (j - it * group) * out_b, out_b});
     };
     return host_pipeline(c, p);
+}
+
+/* the coset-block form for a host that evaluates h(X) itself but has adopted the block layout: n_blocks x 2^k values per column come
+ * down instead of 2^extended_k (5/8 of the bytes for the reference's circuit), and the quotient goes back up as (j - 1) x 2^k values */
+int trh_domain_coeff_to_extended_blocks_host(trh_domain* d, const uint64_t* const* coeff, uint64_t* const* ext, size_t count, uint32_t n_blocks) {
+    TRH_TRY(check(d, coeff));
+    if (!ext || n_blocks == 0 || n_blocks > (1u << (d->extended_k - d->k))) { set_error("domain blocks: bad arguments"); return TRH_EINVAL; }
+    for (size_t i = 0; i < count; ++i) if (!coeff[i] || !ext[i]) { set_error("domain: column %zu is null", i); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_domain_coeff_to_extended_blocks_host");
+    Ctx& c = ctx();
+    const size_t in_b = (size_t)32 << d->k, out_b = (size_t)n_blocks * in_b, group = group_for(out_b);
+    HostPipe p;
+    p.count = (count + group - 1) / group;
+    p.in_bytes = group * in_b;
+    p.out_bytes = group * out_b;
+    p.upload = [&](size_t it, void* din) -> int {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * in_b, coeff[j], in_b, c.stage.us, true));
+        return TRH_OK;
+    };
+    p.compute = [&](size_t it, void* din, void* dout, hipStream_t s) -> int {
+        return trh_domain_coeff_to_extended_blocks(d, din, dout, count - it * group < group ? count - it * group : group, n_blocks, s);
+    };
+    p.segments = [&](size_t it, const void* dout, std::vector<HostPipe::Seg>& out) {
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) out.push_back(HostPipe::Seg{ext[j], (const char*)dout + (j - it * group) * out_b, out_b});
+    };
+    return host_pipeline(c, p);
+}
+
+/* num_blocks: (j - 1) x 2^k host values of the numerator on blocks 0 .. j - 2; h_coeff: (j - 1) x 2^k host coefficients (may alias) */
+int trh_domain_blocks_to_quotient_host(trh_domain* d, const uint64_t* num_blocks, uint64_t* h_coeff, int divide_by_vanishing) {
+    TRH_TRY(check(d, num_blocks));
+    if (!h_coeff) { set_error("domain: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    Range range("trh_domain_blocks_to_quotient_host");
+    Ctx& c = ctx();
+    TRH_TRY(stage_begin(c));
+    hipStream_t s = c.stage.cs;
+    const size_t bytes = (size_t)(d->j - 1) * ((size_t)32 << d->k);
+    TRH_TRY(c.io.ensure(2 * bytes));
+    TRH_TRY(stage_h2d(c, c.io.p, num_blocks, bytes, s));
+    TRH_TRY(trh_domain_blocks_to_quotient(d, c.io.p, (char*)c.io.p + bytes, divide_by_vanishing, s));
+    TRH_TRY(stage_d2h(c, h_coeff, (char*)c.io.p + bytes, bytes, s));
+    return stage_end(c);
 }
 
 /* h(X): [divide_by_vanishing_poly,] extended_to_coeff on one host polynomial of 2^extended_k values, in place */

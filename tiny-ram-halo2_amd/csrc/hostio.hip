@@ -105,7 +105,7 @@ void stage_release(Ctx& c) {
     st.slot = 0;
 }
 
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch) {
     if (!bytes) return TRH_OK;
     TRH_TRY(stage_ensure(c));
     Stage& st = c.stage;
@@ -115,7 +115,7 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
     } else {
         // a transfer smaller than the ring still wants a few slots in flight: the copy into slot i + 1 hides under the DMA of slot i
         size_t chunk = st.slot;
-        while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a short transfer still gets two slots in flight
+        if (!part_of_batch) while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a lone short transfer still gets two slots in flight
         for (size_t off = 0; off < bytes; off += chunk) {
             const size_t cur = bytes - off < chunk ? bytes - off : chunk;
             const int sl = (int)(st.up_next++ % Stage::NS);
@@ -322,13 +322,13 @@ static int best_fft_batch_host(int field, uint64_t* const* a, size_t count, cons
     const size_t bytes = (size_t)32 << log_n;
     // small transforms travel in groups, so that a pipeline item is worth a few MiB of link time
     size_t group = 1;
-    while (group < 64 && group * bytes < ((size_t)8 << 20)) group <<= 1;
+    while (group < 64 && group * bytes < ((size_t)32 << 20)) group <<= 1;
     HostPipe p;
     p.count = (count + group - 1) / group;
     p.in_bytes = group * bytes;
     p.in_place = true;
     p.upload = [&](size_t it, void* din) -> int {
-        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us));
+        for (size_t j = it * group; j < count && j < (it + 1) * group; ++j) TRH_TRY(stage_h2d(c, (char*)din + (j - it * group) * bytes, a[j], bytes, c.stage.us, true));
         return TRH_OK;
     };
     p.compute = [&](size_t it, void* din, void*, hipStream_t s) -> int {

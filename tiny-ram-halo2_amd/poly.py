@@ -204,6 +204,23 @@ class EvaluationDomain:
         api._check(api.lib().trh_domain_coeff_to_extended_host(self.handle(), api._ptr_array(coeffs), api._ptr_array(ext), len(coeffs)))
         return ext
 
+    def coeff_to_extended_blocks_host(self, coeffs, n_blocks: int | None = None, out=None):
+        """list of (n, 4) host coefficient arrays -> list of (n_blocks, n, 4) host arrays (the coset-block layout)"""
+        nb = self.quotient_poly_degree if n_blocks is None else n_blocks
+        for a in coeffs:
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (self.n, 4)
+        ext = out if out is not None else [np.empty((nb, self.n, 4), dtype=np.uint64) for _ in coeffs]
+        api._check(api.lib().trh_domain_coeff_to_extended_blocks_host(self.handle(), api._ptr_array(coeffs), api._ptr_array(ext), len(coeffs), nb))
+        return ext
+
+    def blocks_to_quotient_host(self, num_blocks, divide_by_vanishing: bool = True):
+        """(quotient_poly_degree, n, 4) host values of the numerator on blocks 0 .. -> (quotient_poly_degree * n, 4) coefficients of h(X)"""
+        d = self.quotient_poly_degree
+        assert num_blocks.dtype == np.uint64 and num_blocks.flags.c_contiguous and num_blocks.size == d * self.n * 4
+        out = np.empty((d * self.n, 4), dtype=np.uint64)
+        api._check(api.lib().trh_domain_blocks_to_quotient_host(self.handle(), api._p(num_blocks), api._p(out), 1 if divide_by_vanishing else 0))
+        return out
+
     def extended_to_coeff_host(self, a, divide_by_vanishing_first: bool = False):
         """in place on one (2^extended_k, 4) host array; returns the truncated view of n * quotient_poly_degree coefficients"""
         assert a.dtype == np.uint64 and a.flags.c_contiguous and a.shape == (self.extended_len(), 4)

@@ -570,6 +570,8 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
         `lagrange_to_coeff` -> trh_best_fft (2^k, both ways over the link), `coeff_to_extended` -> trh_best_fft on the zero-padded
         2^extended_k host vector (64 MiB each way at k = 18); h(X) -> one trh_best_fft of 2^extended_k; the IPA's round MSMs ->
         trh_best_multiexp over the host's folded generators.  One synchronous call at a time, as the Rust loops issue them.
+    level "batched-blocks": as "batched", for a host whose h(X) evaluation has adopted the coset-block layout of the extended domain
+        (trh_domain_coeff_to_extended_blocks_host / trh_domain_blocks_to_quotient_host): 5 x 2^k values per column come down instead of 2^extended_k.
     level "batched": the Params / EvaluationDomain seam with column batches (trh_commit_batch_host,
         trh_domain_lagrange_to_coeff_host, trh_domain_coeff_to_extended_host: only the 2^k coefficients go up, uploads /
         kernels / downloads of consecutive columns overlap), h(X) through trh_domain_extended_to_coeff_host, the opening
@@ -577,8 +579,11 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
     What stays on the Rust host in both (and is NOT timed here): the pointwise steps of EvaluationDomain in the literal level
     (x n^-1, the zeta shift), the lookup / permutation products, h(X)'s gate evaluation, the transcript.  The values passed on
     between steps are therefore not the prover's (timing does not depend on them); `hook` sees inputs and outputs of each call."""
-    assert level in ("literal", "batched") and columns in ("random", "witness")
+    assert level in ("literal", "batched", "batched-blocks") and columns in ("random", "witness")
     import torch
+    blocks_level = level == "batched-blocks"  # as "batched", with the extended domain in the coset-block layout: 5/8 of the bytes come down
+    if blocks_level:
+        level = "batched"
 
     k = 2 + word_bits // 2
     sch = schedule(k)
@@ -664,14 +669,17 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
                     checked += 1
         else:
             if ext_bufs is None or len(ext_bufs) < b:
-                ext_bufs = [np.zeros((N, 4), dtype=np.uint64) for _ in range(b)]
+                ext_bufs = [np.zeros((QUOTIENT_J - 1, n, 4) if blocks_level else (N, 4), dtype=np.uint64) for _ in range(b)]
             lag_in = [c.copy() for c in cols[:3]] if hook is not None and done == 0 else None
             t0 = time.perf_counter()
             pts = params.commit_lagrange_batch_host(cols, blinds)
             t1 = time.perf_counter()
             dom.lagrange_to_coeff_host(cols)
             t2 = time.perf_counter()
-            dom.coeff_to_extended_host(cols, out=ext_bufs[:b])
+            if blocks_level:
+                dom.coeff_to_extended_blocks_host(cols, QUOTIENT_J - 1, out=ext_bufs[:b])
+            else:
+                dom.coeff_to_extended_host(cols, out=ext_bufs[:b])
             t3 = time.perf_counter()
             wall["commit_lagrange"] += t1 - t0
             wall["lagrange_to_coeff"] += t2 - t1
@@ -680,7 +688,7 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
                 for i in range(len(lag_in)):
                     hook("commit_lagrange", dict(scalars=np.concatenate([lag_in[i], blinds[i][None]]), bases=gl), pts[i])
                     hook("lagrange_to_coeff", dict(a=lag_in[i], domain=(field, QUOTIENT_J, k)), cols[i])
-                    hook("coeff_to_extended", dict(a=cols[i], domain=(field, QUOTIENT_J, k)), ext_bufs[i])
+                    hook("coeff_to_extended_blocks" if blocks_level else "coeff_to_extended", dict(a=cols[i], domain=(field, QUOTIENT_J, k), n_blocks=QUOTIENT_J - 1), ext_bufs[i])
                     checked += 3
         for kk in ("commit_lagrange", "lagrange_to_coeff", "coeff_to_extended"):
             counts[kk] += b
@@ -702,11 +710,13 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
         checked += 1
 
     # h(X): the quotient's numerator comes back from the host's gate evaluation as 2^extended_k values
-    h_h = np.ascontiguousarray(synth.field_elements(0xEE, N))
+    h_h = np.ascontiguousarray(synth.field_elements(0xEE, (QUOTIENT_J - 1) * n if blocks_level else N))
     h_in = h_h.copy() if hook is not None else None
     t0 = time.perf_counter()
     if level == "literal":
         api.best_fft_inplace(field, h_h, w_ext_inv, ek)
+    elif blocks_level:
+        h_h = dom.blocks_to_quotient_host(h_h, divide_by_vanishing=True)
     else:
         dom.extended_to_coeff_host(h_h, divide_by_vanishing_first=True)
     wall["extended_to_coeff"] += time.perf_counter() - t0
@@ -714,6 +724,8 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
     if hook is not None:
         if level == "literal":
             hook("best_fft", dict(a=h_in, omega=w_ext_inv, log_n=ek, field=field), h_h)
+        elif blocks_level:
+            hook("blocks_to_quotient", dict(a=h_in, domain=(field, QUOTIENT_J, k), n_blocks=QUOTIENT_J - 1), h_h)
         else:
             hook("divide_and_extended_to_coeff", dict(a=h_in, domain=(field, QUOTIENT_J, k)), h_h[: n * (QUOTIENT_J - 1)])
         checked += 1
@@ -746,7 +758,7 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
     total_s = time.perf_counter() - t_all
     io = api.io_stats()
     in_calls = sum(wall.values())
-    out = {"mode": "dropin-" + level, "word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts,
+    out = {"mode": "dropin-" + level + ("-blocks" if blocks_level else ""), "word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts,
            "wall_ms_incl_pcie": {kk: round(v * 1e3, 3) for kk, v in wall.items()}, "wall_ms_incl_pcie_total": round(in_calls * 1e3, 3),
            "pcie": {"h2d_GB": round(io["h2d_bytes"] / 1e9, 3), "d2h_GB": round(io["d2h_bytes"] / 1e9, 3),
                     "h2d_GBps_in_copies": round(io["h2d_bytes"] / max(io["h2d_seconds"], 1e-9) / 1e9, 2),
@@ -767,7 +779,7 @@ def main():
     ap.add_argument("--no-precompute", action="store_true", help="commit over the plain per-window path (no fixed-base tables)")
     ap.add_argument("--columns", choices=("random", "witness"), default="random", help="uniformly random columns, or the value classes of the reference's witness")
     ap.add_argument("--no-keygen", action="store_true")
-    ap.add_argument("--mode", choices=("resident", "dropin", "dropin-batched"), default="resident",
+    ap.add_argument("--mode", choices=("resident", "dropin", "dropin-batched", "dropin-batched-blocks"), default="resident",
                     help="resident: polynomials live on the device (the restructured prover); dropin: every polynomial in host memory, one "
                          "trh_msm / trh_best_fft call at a time (north_star's literal integration); dropin-batched: host memory, batched host-pointer entries")
     ap.add_argument("--extended", choices=("blocks", "full"), default="blocks", help="resident mode: the extended domain as the 5 coset blocks the quotient needs, or all 2^extended_k points")
@@ -775,7 +787,7 @@ def main():
     ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes: replay only the first N Lagrange columns")
     a = ap.parse_args()
     if a.mode != "resident":
-        run_dropin(a.word_bits, "literal" if a.mode == "dropin" else "batched", a.batch, columns=a.columns, max_columns=a.max_columns)
+        run_dropin(a.word_bits, {"dropin": "literal", "dropin-batched": "batched", "dropin-batched-blocks": "batched-blocks"}[a.mode], a.batch, columns=a.columns, max_columns=a.max_columns)
         return
     run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended, overlap=a.overlap)
 
