@@ -61,15 +61,16 @@ def cpu_baseline_msm(curve: str, log_cap: int = 24):
     from tiny_ram_halo2_amd import synth
 
     threads = usable_cores()
-    # calibrate on 2^16 pairs, then size one MSM for <= ~12 s and repeat it until >= 10 s have been spent
-    n0 = 1 << 16
+    # calibrate on 2^18 pairs (2^16 under-estimates the rate of a 16-thread run by a third), then size one MSM for <= ~16 s -- the headline
+    # 2^24 on a 16-core box, so that the oracle comparison below happens at the headline size -- and repeat it until >= 10 s have been spent
+    n0 = 1 << 18
     bases0 = cpu_ref.gen_bases(curve, synth.BASE_S0, synth.BASE_D, n0, threads)
-    sc0 = synth.msm_scalars(16)
+    sc0 = synth.msm_scalars(18)
     t = time.perf_counter()
     cpu_ref.best_multiexp(curve, sc0, bases0, threads)
     rate0 = n0 / (time.perf_counter() - t)
-    log_n = 16
-    while log_n < log_cap and (1 << (log_n + 1)) / rate0 < 12.0:
+    log_n = 18
+    while log_n < log_cap and (1 << (log_n + 1)) / rate0 < 16.0:
         log_n += 1
     n = 1 << log_n
     bases = cpu_ref.gen_bases(curve, synth.BASE_S0, synth.BASE_D, n, threads)
@@ -151,8 +152,53 @@ MADS_PER_MADD = 738 + 405 + 27
 OTHER_PER_MADD = 1733 - MADS_PER_MADD
 
 
+def single_process_child(devices, steps: int, log_n: int = 26):
+    """ONE 2^26 Pallas MSM through trh_init_multi over `devices` from this process alone (what a single Rust prover process linking
+    libtrh.so gets): bases range-sharded by the library, scalars resident on the first device and handed to the others with peer
+    copies, partial points added on the host.  Prints one JSON line."""
+    import torch
+    from tiny_ram_halo2_amd import api, synth
+    curve = "pallas"
+    torch.cuda.set_device(devices[0])
+    dev = torch.device("cuda", devices[0])
+    api.init_multi(devices)
+    api.set_shard_min(1 << 20)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, block = 1 << log_n, 1 << 22
+    reps = n // block
+    bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+    assert bases.shards() == len(devices), (bases.shards(), devices)
+    blk = torch.from_numpy(synth.field_elements(synth.SEED_MSM | 22, block).view(np.int64)).to(dev)
+    d_sc = blk.repeat(reps, 1).contiguous()
+    for _ in range(2):
+        res = bases.msm_dev(d_sc, n, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = bases.msm_dev(d_sc, n, stream=stream)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    d_can = torch.empty_like(blk)
+    api._check(api.lib().trh_field_op_dev(api.FQ, api.FIELD_OPS["from_mont"], api._devptr(blk), None, api._devptr(d_can), block, stream))
+    torch.cuda.synchronize()
+    can = d_can.cpu().numpy().view(np.uint64)
+    t_0, t_1 = synth.weighted_scalar_sum(can, 1, 0), synth.weighted_scalar_sum(can, 0, 1)
+    total = reps * (synth.BASE_S0 * t_0 + synth.BASE_D * t_1) + synth.BASE_D * block * t_0 * (reps * (reps - 1) // 2)
+    api.set_shard_min(1 << 62)
+    g = api.Bases.generate(curve, 1, 0, 1)
+    want = g.msm(synth.ints_to_limbs([total % Q_MOD * ((1 << 256) % Q_MOD) % Q_MOD]))
+    ok = bool((want == res).all())
+    print(json.dumps({"workload": f"ONE 2^{log_n} Pallas MSM through trh_init_multi over {len(devices)} GPUs from one host process (a child of rank 0): bases range-sharded by "
+                                  "the library, scalars resident on GPU 0 and handed to the other GPUs with peer copies (included), partial points copied to the host and added",
+                      "value": n * steps / el, "unit": "pairs/s", "ms_per_msm": el / steps * 1e3, "check": "closed-form ok" if ok else "MISMATCH",
+                      "peer_access": bool(api.lib().trh_group_peer_access())}))
+    sys.stdout.flush()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--single-process-child", default=None, help="internal: comma-separated device list; run the single-process device-group MSM and exit")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -163,6 +209,8 @@ def main():
     ap.add_argument("--global-log-n", type=int, default=0, help="strong scaling: 2^L pairs in TOTAL, range-sharded over the ranks (default: weak, 2^log-n per GPU)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep / strong-scaling / single-process extras (profiling runs)")
     args = ap.parse_args()
+    if args.single_process_child is not None:
+        sys.exit(single_process_child([int(v) for v in args.single_process_child.split(",")], args.steps))
 
     import torch
     import torch.distributed as dist
@@ -428,32 +476,23 @@ def main():
             strong = {"workload": f"ONE 2^{L} Pallas MSM range-sharded over {world} ranks ({hi5 - lo5} pairs each), RCCL all-gather of the 96-byte partials, host add",
                       "value": (1 << L) * max(args.steps // 2, 3) / el5, "unit": "pairs/s", "ms_per_msm": el5 / max(args.steps // 2, 3) * 1e3, "scaling": "strong", "check": chk5,
                       "accumulate_kernel_ms": acc5, "window_bits": tm5["window_bits"]}
-        # the same MSM from ONE process through the C ABI's device group (rank 0 only; the other ranks wait on the store, no GPU spinning)
+        # the same MSM from ONE process through the C ABI's device group: a CHILD process of rank 0 (its own libtrh, trh_init_multi over the
+        # N GPUs) under a timeout, so that a fault of this never-on-hardware-tested leg cannot take the scaling run with it; the other ranks
+        # wait on the store, no GPU spinning
         if os.environ.get("TRH_BENCH_SINGLE_PROCESS", "1") != "0":
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
+                import subprocess
+                devs = list(range(world)) if backend == "nccl" else [dev_index] * world  # gloo runs fold the ranks onto the GPUs present
                 try:
-                    api.init_multi(list(range(world)) if backend == "nccl" else [dev_index] * world)  # gloo runs fold the ranks onto the GPUs present
-                    api.set_shard_min(1 << 20)
-                    wsp = Workload(0, 1 << L)  # trh_bases_generate range-shards over the group; scalars resident on device 0
-                    assert wsp.bases.shards() == world
-                    for _ in range(2):
-                        rsp = wsp.local_msm()
-                    torch.cuda.synchronize()
-                    k5 = max(args.steps // 2, 3)
-                    t0 = time.perf_counter()
-                    for _ in range(k5):
-                        rsp = wsp.local_msm()
-                    torch.cuda.synchronize()
-                    el = time.perf_counter() - t0
-                    ok = bool((expected_point(wsp.weighted_sum()) == rsp).all())
-                    if not ok:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-child", ",".join(map(str, devs)), "--steps", str(max(args.steps // 2, 3))],
+                                       capture_output=True, text=True, timeout=float(os.environ.get("TRH_BENCH_CHILD_TIMEOUT", "300")))
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    single = json.loads(lines[-1]) if lines else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+                    if single.get("check") == "MISMATCH":
                         failed.append("single-process msm")
-                    single = {"workload": f"ONE 2^{L} Pallas MSM through trh_init_multi over {world} GPUs from one host process: bases range-sharded by the library, "
-                                          "scalars resident on GPU 0 and handed to the other GPUs with peer copies (included), partial points copied to the host and added",
-                              "value": (1 << L) * k5 / el, "unit": "pairs/s", "ms_per_msm": el / k5 * 1e3, "check": "closed-form ok" if ok else "MISMATCH"}
-                    wsp.destroy()
-                    api.set_shard_min(1 << 62)
+                except subprocess.TimeoutExpired:
+                    single = {"error": "timeout"}
                 except Exception as exc:  # reported, never fatal to the headline
                     single = {"error": repr(exc)[:300]}
                 store.set("trh_single_process_done", "1")

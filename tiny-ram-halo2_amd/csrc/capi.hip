@@ -336,6 +336,7 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
     Range range(curve == TRH_PALLAS ? "trh_best_multiexp_pallas" : "trh_best_multiexp_vesta");
     if (!out || (n && (!coeffs || !bases))) { set_error("best_multiexp: null pointer"); return TRH_EINVAL; }
     if (n >= ((size_t)1 << 31)) { set_error("best_multiexp: n too large"); return TRH_EINVAL; }
+    if (n == 0) { memset(out, 0, 96); return TRH_OK; }  // the empty sum: the identity (an empty Rust slice may carry any pointer)
     static const int cache_on = getenv("TRH_BASES_CACHE") ? atoi(getenv("TRH_BASES_CACHE")) : 0;
     if (cache_on && n >= 1024) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
