@@ -300,6 +300,8 @@ int main(int argc, char** argv) {
     bool witness = false;
     std::string mode = "resident";
     int max_columns = 0;
+    bool overlap = false;
+    for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--overlap") { overlap = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i + 1 < argc; i += 2) {
         if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
         else if (std::string(argv[i]) == "--batch") batch = (size_t)std::atol(argv[i + 1]);
@@ -625,11 +627,74 @@ int main(int argc, char** argv) {
         (void)cfp;
         expect(tr.points == 1 + 2 * (int)k && tr.scalars == 2, "IPA transcript: S, L_j / R_j per round, then c and f");
 
+        // --overlap: the per-column phase once more over resident batches, step by step and with the transforms of batch i - 1 on a SECOND
+        // context (own scratch, own stream, a second host thread: trh_ctx_create / trh_ctx_set_current) while this thread commits batch i
+        double loop_seq_ms = 0, loop_ovl_ms = 0;
+        if (overlap) {
+            DeviceBuffer all_cols((size_t)lag_total * n * 32), work((size_t)lag_total * n * 32);
+            SplitMix r2{0xc01};
+            for (int done = 0; done < lag_total; done += (int)batch) {
+                const size_t b = std::min(batch, (size_t)(lag_total - done));
+                for (size_t c = 0; c < b; ++c) {
+                    if (witness) fill_witness_column(kinds[done + c].first, kinds[done + c].second, r2, word_bits, n, host_cols.data() + c * n);
+                    else for (size_t i = 0; i < n; ++i) host_cols[c * n + i] = r2.element();
+                }
+                all_cols.upload(host_cols.data(), b * n * 32, (size_t)done * n * 32);
+                if (witness) check(trh_field_op_dev((int)field, 6, all_cols.at((size_t)done * n * 32), nullptr, all_cols.at((size_t)done * n * 32), b * n, nullptr), "to_mont");
+            }
+            check(trh_stream_synchronize(nullptr), "sync");
+            trh_ctx_t ctx2 = nullptr;
+            check(trh_ctx_create(0, &ctx2), "ctx_create");
+            int bad = 0;
+            auto transforms = [&](void* cols_dev, size_t b) {  // on the second context and its own stream
+                if (trh_ctx_set_current(ctx2) != TRH_OK) { ++bad; return; }
+                void* s2 = trh_ctx_stream(ctx2);  // the context's own stream: the null stream would serialise with the commitments
+                try {
+                    dom.lagrange_to_coeff(cols_dev, b, s2);
+                    dom.coeff_to_extended_blocks(cols_dev, ext.data(), b, D, s2);
+                    (void)eval_polynomials(field, cols_dev, n, b, x_eval, s2);
+                    check(trh_stream_synchronize(s2), "sync");
+                } catch (const std::exception&) { ++bad; }
+                (void)trh_ctx_set_current(nullptr);
+            };
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int done = 0; done < lag_total; done += (int)batch) {  // fresh copies: the transforms work in place
+                    const size_t b = std::min(batch, (size_t)(lag_total - done));
+                    std::vector<Limbs> unit(1, host::one(field));
+                    for (size_t c = 0; c < b; ++c) lincomb(field, all_cols.at(((size_t)done + c) * n * 32), n, unit, work.at(((size_t)done + c) * n * 32));
+                }
+                if (pass == 0) transforms(work.data(), 1);  // the second context builds its twiddle tables once (column 0 is restored below)
+                if (pass == 0) { std::vector<Limbs> unit(1, host::one(field)); lincomb(field, all_cols.data(), n, unit, work.data()); }
+                check(trh_stream_synchronize(nullptr), "sync");
+                const double t0 = now_ms();
+                void* prev = nullptr;
+                size_t prev_b = 0;
+                for (int done = 0; done < lag_total; done += (int)batch) {
+                    const size_t b = std::min(batch, (size_t)(lag_total - done));
+                    std::thread th;
+                    if (prev && pass == 1) th = std::thread(transforms, prev, prev_b);
+                    else if (prev) transforms(prev, prev_b);
+                    for (size_t i = 0; i < b; ++i) blinds[i] = rng.element();
+                    std::vector<Point> pts(b);
+                    check(trh_commit_batch_dev(params.g_lagrange().handle(), work.at((size_t)done * n * 32), n, b, (const uint64_t*)blinds.data(), nullptr, (uint64_t*)pts.data()), "commit");
+                    if (th.joinable()) th.join();
+                    prev = work.at((size_t)done * n * 32);
+                    prev_b = b;
+                }
+                transforms(prev, prev_b);
+                check(trh_stream_synchronize(nullptr), "sync");
+                (pass == 0 ? loop_seq_ms : loop_ovl_ms) = now_ms() - t0;
+            }
+            trh_ctx_destroy(ctx2);
+            expect(bad == 0, "two-context column loop");
+        }
+
         const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_multiopen + ms_ipa;
         std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"extended_domain\": \"5 of 8 coset blocks\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"keygen_ms\": %.3f, "
                     "\"ms\": {\"lookup_permute\": %.3f, \"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
-                    "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f}\n",
-                    word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total);
+                    "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f, \"column_loop_ms\": {\"step_by_step\": %.3f, \"two_contexts_overlapped\": %.3f}}\n",
+                    word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total,
+                    loop_seq_ms, loop_ovl_ms);
         trh_shutdown();
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -86,6 +86,9 @@ int trh_ctx_create(int device, trh_ctx_t* out);
 void trh_ctx_destroy(trh_ctx_t ctx);
 int trh_ctx_set_current(trh_ctx_t ctx_or_null);  /* binds the calling THREAD; NULL = back to the process default */
 int trh_ctx_device(trh_ctx_t ctx_or_null);       /* device index of the context (NULL: of the calling thread's), -1 if none */
+/* the context's own non-blocking stream (a hipStream_t), for hosts without a HIP toolchain of their own (the Rust shim, the C++ driver):
+ * pass it as the `stream` argument of the *_dev entries so that two contexts' work overlaps instead of meeting on the null stream */
+void* trh_ctx_stream(trh_ctx_t ctx_or_null);
 
 /* ---- halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve ------------------
  * coeffs: n x 4 u64 (scalar field, Montgomery -- the memory image of `&[C::Scalar]`),

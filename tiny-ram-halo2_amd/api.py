@@ -77,6 +77,7 @@ _SIGNATURES = {
     "trh_ctx_destroy": ([_vp], None),
     "trh_ctx_set_current": ([_vp], ctypes.c_int),
     "trh_ctx_device": ([_vp], ctypes.c_int),
+    "trh_ctx_stream": ([_vp], _vp),
     "trh_best_multiexp_pallas": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_best_multiexp_vesta": ([_u64p, _u64p, ctypes.c_size_t, _u64p], ctypes.c_int),
     "trh_best_fft_fp": ([_u64p, _u64p, ctypes.c_uint32], ctypes.c_int),

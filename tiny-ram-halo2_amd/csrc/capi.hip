@@ -613,6 +613,10 @@ int trh_ctx_set_current(trh_ctx_t c) {
     t_bound = c;
     return TRH_OK;
 }
+void* trh_ctx_stream(trh_ctx_t c) {
+    Ctx* cc = c ? (Ctx*)c : thread_ctx();
+    return cc ? (void*)cc->own_stream : nullptr;
+}
 int trh_ctx_device(trh_ctx_t c) {
     Ctx* cc = c ? (Ctx*)c : thread_ctx();
     return cc ? cc->device : -1;
