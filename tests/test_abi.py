@@ -50,6 +50,23 @@ def test_no_device_fails_loudly():
         api.best_multiexp("pallas", np.zeros((1, 4), np.uint64), np.zeros((1, 8), np.uint64))
 
 
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
+def test_no_device_host_pointer_entries_fail_loudly():
+    """round 3's host-pointer entries (batch FFT, batched commitments, page-locking helpers, io stats): TRH_ENODEV without a GPU,
+    never a silent CPU path"""
+    import ctypes
+    lib = api.lib()
+    col = np.zeros((4, 4), np.uint64)
+    with pytest.raises(api.TrhError):
+        api.best_fft_batch("fp", [col], np.zeros(4, np.uint64), 2)
+    p = ctypes.c_void_p()
+    assert lib.trh_host_alloc(ctypes.byref(p), 4096) == -2 and b"trh_init" in lib.trh_last_error()
+    assert lib.trh_host_register(col.ctypes.data_as(ctypes.c_void_p), col.nbytes) == -2
+    st = api.IoStats()
+    assert lib.trh_io_stats(ctypes.byref(st), 0) == -2
+    assert lib.trh_ctx_stream(None) is None and lib.trh_group_peer_access() in (0, 1)
+
+
 def test_best_multiexp_length_mismatch_panics_like_reference():
     with pytest.raises(AssertionError):
         api.best_multiexp("pallas", np.zeros((3, 4), np.uint64), np.zeros((2, 8), np.uint64))
