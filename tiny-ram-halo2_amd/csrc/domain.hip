@@ -6,6 +6,7 @@
 // coeff_to_extended), and the division by the vanishing polynomial on the coset.
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "ctx.h"
@@ -30,6 +31,7 @@ struct trh_domain {
                                      // plain and with column r divided by (c_r - 1) (the vanishing polynomial's value on block r)
     void* d_pre_sub = nullptr;       // the first pre_sub_blocks rows as a table of its own (the kernel addresses planes by the row count)
     uint32_t pre_sub_blocks = 0;
+    std::mutex mu;                   // a domain is shared by the contexts of its device: the lazily built block tables are created under this lock
 };
 
 namespace trh {
@@ -143,6 +145,7 @@ __global__ void __launch_bounds__(256) block_combine_kernel(const uint4* __restr
 // block tables and the interpolation matrices, built at first use
 template <class F>
 int build_blocks(trh_domain* d, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(d->mu);
     if (d->d_post_blocks) return TRH_OK;
     const uint32_t nblk = 1u << (d->extended_k - d->k), D = d->j - 1;
     if (D > 8 || D > nblk) { set_error("domain blocks: quotient degree %u unsupported", D); return TRH_EINVAL; }
@@ -335,12 +338,18 @@ int trh_domain_coeff_to_extended_blocks(trh_domain* d, const void* coeff_dev, vo
     hipStream_t s = (hipStream_t)stream;
     TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
     // (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: built once per block count (the kernel addresses the table's planes by it)
-    if (d->pre_sub_blocks != n_blocks) {
-        if (d->d_pre_sub) { TRH_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(d->d_pre_sub); d->d_pre_sub = nullptr; d->pre_sub_blocks = 0; }
-        TRH_HIP_TRY(hipMalloc(&d->d_pre_sub, ntt_block_table_bytes(n_blocks, d->k)));
-        const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
-        TRH_TRY(ntt_block_table_build(d->field, d->d_pre_sub, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s));
-        d->pre_sub_blocks = n_blocks;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (d->pre_sub_blocks != n_blocks) {
+            // (a change of the block count while another context still transforms with the old table is excluded by a device-wide drain:
+            //  a prover uses one count per domain, this is the rare path)
+            if (d->d_pre_sub) { TRH_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(d->d_pre_sub); d->d_pre_sub = nullptr; d->pre_sub_blocks = 0; }
+            TRH_HIP_TRY(hipMalloc(&d->d_pre_sub, ntt_block_table_bytes(n_blocks, d->k)));
+            const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
+            TRH_TRY(ntt_block_table_build(d->field, d->d_pre_sub, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s));
+            TRH_HIP_TRY(hipStreamSynchronize(s));  // the table is complete before another context's stream may read it
+            d->pre_sub_blocks = n_blocks;
+        }
     }
     if (ntt_can_fuse(d->k) && ntt_lazy_shift() == 5) {  // the scaling rides on the loads of pass 0
         NttFusion fu;

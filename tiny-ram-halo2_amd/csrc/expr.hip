@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "ctx.h"
@@ -38,6 +39,7 @@ struct trh_expr {
     void* d_consts = nullptr;  // n_consts x 32 B
     void* d_ptrs = nullptr;    // n_columns + n_outputs device pointers, refreshed per evaluation
     std::vector<const void*> h_ptrs;
+    std::mutex mu;  // an evaluation stages the column pointers in the handle: one evaluation at a time, whichever context calls
 };
 
 namespace trh {
@@ -382,6 +384,7 @@ static int expr_eval(trh_expr* e, const void* const* columns_dev, void* const* o
     TRH_TRY(require_init());
     if (!e || !outputs_dev || (e->n_columns && !columns_dev)) { set_error("expr_eval: null pointer"); return TRH_EINVAL; }
     if (log_n > 30) { set_error("expr_eval: log_n %u too large", log_n); return TRH_EINVAL; }
+    std::lock_guard<std::mutex> lk(e->mu);
     for (uint32_t i = 0; i < e->n_columns; ++i) {
         if (!columns_dev[i]) { set_error("expr_eval: column %u is null", i); return TRH_EINVAL; }
         e->h_ptrs[i] = columns_dev[i];
