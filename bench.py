@@ -486,7 +486,7 @@ def main():
                 devs = list(range(world)) if backend == "nccl" else [dev_index] * world  # gloo runs fold the ranks onto the GPUs present
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-child", ",".join(map(str, devs)), "--steps", str(max(args.steps // 2, 3))],
-                                       capture_output=True, text=True, timeout=float(os.environ.get("TRH_BENCH_CHILD_TIMEOUT", "300")))
+                                       capture_output=True, text=True, timeout=float(os.environ.get("TRH_BENCH_CHILD_TIMEOUT", "240")))
                     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     single = json.loads(lines[-1]) if lines else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
                     if single.get("check") == "MISMATCH":
@@ -497,7 +497,8 @@ def main():
                     single = {"error": repr(exc)[:300]}
                 store.set("trh_single_process_done", "1")
             else:
-                store.wait(["trh_single_process_done"])
+                import datetime
+                store.wait(["trh_single_process_done"], datetime.timedelta(seconds=900))  # longer than the child's own timeout
 
     if rank == 0:
         roof, valu = msm_roofline(n if n <= (1 << 25) else (1 << 25), acc, tm, load_traffic(f"msm_accumulate_2^{max(n - 1, 1).bit_length()}"))
