@@ -12,7 +12,7 @@ rng = random.Random(seed)
 api.init(0)
 MOD = {"fp": poly._MODULUS["fp"], "fq": poly._MODULUS["fq"]}
 t_end = time.time() + budget
-stats = {"msm": 0, "ntt": 0, "lookup": 0}
+stats = {"msm": 0, "ntt": 0, "lookup": 0, "blocks": 0, "hostio": 0}
 fails = 0
 
 
@@ -38,7 +38,7 @@ def scalars(field, n, kind):
 
 
 while time.time() < t_end:
-    which = rng.choice(["msm", "msm", "ntt", "lookup"])
+    which = rng.choice(["msm", "msm", "ntt", "lookup", "blocks", "hostio"])
     if which == "msm":
         curve = rng.choice(["pallas", "vesta"])
         sf = api.SCALAR_FIELD[curve]
@@ -92,6 +92,67 @@ while time.time() < t_end:
         if not ok:
             fails += 1
             print("NTT MISMATCH", field, k, batch, flush=True)
+    elif which == "blocks":
+        # the coset-block form of the extended domain against the full one (round 3): every block entry, and the quotient back from j - 1 blocks
+        field = rng.choice(["fp", "fq"])
+        k = rng.randrange(1, 17)
+        j = rng.choice([3, 4, 5, 6, 8])
+        batch = rng.randrange(1, 4)
+        dom = poly.EvaluationDomain(field, j, k)
+        n, step, D = 1 << k, 1 << (dom.extended_k - k), j - 1
+        a = synth.field_elements(rng.randrange(1 << 30), batch * n).reshape(batch, n, 4)
+        d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        full = dom.coeff_to_extended(d).cpu().numpy().view(np.uint64).reshape(batch, n * step, 4)
+        nb = rng.choice([D, step, rng.randrange(1, step + 1)])
+        blk = dom.coeff_to_extended_blocks(d, nb).cpu().numpy().view(np.uint64).reshape(batch, nb, n, 4)
+        ok = all((blk[:, r] == full[:, r::step]).all() for r in range(nb))
+        # a polynomial of degree < D n given by its values on D blocks comes back (no division)
+        h = synth.field_elements(rng.randrange(1 << 30), D * n)
+        pieces = torch.from_numpy(h.reshape(D, n, 4).view(np.int64).copy()).cuda()
+        # values of h on block r = sum_i c_r^i * (block r of piece i): use the library's own block transform per piece, combined on the host ring
+        vals = dom.coeff_to_extended_blocks(pieces, D)  # (D pieces, D blocks, n, 4): piece i on block r
+        # the full-domain chain on h zero-padded is the cross-check: extended_to_coeff(coeff_to_extended) is only defined for n coefficients,
+        # so compare blocks_to_quotient against the identity on ONE piece: h = piece 0 (degree < n): its blocks are vals[0]
+        back = dom.blocks_to_quotient(vals[0].contiguous().clone(), divide_by_vanishing=False).cpu().numpy().view(np.uint64)
+        ok = ok and (back[:n] == h[:n]).all() and (back[n:] == 0).all()
+        if not ok:
+            fails += 1
+            print("BLOCKS MISMATCH", field, k, j, batch, nb, flush=True)
+    elif which == "hostio":
+        # host-pointer entries against the device-resident ones (round 3): batch FFT, batched commitments, range-tiled host MSMs
+        field = rng.choice(["fp", "fq"])
+        k = rng.randrange(1, 19)
+        count = rng.randrange(1, 9)
+        m = MOD[field]
+        dom = poly.EvaluationDomain(field, 3, k)
+        w = dom._w["omega"]
+        cols = [np.ascontiguousarray(synth.field_elements(rng.randrange(1 << 30), 1 << k)) for _ in range(count)]
+        single = [api.best_fft(field, c, w, k) for c in cols]
+        api.best_fft_batch(field, cols, w, k)
+        ok = all((a == b).all() for a, b in zip(cols, single))
+        curve = rng.choice(["pallas", "vesta"])
+        n = rng.randrange(1, 1 << 15)
+        bases = api.Bases.generate(curve, rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30), n + 1)
+        if rng.random() < 0.5:
+            try:
+                bases.precompute(0)
+            except api.TrhError:
+                pass
+        batch = rng.randrange(1, 40)
+        sf = api.SCALAR_FIELD[curve]
+        polys = [np.ascontiguousarray(scalars(sf, n, rng.choice(["uniform", "small", "edge"]))) for _ in range(batch)]
+        blinds = synth.field_elements(rng.randrange(1 << 30), batch)
+        got = bases.commit_batch_host(polys, blinds)
+        pick = rng.randrange(batch)
+        ok = ok and (got[pick] == bases.msm(np.concatenate([polys[pick], blinds[pick][None]]))).all()
+        os.environ["TRH_HOST_TILE_LOG"] = str(rng.randrange(10, 15))
+        xy = bases.download()
+        sc = np.concatenate([polys[0], blinds[0][None]])
+        ok = ok and (api.best_multiexp(curve, sc, xy) == got[0]).all() and (bases.msm(sc) == got[0]).all()
+        del os.environ["TRH_HOST_TILE_LOG"]
+        if not ok:
+            fails += 1
+            print("HOSTIO MISMATCH", field, k, count, curve, n, batch, flush=True)
     else:
         field = rng.choice(["fp", "fq"])
         n = rng.choice([rng.randrange(1, 100), rng.randrange(100, 1 << 12), rng.randrange(1 << 12, 1 << 17)])
