@@ -129,7 +129,7 @@ void host_scale(Field f, Limbs* a, size_t n, const Limbs* factors, size_t period
 // crosses PCIe inside the libtrh calls; see tiny-ram-halo2_amd/replay.py::run_dropin for the two levels.  Here the compiled host
 // also does EvaluationDomain's pointwise steps itself (timed apart as host_pointwise_ms), so the values ARE the prover's and the two
 // levels can be checked against each other: same commitments, same coefficient forms, same extended cosets.
-int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_columns) {
+int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_columns, bool pinned) {
     init(0);
     const uint32_t k = 2 + word_bits / 2;
     const size_t n = (size_t)1 << k;
@@ -152,6 +152,12 @@ int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_
     std::vector<std::vector<Limbs>> cols(batch, std::vector<Limbs>(n)), exts(batched ? batch : 2, std::vector<Limbs>(N));
     std::vector<Limbs> blinds(batch);
     DeviceBuffer scratch(batch * n * 32);
+    // --pinned: the host keeps its polynomials in a page-locked arena (here: the reused column / coset buffers are registered once):
+    // the DMA engine then reads and writes them directly, no staging ring, no copy threads
+    if (pinned) {
+        for (auto& c : cols) check(trh_host_register(c.data(), c.size() * 32), "host_register");
+        for (auto& e : exts) check(trh_host_register(e.data(), e.size() * 32), "host_register");
+    }
     trh_io_stats_t io0;
     check(trh_io_stats(&io0, 1), "io_stats");
     // cross-check state: the first batch is replayed through BOTH levels
@@ -280,12 +286,16 @@ int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_
     }
     trh_io_stats_t io;
     check(trh_io_stats(&io, 0), "io_stats");
+    if (pinned) {
+        for (auto& c : cols) (void)trh_host_unregister(c.data());
+        for (auto& e : exts) (void)trh_host_unregister(e.data());
+    }
     const double total = ms_commit + ms_intt + ms_ext + ms_commit_coeff + ms_ext_inv + ms_ipa;
     std::printf("{\"driver\": \"examples/replay.cpp\", \"mode\": \"%s\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"columns_replayed\": %d, \"checks_failed\": %d, "
                 "\"wall_ms_incl_pcie\": {\"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"commit\": %.3f, \"extended_to_coeff\": %.3f, \"ipa\": %.3f}, "
                 "\"wall_ms_incl_pcie_total\": %.3f, \"host_pointwise_ms\": %.3f, \"pcie\": {\"h2d_GB\": %.3f, \"d2h_GB\": %.3f, \"h2d_GBps_in_copies\": %.2f, \"d2h_GBps_in_copies\": %.2f, "
                 "\"GBps_over_call_time\": %.2f, \"link_peak_GBps_per_direction\": 57.0}}\n",
-                batched ? "dropin-batched" : "dropin-literal", word_bits, k, batch, witness ? "witness" : "random", lag_total, failures, ms_commit, ms_intt, ms_ext, ms_commit_coeff, ms_ext_inv, ms_ipa, total,
+                pinned ? (batched ? "dropin-batched-pinned" : "dropin-literal-pinned") : (batched ? "dropin-batched" : "dropin-literal"), word_bits, k, batch, witness ? "witness" : "random", lag_total, failures, ms_commit, ms_intt, ms_ext, ms_commit_coeff, ms_ext_inv, ms_ipa, total,
                 ms_host, io.h2d_bytes / 1e9, io.d2h_bytes / 1e9, io.h2d_bytes / std::max(io.h2d_seconds, 1e-9) / 1e9, io.d2h_bytes / std::max(io.d2h_seconds, 1e-9) / 1e9,
                 (io.h2d_bytes + io.d2h_bytes) / std::max(total * 1e-3, 1e-9) / 1e9);
     trh_shutdown();
@@ -300,8 +310,9 @@ int main(int argc, char** argv) {
     bool witness = false;
     std::string mode = "resident";
     int max_columns = 0;
-    bool overlap = false;
+    bool overlap = false, pinned = false;
     for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--overlap") { overlap = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
+    for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--pinned") { pinned = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i + 1 < argc; i += 2) {
         if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
         else if (std::string(argv[i]) == "--batch") batch = (size_t)std::atol(argv[i + 1]);
@@ -310,7 +321,7 @@ int main(int argc, char** argv) {
         else if (std::string(argv[i]) == "--max-columns") max_columns = std::atoi(argv[i + 1]);
     }
     try {
-        if (mode == "dropin" || mode == "dropin-batched") return run_dropin(word_bits, batch, witness, mode == "dropin-batched", max_columns);
+        if (mode == "dropin" || mode == "dropin-batched") return run_dropin(word_bits, batch, witness, mode == "dropin-batched", max_columns, pinned);
         init(0);
         const uint32_t k = 2 + word_bits / 2;
         const size_t n = (size_t)1 << k;
