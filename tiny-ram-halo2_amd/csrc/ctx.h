@@ -63,7 +63,8 @@ struct TwiddleEntry {
     DevBuf lo, hi;  // lo[i] = omega^i (i < 2^lo_bits), hi[i] = omega^(i << lo_bits)
     DevBuf zlo, zhi;  // the same in the lazy domain's Montgomery form (x 2^270, < 2 m)
     DevBuf direct[8]; // per pass p >= 1: omega^((k r) << shift) at [r * Ns + k], lazy form (absent when too large)
-    void release_all() { lo.release(); hi.release(); zlo.release(); zhi.release(); for (DevBuf& d : direct) d.release(); }
+    DevBuf tile9;     // in-tile twiddles of a 9-stage pass, omega_512^i (i < 256), raw balanced limbs in three planes (signed passes)
+    void release_all() { lo.release(); hi.release(); zlo.release(); zhi.release(); tile9.release(); for (DevBuf& d : direct) d.release(); }
     int lo_bits, hi_bits;
     u64 stamp;
 };

@@ -575,17 +575,39 @@ __device__ __forceinline__ Fy<F> load_direct_y(const uint4* __restrict__ d, size
     r.l[8] = (i32)((const u32*)(d + 2 * M))[i];
     return r;
 }
-template <class F, bool TWL>
+// in-tile twiddles omega_R^i (i < R / 2) of an s-stage pass as raw balanced limbs, three planes over R / 2 entries: what a 9-stage
+// pass copies its LDS table from and reads its last stage's factors from (TWM 2 below)
+template <class F>
+__global__ void __launch_bounds__(256) ntt_tile_table_y_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
+                                                               int log_n, int s) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 M = 1u << (s - 1);
+    if (i >= M) return;
+    const Fy<F> w = fy_balance(twiddle_y<F>(z_lo, z_hi, i << (log_n - s), lo_bits));
+    d[i] = make_uint4((u32)w.l[0], (u32)w.l[1], (u32)w.l[2], (u32)w.l[3]);
+    d[M + i] = make_uint4((u32)w.l[4], (u32)w.l[5], (u32)w.l[6], (u32)w.l[7]);
+    ((u32*)(d + 2 * M))[i] = (u32)w.l[8];
+}
+// in-tile twiddle table of the signed passes.  TWM 0: the eight packed words of R / 2 entries (unsigned, unpacked on every use);
+// TWM 1: R / 2 entries as nine balanced limbs (fits beside the data for s <= 8); TWM 2 (s = 9): the R / 4 EVEN-index entries as
+// limbs -- every stage but the last reads even indices only -- and the last stage's factors straight from the 9 KiB global table g
+// (two per thread, L1-resident): 76.5 KiB per workgroup, so the 9-stage pass gets the balanced schedule of round_stage_y as well
+template <class F, int TWM>
 struct TileTwiddlesY {
+    static constexpr bool HALF = TWM == 2;
     uint4* a;
     uint4* b;
     u32* c;
+    const uint4* g;
+    int half_r;
     __device__ __forceinline__ Fy<F> operator()(int idx) const {
-        if constexpr (TWL) return lds_load_limbs_y<F>(a, b, c, idx);
+        if constexpr (TWM == 2) return lds_load_limbs_y<F>(a, b, c, idx >> 1);
+        else if constexpr (TWM == 1) return lds_load_limbs_y<F>(a, b, c, idx);
         else { const uint4 x = a[idx], y = b[idx]; return fy_load<F>(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w); }
     }
+    __device__ __forceinline__ Fy<F> tail(int idx) const { return load_direct_y<F>(g, (size_t)half_r, (size_t)idx); }
     __device__ __forceinline__ void put(int idx, const Fy<F>& v) const {
-        if constexpr (TWL) lds_store_limbs_y<F>(a, b, c, idx, fy_balance(v));  // balanced: see round_stage_y
+        if constexpr (TWM != 0) lds_store_limbs_y<F>(a, b, c, idx, fy_balance(v));  // balanced: see round_stage_y
         else { u32 w[8]; fy_store(v, w); a[idx] = make_uint4(w[0], w[1], w[2], w[3]); b[idx] = make_uint4(w[4], w[5], w[6], w[7]); }
     }
 };
@@ -623,7 +645,10 @@ __device__ __forceinline__ void round_stage_y(Fy<F> (&x)[1 << LG], const TW& tw,
             x[u | (1 << V)] = x[u];  // a + w * 0 = a - w * 0
         } else {
             const u32 idx = (L + ((u32)(u & ((1 << V) - 1)) << stl)) << sh;
-            const Fy<F> t = fy_mul(x[u | (1 << V)], tw((int)idx));  // idx 0 holds the lazy one
+            Fy<F> w;
+            if (TW::HALF && sh == 0) w = tw.tail((int)idx);  // the pass's last stage: odd indices too
+            else w = tw((int)idx);                          // idx 0 holds the lazy one
+            const Fy<F> t = fy_mul(x[u | (1 << V)], w);
             const Fy<F> a = (!(BAL && LG == 2) || first) ? fy_norm(x[u]) : x[u];
             x[u] = fy_add_lazy(a, t);
             x[u | (1 << V)] = fy_sub_lazy(a, t);
@@ -662,10 +687,11 @@ __device__ __forceinline__ void fy_canonical_words(const Fy<F>& v, u32* w) {
 
 // in / out: eight-word elements (the caller's buffer: pass 0 input, last pass output) or raw nine-limb planes of the scratch
 // (raw_in / raw_out: [N x 16 B][N x 16 B][N x 4 B] per transform)
-template <class F, int LG, int TLOG, bool TWL, bool FUSE>
+template <class F, int LG, int TLOG, int TWM, bool FUSE>
 __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
                                                                const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last, int raw_in, int raw_out,
-                                                               const uint4* __restrict__ direct, NttFusion fu, int batch_major) {
+                                                               const uint4* __restrict__ direct, NttFusion fu, int batch_major, const uint4* __restrict__ tile_tab) {
+    constexpr bool TWL = TWM != 0;  // balanced limb twiddles: the schedule with half the normalisations
     constexpr int G = 1 << LG, T = 1 << TLOG;
     // grid order: tile-major (x = tile, y = transform) or batch-major (x = transform, y = tile: consecutive workgroups run the SAME
     // tile of consecutive transforms, so the rows of the shared inter-pass twiddle table they read stay in L2)
@@ -676,10 +702,11 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     const int C = 1 << log_c;
     uint4* pa = (uint4*)smem;
     uint4* pb = pa + T;
+    const int tw_n = TWM == 2 ? (R >> 2) : (R >> 1);
     uint4* tw_lo = pb + T;
-    uint4* tw_hi = tw_lo + (R >> 1);
-    u32* pc = (u32*)(tw_hi + (R >> 1));
-    const TileTwiddlesY<F, TWL> tw{tw_lo, tw_hi, pc + T};
+    uint4* tw_hi = tw_lo + tw_n;
+    u32* pc = (u32*)(tw_hi + tw_n);
+    const TileTwiddlesY<F, TWM> tw{tw_lo, tw_hi, pc + T, tile_tab, R >> 1};
 
     const size_t N = (size_t)1 << log_n;
     const bool padded = FUSE && fu.in_dev;
@@ -726,7 +753,11 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
         x[0] = load_row(0); x[4] = load_row(1); x[2] = load_row(2); x[6] = load_row(3);
         x[1] = load_row(4); x[5] = load_row(5); x[3] = load_row(6); x[7] = load_row(7);
     }
-    for (int i = tid; i < (R >> 1); i += (T >> LG)) tw.put(i, twiddle_y<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
+    if constexpr (TWM == 2) {
+        for (int i = tid; i < tw_n; i += (T >> LG)) lds_store_limbs_y<F>(tw_lo, tw_hi, pc + T, i, load_direct_y<F>(tile_tab, (size_t)(R >> 1), (size_t)(2 * i)));
+    } else {
+        for (int i = tid; i < tw_n; i += (T >> LG)) tw.put(i, twiddle_y<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
+    }
     __syncthreads();
 
     u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;
@@ -915,6 +946,14 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
             log_ns += sizes[p];
         }
     }
+    static const int half_on = getenv("TRH_NTT_HALF") ? atoi(getenv("TRH_NTT_HALF")) : 1;  // 0: 9-stage passes with packed in-tile twiddles (A/B)
+    bool nine = false;
+    for (int p = 0; p < P; ++p) nine = nine || sizes[p] == 9;
+    if (rc == TRH_OK && half_on && nine && signed_enabled() && tlog == TILE_LOG && log_n >= TILE_LOG) {
+        rc = t->tile9.ensure((size_t)256 * 36);
+        if (rc == TRH_OK)
+            hipLaunchKernelGGL((ntt_tile_table_y_kernel<F>), dim3(1), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, t->tile9.as<uint4>(), log_n, 9);
+    }
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipStreamSynchronize(s));  // pw is a stack buffer
     if (rc != TRH_OK) { t->release_all(); delete t; return rc; }
@@ -968,13 +1007,17 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 const uint4* src = p == 0 ? base : (const uint4*)raw[(p - 1) & 1];
                 uint4* dst = p == P - 1 ? base : (uint4*)raw[p & 1];
                 const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
-#define TRH_LAUNCH_PASSY(TWL, FUSE, LDS)                                                                                                       \
-    hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
-                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major)
-                if (sp <= 8 && !fused) TRH_LAUNCH_PASSY(true, false, ldl);
-                else if (sp <= 8) TRH_LAUNCH_PASSY(true, true, ldl);
-                else if (!fused) TRH_LAUNCH_PASSY(false, false, ldz);
-                else TRH_LAUNCH_PASSY(false, true, ldz);
+                const size_t ldh = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 2));
+                const uint4* tile_tab = (sp == 9 && t->tile9.p) ? t->tile9.as<uint4>() : nullptr;
+#define TRH_LAUNCH_PASSY(TWM, FUSE, LDS)                                                                                                       \
+    hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWM, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
+                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major, tile_tab)
+                if (sp <= 8 && !fused) TRH_LAUNCH_PASSY(1, false, ldl);
+                else if (sp <= 8) TRH_LAUNCH_PASSY(1, true, ldl);
+                else if (tile_tab && !fused) TRH_LAUNCH_PASSY(2, false, ldh);
+                else if (tile_tab) TRH_LAUNCH_PASSY(2, true, ldh);
+                else if (!fused) TRH_LAUNCH_PASSY(0, false, ldz);
+                else TRH_LAUNCH_PASSY(0, true, ldz);
 #undef TRH_LAUNCH_PASSY
                 log_ns += sp;
             }
@@ -1065,9 +1108,10 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
         TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
 #undef TRH_PASSZ_ATTR
-#define TRH_PASSY_ATTR(FIELD, TWL, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passy_kernel<FIELD, 2, TILE_LOG, TWL, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
-        TRH_PASSY_ATTR(FpParams, true, false); TRH_PASSY_ATTR(FpParams, true, true); TRH_PASSY_ATTR(FpParams, false, false); TRH_PASSY_ATTR(FpParams, false, true);
-        TRH_PASSY_ATTR(FqParams, true, false); TRH_PASSY_ATTR(FqParams, true, true); TRH_PASSY_ATTR(FqParams, false, false); TRH_PASSY_ATTR(FqParams, false, true);
+#define TRH_PASSY_ATTR(FIELD, TWM, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passy_kernel<FIELD, 2, TILE_LOG, TWM, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
+        TRH_PASSY_ATTR(FpParams, 1, false); TRH_PASSY_ATTR(FpParams, 1, true); TRH_PASSY_ATTR(FpParams, 0, false); TRH_PASSY_ATTR(FpParams, 0, true);
+        TRH_PASSY_ATTR(FqParams, 1, false); TRH_PASSY_ATTR(FqParams, 1, true); TRH_PASSY_ATTR(FqParams, 0, false); TRH_PASSY_ATTR(FqParams, 0, true);
+        TRH_PASSY_ATTR(FpParams, 2, false); TRH_PASSY_ATTR(FpParams, 2, true); TRH_PASSY_ATTR(FqParams, 2, false); TRH_PASSY_ATTR(FqParams, 2, true);
 #undef TRH_PASSY_ATTR
         ctx().attr_done |= ATTR_NTT;
     }
