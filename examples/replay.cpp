@@ -492,6 +492,32 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < n; ++i) ok = ok && zh[i] == host::one(field);
             expect(ok, "permutation product over the identity permutation stays at 1");
             if (std::getenv("TRH_REPLAY_VERBOSE")) std::fprintf(stderr, "permutation product column: %.3f ms\n", ms_perm);
+            // the same chunk three times plus a lookup-shaped row through the fixed-function form (every product column in one launch)
+            std::vector<std::vector<trh_product_term_t>> nrows, drows;
+            for (int rep = 0; rep < 3; ++rep) {
+                std::vector<trh_product_term_t> nr, dr;
+                Limbs dj2 = host::one(field);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    nr.push_back(product_term(ext.at(j * EN * 32), omegas.data(), host::mul(field, beta, dj2), gamma));
+                    dr.push_back(product_term(ext.at(j * EN * 32), sig.at(j * n * 32), beta, gamma));
+                    dj2 = host::mul(field, dj2, delta);
+                }
+                nrows.push_back(nr); drows.push_back(dr);
+            }
+            // lookup-shaped: (A + beta)(S + gamma) / ((A' + beta)(S' + gamma)) with A' = A, S' = S: stays at 1 as well
+            nrows.push_back({product_term(ext.at(0), nullptr, Limbs{0, 0, 0, 0}, beta), product_term(sig.data(), nullptr, Limbs{0, 0, 0, 0}, gamma)});
+            drows.push_back({product_term(ext.at(0), nullptr, Limbs{0, 0, 0, 0}, beta), product_term(sig.data(), nullptr, Limbs{0, 0, 0, 0}, gamma)});
+            DeviceBuffer zall(4 * n * 32);
+            Timer tg;
+            grand_products(field, k, nrows, drows, zall.data());
+            const double ms_gp = tg.stop();
+            bool ok2 = true;
+            for (int r = 0; r < 4; ++r) {
+                zall.download(zh.data(), n * 32, (size_t)r * n * 32);
+                for (size_t i = 0; i < n; ++i) ok2 = ok2 && zh[i] == host::one(field);
+            }
+            expect(ok2, "grand_products (fixed-function rows) over identity permutations / equal lookups stays at 1");
+            if (std::getenv("TRH_REPLAY_VERBOSE")) std::fprintf(stderr, "grand_products, 4 rows: %.3f ms\n", ms_gp);
         }
 
         // coefficient-basis commits: the random vanishing polynomial and the h pieces

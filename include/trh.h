@@ -278,6 +278,21 @@ int trh_ipa_create_proof(trh_bases_t g_w, const uint64_t u_xy[8], uint32_t k, co
  * running product z[0] = 1, z[i] = z[i-1] * numerator[i-1] / denominator[i-1])                    */
 /* ff::BatchInvert: a[i] <- a[i]^-1 in place, zeros stay zero */
 int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream);
+/* the division the product columns need, in the same pass: a[i] <- num[i] * a[i]^-1 (a zero denominator stays zero) */
+int trh_field_batch_invert_mul_dev(int field, void* a_dev, const void* num_dev, size_t n, void* stream);
+/* the products the running product is taken over, for every product column of a proof in ONE launch:
+ *     out[r][i] = prod_{t in row r} (x_t[i] + c_t * y_t[i] + g_t)      (y_t NULL: x_t[i] + g_t),   i < n
+ * row r owns terms[row_start[r] .. row_start[r + 1]) (row_start has rows + 1 entries, row_start[0] = 0).  Permutation chunk
+ * (plonk/permutation/prover.rs Argument::commit): numerator terms (v_j, omega^i column, beta * delta^(col j), gamma), denominator
+ * terms (v_j, sigma_j, beta, gamma); lookup product (plonk/lookup/prover.rs commit_product): numerator (A, -, -, beta)(S, -, -, gamma),
+ * denominator (A', -, -, beta)(S', -, -, gamma).  c / g: Montgomery words; columns: n elements in device memory.              */
+typedef struct trh_product_term {
+    const void* x;
+    const void* y;
+    uint64_t c[4];
+    uint64_t g[4];
+} trh_product_term_t;
+int trh_product_terms_dev(int field, const trh_product_term_t* terms, const uint32_t* row_start, uint32_t rows, size_t n, void* out_dev, void* stream);
 /* out[i] = prod_{j < i} a[j], out[0] = 1 (exclusive scan; out must not alias a) */
 int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream);
 /* the same for `rows` independent vectors of n elements stored back to back (all product columns of a proof at once) */

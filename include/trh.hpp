@@ -489,6 +489,34 @@ private:
     DeviceBuffer num_, den_, ratio_;
 };
 
+// Every product column of a proof at once, fixed-function (trh_product_terms_dev): a row is the list of the factors
+// (x[i] + c y[i] + g) of one numerator or denominator product.  permutation chunk: numerator {v_j, omega^i column, beta delta^col_j, gamma},
+// denominator {v_j, sigma_j, beta, gamma}; lookup: numerator {A, -, -, beta}{S, -, -, gamma}, denominator {A', -, -, beta}{S', -, -, gamma}
+inline trh_product_term_t product_term(const void* x, const void* y, const Limbs& c, const Limbs& g) {
+    trh_product_term_t t{};
+    t.x = x; t.y = y;
+    for (int i = 0; i < 4; ++i) { t.c[i] = c[i]; t.g[i] = g[i]; }
+    return t;
+}
+// z_dev: rows x 2^k elements, z[r][0] = 1, z[r][i + 1] = z[r][i] * num_r(i) / den_r(i) (a zero denominator gives a zero ratio, as
+// ff::BatchInvert followed by the multiplication does)
+inline void grand_products(Field f, uint32_t k, const std::vector<std::vector<trh_product_term_t>>& num_rows, const std::vector<std::vector<trh_product_term_t>>& den_rows,
+                           void* z_dev, void* stream = nullptr) {
+    if (num_rows.size() != den_rows.size()) throw Error("grand_products: numerator / denominator row counts differ");
+    const size_t rows = num_rows.size(), n = (size_t)1 << k;
+    if (!rows) return;
+    std::vector<trh_product_term_t> flat;
+    std::vector<uint32_t> start{0};
+    for (const auto* part : {&num_rows, &den_rows})
+        for (const auto& row : *part) { flat.insert(flat.end(), row.begin(), row.end()); start.push_back((uint32_t)flat.size()); }
+    DeviceBuffer nd(2 * rows * n * 32);
+    check(trh_product_terms_dev((int)f, flat.data(), start.data(), (uint32_t)(2 * rows), n, nd.data(), stream), "product_terms");
+    char* den = (char*)nd.data() + rows * n * 32;
+    check(trh_field_batch_invert_mul_dev((int)f, den, nd.data(), rows * n, stream), "batch_invert_mul");
+    check(trh_field_prefix_product_rows_dev((int)f, den, z_dev, n, rows, stream), "prefix_product_rows");
+    check(trh_stream_synchronize(stream), "grand_products sync");  // nd is released on return
+}
+
 // arithmetic::kate_division by (X - z) for polynomials of n coefficients.  The powers of z and 1 / z are built once, on the stream
 // the divisions will run on (the constructor takes it: tables built on another stream could still be in flight when divide() reads
 // them); z = 0 (z_inv ignored) divides by X: the quotient is the coefficient list shifted down by one.

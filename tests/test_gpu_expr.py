@@ -344,7 +344,8 @@ def test_lookup_permuted_columns(field):
 @pytest.mark.parametrize("field", ["fp", "fq"])
 def test_lookup_permuted_columns_batch(field):
     """trh_lookup_permute_batch_dev: several lookups of different character in ONE call (a 16-bit range table, full-size values, a
-    single run, values that share their top limb -- the tie that sends a lookup through the all-limbs sort --, a constant column),
+    single run, values that share their top limb or all but its low bits -- the ties that send a lookup through the all-limbs sort --, a
+    constant column),
     usable_rows below the column length, every lookup against the oracle; an input missing from its table names the lookup"""
     from tiny_ram_halo2_amd import permutation
     f = o.FIELDS[field]
@@ -358,6 +359,9 @@ def test_lookup_permuted_columns_batch(field):
         elif kind == "ties":   # same top limb, different low limbs: the fast sort cannot order these
             top = rng.randrange(1 << 60) << 192
             distinct = [top + rng.randrange(1 << 190) for _ in range(50)] + [top + (v << 64) + 7 for v in range(20)] + [top + 7 + v for v in range(20)]
+        elif kind == "low-ties":  # spread-out values, some of which differ only in the LOW bits of the top limb -- below the bits the fast
+            distinct = [rng.randrange(f.m) for _ in range(600)]  # sort goes by (FAST_KEY_BITS): detected as ties, redone in the general form
+            distinct += [v ^ (1 << 192) for v in distinct[:20]] + [v ^ (0x5A5 << 192) for v in distinct[20:40]] + [(v ^ (3 << 192)) + 1 for v in distinct[40:50]]
         elif kind == "one-run":
             distinct = [5]
         else:  # "constant": input constant, table with one more value
@@ -367,7 +371,7 @@ def test_lookup_permuted_columns_batch(field):
         inp = [distinct[0]] * n if kind == "constant" else [rng.choice(distinct) for _ in range(n)]
         pad = [rng.randrange(f.m) for _ in range(rows - n)]   # rows behind usable_rows: ignored
         return inp + pad, table + pad[::-1]
-    kinds = ["range", "wide", "ties", "one-run", "constant", "range", "ties", "wide"]
+    kinds = ["range", "wide", "ties", "one-run", "constant", "range", "ties", "wide", "low-ties"]
     pairs = [column_pair(kd) for kd in kinds]
     to_t = lambda cols: torch.from_numpy(np.array([[f.limbs(v) for v in c] for c in cols], dtype=np.uint64).view(np.int64)).cuda()
     a, s = permutation.lookup_permute_batch(field, to_t([p[0] for p in pairs]), to_t([p[1] for p in pairs]), n)
@@ -498,3 +502,77 @@ def test_grand_products_batch_equals_single_columns():
     z = permutation.grand_products_batch(field, k, [pc.evaluator(beta, gamma) for pc in pcs], [pcs[c].columns(vals[c], sigs[c]) for c in range(chunks)])
     for c in range(chunks):
         assert from_dev(f, z[c]) == singles[c], c
+
+
+@pytest.mark.parametrize("field", ["fp", "fq"])
+def test_grand_products_terms_vs_big_ints(field):
+    """the fixed-function form (trh_product_terms_dev + trh_field_batch_invert_mul_dev + batched prefix product): permutation chunks
+    (a ragged last chunk, a zero denominator) and lookup products in ONE call against big-int arithmetic and the expression-program path"""
+    from tiny_ram_halo2_amd import api, permutation
+    f = o.FIELDS[field]
+    k, ncol, n_columns, lookups = 9, 4, 10, 3  # chunks of 4, 4, 2 columns
+    n = 1 << k
+    rng = random.Random(0x7E2)
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    beta, gamma = rng.randrange(f.m), rng.randrange(f.m)
+    vals = [[rng.randrange(f.m) for _ in range(n)] for _ in range(n_columns)]
+    sigs = [[rng.randrange(f.m) for _ in range(n)] for _ in range(n_columns)]
+    vals[5][17] = (-(beta * sigs[5][17] + gamma)) % f.m  # a zero denominator term: ff::BatchInvert leaves the zero, the ratio is 0
+    d_vals, d_sigs = [dev(c) for c in vals], [dev(c) for c in sigs]
+    w, delta = f.omega(k), permutation.delta(field)
+    om = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    api.powers_dev(field, om, n, np.array(f.limbs(w), dtype=np.uint64))
+    num_rows, den_rows, want = [], [], []
+    for c0 in range(0, n_columns, ncol):
+        c1 = min(c0 + ncol, n_columns)
+        nr, dr = permutation.permutation_terms(field, d_vals[c0:c1], d_sigs[c0:c1], om, beta, gamma, first_column=c0)
+        num_rows.append(nr); den_rows.append(dr)
+        z, acc = [], 1
+        for i in range(n):
+            z.append(acc)
+            num = den = 1
+            for j in range(c0, c1):
+                num = num * (vals[j][i] + beta * pow(delta, j, f.m) * pow(w, i, f.m) + gamma) % f.m
+                den = den * (vals[j][i] + beta * sigs[j][i] + gamma) % f.m
+            acc = acc * num * (pow(den, -1, f.m) if den else 0) % f.m
+        want.append(z)
+    for li in range(lookups):
+        table = [rng.randrange(f.m) for _ in range(n)]
+        a = [table[rng.randrange(n)] for _ in range(n)]
+        ap, sp = sorted(a), list(table)
+        rng.shuffle(sp)
+        nr, dr = permutation.lookup_terms(field, dev(a), dev(table), dev(ap), dev(sp), beta, gamma)
+        num_rows.append(nr); den_rows.append(dr)
+        z, acc = [], 1
+        for i in range(n):
+            z.append(acc)
+            acc = acc * (a[i] + beta) * (table[i] + gamma) % f.m * pow((ap[i] + beta) * (sp[i] + gamma), -1, f.m) % f.m
+        assert acc == 1
+        want.append(z)
+    z = permutation.grand_products_terms(field, k, num_rows, den_rows)
+    assert z.shape == (len(want), n, 4)
+    for r in range(len(want)):
+        assert from_dev(f, z[r]) == want[r], r
+    # the expression-program path gives the same first chunk
+    pc = permutation.ProductColumn(field, k, ncol, first_column=0)
+    assert from_dev(f, pc.compute(d_vals[:ncol], d_sigs[:ncol], beta, gamma)) == want[0]
+
+
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 256 * 64, 256 * 64 + 1, 3 * 256 * 64 - 5])
+def test_batch_invert_sizes_and_zeros(n):
+    """ff::BatchInvert over the interleaved chunks: every size class of the last workgroup, zeros left alone, and the fused multiply"""
+    from tiny_ram_halo2_amd import api
+    field = "fp"
+    f = o.FIELDS[field]
+    rng = random.Random(n)
+    a = [rng.randrange(1, f.m) for _ in range(n)]
+    for z in range(0, n, 97):
+        a[z] = 0
+    b = [rng.randrange(f.m) for _ in range(n)]
+    dev = lambda col: torch.from_numpy(np.array([f.limbs(v) for v in col], dtype=np.uint64).view(np.int64)).cuda()
+    d = dev(a)
+    api.batch_invert_dev(field, d, n)
+    assert from_dev(f, d) == [pow(v, -1, f.m) if v else 0 for v in a]
+    d = dev(a)
+    api.batch_invert_mul_dev(field, d, dev(b), n)
+    assert from_dev(f, d) == [pow(v, -1, f.m) * w % f.m if v else 0 for v, w in zip(a, b)]

@@ -121,6 +121,8 @@ _SIGNATURES = {
     "trh_ipa_create_proof": ([_vp, _u64p, ctypes.c_uint32, _vp, _u64p, _u64p, _vp, _u64p, ctypes.POINTER(Transcript), RNG_FN, _vp, _vp, _u64p, _u64p], ctypes.c_int),
     "trh_poly_eval_batch_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp, _u64p], ctypes.c_int),
     "trh_field_batch_invert_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_field_batch_invert_mul_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
+    "trh_product_terms_dev": ([ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_size_t, _vp, _vp], ctypes.c_int),
     "trh_field_prefix_product_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_lookup_permute_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp], ctypes.c_int),
     "trh_lookup_permute_batch_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp], ctypes.c_int),
@@ -432,6 +434,36 @@ def point_fft_dev(curve: str, points_dev, log_n: int, omega, scale=None, stream=
 def batch_invert_dev(field: str, a_dev, n: int, stream=None):
     """ff::BatchInvert on a device vector, in place (zeros stay zero)"""
     _check(lib().trh_field_batch_invert_dev(FIELD_ID[field], _devptr(a_dev), n, stream))
+
+
+class ProductTerm(ctypes.Structure):
+    """trh_product_term_t: x[i] + c * y[i] + g (y null: x[i] + g); c / g Montgomery words"""
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("c", ctypes.c_uint64 * 4), ("g", ctypes.c_uint64 * 4)]
+
+
+def product_terms_dev(field: str, rows, n: int, out_dev, stream=None):
+    """rows: a list of rows, each a list of terms (x_dev, y_dev or None, c limbs or None, g limbs); out[r][i] = prod of row r's terms
+    at i -- the numerator / denominator products of every product column of a proof in one launch (trh_product_terms_dev)"""
+    flat = [t for row in rows for t in row]
+    arr = (ProductTerm * len(flat))()
+    for d, (x, y, c, g) in zip(arr, flat):
+        d.x = _devptr(x)
+        d.y = _devptr(y) if y is not None else None
+        if c is not None:
+            d.c[:] = [int(v) for v in c]
+        d.g[:] = [int(v) for v in g]
+    starts = (ctypes.c_uint32 * (len(rows) + 1))()
+    acc = 0
+    for i, row in enumerate(rows):
+        starts[i] = acc
+        acc += len(row)
+    starts[len(rows)] = acc
+    _check(lib().trh_product_terms_dev(FIELD_ID[field], ctypes.cast(arr, ctypes.c_void_p), starts, len(rows), n, _devptr(out_dev), stream))
+
+
+def batch_invert_mul_dev(field: str, a_dev, num_dev, n: int, stream=None):
+    """a[i] <- num[i] / a[i] in place (a zero denominator stays zero): ff::BatchInvert and the multiply that follows it, one pass"""
+    _check(lib().trh_field_batch_invert_mul_dev(FIELD_ID[field], _devptr(a_dev), _devptr(num_dev), n, stream))
 
 
 def prefix_product_dev(field: str, a_dev, out_dev, n: int, stream=None):

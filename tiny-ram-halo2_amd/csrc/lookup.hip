@@ -30,6 +30,7 @@ constexpr int TILE = 2048;      // elements per workgroup of the sort / scan ker
 constexpr int THREADS = 256;
 constexpr int ITEMS = TILE / THREADS;
 constexpr int RADIX_BITS = 4, RADIX = 1 << RADIX_BITS, PASSES = 64 / RADIX_BITS;
+constexpr int FAST_KEY_BITS = 48;  // varying bits the fast path sorts by (see select_limb_kernel)
 
 template <class F>
 __device__ __forceinline__ Fe<F> ldf(const uint4* p) {
@@ -86,7 +87,14 @@ __global__ void select_limb_kernel(const u64* __restrict__ varies, u32 cols, int
     if (step < 0) { for (int j = 3; j >= 0; --j) if (varies[c * 4 + j]) { k = j; break; } }
     else if (varies[c * 4 + step]) k = step;
     key_limb[c] = k;
-    key_mask[c] = k >= 0 ? varies[c * 4 + k] : 0ull;
+    u64 mask = k >= 0 ? varies[c * 4 + k] : 0ull;
+    if (step < 0) {
+        // the fast path only has to SEPARATE the column's values: FAST_KEY_BITS varying bits from the top do that for 2^18 spread-out
+        // values with probability 1 - 2^-13 per column, and a tie between different values is detected (tie_check_kernel compares
+        // under this mask) and redone in the general form anyway -- so the low digits beyond them are not sorted by: 12 passes, not 16
+        for (int d = 0; d < PASSES && __popcll(mask >> (RADIX_BITS * (d + 1))) >= FAST_KEY_BITS; ++d) mask &= ~((u64)(RADIX - 1) << (RADIX_BITS * d));
+    }
+    key_mask[c] = mask;
     (void)side;
 }
 // keys[side[c]][c][i] = limb key_limb[c] of the element the current order has at position i
@@ -253,14 +261,15 @@ __device__ __forceinline__ int cmp_keys(const u64* __restrict__ pa, const u32* _
     return 0;
 }
 // after the fast path: bad[c] = 1 when two neighbours agree in the limb sorted by but are different values (their order is then unknown)
-__global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, const int* __restrict__ key_limb, u32* __restrict__ bad) {
+__global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, const int* __restrict__ key_limb, const u64* __restrict__ key_mask,
+                                                        u32* __restrict__ bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 c = blockIdx.y;
     const int primary = key_limb[c];
     if (i == 0 || i >= n || primary < 0) return;
     const u64* pl = planes + (size_t)c * 4 * n;
     const u32 a = perm[(size_t)c * n + i - 1], b = perm[(size_t)c * n + i];
-    if (pl[(size_t)primary * n + a] != pl[(size_t)primary * n + b]) return;
+    if ((pl[(size_t)primary * n + a] ^ pl[(size_t)primary * n + b]) & key_mask[c]) return;  // separated by the bits sorted by
     for (int k = 0; k < 4; ++k)
         if (pl[(size_t)k * n + a] != pl[(size_t)k * n + b]) { bad[c] = 1u; return; }
 }
@@ -437,7 +446,7 @@ int lookup_permute_batch_t(const void* inputs, const void* tables, size_t n, siz
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb, cols), dim3(256), 0, s, (const uint4*)inputs, (const uint4*)tables, stride, batch, n, sc.planes.as<u64>(), sc.perm0.as<u32>());
     hipLaunchKernelGGL(plane_varies_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, varies);
     TRH_TRY(sort_columns(sc, n, cols, general, varies, key_limb, key_mask, side, sel, s));
-    if (!general) hipLaunchKernelGGL(tie_check_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), key_limb, bad);
+    if (!general) hipLaunchKernelGGL(tie_check_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), key_limb, key_mask, bad);
     hipLaunchKernelGGL(gather_elems_kernel, dim3(gb, batch), dim3(256), 0, s, (const uint4*)inputs, stride, sc.perm0.as<u32>(), (uint4*)out_inputs, n);
     hipLaunchKernelGGL(repeat_flags_kernel, dim3(gb, batch), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), sc.flags.as<u32>());
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, s, sc.keep.as<u32>(), bn, 1u);

@@ -27,26 +27,55 @@ __device__ __forceinline__ void stf(uint4* p, const Fe<F>& v) {
 
 constexpr int INV_CHUNK = 64;  // elements per thread: one field inversion (~380 multiplies) per chunk
 
-// a[i] <- a[i]^-1 (0 stays 0); scratch holds the running products of the chunk
+// a[i] <- a[i]^-1 (0 stays 0), or num[i] * a[i]^-1 with a numerator column; scratch holds the running products of the chunk.
+// Inverses are element-wise facts, so a thread's chunk need not be contiguous: thread t of a workgroup takes the elements
+// base + i * 256 + t (i < INV_CHUNK) and every load and store of a wave is one contiguous 2 KiB run
 template <class F>
-__global__ void __launch_bounds__(256) batch_invert_kernel(uint4* __restrict__ a, uint4* __restrict__ scratch, size_t n) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t lo = t * INV_CHUNK;
-    if (lo >= n) return;
-    const size_t hi = lo + INV_CHUNK < n ? lo + INV_CHUNK : n;
+__global__ void __launch_bounds__(256) batch_invert_kernel(uint4* __restrict__ a, uint4* __restrict__ scratch, const uint4* __restrict__ num, size_t n) {
+    const size_t base = (size_t)blockIdx.x * (256 * INV_CHUNK) + threadIdx.x;
+    if (base >= n) return;
+    const size_t left = (n - base + 255) / 256;
+    const int cnt = left < (size_t)INV_CHUNK ? (int)left : INV_CHUNK;
     Fe<F> acc = fe_one<F>();
-    for (size_t i = lo; i < hi; ++i) {
-        stf<F>(scratch + 2 * i, acc);  // product of the non-zero elements before i
-        const Fe<F> v = ldf<F>(a + 2 * i);
+    for (int i = 0; i < cnt; ++i) {
+        const size_t e = base + (size_t)i * 256;
+        stf<F>(scratch + 2 * e, acc);  // product of the non-zero elements before this one
+        const Fe<F> v = ldf<F>(a + 2 * e);
         if (!fe_is_zero(v)) acc = fe_mul(acc, v);
     }
     Fe<F> inv = fe_inv(acc);
-    for (size_t i = hi; i-- > lo;) {
-        const Fe<F> v = ldf<F>(a + 2 * i);
+    for (int i = cnt; i-- > 0;) {
+        const size_t e = base + (size_t)i * 256;
+        const Fe<F> v = ldf<F>(a + 2 * e);
         if (fe_is_zero(v)) continue;
-        stf<F>(a + 2 * i, fe_mul(inv, ldf<F>(scratch + 2 * i)));
+        Fe<F> r = fe_mul(inv, ldf<F>(scratch + 2 * e));
+        if (num) r = fe_mul(r, ldf<F>(num + 2 * e));
+        stf<F>(a + 2 * e, r);
         inv = fe_mul(inv, v);
     }
+}
+
+// out[r][i] = prod over the terms t of row r of (x_t[i] + c_t * y_t[i] + g_t)   (y_t null: x_t[i] + g_t) -- the numerator and
+// denominator products of the permutation argument's chunks and of the lookup argument, every row of a proof in one launch
+struct DevTerm {
+    const uint4* x;
+    const uint4* y;
+    FeMem c, g;
+};
+template <class F>
+__global__ void __launch_bounds__(256) product_terms_kernel(const DevTerm* __restrict__ terms, const u32* __restrict__ row_start, size_t n, uint4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = blockIdx.y;
+    const u32 t0 = row_start[r], t1 = row_start[r + 1];
+    Fe<F> acc = fe_one<F>();
+    for (u32 t = t0; t < t1; ++t) {  // uniform: the descriptors are scalar loads
+        const DevTerm& d = terms[t];
+        Fe<F> v = fe_add(ldf<F>(d.x + 2 * i), fe_load<F>(d.g));
+        if (d.y) v = fe_add(v, fe_mul(ldf<F>(d.y + 2 * i), fe_load<F>(d.c)));
+        acc = t == t0 ? v : fe_mul(acc, v);
+    }
+    stf<F>(out + 2 * ((size_t)r * n + i), acc);
 }
 
 constexpr int SCAN_PER_THREAD = 16;
@@ -178,11 +207,11 @@ __global__ void __launch_bounds__(256) kate_finish_kernel(const uint4* __restric
 }
 
 template <class F>
-int batch_invert_t(void* a, size_t n, hipStream_t s) {
+int batch_invert_t(void* a, const void* num, size_t n, hipStream_t s) {
     Ctx& c = ctx();
     TRH_TRY(c.scan2.ensure(n * 32 + 32));
-    const size_t threads = (n + INV_CHUNK - 1) / INV_CHUNK;
-    hipLaunchKernelGGL((batch_invert_kernel<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (uint4*)a, c.scan2.as<uint4>(), n);
+    const size_t per_block = (size_t)256 * INV_CHUNK;
+    hipLaunchKernelGGL((batch_invert_kernel<F>), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, s, (uint4*)a, c.scan2.as<uint4>(), (const uint4*)num, n);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -203,8 +232,51 @@ int trh_field_batch_invert_dev(int field, void* a_dev, size_t n, void* stream) {
     Range range("trh_field_batch_invert_dev");
     Ctx& c = ctx();
     (void)c;
-    if (field == TRH_FP) return batch_invert_t<FpParams>(a_dev, n, (hipStream_t)stream);
-    return batch_invert_t<FqParams>(a_dev, n, (hipStream_t)stream);
+    if (field == TRH_FP) return batch_invert_t<FpParams>(a_dev, nullptr, n, (hipStream_t)stream);
+    return batch_invert_t<FqParams>(a_dev, nullptr, n, (hipStream_t)stream);
+}
+
+int trh_field_batch_invert_mul_dev(int field, void* a_dev, const void* num_dev, size_t n, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (n && (!a_dev || !num_dev)) { set_error("batch_invert_mul: null pointer"); return TRH_EINVAL; }
+    if (!n) return TRH_OK;
+    TRH_ENTER(stream);
+    Range range("trh_field_batch_invert_mul_dev");
+    Ctx& c = ctx();
+    (void)c;
+    if (field == TRH_FP) return batch_invert_t<FpParams>(a_dev, num_dev, n, (hipStream_t)stream);
+    return batch_invert_t<FqParams>(a_dev, num_dev, n, (hipStream_t)stream);
+}
+
+int trh_product_terms_dev(int field, const trh_product_term_t* terms, const uint32_t* row_start, uint32_t rows, size_t n, void* out_dev, void* stream) {
+    TRH_TRY(require_init());
+    if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
+    if (!rows || !n) return TRH_OK;
+    if (!terms || !row_start || !out_dev) { set_error("product_terms: null pointer"); return TRH_EINVAL; }
+    if (rows > 32768) { set_error("product_terms: more than 32768 rows"); return TRH_EINVAL; }
+    const uint32_t n_terms = row_start[rows];
+    if (row_start[0] != 0 || n_terms > (1u << 20)) { set_error("product_terms: bad row_start"); return TRH_EINVAL; }
+    for (uint32_t r = 0; r < rows; ++r)
+        if (row_start[r + 1] <= row_start[r]) { set_error("product_terms: row %u has no terms", r); return TRH_EINVAL; }
+    for (uint32_t t = 0; t < n_terms; ++t)
+        if (!terms[t].x) { set_error("product_terms: term %u has a null column", t); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    Range range("trh_product_terms_dev");
+    Ctx& c = ctx();
+    hipStream_t s = (hipStream_t)stream;
+    static_assert(sizeof(DevTerm) == sizeof(trh_product_term_t), "descriptor layout");
+    const size_t term_bytes = (size_t)n_terms * sizeof(DevTerm), start_bytes = ((size_t)rows + 1) * 4;
+    TRH_TRY(c.scan.ensure(term_bytes + start_bytes));
+    TRH_HIP_TRY(hipMemcpyAsync(c.scan.p, terms, term_bytes, hipMemcpyHostToDevice, s));
+    TRH_HIP_TRY(hipMemcpyAsync((char*)c.scan.p + term_bytes, row_start, start_bytes, hipMemcpyHostToDevice, s));
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // the caller's descriptor arrays may be reused
+    const dim3 grid((unsigned)((n + 255) / 256), rows);
+    if (field == TRH_FP) hipLaunchKernelGGL((product_terms_kernel<FpParams>), grid, dim3(256), 0, s, (const DevTerm*)c.scan.p, (const u32*)((char*)c.scan.p + term_bytes), n, (uint4*)out_dev);
+    else hipLaunchKernelGGL((product_terms_kernel<FqParams>), grid, dim3(256), 0, s, (const DevTerm*)c.scan.p, (const u32*)((char*)c.scan.p + term_bytes), n, (uint4*)out_dev);
+    TRH_HIP_TRY(hipGetLastError());
+    TRH_HIP_TRY(hipStreamSynchronize(s));  // c.scan is shared scratch
+    return TRH_OK;
 }
 
 int trh_field_prefix_product_dev(int field, const void* a_dev, void* out_dev, size_t n, void* stream) {

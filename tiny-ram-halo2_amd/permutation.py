@@ -73,6 +73,40 @@ def grand_products_batch(field: str, k: int, evaluators, column_sets, rot_step: 
     return z
 
 
+def permutation_terms(field: str, values, sigmas, omega_powers, beta: int, gamma: int, first_column: int = 0):
+    """-> (numerator row, denominator row) of one chunk for grand_products_terms: prod_j (v_j + beta delta^(first_column + j) omega^i + gamma)
+    and prod_j (v_j + beta sigma_j + gamma) (plonk/permutation/prover.rs Argument::commit)"""
+    m = _MODULUS[field]
+    g, b = expr._limbs(field, gamma), expr._limbs(field, beta)
+    d = delta(field)
+    num = [(v, omega_powers, expr._limbs(field, beta * pow(d, first_column + j, m) % m), g) for j, v in enumerate(values)]
+    den = [(v, sg, b, g) for v, sg in zip(values, sigmas)]
+    return num, den
+
+
+def lookup_terms(field: str, a, s_, a_perm, s_perm, beta: int, gamma: int):
+    """-> (numerator row, denominator row) of one lookup: (A + beta)(S + gamma) over the compressed input / table, (A' + beta)(S' + gamma)
+    over the permuted ones (plonk/lookup/prover.rs commit_product)"""
+    b, g = expr._limbs(field, beta), expr._limbs(field, gamma)
+    return [(a, None, None, b), (s_, None, None, g)], [(a_perm, None, None, b), (s_perm, None, None, g)]
+
+
+def grand_products_terms(field: str, k: int, num_rows, den_rows):
+    """All product columns of a proof from their term rows (permutation_terms / lookup_terms): ONE launch for every numerator and
+    denominator product, ONE batch inversion that also multiplies, one batched prefix product.  Returns z as (len, n, 4)."""
+    import torch
+    n, rows = 1 << k, len(num_rows)
+    assert rows == len(den_rows) and rows > 0
+    first = num_rows[0][0][0]
+    st = torch.cuda.current_stream(first.device).cuda_stream
+    nd = torch.empty((2 * rows, n, 4), dtype=first.dtype, device=first.device)
+    api.product_terms_dev(field, list(num_rows) + list(den_rows), n, nd, stream=st)
+    num, den = nd[:rows], nd[rows:]
+    api.batch_invert_mul_dev(field, den, num, rows * n, stream=st)
+    api._check(api.lib().trh_field_prefix_product_rows_dev(api.FIELD_ID[field], api._devptr(den), api._devptr(num), n, rows, st))
+    return num
+
+
 def lookup_product(field: str, k: int, beta: int, gamma: int) -> GrandProduct:
     """columns: ("advice", 0) = compressed input A, 1 = compressed table S, 2 = permuted input A', 3 = permuted table S'"""
     a, s_, ap, sp = (expr.Advice(i, 0) for i in range(4))

