@@ -205,3 +205,29 @@ def test_busy_context_is_reported_and_recovers():
     got = b.msm_dev_finish()
     assert (b.msm(sc) == got).all()
     os.environ.pop("TRH_HOST_TILE_LOG", None)
+
+
+def test_device_block_pool_reuses_and_isolates():
+    """trh_malloc / trh_free keep freed blocks per (device, rounded size): the same block comes back, live blocks are never shared,
+    contents written through one block are read back from it"""
+    lib = api.lib()
+    size = (3 << 20) + 17
+    p, q, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    api._check(lib.trh_malloc(ctypes.byref(p), size))
+    api._check(lib.trh_malloc(ctypes.byref(q), size))
+    assert p.value and q.value and p.value != q.value
+    src = np.arange(size // 8, dtype=np.uint64)
+    api._check(lib.trh_memcpy_h2d(p, src.ctypes.data_as(ctypes.c_void_p), src.nbytes))
+    first = p.value
+    api._check(lib.trh_free(p))
+    api._check(lib.trh_malloc(ctypes.byref(r), size - 5))   # same rounded size: the idle block
+    if os.environ.get("TRH_POOL_MB", "1") != "0":
+        assert r.value == first
+    assert r.value != q.value
+    back = np.zeros_like(src)
+    api._check(lib.trh_memcpy_h2d(r, src.ctypes.data_as(ctypes.c_void_p), src.nbytes))
+    api._check(lib.trh_memcpy_d2h(back.ctypes.data_as(ctypes.c_void_p), r, src.nbytes))
+    assert (back == src).all()
+    api._check(lib.trh_free(r))
+    api._check(lib.trh_free(q))
+    assert lib.trh_free(None) == 0

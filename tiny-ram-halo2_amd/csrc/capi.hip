@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <memory>
 
 #include "ctx.h"
@@ -135,6 +136,36 @@ static int create_ctx(int device, Ctx** out) {
     *out = c;
     return TRH_OK;
 }
+
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::map<void*, std::pair<int, size_t>> live;                 // block -> (device, rounded size), blocks handed out
+    std::multimap<std::pair<int, size_t>, void*> idle;            // (device, rounded size) -> block
+    size_t idle_bytes = 0;
+};
+DevPool g_pool;
+size_t pool_cap() {
+    static const size_t cap = (size_t)(getenv("TRH_POOL_MB") ? atoll(getenv("TRH_POOL_MB")) : 4096) << 20;
+    return cap;
+}
+size_t pool_round(size_t bytes) {
+    if (bytes < 16) bytes = 16;
+    const size_t q = bytes < ((size_t)1 << 20) ? (size_t)4096 : (size_t)1 << 20;
+    return (bytes + q - 1) / q * q;
+}
+void pool_release_idle() {  // g_pool.mu held
+    for (auto& kv : g_pool.idle) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(kv.first.first);
+        (void)hipFree(kv.second);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    g_pool.idle.clear();
+    g_pool.idle_bytes = 0;
+}
+}  // namespace
 
 static void destroy_ctx(Ctx* c) {
     if (!c) return;
@@ -594,6 +625,7 @@ int trh_set_shard_min(size_t n_pairs) { g_shard_min = n_pairs ? n_pairs : 1; ret
 
 void trh_shutdown(void) {
     bases_cache_clear();  // before the registry lock: destroying a cached set enters its context
+    { std::lock_guard<std::mutex> pl(g_pool.mu); pool_release_idle(); }
     std::lock_guard<std::mutex> lk(g_reg_mu);
     for (Ctx* c : g_group) destroy_ctx(c);
     g_group.clear();
@@ -923,16 +955,75 @@ int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out,
     return TRH_OK;
 }
 
+// trh_malloc / trh_free keep freed blocks for reuse (per device, by rounded size): a host that allocates per call -- the polynomial
+// side of multiopen makes two dozen short-lived n-element buffers per proof -- otherwise pays a map and an unmap of device memory
+// (hundreds of microseconds each) around kernels of tens.  trh_free keeps hipFree's ordering: it returns once the device has
+// finished everything queued, so a block never re-enters circulation under a kernel that still uses it.  TRH_POOL_MB caps the
+// bytes kept (default 4096; 0: plain hipMalloc / hipFree); a failed allocation empties the pool and tries once more.
 int trh_malloc(void** dev, size_t bytes) {
     if (!dev) { set_error("trh_malloc: null pointer"); return TRH_EINVAL; }
     TRH_ENTER(0);
-    hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
-    if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
+    if (!pool_cap()) {
+        hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
+        return TRH_OK;
+    }
+    const size_t rounded = pool_round(bytes);
+    const int device = ctx().device;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.idle.find({device, rounded});
+    if (it != g_pool.idle.end()) {
+        *dev = it->second;
+        g_pool.idle.erase(it);
+        g_pool.idle_bytes -= rounded;
+    } else {
+        hipError_t e = hipMalloc(dev, rounded);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            pool_release_idle();
+            e = hipMalloc(dev, rounded);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return TRH_ENOMEM; }
+    }
+    g_pool.live[*dev] = {device, rounded};
     return TRH_OK;
 }
 int trh_free(void* dev) {
+    if (!dev) return TRH_OK;
     TRH_ENTER(0);
-    TRH_HIP_TRY(hipFree(dev));
+    std::unique_lock<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.live.find(dev);
+    if (it == g_pool.live.end()) {  // not one of trh_malloc's (or the pool is off)
+        lk.unlock();
+        TRH_HIP_TRY(hipFree(dev));
+        return TRH_OK;
+    }
+    const std::pair<int, size_t> key = it->second;
+    g_pool.live.erase(it);
+    lk.unlock();
+    int prev = -1;
+    TRH_HIP_TRY(hipGetDevice(&prev));
+    if (prev != key.first) TRH_HIP_TRY(hipSetDevice(key.first));
+    hipError_t e = hipDeviceSynchronize();  // what hipFree would have waited for
+    if (e == hipSuccess && key.second > pool_cap()) e = hipFree(dev);
+    else if (e == hipSuccess) {
+        lk.lock();
+        while (g_pool.idle_bytes + key.second > pool_cap() && !g_pool.idle.empty()) {  // make room: drop the largest idle blocks of this device first
+            auto victim = std::prev(g_pool.idle.end());
+            int vprev = -1;
+            (void)hipGetDevice(&vprev);
+            (void)hipSetDevice(victim->first.first);
+            (void)hipFree(victim->second);
+            (void)hipSetDevice(vprev);
+            g_pool.idle_bytes -= victim->first.second;
+            g_pool.idle.erase(victim);
+        }
+        g_pool.idle.insert({key, dev});
+        g_pool.idle_bytes += key.second;
+        lk.unlock();
+    }
+    if (prev != key.first) (void)hipSetDevice(prev);
+    TRH_HIP_TRY(e);
     return TRH_OK;
 }
 int trh_memcpy_h2d(void* dev, const void* host, size_t bytes) {
