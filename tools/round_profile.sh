@@ -34,6 +34,7 @@ if [ "$MODE" = collect ]; then
     [ -x tools/issue_probe ] && ./tools/issue_probe > gpurun_out/issue_probe_$TAG.txt 2>&1
     bash tools/pmc_valu.sh $TAG 24 > gpurun_out/msm_valu_counters_$TAG.txt 2>&1
     bash tools/prof_cmd.sh msm20_$TAG tools/msm_probe.py 20 pallas 0 0 > gpurun_out/msm_2_20_kernel_stats_$TAG.txt 2>&1
+    python3 tools/products_probe.py 2>/dev/null > gpurun_out/products_probe_$TAG.txt
     head -c 160 gpurun_out/bench_$TAG.json; echo
 else
     python3 tools/summarize_prof.py gpurun_out/prof_$TAG "$TAG" | tail -2
@@ -42,7 +43,7 @@ else
     [ -f gpurun_out/microbench_$TAG.txt ] && cp gpurun_out/microbench_$TAG.txt profiles/
     for m in dropin dropin-batched; do for f in replay_${m} replay_${m}_k10 native_replay_${m}; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done; done
     for f in replay_witness_full_domain dropin_probe; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done
-    for f in pcie_probe issue_probe; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/; done
+    for f in pcie_probe issue_probe products_probe; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/; done
     [ -s gpurun_out/msm_valu_counters_$TAG.txt ] && grep -v "^\[" gpurun_out/msm_valu_counters_$TAG.txt > profiles/${TAG}_msm_valu_counters.txt
     [ -s gpurun_out/msm_2_20_kernel_stats_$TAG.txt ] && cp gpurun_out/msm_2_20_kernel_stats_$TAG.txt profiles/${TAG}_msm_2_20_kernel_stats.txt
     ls profiles
