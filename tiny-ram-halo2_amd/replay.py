@@ -31,6 +31,8 @@ can compare them with the oracle (tests/test_gpu_replay.py); the module itself n
 from __future__ import annotations
 
 import argparse
+import os
+import sys
 import json
 import time
 
@@ -114,6 +116,27 @@ class _FixedTranscript:
         return (w[0] | w[1] << 64 | w[2] << 128 | w[3] << 192) % self.m
 
 
+def _warm_clocks(dom, n, dev, limit_s: float = 5.0) -> dict:
+    """Shader clocks of an idle GPU take a while to come up (the first process on a fresh box ran its whole per-column phase 3.7 x
+    slower, memory-bound steps unaffected): repeat a small batch of transforms until its time has settled near the usual figure, so that
+    the timed phase that follows measures the arithmetic and not the ramp.  Returns what it saw (kept in the result line)."""
+    import torch
+    t = torch.zeros((16, n, 4), dtype=torch.int64, device=dev)
+    seen = []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < limit_s:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            dom.lagrange_to_coeff(t)
+        e1.record()
+        torch.cuda.synchronize()
+        seen.append(e0.elapsed_time(e1) / 8)
+        if len(seen) >= 6 and max(seen[-4:]) < 1.03 * min(seen[-4:]) and seen[-1] < 1.15 * min(seen):
+            break
+    return {"iterations": len(seen), "first_ms": round(seen[0], 3), "last_ms": round(seen[-1], 3), "seconds": round(time.perf_counter() - t0, 2)}
+
+
 def _column_loop_two_contexts(params, dom, batches, blinds, ext_buf, D, blocks, x_eval, field, n, dev, overlapped: bool) -> float:
     """The per-column phase of create_proof (commit_lagrange, lagrange_to_coeff, coeff_to_extended, the evaluations) over resident
     column batches, either one step after the other or with the transforms of batch i - 1 on a SECOND libtrh context (own scratch, own
@@ -143,9 +166,11 @@ def _column_loop_two_contexts(params, dom, batches, blinds, ext_buf, D, blocks, 
             api.Context.unbind()
 
     try:
-        warm = batches[0].clone()
-        transforms(warm)  # the second context builds its twiddle tables once
-        del warm
+        for w in range(min(3, len(batches))):  # untimed: the second context builds its twiddle tables, and the clocks are up when the
+            warm = batches[w].clone()          # timed loop starts (the caller has just spent seconds generating columns on the host)
+            params.commit_lagrange_batch(warm, blinds[w])
+            transforms(warm)
+            del warm
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         prev = None
@@ -155,8 +180,15 @@ def _column_loop_two_contexts(params, dom, batches, blinds, ext_buf, D, blocks, 
                 th = threading.Thread(target=transforms, args=(prev,))
                 th.start()
             elif prev is not None:
+                ta = time.perf_counter()
                 transforms(prev)
+                if os.environ.get("TRH_REPLAY_VERBOSE"):
+                    print(f"  transforms: {(time.perf_counter() - ta) * 1e3:.2f} ms", file=sys.stderr)
+            ta = time.perf_counter()
             params.commit_lagrange_batch(cols, bl)
+            if os.environ.get("TRH_REPLAY_VERBOSE"):
+                torch.cuda.synchronize()
+                print(f"  commit: {(time.perf_counter() - ta) * 1e3:.2f} ms", file=sys.stderr)
             if th is not None:
                 th.join()
             prev = cols
@@ -320,6 +352,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         del cols
         done += b
     torch.cuda.synchronize()
+    warm = _warm_clocks(dom, n, dev)
     done = 0
     while done < lag_total:
         b = min(batch, lag_total - done)
@@ -375,10 +408,17 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
             batches.append(make_columns(d0, b)[1])
             bls.append(synth.field_elements(seed + 0x100000 + d0, b))
             d0 += b
-        copies = [t.clone() for t in batches]
-        loop_ms = {"step_by_step": round(_column_loop_two_contexts(params, dom, copies, bls, ext_buf, D, blocks, x_eval, field, n, dev, False), 3)}
-        del copies
-        loop_ms["two_contexts_overlapped"] = round(_column_loop_two_contexts(params, dom, batches, bls, ext_buf, D, blocks, x_eval, field, n, dev, True), 3)
+        # each form twice over fresh copies, the faster one counts: the first pass over a new context / stream also pays one-off costs of
+        # the HIP runtime (a 37 ms stall inside one launch was measured at a fixed position of the first pass)
+        loop_ms = {}
+        for name, ovl in (("step_by_step", False), ("two_contexts_overlapped", True)):
+            best = None
+            for _ in range(2):
+                copies = [t.clone() for t in batches]
+                ms = _column_loop_two_contexts(params, dom, copies, bls, ext_buf, D, blocks, x_eval, field, n, dev, ovl)
+                del copies
+                best = ms if best is None else min(best, ms)
+            loop_ms[name] = round(best, 3)
         del batches
         ext_keep = keep_ext
 
@@ -571,7 +611,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
            "gpu_ms_total_with_real_gates": round(sum(times.values()) - times["h_eval"] + real["ms"], 3) if real else None,
            "scope": "GPU time of the offloaded arithmetic of ONE create_proof incl. the multiopen folds / divisions; witness generation, the transcript and PCIe are not in it",
            "keygen_gpu_ms": keygen_ms, "fixed_base_tables": bool(precompute), "setup_precompute_ms": round(precompute_ms, 3),
-           "wall_s_including_host_input_generation": round(wall, 3), "checked_against_oracle": checked}
+           "wall_s_including_host_input_generation": round(wall, 3), "checked_against_oracle": checked, "clock_warmup": warm}
     if verbose:
         print(json.dumps(out))
     return out
