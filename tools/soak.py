@@ -12,7 +12,7 @@ rng = random.Random(seed)
 api.init(0)
 MOD = {"fp": poly._MODULUS["fp"], "fq": poly._MODULUS["fq"]}
 t_end = time.time() + budget
-stats = {"msm": 0, "ntt": 0, "lookup": 0, "blocks": 0, "hostio": 0}
+stats = {"msm": 0, "ntt": 0, "lookup": 0, "blocks": 0, "hostio": 0, "products": 0}
 fails = 0
 
 
@@ -38,7 +38,7 @@ def scalars(field, n, kind):
 
 
 while time.time() < t_end:
-    which = rng.choice(["msm", "msm", "ntt", "lookup", "blocks", "hostio"])
+    which = rng.choice(["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products"])
     if which == "msm":
         curve = rng.choice(["pallas", "vesta"])
         sf = api.SCALAR_FIELD[curve]
@@ -153,6 +153,55 @@ while time.time() < t_end:
         if not ok:
             fails += 1
             print("HOSTIO MISMATCH", field, k, count, curve, n, batch, flush=True)
+    elif which == "products":
+        # product columns from rows of factors (trh_product_terms_dev + batch_invert_mul + batched prefix product) against big integers,
+        # and ff::BatchInvert alone at an arbitrary length (a * a^-1 == 1 wherever a != 0, zeros left alone)
+        field = rng.choice(["fp", "fq"])
+        m = MOD[field]
+        k = rng.randrange(1, 13)
+        n = 1 << k
+        rinv = pow(1 << 256, -1, m)
+        pool_h = [synth.field_elements(rng.randrange(1 << 30), n) for _ in range(5)]
+        pool_d = [torch.from_numpy(c.view(np.int64)).cuda() for c in pool_h]
+        pool_i = [[int.from_bytes(r.tobytes(), "little") * rinv % m for r in c] for c in pool_h]
+        def row():
+            terms_d, terms_i = [], []
+            for _ in range(rng.randrange(1, 5)):
+                x, g = rng.randrange(5), rng.randrange(m)
+                y = rng.randrange(5) if rng.random() < 0.6 else None
+                c = rng.randrange(m)
+                terms_d.append((pool_d[x], pool_d[y] if y is not None else None, limbs(field, c) if y is not None else None, limbs(field, g)))
+                terms_i.append((x, y, c, g))
+            return terms_d, terms_i
+        rows = [(row(), row()) for _ in range(rng.randrange(1, 5))]
+        z = permutation.grand_products_terms(field, k, [r[0][0] for r in rows], [r[1][0] for r in rows]).cpu().numpy().view(np.uint64)
+        ok = True
+        val = lambda terms, i: __import__("functools").reduce(lambda a, t: a * ((pool_i[t[0]][i] + (t[2] * pool_i[t[1]][i] if t[1] is not None else 0) + t[3]) % m) % m, terms, 1)
+        for r, (nr, dr) in enumerate(rows):
+            acc = 1
+            for i in range(n):
+                if int.from_bytes(z[r][i].tobytes(), "little") * rinv % m != acc:
+                    ok = False
+                    break
+                d = val(dr[1], i)
+                acc = acc * val(nr[1], i) * (pow(d, -1, m) if d else 0) % m
+        cnt = rng.choice([rng.randrange(1, 300), rng.randrange(300, 1 << 15), rng.randrange(1 << 15, 1 << 18)])
+        a = synth.field_elements(rng.randrange(1 << 30), cnt).copy()
+        for zi in range(0, cnt, rng.randrange(50, 5000)):
+            a[zi] = 0
+        da = torch.from_numpy(a.view(np.int64)).cuda()
+        inv = da.clone()
+        api.batch_invert_dev(field, inv, cnt)
+        prod = torch.empty_like(da)
+        api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["mul"], api._devptr(da), api._devptr(inv), api._devptr(prod), cnt, None))
+        torch.cuda.synchronize()
+        ph, ih = prod.cpu().numpy().view(np.uint64), inv.cpu().numpy().view(np.uint64)
+        zero = ~a.any(axis=1)
+        one = np.array(limbs(field, 1), dtype=np.uint64)
+        ok = ok and (ph[~zero] == one).all() and not ih[zero].any()
+        if not ok:
+            fails += 1
+            print("PRODUCTS MISMATCH", field, k, cnt, flush=True)
     else:
         field = rng.choice(["fp", "fq"])
         n = rng.choice([rng.randrange(1, 100), rng.randrange(100, 1 << 12), rng.randrange(1 << 12, 1 << 17)])
@@ -168,6 +217,10 @@ while time.time() < t_end:
         eq_prev = np.concatenate([[False], (pa_h[1:] == pa_h[:-1]).all(axis=1)])
         ok = ((pa_h == ps_h).all(axis=1) | eq_prev).all()
         ok = ok and sorted(map(bytes, pa_h)) == sorted(map(bytes, inp)) and sorted(map(bytes, ps_h)) == sorted(map(bytes, table))
+        if n <= 4096:  # A' is in the order of the canonical integers
+            rinv = pow(1 << 256, -1, m)
+            ints = [int.from_bytes(r.tobytes(), "little") * rinv % m for r in pa_h]
+            ok = ok and ints == sorted(ints)
         if not ok:
             fails += 1
             print("LOOKUP MISMATCH", field, n, tsize, flush=True)
