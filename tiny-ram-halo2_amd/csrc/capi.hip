@@ -167,6 +167,11 @@ void pool_release_idle() {  // g_pool.mu held
 }
 }  // namespace
 
+void pool_trim() {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    pool_release_idle();
+}
+
 static void destroy_ctx(Ctx* c) {
     if (!c) return;
     {

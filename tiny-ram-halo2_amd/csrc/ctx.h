@@ -37,6 +37,7 @@ void set_error(const char* fmt, ...);
         if (_rc != TRH_OK) return _rc; \
     } while (0)
 
+void pool_trim();  // capi.hip: returns the idle blocks of trh_malloc / trh_free to the device
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -46,6 +47,8 @@ struct DevBuf {
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
+            pool_trim();  // the library's own scratch goes before blocks kept for the host's next allocation
             e = hipMalloc(&p, bytes);
             want = bytes;
         }
