@@ -262,14 +262,16 @@ __device__ __forceinline__ int cmp_keys(const u64* __restrict__ pa, const u32* _
 }
 // after the fast path: bad[c] = 1 when two neighbours agree in the limb sorted by but are different values (their order is then unknown)
 __global__ void __launch_bounds__(256) tie_check_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, const int* __restrict__ key_limb, const u64* __restrict__ key_mask,
-                                                        u32* __restrict__ bad) {
+                                                        const u64* __restrict__ keys0, const u64* __restrict__ keys1, const u32* __restrict__ side, u32* __restrict__ bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 c = blockIdx.y;
     const int primary = key_limb[c];
     if (i == 0 || i >= n || primary < 0) return;
+    // the sorted keys lie in order on the side the last pass wrote (coalesced); the planes are only gathered for neighbours the sort did not separate
+    const u64* keys = (side[c] ? keys1 : keys0) + (size_t)c * n;
+    if ((keys[i - 1] ^ keys[i]) & key_mask[c]) return;  // separated by the bits sorted by
     const u64* pl = planes + (size_t)c * 4 * n;
     const u32 a = perm[(size_t)c * n + i - 1], b = perm[(size_t)c * n + i];
-    if ((pl[(size_t)primary * n + a] ^ pl[(size_t)primary * n + b]) & key_mask[c]) return;  // separated by the bits sorted by
     for (int k = 0; k < 4; ++k)
         if (pl[(size_t)k * n + a] != pl[(size_t)k * n + b]) { bad[c] = 1u; return; }
 }
@@ -282,14 +284,19 @@ __global__ void __launch_bounds__(256) gather_elems_kernel(const uint4* __restri
     uint4* o = out + 2 * ((size_t)l * stride + i);
     o[0] = p[0]; o[1] = p[1];
 }
-// flags[l][i] = 1 when sorted input element i REPEATS its predecessor (0 at run starts)
-__global__ void __launch_bounds__(256) repeat_flags_kernel(const u64* __restrict__ planes, size_t n, const u32* __restrict__ perm, u32* __restrict__ flags) {
+// flags[l][i] = 1 when sorted input element i REPEATS its predecessor (0 at run starts); read from the gathered sorted column (equal
+// Montgomery words <=> equal values; coalesced, where the planes would be two random gathers per row)
+__global__ void __launch_bounds__(256) repeat_flags_kernel(const uint4* __restrict__ a_sorted, size_t stride, size_t n, u32* __restrict__ flags) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 l = blockIdx.y;
     if (i >= n) return;
-    const u64* pl = planes + (size_t)l * 4 * n;
-    const u32* pm = perm + (size_t)l * n;
-    flags[(size_t)l * n + i] = (i != 0 && cmp_keys(pl, pm, i, pl, pm, i - 1, n) == 0) ? 1u : 0u;
+    u32 rep = 0u;
+    if (i != 0) {
+        const uint4* p = a_sorted + 2 * ((size_t)l * stride + i);
+        const uint4 a0 = p[0], a1 = p[1], b0 = p[-2], b1 = p[-1];
+        rep = (a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w) ? 1u : 0u;
+    }
+    flags[(size_t)l * n + i] = rep;
 }
 // every run start of the sorted input removes the first table instance of its value: keep[l][pos] = 0 (initialised to 1); missing -> err[l] = 1
 __global__ void __launch_bounds__(256) remove_from_table_kernel(const u64* __restrict__ planes, const u32* __restrict__ perm, const u32* __restrict__ repeats, size_t n, u32 batch,
@@ -446,9 +453,9 @@ int lookup_permute_batch_t(const void* inputs, const void* tables, size_t n, siz
     hipLaunchKernelGGL((canon_planes_kernel<F>), dim3(gb, cols), dim3(256), 0, s, (const uint4*)inputs, (const uint4*)tables, stride, batch, n, sc.planes.as<u64>(), sc.perm0.as<u32>());
     hipLaunchKernelGGL(plane_varies_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, varies);
     TRH_TRY(sort_columns(sc, n, cols, general, varies, key_limb, key_mask, side, sel, s));
-    if (!general) hipLaunchKernelGGL(tie_check_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), key_limb, key_mask, bad);
+    if (!general) hipLaunchKernelGGL(tie_check_kernel, dim3(gb, cols), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), key_limb, key_mask, sc.keys0.as<u64>(), sc.keys1.as<u64>(), side, bad);
     hipLaunchKernelGGL(gather_elems_kernel, dim3(gb, batch), dim3(256), 0, s, (const uint4*)inputs, stride, sc.perm0.as<u32>(), (uint4*)out_inputs, n);
-    hipLaunchKernelGGL(repeat_flags_kernel, dim3(gb, batch), dim3(256), 0, s, sc.planes.as<u64>(), n, sc.perm0.as<u32>(), sc.flags.as<u32>());
+    hipLaunchKernelGGL(repeat_flags_kernel, dim3(gb, batch), dim3(256), 0, s, (const uint4*)out_inputs, stride, n, sc.flags.as<u32>());
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, s, sc.keep.as<u32>(), bn, 1u);
     hipLaunchKernelGGL(remove_from_table_kernel, dim3(gb, batch), dim3(256), 0, s, sc.planes.as<u64>(), sc.perm0.as<u32>(), sc.flags.as<u32>(), n, batch, sc.keep.as<u32>(), err);
     // repeated input rows (ascending) and left-over table positions (ascending)
