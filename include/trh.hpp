@@ -528,16 +528,19 @@ public:
         check(trh_field_powers_dev((int)f, pz_.data(), n, z.data(), stream), "powers");
         check(trh_field_powers_dev((int)f, pzinv_.data(), n, z_inv.data(), stream), "powers");
     }
-    // a_dev: n coefficients, q_dev: n - 1 coefficients; runs on the constructor's stream
-    void divide(const void* a_dev, void* q_dev) {
+    // a_dev: len coefficients (default: n; a shorter polynomial uses the prefixes of the power tables -- the multiopen sets divide by the
+    // same point at lengths n, n - 1, ...), q_dev: len - 1 coefficients; runs on the constructor's stream
+    void divide(const void* a_dev, void* q_dev, size_t len = 0) {
+        if (len == 0) len = n;
+        require(len <= n, "kate_division: polynomial longer than the divider's tables");
         if (zero_) {  // a(X) / X, remainder a_0 dropped: host-ordered device-to-device copy through the ABI's helpers
-            std::vector<Limbs> tmp(n);
+            std::vector<Limbs> tmp(len);
             check(trh_stream_synchronize(stream_), "sync");
-            check(trh_memcpy_d2h(tmp.data(), a_dev, n * 32), "d2h");
-            check(trh_memcpy_h2d(q_dev, tmp.data() + 1, (n - 1) * 32), "h2d");
+            check(trh_memcpy_d2h(tmp.data(), a_dev, len * 32), "d2h");
+            check(trh_memcpy_h2d(q_dev, tmp.data() + 1, (len - 1) * 32), "h2d");
             return;
         }
-        check(trh_poly_kate_division_dev((int)field, a_dev, n, pz_.data(), pzinv_.data(), scratch_.data(), q_dev, stream_), "kate_division");
+        check(trh_poly_kate_division_dev((int)field, a_dev, len, pz_.data(), pzinv_.data(), scratch_.data(), q_dev, stream_), "kate_division");
     }
     Field field;
     size_t n;

@@ -17,6 +17,22 @@ def _limbs(field: str, v: int) -> np.ndarray:
     return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+def _limbs_many(field: str, values) -> np.ndarray:
+    """(len, 4) Montgomery limbs of a list of integers (one bytes join instead of a numpy array per value: the x1 fold has 400 of them)"""
+    m = _MODULUS[field]
+    r = (1 << 256) % m
+    buf = b"".join((v % m * r % m).to_bytes(32, "little") for v in values)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(len(values), 4).copy()
+
+
+def _powers_desc(x: int, count: int, m: int):
+    """[x^(count-1), ..., x, 1] by running products (pow() per entry costs a square-and-multiply chain each)"""
+    out = [1] * count
+    for j in range(count - 2, -1, -1):
+        out[j] = out[j + 1] * x % m
+    return out
+
+
 def lincomb(field: str, polys, coeffs, out=None):
     """sum_b coeffs[b] * polys[b]; polys: device tensor (batch, n, 4), coeffs: ints"""
     import torch
@@ -24,7 +40,7 @@ def lincomb(field: str, polys, coeffs, out=None):
     assert len(coeffs) == batch and polys.is_contiguous()
     if out is None:
         out = torch.empty((n, 4), dtype=polys.dtype, device=polys.device)
-    c = np.stack([_limbs(field, v) for v in coeffs])
+    c = _limbs_many(field, coeffs)
     api._check(api.lib().trh_poly_lincomb_dev(api.FIELD_ID[field], api._devptr(polys), n, batch, api._p(c), api._devptr(out),
                                              torch.cuda.current_stream(polys.device).cuda_stream))
     return out
@@ -33,11 +49,15 @@ def lincomb(field: str, polys, coeffs, out=None):
 class KateDivider:
     """kate_division by (X - z) for polynomials of n coefficients; the powers of z and z^-1 are built once per point"""
 
-    def __init__(self, field: str, n: int, z: int, device):
+    def __init__(self, field: str, n: int, z: int, device, share=None):
+        """share: a KateDivider of the same point and at least n coefficients whose power tables are reused (their prefixes)"""
         import torch
         m = _MODULUS[field]
         self.field, self.n, self.z = field, n, z % m
-        if self.z:
+        if self.z and share is not None:
+            assert share.z == self.z and share.n >= n
+            self.pz, self.pzinv, self.scratch = share.pz[:n], share.pzinv[:n], share.scratch[: 2 * n]
+        elif self.z:
             self.pz = torch.empty((n, 4), dtype=torch.int64, device=device)
             self.pzinv = torch.empty((n, 4), dtype=torch.int64, device=device)
             st = torch.cuda.current_stream(device).cuda_stream
@@ -114,20 +134,27 @@ def create_proof(params, rng, transcript, queries, polys: dict, blinds: dict, s_
     members = [[key for key, s in commitments if s == i] for i in range(nsets)]
     q_polys, q_blinds = [], []
     for keys in members:  # q = (((p_0 x1 + p_1) x1 + p_2) ...): coefficient of p_j is x1^(len - 1 - j)
-        coeffs = [pow(x1, len(keys) - 1 - j, m) for j in range(len(keys))]
+        coeffs = _powers_desc(x1, len(keys), m)
         stack = _stack([polys[k] for k in keys])
         q_polys.append(lincomb(sf, stack, coeffs))
         q_blinds.append(sum(c * blinds[k] for c, k in zip(coeffs, keys)) % m)
     dev = q_polys[0].device
     divided = []
+    dividers = {}  # per point: the tables of z^i / z^-i at full length serve every later, shorter division by the same point
     for pts, q in zip(point_sets, q_polys):
         cur = q
         for z in pts:
-            cur = KateDivider(sf, cur.shape[0], z, dev).divide(cur)
+            have = dividers.get(z % m)
+            if have is not None and have.n < cur.shape[0]:
+                have = None  # a longer polynomial than the tables reach: build them anew
+            kd = KateDivider(sf, cur.shape[0], z, dev, share=have)
+            if have is None:
+                dividers[z % m] = kd
+            cur = kd.divide(cur)
         pad = torch.zeros((n, 4), dtype=q.dtype, device=dev)   # poly.resize(params.n, 0)
         pad[: cur.shape[0]] = cur
         divided.append(pad)
-    q_prime = lincomb(sf, torch.stack(divided).contiguous(), [pow(x2, nsets - 1 - i, m) for i in range(nsets)])
+    q_prime = lincomb(sf, torch.stack(divided).contiguous(), _powers_desc(x2, nsets, m))
     q_prime_blind = rng()
     transcript.write_point(params.commit(q_prime, _limbs(sf, q_prime_blind)))
     x3 = transcript.squeeze_challenge_scalar()
