@@ -948,6 +948,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // the slice offset, so long slices do less work per bucket but are a long serial chain: a lone MSM
     // (latency-bound) gets 2048-4096 threads per window, a batch (throughput-bound) as few as 256
     u32 tpw = nbk >= (1u << 15) ? 4096 : 2048;  // slices of >= 8 buckets (measured: 2^20..2^24 pairs gain 0.07-0.16 ms, 2^18 loses with 4096)
+    if (fb) tpw = 16384;  // one flat window per item: slices of 2 buckets while the batch is small (the cap below takes over for batches) -- the
+                          // opening's rounds are two such items each: reduce 240 -> 190 us per round, k = 18 opening 15.4 -> 14.6 ms
     if (const char* e = getenv("TRH_REDUCE_TPW")) { int v = atoi(e); if (v >= 256 && v <= 65536 && (v & (v - 1)) == 0) tpw = (u32)v; }  // tuning knob
     while (tpw > 256 && (size_t)Ws * tpw * chunk > ((size_t)1 << 16)) tpw >>= 1;  // 2^16 threads = one wave per SIMD (batch of 64 commits: 0.79 -> 0.62 ms)
     if (tpw > nbk) tpw = nbk;
