@@ -70,6 +70,10 @@ struct TwiddleEntry {
     void release_all() { lo.release(); hi.release(); zlo.release(); zhi.release(); tile9.release(); for (DevBuf& d : direct) d.release(); }
     int lo_bits, hi_bits;
     u64 stamp;
+    // a constant factor folded into the LAST pass's direct table (every element of that pass is multiplied by one of its entries anyway):
+    // lagrange_to_coeff's 2^-k costs nothing this way.  Part of the cache key; scaled: the factor is in (the table exists)
+    bool has_scale = false, scaled = false;
+    u64 scale[4] = {0, 0, 0, 0};
 };
 
 struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: batch item)
@@ -236,7 +240,9 @@ int ntt_block_table_build(int field, void* table_dev, uint32_t blocks, uint32_t 
 int ntt_block_scale(int field, const void* in_dev, void* out_dev, size_t transforms, uint32_t blocks, uint32_t log_n, const void* table_dev, bool in_per_block, hipStream_t s);
 bool ntt_can_fuse(uint32_t log_n);
 int ntt_lazy_shift();
-int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr);
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr, const u64* scale = nullptr);
+// whether a transform of this size can take a constant factor (Montgomery words) in its last pass's table: ntt_device(..., scale) then returns a . scale
+bool ntt_can_fold_scale(uint32_t log_n);
 void ntt_release_tables();
 // msm.hip
 // fixed-base table of an owned base set: table[j * n + i] = 2^(c j) * P_i (lazy affine form), j < W.  With it the

@@ -256,6 +256,8 @@ int trh_domain_lagrange_to_coeff(trh_domain* d, void* a_dev, size_t batch, void*
     Range range("trh_domain_lagrange_to_coeff");
     Ctx& c = ctx();
     (void)c;
+    if (ntt_can_fold_scale(d->k))  // x 2^-k inside the last pass's inter-pass twiddle table: no multiplication of its own
+        return ntt_device(d->field, a_dev, d->k, (const u64*)&d->omega_inv, batch, (hipStream_t)stream, nullptr, (const u64*)&d->ifft_divisor);
     if (ntt_can_fuse(d->k)) {  // x 2^-k on the final store of the last pass
         NttFusion fu;
         fu.post = tab(d, T_ZIDIV); fu.post_period = 1;

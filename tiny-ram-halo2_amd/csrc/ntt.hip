@@ -556,12 +556,27 @@ __device__ __forceinline__ Fy<F> twiddle_y(const uint4* __restrict__ z_lo, const
 // the balanced form lets the multiplicand be the previous pass's unnormalised output (see round_stage_y)
 template <class F>
 __global__ void __launch_bounds__(256) ntt_direct_table_y_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
-                                                                 int log_ns, int s, int tw_shift) {
+                                                                 int log_ns, int s, int tw_shift, uint4 sc_lo, uint4 sc_hi, int has_scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t M = (size_t)1 << (log_ns + s);
     if (i >= M) return;
     const u32 k = (u32)i & ((1u << log_ns) - 1u), r = (u32)(i >> log_ns);
-    const Fy<F> w = fy_balance(twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits));
+    Fy<F> w = twiddle_y<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits);
+    if (has_scale) {  // the constant's Montgomery words (x 2^256) read five bits lower are 32 (c 2^256) = c 2^261 + j m: the factor in this domain
+        const u32 M29 = (u32)YMASK;
+        Fy<F> c;
+        c.l[0] = (i32)((sc_lo.x << 5) & M29);
+        c.l[1] = (i32)(((sc_lo.x >> 24) | (sc_lo.y << 8)) & M29);
+        c.l[2] = (i32)(((sc_lo.y >> 21) | (sc_lo.z << 11)) & M29);
+        c.l[3] = (i32)(((sc_lo.z >> 18) | (sc_lo.w << 14)) & M29);
+        c.l[4] = (i32)(((sc_lo.w >> 15) | (sc_hi.x << 17)) & M29);
+        c.l[5] = (i32)(((sc_hi.x >> 12) | (sc_hi.y << 20)) & M29);
+        c.l[6] = (i32)(((sc_hi.y >> 9) | (sc_hi.z << 23)) & M29);
+        c.l[7] = (i32)(((sc_hi.z >> 6) | (sc_hi.w << 26)) & M29);
+        c.l[8] = (i32)(sc_hi.w >> 3);
+        w = fy_mul(c, w);
+    }
+    w = fy_balance(w);
     d[i] = make_uint4((u32)w.l[0], (u32)w.l[1], (u32)w.l[2], (u32)w.l[3]);
     d[M + i] = make_uint4((u32)w.l[4], (u32)w.l[5], (u32)w.l[6], (u32)w.l[7]);
     ((u32*)(d + 2 * M))[i] = (u32)w.l[8];
@@ -853,10 +868,11 @@ __global__ void __launch_bounds__(256) ntt_block_scale_kernel(const uint4* __res
     out[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4]) {
+TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4], const u64* scale) {
     Ctx& c = ctx();
     for (TwiddleEntry* t : c.twiddles)
-        if (t->field == field && t->log_n == log_n && memcmp(t->omega, omega, 32) == 0) { t->stamp = ++c.stamp; return t; }
+        if (t->field == field && t->log_n == log_n && memcmp(t->omega, omega, 32) == 0 && t->has_scale == (scale != nullptr) &&
+            (!scale || memcmp(t->scale, scale, 32) == 0)) { t->stamp = ++c.stamp; return t; }
     return nullptr;
 }
 
@@ -889,7 +905,7 @@ bool signed_enabled() {
 }
 
 template <class F>
-int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** out) {
+int build_tables(int log_n, const u64 omega[4], const u64* scale, hipStream_t s, TwiddleEntry** out) {
     Ctx& c = ctx();
     if (c.twiddles.size() >= 16) {  // evict the least recently used entry
         size_t victim = 0;
@@ -902,6 +918,7 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
     }
     TwiddleEntry* t = new TwiddleEntry();
     t->field = F::ID; t->log_n = log_n; memcpy(t->omega, omega, 32);
+    if (scale) { t->has_scale = true; memcpy(t->scale, scale, 32); }
     t->lo_bits = (log_n + 1) / 2; t->hi_bits = log_n - t->lo_bits;
     if (t->lo_bits < 1) t->lo_bits = 1;
     t->stamp = ++c.stamp;
@@ -936,9 +953,14 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
             const size_t entry_bytes = signed_enabled() ? 36 : 32;  // raw limbs for the signed passes
             if (entries * entry_bytes <= ((size_t)1 << 30) + ((size_t)1 << 27)) {
                 rc = t->direct[p].ensure(entries * entry_bytes);
-                if (rc == TRH_OK && signed_enabled())
+                if (rc == TRH_OK && signed_enabled()) {
+                    const bool fold = scale && p == P - 1;
+                    const u32* sw = (const u32*)t->scale;
                     hipLaunchKernelGGL((ntt_direct_table_y_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
-                                       t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
+                                       t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p], make_uint4(sw[0], sw[1], sw[2], sw[3]), make_uint4(sw[4], sw[5], sw[6], sw[7]),
+                                       fold ? 1 : 0);
+                    if (fold) t->scaled = true;
+                }
                 else if (rc == TRH_OK)
                     hipLaunchKernelGGL((ntt_direct_table_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
                                        t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
@@ -963,11 +985,11 @@ int build_tables(int log_n, const u64 omega[4], hipStream_t s, TwiddleEntry** ou
 }
 
 template <class F>
-int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu) {
+int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu, const u64* scale) {
     if (log_n == 0 || batch == 0) return TRH_OK;
     Ctx& c = ctx();
-    TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega);
-    if (!t) TRH_TRY(build_tables<F>((int)log_n, omega, s, &t));
+    TwiddleEntry* t = find_tables(F::ID, (int)log_n, omega, scale);
+    if (!t) TRH_TRY(build_tables<F>((int)log_n, omega, scale, s, &t));
 
     int sizes[8], P = 0, tlog = TILE_LOG;
     plan_passes((int)log_n, sizes, &P, &tlog);
@@ -975,6 +997,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     uint4* a = (uint4*)a_dev;
     bool all_lazy = lazy_enabled() && tlog == TILE_LOG && (int)log_n >= TILE_LOG && P >= 2;
     for (int p = 0; p < P; ++p) all_lazy = all_lazy && sizes[p] >= 2 && sizes[p] <= MAX_PASS_LOG;
+    if (scale && !(all_lazy && signed_enabled() && t->scaled)) { set_error("ntt: this size cannot take a factor in its tables (ntt_can_fold_scale)"); return TRH_EINVAL; }
     if (all_lazy && signed_enabled()) {
         // signed-domain passes: caller's words -> raw nine-limb scratch -> ... -> caller's words (canonical)
         const size_t max_tmp = (size_t)2 << 30;
@@ -1094,7 +1117,15 @@ bool ntt_can_fuse(uint32_t log_n) {
     return fuse != 0;
 }
 
-int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu) {
+bool ntt_can_fold_scale(uint32_t log_n) {
+    static const int direct_on = getenv("TRH_NTT_DIRECT") ? atoi(getenv("TRH_NTT_DIRECT")) : 1;
+    static const int fold_on = getenv("TRH_NTT_FOLD_SCALE") ? atoi(getenv("TRH_NTT_FOLD_SCALE")) : 1;  // 0: the factor as a separate multiplication on the last store (A/B)
+    int sizes[8], P, tlog;
+    plan_passes((int)log_n, sizes, &P, &tlog);
+    return fold_on && direct_on && ntt_can_fuse(log_n) && signed_enabled() && P >= 2 && ((size_t)36 << log_n) <= ((size_t)1 << 30) + ((size_t)1 << 27);
+}
+
+int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu, const u64* scale) {
     if (log_n > 27) { set_error("ntt: log_n %u > 27 unsupported", log_n); return TRH_EINVAL; }
     if (fu && !ntt_can_fuse(log_n)) { set_error("ntt: fused pointwise steps need the lazy passes (log_n >= %d)", TILE_LOG); return TRH_EINVAL; }
     if (!(ctx().attr_done & ATTR_NTT)) {  // per device
@@ -1115,8 +1146,8 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
 #undef TRH_PASSY_ATTR
         ctx().attr_done |= ATTR_NTT;
     }
-    if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu);
-    return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s, fu);
+    if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu, scale);
+    return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s, fu, scale);
 }
 
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s) {
