@@ -60,7 +60,9 @@ template <class SF>
 __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                          u32* __restrict__ digits, u32* __restrict__ bin_counts, int k2, u32 nbins, int use_lds, size_t sstride,
                                                          int one_row /* fixed-base mode: all windows share one histogram */,
-                                                         const uint4* __restrict__ tails /* or null: scalar n - 1 of item z is tails[z] (the commitment blind) */) {
+                                                         const uint4* __restrict__ tails /* or null: scalar n - 1 of item z is tails[z] (the commitment blind) */,
+                                                         unsigned char* __restrict__ tile_flags /* or null; fixed-base mode: [item][tile] = 1 when the partition tile holds an entry */,
+                                                         u32 tile_log, u32 tiles) {
     const size_t z = blockIdx.z;  // batch item
     const u32 rows = one_row ? 1u : (u32)W;
     scalars += z * sstride * 2; digits += z * (size_t)W * n; bin_counts += z * (size_t)rows * nbins;
@@ -87,6 +89,15 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
             if (raw > half) { bucket = (1u << c) - raw; carry = 1; sign = SIGN_BIT; }  // digit raw - 2^c
             else { bucket = raw; carry = 0; }
             digits[(size_t)j * n + i] = bucket ? (bucket | sign) : 0u;
+            if (tile_flags) {  // witness columns leave most tiles of the flat W x n digit space empty: the partition skips those
+                // one store per wave and window, no load: the lowest lane with an entry marks its tile; a lane within the first 64 slots of a
+                // tile marks it too (the wave's lowest entry may lie in the tile before)
+                const unsigned long long nz = __ballot(bucket != 0);
+                const size_t slot = (size_t)j * n + i;
+                const u32 lane = threadIdx.x & 63u;
+                if (bucket && ((nz & ((1ull << lane) - 1ull)) == 0ull || (slot & (((size_t)1 << tile_log) - 1)) < 64))
+                    tile_flags[z * tiles + (slot >> tile_log)] = 1;
+            }
             if (bucket) {
                 const u32 bin = (bucket - 1u) >> k2, row = one_row ? 0u : (u32)j;
                 if (use_lds) atomicAdd(&lhist[row * nbins + bin], 1u);
@@ -149,8 +160,10 @@ __global__ void __launch_bounds__(1024) msm_offsets_kernel(u32* __restrict__ cou
 constexpr int PART_TILE = 16384;
 constexpr int PART_THREADS = 1024;
 __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor,
-                                                                     u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits) {
+                                                                     u32* __restrict__ parted, size_t n, int k2, u32 nbins, int idx_bits,
+                                                                     const unsigned char* __restrict__ tile_flags /* or null: [item][tile], see msm_recode_kernel */) {
     const size_t z = blockIdx.z;  // batch item
+    if (tile_flags && !tile_flags[z * gridDim.x + blockIdx.x]) return;  // no entry in this tile (uniform over the workgroup)
     digits += z * (size_t)gridDim.y * n; parted += z * (size_t)gridDim.y * n; bin_cursor += z * (size_t)gridDim.y * nbins;
     // LDS: the tile's entries staged in bin order (so that every bin's run leaves as one coalesced
     // store instead of PART_TILE scattered 4-byte writes), then per bin: count / cursor, start inside
@@ -968,8 +981,12 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.digits.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.parted.ensure(chunk * W * n * 4 + 16));
     TRH_TRY(L.sorted.ensure(chunk * W * n * 4 + 16));
-    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + 2 * chunk * Ws * 4));  // + the oversize-bin flags of the LDS bin sort and the entry totals (per item and window)
-    u32* const oversize = L.counts.as<u32>() + chunk * Ws * nbins;
+    // L.counts: [bin counts][fixed-base mode: one byte per (item, partition tile)][oversize-bin flags of the LDS bin sort][entry totals per item and window]
+    const u32 part_tiles = (u32)((ns + PART_TILE - 1) / PART_TILE);
+    const size_t flag_bytes = fb ? ((size_t)chunk * part_tiles + 3) / 4 * 4 : 0;
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + flag_bytes + 2 * chunk * Ws * 4));
+    unsigned char* const tile_flags = fb ? (unsigned char*)(L.counts.as<u32>() + chunk * Ws * nbins) : nullptr;
+    u32* const oversize = (u32*)((char*)L.counts.p + chunk * Ws * nbins * 4 + flag_bytes);
     u32* const totals = oversize + chunk * Ws;
     // Batched commitments of WITNESS columns (flags, small words: a few 10^4 entries per column, most of them in a handful of buckets)
     // leave the sorted lists almost empty, and fixed 128-entry segments then mean a few hundred threads each walking a serial chain of 128
@@ -1020,12 +1037,13 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
-        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * Ws * nbins * 4, s));
+        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
         unsigned gb = (unsigned)((n + 255) / 256);
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
                            L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
-                           tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr);
+                           tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr, tile_flags, 14u, part_tiles);
+        static_assert(PART_TILE == 1 << 14, "tile_log of msm_recode_kernel");
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
         if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap,
@@ -1054,7 +1072,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         }
         TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
-                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits);
+                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits, tile_flags);
         {
             const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), Ws, nb);
             const u32* gate = use_bin ? oversize : nullptr;  // the chunked passes return at once when the bin sort did the work
