@@ -794,6 +794,34 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZzMem* __restr
     XYZZz<BF> total = xyzzz_identity<BF>();
     if (t < threads_per_window) {
         const XYZZzMem* bk = buckets + (size_t)j * nbk + (size_t)t * m;
+        // Long slices (batches: 32 buckets per thread) of witness-shaped columns are almost empty -- a flag column fills about a hundred of
+        // its 2^15 buckets --, and the running sums below walk them all: 2 m + ~15 dependent point operations.  A slice with at most four
+        // live buckets takes sum_h id_h * B_h by ONE shared double-and-add over the bucket ids instead (15 doublings + ~7.5 additions per
+        // live bucket, the points re-read from L1 where a bit is set): the kernel lasts as long as its slowest slice, and four is what the
+        // fullest slice of such a batch holds
+        u32 live = 0, kk[4] = {0, 0, 0, 0};
+        if (m >= 16) {
+            for (u32 k = 0; k < m; ++k) {
+                const uint4* p = (const uint4*)&bk[k];
+                const uint4 a = p[4], b = p[5], c2 = p[6];  // zz = words 18 .. 26: exactly zero <=> the bucket is the identity as the combine stored it
+                if (a.z | a.w | b.x | b.y | b.z | b.w | c2.x | c2.y | c2.z) {
+                    if (live < 4) kk[live] = k;
+                    ++live;
+                }
+            }
+        }
+        if (m >= 16 && live <= 4) {
+            XYZZz<BF> sc = xyzzz_identity<BF>();
+            if (live) {
+                const u32 base_id = t * m + 1;  // global id of the slice's first bucket
+                for (int i = 31 - __clz(base_id + kk[live - 1]); i >= 0; --i) {  // the ids of a slice share their top bits: the largest one bounds the loop
+                    sc = xyzzz_dbl(sc);
+                    for (u32 h = 0; h < live; ++h)
+                        if (((base_id + kk[h]) >> i) & 1u) sc = xyzzz_add(sc, load_raw<BF>(&bk[kk[h]]));
+                }
+            }
+            total = sc;
+        } else {
         XYZZz<BF> run = xyzzz_identity<BF>(), acc = xyzzz_identity<BF>();
         for (int k = (int)m - 1; k >= 0; --k) {
             const XYZZz<BF> v = load_raw<BF>(&bk[k]);
@@ -812,6 +840,7 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZzMem* __restr
             acc = xyzzz_add(acc, sc);
         }
         total = acc;
+        }
     }
     sh[threadIdx.x] = total;
     __syncthreads();
