@@ -24,6 +24,14 @@ Outside the timed headline region the same process also reports
                    RCCL all-gather of the 96-byte partials;
   single_process   (N > 1) the same 2^26 MSM through the C ABI's device group from rank 0 alone (trh_init_multi over the N GPUs:
                    what a single Rust prover process linking libtrh.so gets), device-resident scalars handed over with peer copies.
+  e2e              (N = 1) BASELINE config 4 under the driver's clock: the k = 18 witness-shaped create_proof schedule replay
+                   (tiny_ram_halo2_amd.replay) in three modes -- polynomials resident, host polynomials through the batched
+                   host-pointer entries, host polynomials through one trh_msm / trh_best_fft call at a time (north_star's literal
+                   integration) -- with GPU / PCIe-inclusive wall totals, link GB/s against the probed peak and the number of
+                   primitive results compared with the oracle (never the thing timed).  --no-e2e skips it;
+  collective       which backend carried the partials, over how many ranks and which devices, proven by an all-reduce.
+`python bench.py --gpus N` WITHOUT a torch.distributed.run environment spawns its N ranks itself (fresh child processes, started
+before this process makes any GPU call; the parent only waits and relays rank 0's line).
 `--global-log-n L` makes the HEADLINE run strong-scaling instead (2^L pairs in total, split over the ranks); the JSON line
 says which mode produced `value`.  A failed result check prints the line with "check": "MISMATCH" and exits with status 1.
 """
@@ -108,6 +116,10 @@ def cpu_baseline_ntt(field: str, log_n: int):
              "sample": f"{reps} x 2^{log_n} Fp best_fft (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}, last)
 
 
+TRAFFIC_SOURCE = ("profiles/traffic.json: HBM bytes per launch from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over this same command "
+                  "(tools/profile.sh, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); read from the file, NOT measured in this run")
+
+
 def load_traffic(name: str):
     """PMC-derived HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -150,6 +162,127 @@ def msm_roofline(n, acc_ms, tm, traffic):
 # profiles/*_msm_sq_counters.txt) of which 8 x 81 + 2 x 45 product, 9 x 45 reduction and 3 x 9 subtrahend multiply-adds (v_mad_i64_i32)
 MADS_PER_MADD = 738 + 405 + 27
 OTHER_PER_MADD = 1733 - MADS_PER_MADD
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes -- this process has made no GPU call
+    (not even `import torch`) and never will -- with the environment torch.distributed.run would give them, relay rank 0's JSON line,
+    return the worst exit code.  If no rank printed a line (a rank died before the collective came up), print one that says so."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TRH_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("TRH_BENCH_SPAWN_TIMEOUT", "1500"))
+    line, first_fail = None, None
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    open_out = True
+    while any(p.poll() is None for p in procs) or open_out:
+        if open_out and sel.select(timeout=0.5):
+            ln = procs[0].stdout.readline()
+            if ln == "":
+                open_out = False
+                sel.unregister(procs[0].stdout)
+            elif ln.startswith("{"):
+                line = ln.strip()
+        elif not open_out:
+            time.sleep(0.2)
+        rcs = [p.poll() for p in procs]
+        if first_fail is None and any(rc not in (None, 0) for rc in rcs):
+            first_fail = time.time()
+        # a rank that died leaves the others in a rendezvous or a collective: give them a minute, then end OUR children by pid
+        if (first_fail is not None and time.time() - first_fail > 60) or time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    rcs = [p.wait() for p in procs]
+    if line is None:
+        line = json.dumps({"metric": METRIC, "value": None, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                           "collective": {"backend": os.environ.get("TRH_BENCH_BACKEND", "nccl"), "world": args.gpus, "devices": None, "ok": False,
+                                          "error": f"no rank printed a result line; exit codes {rcs}"}})
+    print(line)
+    sys.stdout.flush()
+    return max([abs(rc) for rc in rcs] + [0]) and 1
+
+
+def e2e_replays(modes=("resident", "dropin-batched", "dropin")):
+    """BASELINE config 4 (k = 18, WORD_BITS = 32; /root/reference/src/test_utils.rs:41-49): the create_proof schedule replay over
+    witness-shaped columns in each mode, the first results of the MSM / FFT / domain primitives of every run compared with the oracle
+    (cpu_ref: checker only, outside every timed figure -- the replays time their steps with events / around their own calls)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_ref
+    from tiny_ram_halo2_amd import replay
+    th = usable_cores()
+    out = {"workload": "create_proof schedule of TinyRamCircuit<32, 8> (k = 18: 504 MSMs of 2^18 + 1 pairs, 497 iNTTs, 497 extended-coset transforms, lookups, "
+                       "grand products, h(X), multiopen + IPA), witness-shaped columns, one proof per mode", "modes": {}}
+    for mode in modes:
+        stat = {"checked": 0, "failed": []}
+
+        def hook(kind, inp, res, stat=stat):
+            seen = stat.setdefault("seen", {})
+            seen[kind] = seen.get(kind, 0) + 1
+            first = seen[kind] == 1 or (kind == "commit_lagrange" and "column_class" in inp)
+            ok = None
+            if kind in ("commit_lagrange", "commit") and first:
+                want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", inp["scalars"], inp["bases"].download(), threads=th))
+                ok = bool((np.asarray(res)[:8] == want).all())
+            elif kind == "best_multiexp" and first:
+                want = cpu_ref.to_affine(inp["curve"], cpu_ref.best_multiexp(inp["curve"], inp["scalars"], inp["bases"], threads=th))
+                ok = bool((np.asarray(res)[:8] == want).all())
+            elif kind == "best_fft" and first:
+                ok = bool((np.asarray(res) == cpu_ref.best_fft(inp["field"], inp["a"], inp["omega"], inp["log_n"], threads=th)).all())
+            elif kind == "best_fft_padded" and first:
+                full = np.zeros((1 << inp["log_n"], 4), dtype=np.uint64)
+                full[: inp["a"].shape[0]] = inp["a"]
+                ok = bool((np.asarray(res) == cpu_ref.best_fft(inp["field"], full, inp["omega"], inp["log_n"], threads=th)).all())
+            elif kind == "evals" and first:
+                ok = bool((np.asarray(res) == cpu_ref.eval_polynomial(inp["field"], np.asarray(inp["a"]).reshape(-1, 4), inp["x"])).all())
+            elif kind in ("lagrange_to_coeff", "coeff_to_extended", "coeff_to_extended_blocks") and first:
+                field, j, k = inp["domain"]
+                dom = cpu_ref.EvaluationDomain(field, j, k)
+                a = np.asarray(inp["a"]).reshape(-1, 4)
+                if kind == "lagrange_to_coeff":
+                    ok = bool((np.asarray(res).reshape(-1, 4) == dom.lagrange_to_coeff(a)).all())
+                else:
+                    want = np.asarray(dom.coeff_to_extended(a)).reshape(-1, 4)
+                    if kind == "coeff_to_extended":
+                        ok = bool((np.asarray(res).reshape(-1, 4) == want).all())
+                    else:  # block r, entry q == coeff_to_extended(a)[8 q + r]
+                        nb, step = inp["n_blocks"], want.shape[0] // a.shape[0]
+                        got = np.asarray(res).reshape(nb, a.shape[0], 4)
+                        ok = all(bool((got[r] == want[r::step]).all()) for r in range(nb))
+            if ok is not None:
+                stat["checked"] += 1
+                if not ok:
+                    stat["failed"].append(kind)
+
+        t0 = time.perf_counter()
+        try:
+            if mode == "resident":
+                r = replay.run(32, batch=64, hook=hook, verbose=False, columns="witness", keygen=False)
+                ent = {"gpu_ms_total": r["gpu_ms_total"], "gpu_ms_total_with_real_gates": r["gpu_ms_total_with_real_gates"], "gpu_ms": r["gpu_ms"], "extended_domain": r["extended_domain"],
+                       "scope": r["scope"]}
+            else:
+                r = replay.run_dropin(32, {"dropin": "literal", "dropin-batched": "batched"}[mode], batch=64, hook=hook, verbose=False, columns="witness")
+                pc = r["pcie"]
+                floor_ms = (pc["h2d_GB"] + pc["d2h_GB"]) / pc["link_peak_GBps_per_direction"] * 1e3  # one direction at a time at the probed pinned rate
+                ent = {"wall_ms_incl_pcie_total": r["wall_ms_incl_pcie_total"], "wall_ms_incl_pcie": r["wall_ms_incl_pcie"], "pcie": pc,
+                       "link_floor_ms": round(floor_ms, 1), "link_floor_frac": round(floor_ms / r["wall_ms_incl_pcie_total"], 3), "scope": r["scope"]}
+            ent["checked_against_oracle"] = stat["checked"]
+            ent["check"] = "oracle limb-for-limb ok" if not stat["failed"] and stat["checked"] else ("MISMATCH: " + ",".join(stat["failed"]) if stat["failed"] else "nothing checked")
+        except Exception as exc:  # reported in the line, and a failed e2e fails the run
+            ent = {"error": repr(exc)[:400], "check": "ERROR"}
+        ent["seconds_incl_host_input_generation_and_checks"] = round(time.perf_counter() - t0, 2)
+        out["modes"][mode] = ent
+    return out
 
 
 def single_process_child(devices, steps: int, log_n: int = 26):
@@ -208,9 +341,12 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form result check (keeps profiles free of the extra 1-pair MSM)")
     ap.add_argument("--global-log-n", type=int, default=0, help="strong scaling: 2^L pairs in TOTAL, range-sharded over the ranks (default: weak, 2^log-n per GPU)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep / strong-scaling / single-process extras (profiling runs)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the k = 18 create_proof replays (N = 1 only; implied by --no-sweep)")
     args = ap.parse_args()
     if args.single_process_child is not None:
         sys.exit(single_process_child([int(v) for v in args.single_process_child.split(",")], args.steps))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))  # before torch is imported: this process never touches a GPU
 
     import torch
     import torch.distributed as dist
@@ -230,12 +366,39 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else None
+    props = torch.cuda.get_device_properties(dev_index)
+    my_dev = f"cuda:{dev_index} {props.name} {getattr(props, 'gcnArchName', '')}".strip()
+    try:  # the PCI address tells two physical devices apart (uuid / pci ids are not on every torch build)
+        my_dev += f" pci {props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+    except Exception:
+        pass
+    collective = {"backend": None, "world": world, "devices": [my_dev], "ok": True}
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        collective = {"backend": backend, "world": world, "devices": None, "ok": False}
+        try:
+            tmo = datetime.timedelta(seconds=float(os.environ.get("TRH_BENCH_INIT_TIMEOUT", "180")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+            # proof that the backend really spans `world` ranks: every rank contributes 1 (on its GPU for RCCL) and names its device
+            one = torch.ones(1, dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(one)
+            names = [None] * world
+            dist.all_gather_object(names, my_dev)
+            collective = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": names, "ok": int(one.item()) == world and dist.get_backend() == backend,
+                          "all_reduce_of_ones": int(one.item())}
+            if not collective["ok"]:
+                raise RuntimeError(f"collective check failed: {collective}")
+        except Exception as exc:  # never switch backend silently: the line says what failed and the run exits non-zero
+            collective["error"] = repr(exc)[:400]
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": None, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                                  "higher_is_better": True, "collective": collective}))
+                sys.stdout.flush()
+            sys.exit(1)
     api.init(dev_index)
     stream = torch.cuda.current_stream().cuda_stream
     curve = "pallas"
@@ -464,6 +627,14 @@ def main():
             ms2, chk2 = time_ntt(lg, 20, 3, True)
             e = ntt_entry(lg, ms2, chk2)
             sweep.append({"op": "ntt", "field": "fp", "log_n": lg, "value": e["value"], "unit": "elems/s", "ms": ms2, "check": chk2, "roofline": e["roofline"]})
+    e2e = None
+    if world == 1 and not args.no_sweep and not args.no_e2e:
+        torch.cuda.empty_cache()
+        e2e = e2e_replays()
+        for mname, ent in e2e["modes"].items():
+            if ent.get("check") != "oracle limb-for-limb ok":
+                failed.append(f"e2e {mname}: {ent.get('check')}")
+        torch.cuda.empty_cache()
     if not args.no_sweep and world > 1 and mode == "weak":
         # BASELINE config 5: ONE 2^26 MSM over the N ranks (strong scaling), the same path as the headline
         L = 26
@@ -473,7 +644,7 @@ def main():
         chk5 = check_msm(w5, res5)
         w5.destroy()
         if rank == 0:
-            strong = {"workload": f"ONE 2^{L} Pallas MSM range-sharded over {world} ranks ({hi5 - lo5} pairs each), RCCL all-gather of the 96-byte partials, host add",
+            strong = {"workload": f"ONE 2^{L} Pallas MSM range-sharded over {world} ranks ({hi5 - lo5} pairs each), {collective['backend']} all-gather of the 96-byte partials, host add",
                       "value": (1 << L) * max(args.steps // 2, 3) / el5, "unit": "pairs/s", "ms_per_msm": el5 / max(args.steps // 2, 3) * 1e3, "scaling": "strong", "check": chk5,
                       "accumulate_kernel_ms": acc5, "window_bits": tm5["window_bits"]}
         # the same MSM from ONE process through the C ABI's device group: a CHILD process of rank 0 (its own libtrh, trh_init_multi over the
@@ -514,14 +685,16 @@ def main():
             "higher_is_better": True,
             "scaling": mode,
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "u255 (255-bit modular integers as 9 x 29/30-bit limbs in i32 / i64 lanes)",
             "data": "synthetic",
             "config": {"workload": f"Pallas MSM, {shape}, random 254-bit scalars, distinct bases (s0+i*d)G, inputs resident in HBM: scalars as 32-byte Montgomery words, "
                                    "bases in a resident handle, i.e. already converted to libtrh's 128-byte signed-limb records (once per handle, 1.0 ms at 2^24, "
                                    "outside the timed step; `with_base_conversion` is the rate with that conversion inside every step)", "curve": curve,
                        "pairs_per_gpu": n, "pairs_total": n_total, "mode": f"{mode} scaling" + (" (--global-log-n)" if mode == "strong" else " (default)"),
                        "window_bits": tm["window_bits"], "windows": tm["windows"],
-                       "parallelism": f"range-shard x{world}, one process per GPU, RCCL all-gather of 96-byte partials" if world > 1 else "single GPU"},
+                       "parallelism": f"range-shard x{collective['world']}, one process per GPU, {collective['backend']}" + (" (= RCCL)" if collective["backend"] == "nccl" else "") +
+                                      " all-gather of 96-byte partials" if world > 1 else "single GPU"},
+            "collective": collective,
             "roofline": roof,
             # what actually bounds the kernel: VALU issue.  Per mixed add 1170 v_mad_i64_i32 (8 products of 81, 2 squares of 45, 9 reductions
             # of 45, 27 for the fused subtrahends) and ~560 other ALU instructions (SQ_INSTS_VALU: 1733 per mixed add and wave); peaks are the
@@ -532,8 +705,13 @@ def main():
             "check": check,
             "secondary": ntt,
         }
+        out["roofline"]["traffic_source"] = TRAFFIC_SOURCE
+        if ntt is not None:
+            ntt["roofline"]["traffic_source"] = TRAFFIC_SOURCE
         if sweep is not None:
             out["sweep"] = sweep
+        if e2e is not None:
+            out["e2e"] = e2e
         if strong is not None:
             out["strong"] = strong
         if single is not None:

@@ -3,6 +3,7 @@
 // address) by tests/test_hostcombine.py: the hand-over through the generation counter / pending count must be race-free.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -30,6 +31,27 @@ int main() {
     run(none, 4u, &f[3]);
     a.join(); b.join(); c.join();
     for (int v : f) bad += v;
+    // zero detection (the zero-padded vectors of coeff_to_extended): an all-zero source is reported and dst is left alone; a source
+    // whose tail is zero is copied with the skipped parts cleared; a single non-zero byte anywhere defeats the detection
+    for (trh::CopyPool* pool : {up, none}) {
+        const size_t sizes[] = {1, 4096, (1u << 20) - 1, (1u << 20) + 1, (5u << 20) + 777, 16u << 20};
+        for (size_t sz : sizes) {
+            std::vector<unsigned char> src(sz, 0), dst(sz, 0xEE);
+            if (!pool->copy((char*)dst.data(), (const char*)src.data(), sz, true)) ++bad;                      // zero throughout
+            for (size_t i = 0; i < sz; i += 997) if (dst[i] != 0xEE) { ++bad; break; }                           // ... and dst untouched
+            for (size_t pos : {(size_t)0, sz / 2, sz - 1}) {
+                std::fill(src.begin(), src.end(), 0); std::fill(dst.begin(), dst.end(), 0xEE);
+                src[pos] = 7;
+                if (pool->copy((char*)dst.data(), (const char*)src.data(), sz, true)) ++bad;
+                if (memcmp(dst.data(), src.data(), sz) != 0) ++bad;                                                // the zero parts were cleared
+            }
+            std::fill(dst.begin(), dst.end(), 0xEE);
+            for (size_t i = 0; i < sz / 8 + 1 && i < sz; ++i) src[i] = (unsigned char)(i * 31 + 1);               // data, then padding
+            if (pool->copy((char*)dst.data(), (const char*)src.data(), sz, true)) ++bad;
+            if (memcmp(dst.data(), src.data(), sz) != 0) ++bad;
+        }
+    }
+    delete up; delete down; delete none;  // the destructor stops and joins the workers (per-context pools die with their context)
     std::printf(bad ? "copypool: FAILED (%d)\n" : "copypool: ok\n", bad);
     return bad ? 1 : 0;
 }

@@ -1,6 +1,7 @@
 // Host threads that move bytes between pageable memory and the pinned staging rings of hostio.hip (no HIP in here: the pool is
 // compiled and run on its own under -fsanitize=thread by tests/native/copypool_test.cpp).
 #pragma once
+#include <stdint.h>
 #include <string.h>
 
 #include <atomic>
@@ -11,54 +12,107 @@
 
 namespace trh {
 
-// One pool per direction (the upload side runs on the calling thread, the download side of a pipeline on its helper thread: they
-// must not queue behind each other).  Heap-allocated and never destroyed: worker threads parked on a condition variable at
-// process exit are harmless, a destructor joining them from a static object is not.
+// true when every byte of [p, p + bytes) is zero.  Data that is not zero answers after the first word; a zero range costs one read pass
+// (no write), which is what the zero-padded vectors of coeff_to_extended are for 7/8 of their length.
+inline bool all_zero(const char* p, size_t bytes) {
+    size_t i = 0;
+    for (; i < bytes && ((uintptr_t)(p + i) & 7); ++i) if (p[i]) return false;
+    const uint64_t* w = (const uint64_t*)(p + i);
+    const size_t nw = (bytes - i) / 8;
+    size_t k = 0;
+    for (; k + 8 <= nw; k += 8)
+        if (w[k] | w[k + 1] | w[k + 2] | w[k + 3] | w[k + 4] | w[k + 5] | w[k + 6] | w[k + 7]) return false;
+    for (; k < nw; ++k) if (w[k]) return false;
+    for (i += nw * 8; i < bytes; ++i) if (p[i]) return false;
+    return true;
+}
+
+// One pool per direction and context (the upload side runs on the calling thread, the download side of a pipeline on its helper
+// thread: they must not queue behind each other; two contexts -- two GPUs -- must not queue behind each other either).  A context's
+// pools die with it (the destructor parks no thread: it stops and joins them); the process-wide pools of tests are heap-allocated
+// and never destroyed (a destructor joining threads from a static object at process exit is not harmless).
 class CopyPool {
   public:
-    explicit CopyPool(int threads) : T(threads) {
+    explicit CopyPool(int threads) : T(threads < 0 ? 0 : threads > 62 ? 62 : threads) {  // the zero mask has a bit per part
         for (int i = 0; i < T; ++i) th.emplace_back([this, i] { worker(i); });
-        for (std::thread& t : th) t.detach();
     }
-    // dst <- src, split over the pool and the calling thread; serialised per pool
-    void copy(char* dst, const char* src, size_t bytes) {
-        if (bytes < ((size_t)1 << 20) || T == 0) { memcpy(dst, src, bytes); return; }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            ++gen;
+            gen_atomic.store(gen, std::memory_order_release);
+        }
+        cv_work.notify_all();
+        for (std::thread& t : th) t.join();
+    }
+    CopyPool(const CopyPool&) = delete;
+    CopyPool& operator=(const CopyPool&) = delete;
+
+    // dst <- src, split over the pool and the calling thread; serialised per pool.
+    // detect_zero: a source that is zero throughout is NOT copied and the call returns true (the caller replaces the transfer by a
+    // device-side memset); parts of a mixed source that are zero are cleared in dst, the call returns false.
+    bool copy(char* dst, const char* src, size_t bytes, bool detect_zero = false) {
+        if (bytes < ((size_t)1 << 20) || T == 0) {
+            if (detect_zero && bytes && all_zero(src, bytes)) return true;
+            memcpy(dst, src, bytes);
+            return false;
+        }
         std::lock_guard<std::mutex> call(call_mu);
         const size_t parts = (size_t)T + 1;
         const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
         {
             std::lock_guard<std::mutex> lk(mu);
-            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per;
+            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per; job_detect = detect_zero;
+            zero_mask = 0;
             pending = T;
             pending_atomic.store(T, std::memory_order_release);
             ++gen;
             gen_atomic.store(gen, std::memory_order_release);
         }
         cv_work.notify_all();
-        memcpy(dst, src, per < bytes ? per : bytes);  // part 0 on the caller
+        const bool z0 = part(0, dst, src, bytes, per, detect_zero);  // part 0 on the caller
         for (int spin = 0; spin < 20000 && pending_atomic.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
+        if (!detect_zero) return false;
+        uint64_t mask = zero_mask | (z0 ? 1u : 0u);
+        size_t live = 0;
+        for (size_t k = 0; k < parts; ++k) if (k * per < bytes) ++live;
+        if (mask == (live >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << live) - 1))) return true;  // zero throughout: dst untouched
+        for (size_t k = 0; k < live; ++k)  // a mixed slot (the boundary between the data and its padding): the skipped parts are cleared
+            if (mask >> k & 1) memset(dst + k * per, 0, (k + 1) * per < bytes ? per : bytes - k * per);
+        return false;
     }
 
   private:
+    // part k of the job; returns true when detect was asked and the part is zero (and was therefore NOT written)
+    static bool part(size_t k, char* dst, const char* src, size_t bytes, size_t per, bool detect) {
+        const size_t lo = k * per;
+        if (lo >= bytes) return false;
+        const size_t len = lo + per < bytes ? per : bytes - lo;
+        if (detect && all_zero(src + lo, len)) return true;
+        memcpy(dst + lo, src + lo, len);
+        return false;
+    }
     void worker(int id) {
         unsigned seen = 0;
         for (;;) {
-            char* dst; const char* src; size_t bytes, per;
+            char* dst; const char* src; size_t bytes, per; bool detect;
             {
                 // jobs arrive every few hundred microseconds while a transfer runs: spin briefly before sleeping (a condition-variable
                 // wake-up costs 30-50 us, a quarter of a slot's DMA time)
                 for (int spin = 0; spin < 20000 && gen_atomic.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return gen != seen; });
+                if (stop) return;
                 seen = gen;
-                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per;
+                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per; detect = job_detect;
             }
-            const size_t lo = (size_t)(id + 1) * per;
-            if (lo < bytes) memcpy(dst + lo, src + lo, lo + per < bytes ? per : bytes - lo);
+            const bool z = part((size_t)id + 1, dst, src, bytes, per, detect);
             {
                 std::lock_guard<std::mutex> lk(mu);
+                if (z) zero_mask |= (uint64_t)1 << (id + 1);
                 pending_atomic.store(pending - 1, std::memory_order_release);
                 if (--pending == 0) cv_done.notify_one();
             }
@@ -69,6 +123,8 @@ class CopyPool {
     std::mutex mu, call_mu;
     std::condition_variable cv_work, cv_done;
     char* job_dst = nullptr; const char* job_src = nullptr; size_t job_bytes = 0, job_per = 0;
+    bool job_detect = false, stop = false;
+    uint64_t zero_mask = 0;
     unsigned gen = 0;
     int pending = 0;
     std::atomic<unsigned> gen_atomic{0};

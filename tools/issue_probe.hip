@@ -5,7 +5,12 @@
 //   add        8 independent v_add_u32
 //   mix_indep  8 mads + 4 adds, all independent                       (the kernel's 1170 : 563 ratio)
 //   mix_dep    the reduction-round shape: and -> shift-add -> 5 mads that use the and's result, round after round
-// Reports SIMD cycles per wave instruction from the wall time and the clock measured with s_memrealtime / wall_clock64.
+//   mix_<op>   8 mads + 4 <op> for the other instruction classes of the kernel's carry handling: v_and_b32, v_ashrrev_i64 (64-bit shift),
+//              v_lshl_add_u64 (64-bit add), v_mov_b32
+// Reports, per row, the AVERAGE SIMD cycles per wave instruction and -- what the issue model needs (round 3 read the
+// average of the 8 + 4 mix as the cost of the add) -- the MARGINAL cost of the non-mad instruction:
+//     (cycles of the mixed loop - mads x cycles per mad in the pure-mad loop at the same occupancy) / others
+// once from clock64 (wave lifetimes, independent of the clock the run happened to get) and once from the wall times of the launches.
 // build: hipcc -O3 --offload-arch=gfx950 tools/issue_probe.hip -o tools/issue_probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,6 +27,30 @@ __device__ unsigned long long g_cycles[4096 * 4];
 
 __device__ __forceinline__ void mac(i64& acc, i32 a, i32 b) { asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
 __device__ __forceinline__ void add(i32& x, i32 b) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b)); }
+struct OpAnd { typedef i32 T; static __device__ __forceinline__ void op(T& y, i32 b) { asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(y)); } };
+struct OpMov { typedef i32 T; static __device__ __forceinline__ void op(T& y, i32 b) { asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(b)); } };
+struct OpShr64 { typedef i64 T; static __device__ __forceinline__ void op(T& y, i32 b) { asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(y)); } };
+struct OpAdd64 { typedef i64 T; static __device__ __forceinline__ void op(T& y, i32 b) { asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(y) : "v"((i64)b)); } };
+
+// 8 mads + 4 Op per iteration, all independent (the shape of k_mix_indep with another instruction class in the add's place)
+template <class Op>
+__global__ void __launch_bounds__(256) k_mix_op(u64* out, i32 a, i32 b) {
+    const u64 t_begin = clock64();
+    i64 x[8];
+    typename Op::T y[4];
+    for (int k = 0; k < 8; ++k) x[k] = threadIdx.x + k;
+    for (int k = 0; k < 4; ++k) y[k] = threadIdx.x + k;
+    i32 aa = a + threadIdx.x, bb = b + threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mac(x[2 * k], aa, bb); Op::op(y[k], bb); mac(x[2 * k + 1], aa, bb); }
+    }
+    u64 r = 0;
+    for (int k = 0; k < 8; ++k) r ^= (u64)x[k];
+    for (int k = 0; k < 4; ++k) r ^= (u64)y[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) g_cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = clock64() - t_begin;
+}
 
 __global__ void __launch_bounds__(256) k_mad(u64* out, i32 a, i32 b) {
     const u64 t_begin = clock64();
@@ -129,23 +158,38 @@ int main() {
     int wall_khz = 0;
     CK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
     printf("device %s, %d CUs, clockRate %d kHz, wall clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, wall_khz);
+    printf("avg = SIMD cycles per wave instruction over ALL instructions of the loop; marginal = cycles the non-mad instruction adds to a stream of mads\n"
+           "  = (loop cycles - mads x cycles per mad of the pure-mad row at the same occupancy) / others; `norm` rescales so that the mad row is 4.00\n");
     const int cus = prop.multiProcessorCount;
+    constexpr int NR = 8;
     for (int wps : {2, 3, 4, 8}) {
         const int blocks = cus * wps;  // 256-thread workgroups = 4 waves = one per SIMD
-        struct { const char* name; double mads, others; double ms; } rows[4] = {
-            {"mad", 8.0 * ITERS, 0, 0}, {"add", 0, 8.0 * ITERS, 0}, {"mix_indep 8 mad + 4 add", 8.0 * ITERS, 4.0 * ITERS, 0}, {"mix_dep 5 mad + 3 alu per round", 5.0 * ITERS, 3.0 * ITERS, 0}};
-        double cyc[4];
+        struct { const char* name; double mads, others; double ms; } rows[NR] = {
+            {"mad", 8.0 * ITERS, 0, 0}, {"add", 0, 8.0 * ITERS, 0}, {"mix_indep 8 mad + 4 v_add_u32", 8.0 * ITERS, 4.0 * ITERS, 0}, {"mix_dep 5 mad + 3 alu per round", 5.0 * ITERS, 3.0 * ITERS, 0},
+            {"mix 8 mad + 4 v_and_b32", 8.0 * ITERS, 4.0 * ITERS, 0}, {"mix 8 mad + 4 v_mov_b32", 8.0 * ITERS, 4.0 * ITERS, 0},
+            {"mix 8 mad + 4 v_ashrrev_i64", 8.0 * ITERS, 4.0 * ITERS, 0}, {"mix 8 mad + 4 v_lshl_add_u64", 8.0 * ITERS, 4.0 * ITERS, 0}};
+        double cyc[NR];
         rows[0].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mad, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[0]);
         rows[1].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_add, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[1]);
         rows[2].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_indep, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[2]);
         rows[3].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_dep, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[3]);
-        for (int i = 0; i < 4; ++i) {
+        rows[4].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_op<OpAnd>, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[4]);
+        rows[5].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_op<OpMov>, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[5]);
+        rows[6].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_op<OpShr64>, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[6]);
+        rows[7].ms = run([](int b, u64* o) { hipLaunchKernelGGL(k_mix_op<OpAdd64>, dim3(b), dim3(256), 0, 0, o, 3, 5); }, blocks, d_out, &cyc[7]);
+        // every SIMD holds wps waves for the whole kernel: SIMD cycles per wave instruction = wave lifetime / (instructions per wave x wps)
+        const double mad_cyc = cyc[0] / (rows[0].mads * wps);      // cycles per mad, pure-mad loop
+        const double mad_ms = rows[0].ms / (rows[0].mads * wps);   // the same in wall time
+        for (int i = 0; i < NR; ++i) {
             auto& r = rows[i];
-            // every SIMD holds wps waves for the whole kernel: SIMD cycles per wave instruction = wave lifetime / (instructions per wave x wps)
             const double per_inst = cyc[i] / ((r.mads + r.others) * wps);
-            const double model2 = (r.mads * 4 + r.others * 2) / (r.mads + r.others);
-            printf("waves/SIMD %d  %-34s %8.3f ms  %5.2f SIMD cycles per wave instruction (clock64; effective clock %.2f GHz)   4/2-cycle model %.2f, all-4 model 4.00\n", wps, r.name, r.ms,
-                   per_inst, cyc[i] / (r.ms * 1e-3) / 1e9, model2);
+            printf("waves/SIMD %d  %-32s %8.3f ms  avg %5.2f (norm %5.2f) cycles/inst, clock %.2f GHz", wps, r.name, r.ms, per_inst, per_inst * 4.0 / mad_cyc, cyc[i] / (r.ms * 1e-3) / 1e9);
+            if (r.others > 0) {
+                const double marg_cyc = (cyc[i] / wps - r.mads * mad_cyc) / r.others;
+                const double marg_ms = (r.ms / wps - r.mads * mad_ms) / r.others;
+                printf("   MARGINAL non-mad: %5.2f cycles (norm %5.2f; from wall times, in units of a mad's time / 4: %5.2f)", marg_cyc, marg_cyc * 4.0 / mad_cyc, marg_ms * 4.0 / mad_ms);
+            }
+            printf("\n");
         }
     }
     hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, 0, d_out);

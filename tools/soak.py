@@ -1,19 +1,19 @@
-"""Randomised self-consistency soak of libtrh (no oracle: different code paths of the library must agree bit for bit).
-tools/soak.py [seconds] [seed]"""
+"""Randomised soak of libtrh: different code paths of the library must agree bit for bit (no oracle needed), and -- when the caller
+passes the oracle module (tests/test_gpu_soak.py does; the product side never imports it) -- a share of the MSM / NTT trials is also
+compared with cpu_ref.best_multiexp / best_fft.
+    tools/soak.py [seconds] [seed]            stand-alone, self-consistency only
+    run(budget_s, seed, oracle=None) -> (stats, failures)   from a test"""
 import os, random, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 import torch
 from tiny_ram_halo2_amd import api, permutation, poly, synth
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = random.Random(seed)
-api.init(0)
 MOD = {"fp": poly._MODULUS["fp"], "fq": poly._MODULUS["fq"]}
-t_end = time.time() + budget
-stats = {"msm": 0, "ntt": 0, "lookup": 0, "blocks": 0, "hostio": 0, "products": 0}
-fails = 0
+KINDS = ["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products"]
+rng = random.Random(1)  # re-seeded by run()
+cpu_ref = None          # the oracle module when a test hands it over
 
 
 def limbs(field, v):
@@ -37,8 +37,8 @@ def scalars(field, n, kind):
     return a
 
 
-while time.time() < t_end:
-    which = rng.choice(["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products"])
+def trial(which, fails):
+    """one random trial of kind `which`; a mismatch is printed with its parameters and appended to `fails`"""
     if which == "msm":
         curve = rng.choice(["pallas", "vesta"])
         sf = api.SCALAR_FIELD[curve]
@@ -71,8 +71,12 @@ while time.time() < t_end:
         except api.TrhError:
             pass
         ok = ok and (api.best_multiexp(curve, sc, xy) == ref).all()
+        if cpu_ref is not None and n <= (1 << 16):  # the oracle's best_multiexp on the same host arrays (incl. the identity / duplicate bases)
+            want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, sc, xy, threads=cpu_ref.hardware_threads()))
+            ok = ok and (np.asarray(ref)[:8] == want).all()
+            _ORACLE_COUNT[0] += 1
         if not ok:
-            fails += 1
+            fails.append(which)
             print("MSM MISMATCH", curve, n, flush=True)
     elif which == "ntt":
         field = rng.choice(["fp", "fq"])
@@ -83,14 +87,20 @@ while time.time() < t_end:
         a = synth.field_elements(rng.randrange(1 << 30), batch * n).reshape(batch, n, 4)
         d = torch.from_numpy(a.view(np.int64).copy()).cuda()
         lag = dom.coeff_to_lagrange(d.clone())
+        if cpu_ref is not None and k <= 18:  # coeff_to_lagrange is best_fft with omega: the oracle's transform of the first column
+            want = cpu_ref.best_fft(field, a[0], np.asarray(dom._w["omega"], dtype=np.uint64), k, threads=cpu_ref.hardware_threads())
+            okf = (lag[0].cpu().numpy().view(np.uint64) == want).all()
+            _ORACLE_COUNT[0] += 1
+        else:
+            okf = True
         back = dom.lagrange_to_coeff(lag)
-        ok = (back.cpu().numpy().view(np.uint64) == a).all()
+        ok = okf and (back.cpu().numpy().view(np.uint64) == a).all()
         if dom.extended_k <= 22:
             ext = dom.coeff_to_extended(d)
             bk = dom.extended_to_coeff(ext).cpu().numpy().view(np.uint64)
             ok = ok and (bk[:, :n] == a).all() and (bk[:, n:] == 0).all()
         if not ok:
-            fails += 1
+            fails.append(which)
             print("NTT MISMATCH", field, k, batch, flush=True)
     elif which == "blocks":
         # the coset-block form of the extended domain against the full one (round 3): every block entry, and the quotient back from j - 1 blocks
@@ -116,7 +126,7 @@ while time.time() < t_end:
         back = dom.blocks_to_quotient(vals[0].contiguous().clone(), divide_by_vanishing=False).cpu().numpy().view(np.uint64)
         ok = ok and (back[:n] == h[:n]).all() and (back[n:] == 0).all()
         if not ok:
-            fails += 1
+            fails.append(which)
             print("BLOCKS MISMATCH", field, k, j, batch, nb, flush=True)
     elif which == "hostio":
         # host-pointer entries against the device-resident ones (round 3): batch FFT, batched commitments, range-tiled host MSMs
@@ -151,7 +161,7 @@ while time.time() < t_end:
         ok = ok and (api.best_multiexp(curve, sc, xy) == got[0]).all() and (bases.msm(sc) == got[0]).all()
         del os.environ["TRH_HOST_TILE_LOG"]
         if not ok:
-            fails += 1
+            fails.append(which)
             print("HOSTIO MISMATCH", field, k, count, curve, n, batch, flush=True)
     elif which == "products":
         # product columns from rows of factors (trh_product_terms_dev + batch_invert_mul + batched prefix product) against big integers,
@@ -200,7 +210,7 @@ while time.time() < t_end:
         one = np.array(limbs(field, 1), dtype=np.uint64)
         ok = ok and (ph[~zero] == one).all() and not ih[zero].any()
         if not ok:
-            fails += 1
+            fails.append(which)
             print("PRODUCTS MISMATCH", field, k, cnt, flush=True)
     else:
         field = rng.choice(["fp", "fq"])
@@ -222,8 +232,35 @@ while time.time() < t_end:
             ints = [int.from_bytes(r.tobytes(), "little") * rinv % m for r in pa_h]
             ok = ok and ints == sorted(ints)
         if not ok:
-            fails += 1
+            fails.append(which)
             print("LOOKUP MISMATCH", field, n, tsize, flush=True)
-    stats[which] += 1
-print("soak:", stats, "failures:", fails)
-sys.exit(1 if fails else 0)
+
+
+def run(budget_s: float, seed: int, oracle=None, kinds=None):
+    """random trials for budget_s seconds from `seed` (logged); returns (stats, failures)"""
+    global rng, cpu_ref
+    rng = random.Random(seed)
+    cpu_ref = oracle
+    api.init(0)
+    stats = {k: 0 for k in dict.fromkeys(KINDS)}
+    stats["vs_oracle"] = 0
+    fails = []
+    t_end = time.time() + budget_s
+    print(f"soak: seed {seed}, budget {budget_s:.0f} s, oracle {'yes' if oracle is not None else 'no'}", flush=True)
+    while time.time() < t_end:
+        which = rng.choice(kinds or KINDS)
+        before = _ORACLE_COUNT[0]
+        trial(which, fails)
+        stats[which] += 1
+        stats["vs_oracle"] += _ORACLE_COUNT[0] - before
+    return stats, fails
+
+
+_ORACLE_COUNT = [0]
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    stats, fails = run(budget, seed)
+    print("soak:", stats, "failures:", len(fails))
+    sys.exit(1 if fails else 0)
