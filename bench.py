@@ -144,24 +144,32 @@ def msm_roofline(n, acc_ms, tm, traffic):
             "traffic": traffic, "kernel_ms": acc_ms, "algorithmic_bytes": 96 * n,
             # the kernel is limited by VALU issue, not by HBM (see `valu`): the counter traffic is what it actually pulls per launch
             "limiter": "valu-issue", "traffic_gbs": (traffic / (acc_ms * 1e-3) / 1e9) if traffic else None}
-    # issue model (tools/issue_probe.hip, profiles/issue_probe_r03.txt): a v_mad_i64_i32 occupies its SIMD for 4 cycles; a 32-bit ALU
-    # instruction for 2 in a loop of its own, but for 3.3-3.9 (3.6 here) between multiply-adds at the 2-4 waves per SIMD this
-    # 160-VGPR kernel can have.  `issue_frac` prices the non-mad instructions that way; the two-rate figure (every non-mad at 2
-    # cycles) is kept as the bound on what >= 8 waves per SIMD could buy.
-    mad_peak = 32.7e12
-    other_mixed = mad_peak * 4.0 / 3.6
-    valu = {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / (acc_ms * 1e-3),
-            "mad_i64_i32_per_s": MADS_PER_MADD * madds / (acc_ms * 1e-3), "mad_peak_per_s": mad_peak,
-            "other_valu_per_s": OTHER_PER_MADD * madds / (acc_ms * 1e-3), "other_peak_per_s_mixed_stream": other_mixed, "other_peak_per_s_alone": 65e12,
-            "issue_frac": (MADS_PER_MADD * madds / mad_peak + OTHER_PER_MADD * madds / other_mixed) / (acc_ms * 1e-3),
-            "issue_frac_two_rate_model": (MADS_PER_MADD * madds / mad_peak + OTHER_PER_MADD * madds / 65e12) / (acc_ms * 1e-3)}
+    # issue model, corrected in round 4: every instruction class of the mixed addition is priced at its MARGINAL cost in a
+    # stream of multiply-adds at the kernel's 3 waves per SIMD (tools/issue_probe.hip, profiles/issue_probe_r04.txt, normalised to
+    # v_mad_i64_i32 = 4.00 cycles) -- round 3 had read the AVERAGE of an 8 mad + 4 add loop (3.6) as the cost of the add.  The counts are the
+    # static instruction mix of the kernel's main line (llvm disassembly of msm_accumulate_seg_kernel<Fp>: blocks BB11_16 + BB11_26).
+    mad_peak = 32.7e12  # lane-operations/s of a pure v_mad_i64_i32 stream (tools/microbench.hip)
+    mad_equiv = sum(cnt * ISSUE_CYCLES[k] / 4.0 for k, cnt in MADD_MIX.items())
+    other = sum(cnt for k, cnt in MADD_MIX.items() if k != "v_mad_i64_i32")
+    t = acc_ms * 1e-3
+    valu = {"mixed_adds_per_launch": madds, "mixed_adds_per_s": madds / t,
+            "instruction_mix_per_mixed_add": MADD_MIX, "marginal_issue_cycles_at_3_waves_per_simd": ISSUE_CYCLES,
+            "mad_i64_i32_per_s": MADD_MIX["v_mad_i64_i32"] * madds / t, "mad_peak_per_s": mad_peak, "other_valu_per_s": other * madds / t,
+            "mad_equivalents_per_mixed_add": mad_equiv, "model_cycles_per_valu_instruction": 4.0 * mad_equiv / sum(MADD_MIX.values()),
+            # the launch against the per-class issue model at the pure-multiply-add stream's rate (that stream holds ~2.0 GHz, this kernel ~1.82:
+            # at the kernel's own clock -- SQ counters, profiles/r04_msm_stall_counters.txt -- the same model gives 3.69 / 4.06 = 0.91)
+            "issue_frac": mad_equiv * madds / mad_peak / t,
+            "issue_frac_all_non_mad_at_2_cycles": (MADD_MIX["v_mad_i64_i32"] + other * 0.5) * madds / mad_peak / t,
+            "not_a_term": "instruction fetch (SQC_ICACHE hit rate 99.9999 %), exposed gather latency (7 % of wave time parked, overlapped by the SIMD's other two waves)"}
     return roof, valu
 
 
 # instruction mix of one mixed addition in the signed 29-bit domain: 1733 VALU instructions per wave and mixed add (SQ_INSTS_VALU,
-# profiles/*_msm_sq_counters.txt) of which 8 x 81 + 2 x 45 product, 9 x 45 reduction and 3 x 9 subtrahend multiply-adds (v_mad_i64_i32)
-MADS_PER_MADD = 738 + 405 + 27
-OTHER_PER_MADD = 1733 - MADS_PER_MADD
+# profiles/*_msm_sq_counters.txt); by class from the disassembly of the kernel's main line: 8 x 81 + 2 x 45 product, 9 x 45 reduction and
+# 3 x 9 subtrahend multiply-adds (+ 9 from address / bookkeeping arithmetic), the carry handling's mask / 64-bit shift / 64-bit add triples
+MADD_MIX = {"v_mad_i64_i32": 1179, "v_and_b32": 156, "v_lshl_add_u64": 147, "v_ashrrev_i64": 144, "v_mov_b32": 23, "other_32bit_alu": 84}
+# marginal SIMD cycles next to multiply-adds at 3 waves per SIMD (profiles/issue_probe_r04.txt, `norm` column; other_32bit_alu priced as v_add_u32)
+ISSUE_CYCLES = {"v_mad_i64_i32": 4.0, "v_and_b32": 2.80, "v_lshl_add_u64": 3.58, "v_ashrrev_i64": 3.11, "v_mov_b32": 1.50, "other_32bit_alu": 2.80}
 
 
 def spawn_ranks(args) -> int:

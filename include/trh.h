@@ -119,6 +119,8 @@ int trh_host_alloc(void** host, size_t bytes);
 int trh_host_free(void* host);
 typedef struct trh_io_stats {
     double h2d_bytes, d2h_bytes, h2d_seconds, d2h_seconds;
+    double h2d_zero_bytes; /* of h2d_bytes: pinned slots that were zero throughout (the padding of trh_best_fft's zero-padded vectors)
+                              and were cleared on the device instead of crossing the link */
 } trh_io_stats_t;
 int trh_io_stats(trh_io_stats_t* out, int reset);
 
@@ -157,7 +159,9 @@ int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
                         int scalars_are_montgomery, void* stream);
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
-/* batch of MSMs over the same bases (one per column): scalars_dev holds batch x n x 4 u64 */
+/* batch of MSMs over the same bases (one per column): scalars_dev holds batch x n x 4 u64.  Batches of >= 8 items run in chunks
+ * of <= 64 and synchronise `stream` once per chunk (the entry counts of the chunk are read back to size the accumulation's segments
+ * for sparse -- witness-shaped -- columns), so the call is not fully asynchronous even before the final hand-over of the points. */
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch,
                       int scalars_are_montgomery, void* stream, uint64_t* out_xyz /* batch x 12 */);
 /* Params::commit / commit_lagrange for `batch` polynomials already in device memory (batch x n x 4 u64, back to back):
@@ -382,9 +386,16 @@ int trh_field_op_dev(int field, int op, const void* a_dev, const void* b_dev, vo
  * out Jacobian normalised */
 int trh_point_op_dev(int curve, int op, const void* p_dev, const void* q_dev, void* out_dev, size_t n, void* stream);
 
-/* ---- plain device memory helpers so that non-HIP hosts (Rust, ctypes) can stage buffers ---- */
+/* ---- plain device memory helpers so that non-HIP hosts (Rust, ctypes) can stage buffers ----
+ * trh_free keeps freed blocks for reuse by trh_malloc (per device, by rounded size; it returns when the device has drained, as
+ * hipFree does): at most TRH_POOL_MB MiB (environment, default 4096; 0 switches the pool off), evicting the device's largest idle
+ * blocks first.  The idle blocks are invisible to any other allocator in the process (torch's caching allocator, say): libtrh
+ * returns them when one of its own allocations fails, and trh_pool_trim() returns them on request.  Freeing a block twice is
+ * reported (TRH_EINVAL) while it still waits in the pool. */
 int trh_malloc(void** dev, size_t bytes);
 int trh_free(void* dev);
+int trh_pool_trim(void);
+size_t trh_pool_idle_bytes(void);
 int trh_memcpy_h2d(void* dev, const void* host, size_t bytes);
 int trh_memcpy_d2h(void* host, const void* dev, size_t bytes);
 int trh_stream_synchronize(void* stream);

@@ -60,7 +60,8 @@ class Timing(ctypes.Structure):
 
 
 class IoStats(ctypes.Structure):
-    _fields_ = [("h2d_bytes", ctypes.c_double), ("d2h_bytes", ctypes.c_double), ("h2d_seconds", ctypes.c_double), ("d2h_seconds", ctypes.c_double)]
+    _fields_ = [("h2d_bytes", ctypes.c_double), ("d2h_bytes", ctypes.c_double), ("h2d_seconds", ctypes.c_double), ("d2h_seconds", ctypes.c_double),
+                ("h2d_zero_bytes", ctypes.c_double)]
 
 
 _SIGNATURES = {
@@ -140,6 +141,8 @@ _SIGNATURES = {
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
     "trh_free": ([_vp], ctypes.c_int),
+    "trh_pool_trim": ([], ctypes.c_int),
+    "trh_pool_idle_bytes": ([], ctypes.c_size_t),
     "trh_memcpy_h2d": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
     "trh_memcpy_d2h": ([_vp, _vp, ctypes.c_size_t], ctypes.c_int),
     "trh_stream_synchronize": ([_vp], ctypes.c_int),

@@ -5,8 +5,11 @@
 
 #include <map>
 #include <memory>
+#include <string>
+#include <thread>
 
 #include "ctx.h"
+#include "devpool.h"
 
 #ifndef TRH_BUILD_ID
 #define TRH_BUILD_ID "unknown"
@@ -138,22 +141,15 @@ static int create_ctx(int device, Ctx** out) {
 }
 
 namespace {
-struct DevPool {
+struct DevPool : DevPoolIndex {  // devpool.h: live / idle maps and the eviction order (tested on its own with made-up device ids)
     std::mutex mu;
-    std::map<void*, std::pair<int, size_t>> live;                 // block -> (device, rounded size), blocks handed out
-    std::multimap<std::pair<int, size_t>, void*> idle;            // (device, rounded size) -> block
-    size_t idle_bytes = 0;
 };
 DevPool g_pool;
 size_t pool_cap() {
     static const size_t cap = (size_t)(getenv("TRH_POOL_MB") ? atoll(getenv("TRH_POOL_MB")) : 4096) << 20;
     return cap;
 }
-size_t pool_round(size_t bytes) {
-    if (bytes < 16) bytes = 16;
-    const size_t q = bytes < ((size_t)1 << 20) ? (size_t)4096 : (size_t)1 << 20;
-    return (bytes + q - 1) / q * q;
-}
+size_t pool_round(size_t bytes) { return DevPoolIndex::round(bytes); }
 void pool_release_idle() {  // g_pool.mu held
     for (auto& kv : g_pool.idle) {
         int prev = -1;
@@ -321,6 +317,7 @@ struct PendingGuard {
 int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host, trh_bases* res, size_t offset, size_t n, int mont, uint64_t* out) {
     Ctx& c = ctx();
     TRH_TRY(stage_begin(c));
+    StageScope scope(c);
     Stage& st = c.stage;
     // range boundaries
     std::vector<size_t> cut(1, 0);
@@ -346,9 +343,10 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
     }
     for (size_t t = 0; t < ntiles; ++t) {
         const size_t slot = t & 1, off = cut[t], cur = cut[t + 1] - cut[t];
-        TRH_TRY(stage_h2d(c, st.ring_in[slot].p, coeffs + 4 * off, cur * 32, st.us));
+        // (only the call's first bytes gate anything: every later range streams behind the one before it, full slots throughout)
+        TRH_TRY(stage_h2d(c, st.ring_in[slot].p, coeffs + 4 * off, cur * 32, st.us, t > 0, false, ntiles > 1 || bases_host != nullptr));
         if (bases_host) {
-            TRH_TRY(stage_h2d(c, st.ring_out[slot].p, bases_host + 8 * off, cur * 64, st.us));
+            TRH_TRY(stage_h2d(c, st.ring_out[slot].p, bases_host + 8 * off, cur * 64, st.us, true));
         }
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
         if (t > 0) {  // the previous range finished under this upload
@@ -358,13 +356,15 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
         TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
         const void* bdev = bases_host ? st.ring_out[slot].p : (const void*)((const char*)res->d_xy + (offset + off) * 64);
         const void* bz = bases_host ? nullptr : lazy_bases(res, offset + off, st.cs);
+        // the fixed-base table covers whole sets of at most 2^24 / W pairs, which never split on their own (the growing ranges start above
+        // 3 * 2^21 pairs); only a forced range length (TRH_HOST_TILE_LOG, a test switch) sends a tabled set down the per-window path
         const MsmFixedBase* fb = (!bases_host && ntiles == 1) ? fixed_base(res, offset, n) : nullptr;
         TRH_TRY(msm_enqueue(curve, bdev, bz, st.ring_in[slot].p, cur, 1, cur, mont, st.cs, fb));
     }
     TRH_TRY(msm_finish(curve, st.cs, acc + 12, 1));
     if (ntiles > 1) TRH_TRY(point_sum_host(curve, acc, 2, acc));
     memcpy(out, ntiles > 1 ? acc : acc + 12, 96);
-    return stage_end(c);
+    return scope.finish();
 }
 
 int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases, size_t n, uint64_t* out) {
@@ -467,6 +467,14 @@ int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, 
     return TRH_OK;
 }
 
+// TRH_FORCE_NO_PEER=1: the group behaves as if no pair of devices had peer access -- trh_init_multi enables none, and device-resident
+// scalars reach EVERY shard (the one on the source device included) through the pinned-host hand-over that a box without peer access
+// takes.  For exercising that path on a one-GPU box ({0, 0} groups).
+bool force_no_peer() {  // read per call: a test flips it between two MSMs of one process
+    const char* e = getenv("TRH_FORCE_NO_PEER");
+    return e && atoi(e);
+}
+
 int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out) {
     Range range("trh_msm[sharded]");
     const size_t G = B->shards.size();
@@ -502,23 +510,70 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
     } held(G);
     std::vector<uint64_t> partial(12 * G, 0);
     std::vector<char> active(G, 0);
+    struct Range1 { size_t cnt = 0, local = 0; const char* src = nullptr; };
+    std::vector<Range1> rg(G);
     for (size_t g = 0; g < G; ++g) {
         const size_t lo = B->shard_off[g] > offset ? B->shard_off[g] : offset;
         const size_t hi = B->shard_off[g + 1] < offset + n ? B->shard_off[g + 1] : offset + n;
         if (hi <= lo) continue;
-        trh_bases* sh = B->shards[g];
-        Ctx* sc = sh->owner;
+        Ctx* sc = B->shards[g]->owner;
         held[g].reset(new Enter());
         TRH_TRY(held[g]->begin(sc->own_stream, sc));
-        const size_t cnt = hi - lo, local = lo - B->shard_off[g];
-        TRH_TRY(sc->msm.scalars.ensure(cnt * 32 + 32));
-        const char* src = (const char*)scalars + (lo - offset) * 32;
-        if (scalars_on_host) TRH_TRY(stage_h2d(*sc, sc->msm.scalars.p, src, cnt * 32, sc->own_stream));  // returns when the range left the caller's memory: the DMAs of the G devices overlap
-        else if (src_device == sc->device) TRH_HIP_TRY(hipMemcpyAsync(sc->msm.scalars.p, src, cnt * 32, hipMemcpyDeviceToDevice, sc->own_stream));
-        else TRH_HIP_TRY(hipMemcpyPeerAsync(sc->msm.scalars.p, sc->device, src, src_device, cnt * 32, sc->own_stream));
-        TRH_TRY(msm_enqueue(B->curve, (const char*)sh->d_xy + local * 64, lazy_bases(sh, local, sc->own_stream), sc->msm.scalars.p, cnt, 1, cnt, mont, sc->own_stream,
-                            fixed_base(sh, local, cnt)));
+        rg[g].cnt = hi - lo; rg[g].local = lo - B->shard_off[g];
+        rg[g].src = (const char*)scalars + (lo - offset) * 32;
+        TRH_TRY(sc->msm.scalars.ensure(rg[g].cnt * 32 + 32));
+        if (scalars_on_host) TRH_TRY(stage_ensure(*sc));  // rings and copy threads exist before the uploader threads start
         active[g] = 1;
+    }
+    // Host scalars: ONE uploader thread per shard, each feeding its device through that context's own pinned ring and copy threads (the
+    // G links of a node run in parallel; one thread's memcpy stream -- 60-85 GB/s -- would be the limit of eight 57 GB/s links: a 2^26
+    // MSM over 8 GPUs spent ~30 ms uploading against ~9 ms of arithmetic).  The calling thread holds every shard context's
+    // lock and touches none of their stages meanwhile; it joins uploader g before it enqueues shard g's MSM, so the MSM of shard g starts
+    // while the ranges of the later shards are still crossing.  Caller memory that is page-locked goes to the DMA engines directly.
+    struct Upload { std::thread th; int rc = TRH_OK; std::string err; };
+    std::vector<Upload> up(scalars_on_host ? G : 0);
+    size_t n_active = 0;
+    for (size_t g = 0; g < G; ++g) n_active += active[g] ? 1 : 0;
+    const bool threaded = scalars_on_host && n_active > 1;
+    auto join_all = [&] { for (Upload& u : up) if (u.th.joinable()) u.th.join(); };
+    if (threaded) {
+        for (size_t g = 0; g < G; ++g) {
+            if (!active[g]) continue;
+            Ctx* sc = B->shards[g]->owner;
+            Upload* u = &up[g];
+            const Range1 r = rg[g];
+            u->th = std::thread([sc, u, r] {
+                if (hipSetDevice(sc->device) != hipSuccess) { u->rc = TRH_EHIP; u->err = "hipSetDevice failed in an upload thread"; return; }
+                u->rc = stage_h2d(*sc, sc->msm.scalars.p, r.src, r.cnt * 32, sc->own_stream);
+                if (u->rc != TRH_OK) u->err = trh_last_error();
+            });
+        }
+    }
+    for (size_t g = 0; g < G; ++g) {
+        if (!active[g]) continue;
+        trh_bases* sh = B->shards[g];
+        Ctx* sc = sh->owner;
+        Enter en;
+        int rc = en.begin(sc->own_stream, sc);  // re-entrant: the context is held above, this makes it the active one (and its device current) again
+        if (rc == TRH_OK) {
+            if (threaded) {
+                up[g].th.join();
+                if (up[g].rc != TRH_OK) { set_error("%s", up[g].err.c_str()); rc = up[g].rc; }
+            } else if (scalars_on_host) {
+                rc = stage_h2d(*sc, sc->msm.scalars.p, rg[g].src, rg[g].cnt * 32, sc->own_stream);
+            } else if (force_no_peer() || (!g_peer_ok && src_device != sc->device)) {
+                // no peer access in the group (or forced): through the destination context's pinned ring, stream-ordered on both devices
+                rc = stage_d2d_via_host(*sc, sc->msm.scalars.p, sc->own_stream, rg[g].src, src_device, caller_stream, rg[g].cnt * 32);
+            } else if (src_device == sc->device) {
+                if (hipMemcpyAsync(sc->msm.scalars.p, rg[g].src, rg[g].cnt * 32, hipMemcpyDeviceToDevice, sc->own_stream) != hipSuccess) { set_error("msm[sharded]: device copy failed"); rc = TRH_EHIP; }
+            } else {
+                if (hipMemcpyPeerAsync(sc->msm.scalars.p, sc->device, rg[g].src, src_device, rg[g].cnt * 32, sc->own_stream) != hipSuccess) { set_error("msm[sharded]: peer copy failed: %s", hipGetErrorString(hipGetLastError())); rc = TRH_EHIP; }
+            }
+        }
+        if (rc == TRH_OK)
+            rc = msm_enqueue(B->curve, (const char*)sh->d_xy + rg[g].local * 64, lazy_bases(sh, rg[g].local, sc->own_stream), sc->msm.scalars.p, rg[g].cnt, 1, rg[g].cnt, mont, sc->own_stream,
+                             fixed_base(sh, rg[g].local, rg[g].cnt));
+        if (rc != TRH_OK) { join_all(); return rc; }
     }
     size_t cntp = 0;
     for (size_t g = 0; g < G; ++g) {
@@ -595,10 +650,14 @@ int trh_init_multi(const int* devices, int n_devices) {
         }
         made.push_back(c);
     }
-    // peer access for the hand-over of device-resident scalars.  Not fatal when it cannot be had (hipMemcpyPeerAsync then stages
-    // through the host), but not silent either: trh_group_peer_access() reports it and trh_last_error() names the first pair
+    // peer access for the hand-over of device-resident scalars.  Not fatal when it cannot be had (msm_sharded then hands the
+    // ranges over through pinned host memory, stage_d2d_via_host), but not silent either: trh_group_peer_access() reports it and trh_last_error() names the first pair
     g_peer_ok = 1;
-    for (int i = 0; i < n_devices; ++i)
+    if (force_no_peer()) {
+        g_peer_ok = 0;
+        set_error("trh_init_multi: TRH_FORCE_NO_PEER=1: no peer access enabled; device-resident scalars are handed over through pinned host memory");
+    }
+    for (int i = 0; i < n_devices && !force_no_peer(); ++i)
         for (int j = 0; j < n_devices; ++j)
             if (devices[i] != devices[j]) {
                 int can = 0;
@@ -813,6 +872,7 @@ int trh_commit_batch_host(trh_bases_t bases, const uint64_t* const* polys_host, 
     PendingGuard guard{c};
     if (c.msm.pending_curve >= 0) { guard.armed = false; set_error("commit_batch_host: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
     TRH_TRY(stage_begin(c));
+    StageScope scope(c);
     Stage& st = c.stage;
     size_t chunk = 16;  // 2^18-row columns: 128 MiB and ~7 ms of MSM per chunk
     while (chunk > 1 && chunk * n * 32 > ((size_t)256 << 20)) chunk >>= 1;
@@ -833,7 +893,7 @@ int trh_commit_batch_host(trh_bases_t bases, const uint64_t* const* polys_host, 
         const size_t first = (nchunks - 1) * chunk;
         TRH_TRY(msm_finish(bases->curve, st.cs, out + 12 * first, batch - first));
     }
-    return stage_end(c);
+    return scope.finish();
 }
 
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, int mont, void* stream) {
@@ -976,11 +1036,9 @@ int trh_malloc(void** dev, size_t bytes) {
     const size_t rounded = pool_round(bytes);
     const int device = ctx().device;
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto it = g_pool.idle.find({device, rounded});
-    if (it != g_pool.idle.end()) {
-        *dev = it->second;
-        g_pool.idle.erase(it);
-        g_pool.idle_bytes -= rounded;
+    if (void* hit = g_pool.take(device, rounded)) {
+        *dev = hit;
+        return TRH_OK;
     } else {
         hipError_t e = hipMalloc(dev, rounded);
         if (e != hipSuccess) {
@@ -999,6 +1057,7 @@ int trh_free(void* dev) {
     std::unique_lock<std::mutex> lk(g_pool.mu);
     auto it = g_pool.live.find(dev);
     if (it == g_pool.live.end()) {  // not one of trh_malloc's (or the pool is off)
+        if (g_pool.is_idle(dev)) { set_error("trh_free: block %p was already freed (it waits in the pool)", dev); return TRH_EINVAL; }
         lk.unlock();
         TRH_HIP_TRY(hipFree(dev));
         return TRH_OK;
@@ -1007,29 +1066,43 @@ int trh_free(void* dev) {
     g_pool.live.erase(it);
     lk.unlock();
     int prev = -1;
-    TRH_HIP_TRY(hipGetDevice(&prev));
-    if (prev != key.first) TRH_HIP_TRY(hipSetDevice(key.first));
-    hipError_t e = hipDeviceSynchronize();  // what hipFree would have waited for
-    if (e == hipSuccess && key.second > pool_cap()) e = hipFree(dev);
-    else if (e == hipSuccess) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != key.first) e = hipSetDevice(key.first);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // what hipFree would have waited for
+    if (e != hipSuccess || key.second > pool_cap()) {
+        // not poolable (or the device could not be drained): the block goes back to the runtime either way -- it has left `live`, so keeping
+        // it would leak it and a second trh_free of the pointer would reach hipFree for a block the pool still believes it owns
+        (void)hipGetLastError();
+        const hipError_t ef = hipFree(dev);
+        if (e == hipSuccess) e = ef;
+    } else {
         lk.lock();
-        while (g_pool.idle_bytes + key.second > pool_cap() && !g_pool.idle.empty()) {  // make room: drop the largest idle blocks of this device first
-            auto victim = std::prev(g_pool.idle.end());
+        // make room: drop idle blocks of THIS device, largest first (the keys sort by (device, size), so the device's largest block is
+        // the last entry below (device + 1, 0)); only when the device has none left do other devices' blocks go
+        while (g_pool.idle_bytes + key.second > pool_cap() && !g_pool.idle.empty()) {
+            auto victim = g_pool.victim(key.first);
             int vprev = -1;
             (void)hipGetDevice(&vprev);
             (void)hipSetDevice(victim->first.first);
             (void)hipFree(victim->second);
-            (void)hipSetDevice(vprev);
-            g_pool.idle_bytes -= victim->first.second;
-            g_pool.idle.erase(victim);
+            if (vprev >= 0) (void)hipSetDevice(vprev);
+            g_pool.drop(victim);
         }
-        g_pool.idle.insert({key, dev});
-        g_pool.idle_bytes += key.second;
+        g_pool.put_idle(dev, key);
         lk.unlock();
     }
-    if (prev != key.first) (void)hipSetDevice(prev);
+    if (prev >= 0 && prev != key.first) (void)hipSetDevice(prev);
     TRH_HIP_TRY(e);
     return TRH_OK;
+}
+// gives the blocks trh_free kept back to the device (another allocator in the process -- torch's caching allocator, say -- cannot see them)
+int trh_pool_trim(void) {
+    pool_trim();
+    return TRH_OK;
+}
+size_t trh_pool_idle_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    return g_pool.idle_bytes;
 }
 int trh_memcpy_h2d(void* dev, const void* host, size_t bytes) {
     TRH_ENTER(0);

@@ -11,12 +11,16 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <array>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <vector>
 
 #include "../../include/trh.h"
 #include "curve.h"
+
+namespace trh { class CopyPool; }
 
 namespace trh {
 
@@ -130,6 +134,12 @@ struct Stage {
     DevBuf ring_in[4], ring_out[4];  // device-side ring of the batch pipelines
     // traffic of the host-pointer entry points on this context since trh_io_stats_reset (bytes, host seconds inside the copies)
     double up_bytes = 0, down_bytes = 0, up_s = 0, down_s = 0;
+    double up_zero_bytes = 0;        // of up_bytes: slots that were zero throughout and became a device-side memset instead of a DMA
+    // this context's copy threads (hostio.hip; created at first use, joined in stage_release): one pool per direction, so that uploads and a
+    // pipeline's download helper never queue behind each other, and per CONTEXT, so that the GPUs of a device group are fed in parallel
+    CopyPool* up_pool = nullptr;
+    CopyPool* down_pool = nullptr;
+    std::map<int, std::array<hipEvent_t, NS>> xfer_ev;  // stage_d2d_via_host: "slot filled" events on the source device, per source device
 };
 
 struct Ctx {
@@ -194,8 +204,13 @@ struct Range {
 int stage_ensure(Ctx& c);
 void stage_release(Ctx& c);
 // src_host -> dst_dev on stream s through the upload ring; returns when the source has been read (the last DMA may still be in flight on s)
-// (part_of_batch: more uploads follow at once -- a transfer that fits one slot is then not split, the next call's copy overlaps its DMA)
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch = false);
+// (part_of_batch: more uploads follow at once -- full slots throughout, the next call's copy overlaps this one's DMA; otherwise the
+//  transfer starts and ends with short chunks; head_only: short chunks at the start only -- the first of a run of uploads)
+// (zero_elide: slots whose source is zero throughout become a hipMemsetAsync -- the zero-padded vectors of coeff_to_extended)
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch = false, bool zero_elide = false, bool head_only = false);
+// src (device src_device, ordered behind src_stream) -> dst on dstc's device WITHOUT peer access: slots of dstc's pinned download ring carry
+// the bytes (D2H on src_stream, H2D on dst_stream), everything stream-ordered, no host synchronisation
+int stage_d2d_via_host(Ctx& dstc, void* dst_dev, hipStream_t dst_stream, const void* src_dev, int src_device, hipStream_t src_stream, size_t bytes);
 // src_dev -> dst_host through the download ring, ordered behind the work queued on s; returns when dst_host is complete
 int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
 // Batch pipeline over `count` items (each a group of host buffers): upload (caller thread, stage.us) -> compute(item, in, out,
@@ -214,6 +229,19 @@ struct HostPipe {
 int host_pipeline(Ctx& c, const HostPipe& p);
 int stage_begin(Ctx& c);  // the stage's streams wait for the context's previous work
 int stage_end(Ctx& c);    // drains the three streams
+// Scope of a single-call host entry between stage_begin and its return: on EVERY path out (an error return through TRH_TRY included)
+// the three stage streams are drained first -- kernels and DMAs queued there may still be touching c.io, the rings and the caller's
+// page-locked slice, and the next entry only orders itself behind the stream the context was entered with.
+struct StageScope {
+    Ctx& c;
+    bool done = false;
+    explicit StageScope(Ctx& c_) : c(c_) {}
+    int finish() { done = true; return stage_end(c); }
+    ~StageScope() {
+        if (done) return;
+        (void)hipStreamSynchronize(c.stage.us); (void)hipStreamSynchronize(c.stage.cs); (void)hipStreamSynchronize(c.stage.ds);
+    }
+};
 int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n);
 // ntt.hip
 // pointwise steps of EvaluationDomain fused into the first / last pass of a transform (lazy passes only:

@@ -6,6 +6,7 @@
 // coeff_to_extended), and the division by the vanishing polynomial on the coset.
 #include <string.h>
 
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -29,8 +30,10 @@ struct trh_domain {
     void* d_post_blocks = nullptr;   // [j - 1][2^k]: (zeta extended_omega^r)^-j * 2^-k, the way back from block r
     void* d_vinv = nullptr;          // two (j - 1) x (j - 1) matrices (canonical Montgomery): inverse of V[r][i] = c_r^i, c_r = (zeta extended_omega^r)^(2^k),
                                      // plain and with column r divided by (c_r - 1) (the vanishing polynomial's value on block r)
-    void* d_pre_sub = nullptr;       // the first pre_sub_blocks rows as a table of its own (the kernel addresses planes by the row count)
-    uint32_t pre_sub_blocks = 0;
+    // (zeta extended_omega^r)^j for r < n_blocks as a table of its own PER block count (the kernel addresses the table's planes by the row
+    // count): built at first use, kept until trh_domain_destroy -- a handle is shared by contexts, and a table freed when the count
+    // changed could still be read by another context's queued transform
+    std::map<uint32_t, void*> pre_sub;
     std::mutex mu;                   // a domain is shared by the contexts of its device: the lazily built block tables are created under this lock
 };
 
@@ -236,7 +239,7 @@ void trh_domain_destroy(trh_domain* d) {
     if (d->d_tables) (void)hipFree(d->d_tables);
     if (d->d_post_blocks) (void)hipFree(d->d_post_blocks);
     if (d->d_vinv) (void)hipFree(d->d_vinv);
-    if (d->d_pre_sub) (void)hipFree(d->d_pre_sub);
+    for (auto& kv : d->pre_sub) if (kv.second) (void)hipFree(kv.second);
     delete d;
 }
 uint32_t trh_domain_extended_k(trh_domain* d) { return d ? d->extended_k : 0; }
@@ -339,28 +342,30 @@ int trh_domain_coeff_to_extended_blocks(trh_domain* d, const void* coeff_dev, vo
     (void)c;
     hipStream_t s = (hipStream_t)stream;
     TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
-    // (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: built once per block count (the kernel addresses the table's planes by it)
+    // (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: one table per block count, built at first use
+    const void* pre_tab = nullptr;
     {
         std::lock_guard<std::mutex> lk(d->mu);
-        if (d->pre_sub_blocks != n_blocks) {
-            // (a change of the block count while another context still transforms with the old table is excluded by a device-wide drain:
-            //  a prover uses one count per domain, this is the rare path)
-            if (d->d_pre_sub) { TRH_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(d->d_pre_sub); d->d_pre_sub = nullptr; d->pre_sub_blocks = 0; }
-            TRH_HIP_TRY(hipMalloc(&d->d_pre_sub, ntt_block_table_bytes(n_blocks, d->k)));
+        auto it = d->pre_sub.find(n_blocks);
+        if (it == d->pre_sub.end()) {
+            void* t = nullptr;
+            TRH_HIP_TRY(hipMalloc(&t, ntt_block_table_bytes(n_blocks, d->k)));
             const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
-            TRH_TRY(ntt_block_table_build(d->field, d->d_pre_sub, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s));
-            TRH_HIP_TRY(hipStreamSynchronize(s));  // the table is complete before another context's stream may read it
-            d->pre_sub_blocks = n_blocks;
+            int rc = ntt_block_table_build(d->field, t, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s);
+            if (rc == TRH_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("domain blocks: table kernel failed"); rc = TRH_EHIP; }  // complete before another context's stream may read it
+            if (rc != TRH_OK) { (void)hipFree(t); return rc; }
+            it = d->pre_sub.emplace(n_blocks, t).first;
         }
+        pre_tab = it->second;
     }
     if (ntt_can_fuse(d->k) && ntt_lazy_shift() == 5) {  // the scaling rides on the loads of pass 0
         NttFusion fu;
         fu.in_dev = coeff_dev; fu.in_log = d->k;
-        fu.pre_blocks = d->d_pre_sub; fu.blocks = n_blocks;
+        fu.pre_blocks = pre_tab; fu.blocks = n_blocks;
         return ntt_device(d->field, ext_dev, d->k, (const u64*)&d->omega, batch * n_blocks, s, &fu);
     }
     // small domains: the same two steps unfused
-    TRH_TRY(ntt_block_scale(d->field, coeff_dev, ext_dev, batch * n_blocks, n_blocks, d->k, d->d_pre_sub, false, s));
+    TRH_TRY(ntt_block_scale(d->field, coeff_dev, ext_dev, batch * n_blocks, n_blocks, d->k, pre_tab, false, s));
     return ntt_device(d->field, ext_dev, d->k, (const u64*)&d->omega, batch * n_blocks, s);
 }
 
@@ -487,13 +492,14 @@ int trh_domain_blocks_to_quotient_host(trh_domain* d, const uint64_t* num_blocks
     Range range("trh_domain_blocks_to_quotient_host");
     Ctx& c = ctx();
     TRH_TRY(stage_begin(c));
+    StageScope scope(c);
     hipStream_t s = c.stage.cs;
     const size_t bytes = (size_t)(d->j - 1) * ((size_t)32 << d->k);
     TRH_TRY(c.io.ensure(2 * bytes));
     TRH_TRY(stage_h2d(c, c.io.p, num_blocks, bytes, s));
     TRH_TRY(trh_domain_blocks_to_quotient(d, c.io.p, (char*)c.io.p + bytes, divide_by_vanishing, s));
     TRH_TRY(stage_d2h(c, h_coeff, (char*)c.io.p + bytes, bytes, s));
-    return stage_end(c);
+    return scope.finish();
 }
 
 /* h(X): [divide_by_vanishing_poly,] extended_to_coeff on one host polynomial of 2^extended_k values, in place */
@@ -503,6 +509,7 @@ int trh_domain_extended_to_coeff_host(trh_domain* d, uint64_t* a, int divide_by_
     Range range("trh_domain_extended_to_coeff_host");
     Ctx& c = ctx();
     TRH_TRY(stage_begin(c));
+    StageScope scope(c);
     hipStream_t s = c.stage.cs;
     const size_t bytes = (size_t)32 << d->extended_k;
     TRH_TRY(c.io.ensure(bytes));
@@ -510,7 +517,7 @@ int trh_domain_extended_to_coeff_host(trh_domain* d, uint64_t* a, int divide_by_
     if (divide_by_vanishing_first) TRH_TRY(trh_domain_divide_by_vanishing_poly(d, c.io.p, 1, s));
     TRH_TRY(trh_domain_extended_to_coeff(d, c.io.p, 1, s));
     TRH_TRY(stage_d2h(c, a, c.io.p, bytes, s));
-    return stage_end(c);
+    return scope.finish();
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 //     while range t is computed.
 #include <string.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <deque>
@@ -41,8 +42,36 @@ int copy_threads() {
     }();
     return n;
 }
-CopyPool& up_pool() { static CopyPool* p = new CopyPool(copy_threads()); return *p; }
-CopyPool& down_pool() { static CopyPool* p = new CopyPool(copy_threads()); return *p; }
+
+// Chunk sizes of ONE transfer through a slot ring.  Full slots in the middle; a short head (2 MiB, then 6) when the transfer's first
+// bytes gate the pipeline (an upload: nothing moves until the first chunk sits in pinned memory) and a short tail (6, then 2) when its
+// last bytes do (a download: the caller waits for the copy out of the last chunk; an upload whose host copies are the slower side).
+// The fill / drain of a 16 MiB ring cost 0.25 ms each on a 128 MiB best_fft; uniformly small slots lose to the per-slot hand-over.
+void chunk_plan(size_t bytes, size_t slot, bool head, bool tail, std::vector<size_t>& out) {
+    out.clear();
+    const size_t small = (size_t)2 << 20, mid = (size_t)6 << 20;
+    size_t left = bytes;
+    std::vector<size_t> back;
+    if (head && left > 2 * small) { out.push_back(small); left -= small; if (slot > mid && left > mid + small) { out.push_back(mid); left -= mid; } }
+    if (tail && left > 2 * small) { back.push_back(small); left -= small; if (slot > mid && left > mid + small) { back.push_back(mid); left -= mid; } }
+    while (left) { const size_t cur = left < slot ? left : slot; out.push_back(cur); left -= cur; }
+    for (size_t i = back.size(); i-- > 0;) out.push_back(back[i]);
+}
+
+// TRH_IO_TRACE=1: the single-call host entries print their timeline (microseconds since the call began) to stderr
+thread_local double t_trace_t0 = 0;   // > 0 while a traced call is running on this thread: the staging loops then report every chunk
+struct IoTrace {
+    bool on;
+    double t0;
+    IoTrace() : on(getenv("TRH_IO_TRACE") && atoi(getenv("TRH_IO_TRACE"))), t0(now_s()) { if (on) t_trace_t0 = t0; }
+    ~IoTrace() { t_trace_t0 = 0; }
+    void mark(const char* what, size_t bytes = 0) const {
+        if (on) fprintf(stderr, "[trh io] %9.1f us  %s %zu\n", (now_s() - t0) * 1e6, what, bytes);
+    }
+};
+inline void trace_chunk(const char* what, size_t k, size_t bytes) {
+    if (t_trace_t0 > 0) fprintf(stderr, "[trh io] %9.1f us    %s %zu (%zu bytes)\n", (now_s() - t_trace_t0) * 1e6, what, k, bytes);
+}
 
 // is this host pointer already page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engine reads it directly.
 bool is_pinned(const void* p) {
@@ -57,6 +86,8 @@ bool is_pinned(const void* p) {
 int stage_ensure(Ctx& c) {
     Stage& st = c.stage;
     if (st.up) return TRH_OK;
+    if (!st.up_pool) st.up_pool = new CopyPool(copy_threads());
+    if (!st.down_pool) st.down_pool = new CopyPool(copy_threads());
     size_t slot = (size_t)16 << 20;  // x NS = 4 slots per direction; smaller slots lose to the per-slot hand-over (measured: 16 MiB 32 ms, 8 MiB 39 ms, 4 MiB 45 ms for the 1.6 GB of a 2^24 best_multiexp)
     if (const char* e = getenv("TRH_STAGE_SLOT_MB")) { const long v = atol(e); if (v >= 1 && v <= 256) slot = (size_t)v << 20; }
     hipError_t e = hipHostMalloc((void**)&st.up, slot * Stage::NS, hipHostMallocDefault);
@@ -83,9 +114,13 @@ int stage_ensure(Ctx& c) {
 
 void stage_release(Ctx& c) {
     Stage& st = c.stage;
+    delete st.up_pool; delete st.down_pool;  // stops and joins this context's copy threads
+    st.up_pool = st.down_pool = nullptr;
     if (st.up) (void)hipHostFree(st.up);
     if (st.down) (void)hipHostFree(st.down);
     st.up = st.down = nullptr;
+    for (auto& kv : st.xfer_ev) for (hipEvent_t e : kv.second) if (e) (void)hipEventDestroy(e);
+    st.xfer_ev.clear();
     for (int i = 0; i < Stage::NS; ++i) {
         if (st.up_ev[i]) (void)hipEventDestroy(st.up_ev[i]);
         if (st.down_ev[i]) (void)hipEventDestroy(st.down_ev[i]);
@@ -105,7 +140,7 @@ void stage_release(Ctx& c) {
     st.slot = 0;
 }
 
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch) {
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch, bool zero_elide, bool head_only) {
     if (!bytes) return TRH_OK;
     TRH_TRY(stage_ensure(c));
     Stage& st = c.stage;
@@ -113,18 +148,27 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
     if (is_pinned(src_host)) {
         TRH_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
     } else {
-        // a transfer smaller than the ring still wants a few slots in flight: the copy into slot i + 1 hides under the DMA of slot i
-        size_t chunk = st.slot;
-        if (!part_of_batch) while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a lone short transfer still gets two slots in flight
-        for (size_t off = 0; off < bytes; off += chunk) {
-            const size_t cur = bytes - off < chunk ? bytes - off : chunk;
-            const int sl = (int)(st.up_next++ % Stage::NS);
+        // a lone transfer starts (and ends) with short chunks: the copy into slot i + 1 hides under the DMA of slot i, and nothing hides the
+        // first copy; inside a batch the previous call's DMA is still running, so a transfer that fits one slot is not split
+        std::vector<size_t> plan;
+        chunk_plan(bytes, st.slot, !part_of_batch, !part_of_batch && !head_only, plan);
+        size_t off = 0;
+        for (const size_t cur : plan) {
+            const int sl = (int)(st.up_next % Stage::NS);
             if (st.up_used[sl]) TRH_HIP_TRY(hipEventSynchronize(st.up_ev[sl]));
+            trace_chunk("up: slot free, copy begins", off, cur);
             char* pin = st.up + (size_t)sl * st.slot;
-            up_pool().copy(pin, (const char*)src_host + off, cur);
-            TRH_HIP_TRY(hipMemcpyAsync((char*)dst_dev + off, pin, cur, hipMemcpyHostToDevice, s));
-            TRH_HIP_TRY(hipEventRecord(st.up_ev[sl], s));
-            st.up_used[sl] = true;
+            if (st.up_pool->copy(pin, (const char*)src_host + off, cur, zero_elide)) {
+                // zero throughout (the padding of a zero-padded vector): cleared on the device, nothing crosses the link, the slot stays free
+                TRH_HIP_TRY(hipMemsetAsync((char*)dst_dev + off, 0, cur, s));
+                st.up_zero_bytes += (double)cur;
+            } else {
+                TRH_HIP_TRY(hipMemcpyAsync((char*)dst_dev + off, pin, cur, hipMemcpyHostToDevice, s));
+                TRH_HIP_TRY(hipEventRecord(st.up_ev[sl], s));
+                st.up_used[sl] = true;
+                ++st.up_next;
+            }
+            off += cur;
         }
     }
     st.up_bytes += (double)bytes;
@@ -141,26 +185,79 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
         TRH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
     } else {
-        size_t chunk = st.slot;
-        while (chunk > ((size_t)1 << 20) && bytes < chunk * 2) chunk >>= 1;  // a short transfer still gets two slots in flight
-        const size_t nchunks = (bytes + chunk - 1) / chunk;
+        std::vector<size_t> plan, offs;
+        chunk_plan(bytes, st.slot, false, true, plan);  // short LAST chunks: the caller waits for the copy out of the last one
+        size_t o = 0;
+        for (const size_t cur : plan) { offs.push_back(o); o += cur; }
+        const size_t nchunks = plan.size();
         size_t issued = 0;
         for (size_t k = 0; k < nchunks; ++k) {
             for (; issued < nchunks && issued < k + Stage::NS; ++issued) {  // keep the ring full
-                const size_t off = issued * chunk, cur = bytes - off < chunk ? bytes - off : chunk;
                 const int sl = (int)(issued % Stage::NS);
-                TRH_HIP_TRY(hipMemcpyAsync(st.down + (size_t)sl * st.slot, (const char*)src_dev + off, cur, hipMemcpyDeviceToHost, s));
+                TRH_HIP_TRY(hipMemcpyAsync(st.down + (size_t)sl * st.slot, (const char*)src_dev + offs[issued], plan[issued], hipMemcpyDeviceToHost, s));
                 TRH_HIP_TRY(hipEventRecord(st.down_ev[sl], s));
             }
-            const size_t off = k * chunk, cur = bytes - off < chunk ? bytes - off : chunk;
             const int sl = (int)(k % Stage::NS);
             TRH_HIP_TRY(hipEventSynchronize(st.down_ev[sl]));
-            down_pool().copy((char*)dst_host + off, st.down + (size_t)sl * st.slot, cur);
+            trace_chunk("down: DMA of chunk done", k, plan[k]);
+            st.down_pool->copy((char*)dst_host + offs[k], st.down + (size_t)sl * st.slot, plan[k]);
+            trace_chunk("down: copied out", k, plan[k]);
         }
     }
     st.down_bytes += (double)bytes;
     st.down_s += now_s() - t0;
     return TRH_OK;
+}
+
+// Device-to-device hand-over between two GPUs WITHOUT peer access (or with TRH_FORCE_NO_PEER=1): the bytes travel through the slots of the
+// destination context's pinned download ring -- D2H on the source device's stream, H2D on the destination's -- chained by events only:
+// slot k is written after the H2D that last read it (event wait on the source stream) and read after its D2H (event wait on the
+// destination stream).  No host thread waits; both directions of both links run at once.
+int stage_d2d_via_host(Ctx& dstc, void* dst_dev, hipStream_t dst_stream, const void* src_dev, int src_device, hipStream_t src_stream, size_t bytes) {
+    if (!bytes) return TRH_OK;
+    TRH_TRY(stage_ensure(dstc));
+    Stage& st = dstc.stage;
+    int cur_dev = -1;
+    TRH_HIP_TRY(hipGetDevice(&cur_dev));
+    // events recorded on the SOURCE device's stream have to belong to that device: one set per source device, kept until stage_release
+    auto it = st.xfer_ev.find(src_device);
+    if (it == st.xfer_ev.end()) {
+        std::array<hipEvent_t, Stage::NS> evs{};
+        TRH_HIP_TRY(hipSetDevice(src_device));
+        for (int i = 0; i < Stage::NS; ++i) {
+            const hipError_t e = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int j = 0; j < i; ++j) (void)hipEventDestroy(evs[j]);
+                (void)hipSetDevice(cur_dev);
+                set_error("hand-over through the host: hipEventCreate: %s", hipGetErrorString(e));
+                return TRH_EHIP;
+            }
+        }
+        it = st.xfer_ev.emplace(src_device, evs).first;
+    }
+    hipEvent_t* filled = it->second.data();
+    int rc = TRH_OK;
+    size_t k = 0;
+    for (size_t off = 0; off < bytes && rc == TRH_OK; off += st.slot, ++k) {
+        const size_t cur = bytes - off < st.slot ? bytes - off : st.slot;
+        const int sl = (int)(k % Stage::NS);
+        char* pin = st.down + (size_t)sl * st.slot;
+        hipError_t e = hipSetDevice(src_device);
+        if (e == hipSuccess && k >= (size_t)Stage::NS) e = hipStreamWaitEvent(src_stream, st.down_ev[sl], 0);  // the H2D that read this slot last
+        if (e == hipSuccess) e = hipMemcpyAsync(pin, (const char*)src_dev + off, cur, hipMemcpyDeviceToHost, src_stream);
+        if (e == hipSuccess) e = hipEventRecord(filled[sl], src_stream);
+        if (e == hipSuccess) e = hipSetDevice(dstc.device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(dst_stream, filled[sl], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)dst_dev + off, pin, cur, hipMemcpyHostToDevice, dst_stream);
+        if (e == hipSuccess) e = hipEventRecord(st.down_ev[sl], dst_stream);
+        if (e != hipSuccess) { set_error("hand-over through the host: %s", hipGetErrorString(e)); rc = TRH_EHIP; }
+    }
+    // the ring's next user runs behind dst_stream: the caller entered the destination context with it, so the context's order event is
+    // recorded there when the entry returns, and every later entry (and stage_begin) waits for that event
+    (void)hipSetDevice(cur_dev);
+    st.up_bytes += (double)bytes;
+    st.down_bytes += (double)bytes;
+    return rc;
 }
 
 // the three streams of the stage join the context's order: whatever ran last on the context's scratch finishes first
@@ -200,7 +297,7 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
     const int device = c.device;
     std::thread helper([&] {
         int rc = hipSetDevice(device) == hipSuccess ? TRH_OK : TRH_EHIP;
-        struct Chunk { int slot; char* dst; size_t bytes; size_t item; bool direct; };
+        struct Chunk { int slot; char* dst; size_t bytes; size_t item; bool direct; bool marker; };
         std::deque<Chunk> inflight;
         std::vector<HostPipe::Seg> segs;
         std::vector<size_t> chunks_left(p.count, 0);
@@ -228,11 +325,22 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
                     if (hipStreamWaitEvent(st.ds, st.ev_comp[slot], 0) != hipSuccess) { set_error("host pipeline: hipStreamWaitEvent failed"); fail(TRH_EHIP); cv.notify_all(); return; }
                     segs.clear();
                     p.segments(next_item, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p, segs);
+                    size_t w = 0;  // zero-byte segments carry nothing: dropped here, so that they neither count as a chunk nor complete one early
+                    for (size_t r = 0; r < segs.size(); ++r) if (segs[r].bytes) segs[w++] = segs[r];
+                    segs.resize(w);
                     size_t nch = 0;
                     for (const HostPipe::Seg& sg : segs) nch += is_pinned(sg.dst) ? 1 : (sg.bytes + st.slot - 1) / st.slot;
                     chunks_left[next_item] = nch;
                     have_segs = true; seg_idx = 0; seg_off = 0;
-                    if (nch == 0) { have_segs = false; ++items_done; { std::lock_guard<std::mutex> lk(mu); downloaded = next_item + 1; } cv.notify_all(); ++next_item; continue; }
+                    if (nch == 0) {
+                        // an item with nothing to download completes IN ORDER: behind the chunks of the items before it (publishing it at once
+                        // would free the ring slot of an earlier item that is still in flight)
+                        have_segs = false;
+                        chunks_left[next_item] = 1;
+                        inflight.push_back(Chunk{0, nullptr, 0, next_item, true, true});
+                        ++next_item;
+                        continue;
+                    }
                 }
                 const HostPipe::Seg& sg = segs[seg_idx];
                 const bool direct = is_pinned(sg.dst);
@@ -242,14 +350,14 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
                 hipError_t e = hipMemcpyAsync(land, (const char*)sg.src + seg_off, cur, hipMemcpyDeviceToHost, st.ds);
                 if (e == hipSuccess) e = hipEventRecord(st.down_ev[sl], st.ds);
                 if (e != hipSuccess) { set_error("host pipeline: download failed: %s", hipGetErrorString(e)); fail(TRH_EHIP); cv.notify_all(); return; }
-                inflight.push_back(Chunk{sl, (char*)sg.dst + seg_off, cur, next_item, direct});
+                inflight.push_back(Chunk{sl, (char*)sg.dst + seg_off, cur, next_item, direct, false});
                 seg_off += cur;
                 if (seg_off >= sg.bytes) { seg_off = 0; if (++seg_idx >= segs.size()) { have_segs = false; ++next_item; } }
             }
             if (inflight.empty()) continue;
             const Chunk ch = inflight.front();
-            if (hipEventSynchronize(st.down_ev[ch.slot]) != hipSuccess) { set_error("host pipeline: hipEventSynchronize failed"); fail(TRH_EHIP); cv.notify_all(); return; }
-            if (!ch.direct) down_pool().copy(ch.dst, st.down + (size_t)ch.slot * st.slot, ch.bytes);
+            if (!ch.marker && hipEventSynchronize(st.down_ev[ch.slot]) != hipSuccess) { set_error("host pipeline: hipEventSynchronize failed"); fail(TRH_EHIP); cv.notify_all(); return; }
+            if (!ch.direct) st.down_pool->copy(ch.dst, st.down + (size_t)ch.slot * st.slot, ch.bytes);
             bytes_moved += (double)ch.bytes;
             inflight.pop_front();
             if (--chunks_left[ch.item] == 0) {
@@ -303,13 +411,22 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     TRH_ENTER(0);
     Ctx& c = ctx();
     TRH_TRY(stage_begin(c));
+    StageScope scope(c);
     hipStream_t s = c.stage.cs;
     const size_t bytes = (size_t)32 << log_n;
+    IoTrace tr;
     TRH_TRY(c.io.ensure(bytes));
-    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s));
+    tr.mark("begin, bytes", bytes);
+    // zero slots are not sent (coeff_to_extended hands over a vector that is zero beyond its first 2^k entries: 7/8 of the upload)
+    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true));
+    tr.mark("upload issued");
     TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
+    tr.mark("transform queued");
     TRH_TRY(stage_d2h(c, a, c.io.p, bytes, s));
-    return stage_end(c);
+    tr.mark("download complete");
+    const int rc = scope.finish();
+    tr.mark("end");
+    return rc;
 }
 
 static int best_fft_batch_host(int field, uint64_t* const* a, size_t count, const uint64_t* omega, uint32_t log_n) {
@@ -383,7 +500,8 @@ int trh_io_stats(trh_io_stats_t* out, int reset) {
     TRH_ENTER(0);
     Stage& st = ctx().stage;
     out->h2d_bytes = st.up_bytes; out->d2h_bytes = st.down_bytes; out->h2d_seconds = st.up_s; out->d2h_seconds = st.down_s;
-    if (reset) st.up_bytes = st.down_bytes = st.up_s = st.down_s = 0;
+    out->h2d_zero_bytes = st.up_zero_bytes;
+    if (reset) st.up_bytes = st.down_bytes = st.up_s = st.down_s = st.up_zero_bytes = 0;
     return TRH_OK;
 }
 

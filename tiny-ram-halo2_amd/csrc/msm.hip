@@ -926,6 +926,153 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sparse columns of a fixed-base batch (round 4).  A witness column of the reference's circuit -- flags, <= 32-bit words, even-bits
+// words, sorted small lookup values on n / 4 live rows, zero behind them, a handful of blinding rows -- has 3 * 10^4 .. 2 * 10^5
+// non-zero digits in a flat digit space of W x n = 4 * 10^6 slots.  The dense pipeline above pays for the SLOTS (recode writes them
+// all, the partition and both sort levels walk them, 0.3 ms per stage and batch of 64); the path below pays for the ENTRIES:
+//   sample    one workgroup per column looks at ~1024 rows: a column whose estimated entry count is far above the list capacity is
+//             dense and is left to the pipeline above (a full-size column never enters the kernels below)
+//   emit      one thread per scalar: canonical form, signed digits; every non-zero digit is appended to one of the column's
+//             SP_LISTS compact lists (one wave-aggregated atomic per window and wave) as bucket << 32 | sign | flat table index, and
+//             counted in the column's bucket histogram; a list that runs full marks the column dense (the dense pipeline redoes it)
+//   ranges    msm_bucket_block_sums_kernel / msm_bucket_ranges_kernel over the histogram (the kernels of the chunked passes)
+//   scatter   one thread per entry: position = cursor[bucket]++ (wave-aggregated when the lanes agree: the ~2^15 ones of a flag
+//             column all land in bucket 1), sorted[position] = index | sign
+// and from there the SAME accumulate / combine / reduce launches as every other MSM, over lists of `cap` slots per column.
+// Same group element, hence the same normalised point; which path a column takes is decided by its digits alone.
+// ---------------------------------------------------------------------------------------
+constexpr int SP_LISTS = 16;              // compact lists per column: the 4096 waves of a column appending through ONE counter would serialise
+constexpr u32 SP_PAD = 32;                // u32 words between two list counters (one 128-byte line each)
+constexpr u32 SP_DENSE = 0xFFFFFFFFu;     // counter 0 of a column the sampler found dense
+
+// scalar i of item z (the commitment blind for the last one) as canonical words
+template <class SF>
+__device__ __forceinline__ void sp_load_canonical(const uint4* __restrict__ scalars, const uint4* __restrict__ tails, size_t z, size_t i, size_t n, int mont, u32 w[8]) {
+    const uint4* src = (tails && i == n - 1) ? tails + 2 * z : scalars + 2 * i;
+    const uint4 lo = src[0], hi = src[1];
+    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+    if (mont && (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7])) fe_store(fe_from_mont(fe_load<SF>(w)), w);
+}
+
+template <class SF>
+__global__ void __launch_bounds__(256) msm_sparse_sample_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W, size_t sstride,
+                                                                const uint4* __restrict__ tails, u32* __restrict__ sp_count, u32 dense_limit /* estimated entries above this: dense */) {
+    const size_t z = blockIdx.x;
+    scalars += z * sstride * 2;
+    __shared__ u32 total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const size_t samples = n < 1024 ? n : 1024, step = n / samples;
+    const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
+    u32 mine = 0;
+    for (size_t q = threadIdx.x; q < samples; q += 256) {
+        u32 w[8];
+        sp_load_canonical<SF>(scalars, tails, z, q * step, n, mont, w);
+        u32 carry = 0;
+        for (int j = 0; j < W; ++j) {
+            const u32 raw = (w[0] & mask) + carry;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) w[k] = (w[k] >> c) | (w[k + 1] << (32 - c));
+            w[7] >>= c;
+            carry = raw > half ? 1u : 0u;
+            mine += (raw != 0 && raw != (1u << c)) ? 1u : 0u;  // digit raw - 2^c of raw == 2^c is zero with a carry
+        }
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && (unsigned long long)total * step > dense_limit) sp_count[z * SP_LISTS * SP_PAD] = SP_DENSE;
+}
+
+template <class SF>
+__global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W, size_t sstride,
+                                                              const uint4* __restrict__ tails, u32* __restrict__ sp_count, unsigned long long* __restrict__ entries,
+                                                              u32 subcap, u32* __restrict__ bucket_cnt, u32 nb1) {
+    const size_t z = blockIdx.z;
+    u32* cnt0 = sp_count + z * SP_LISTS * SP_PAD;
+    if (*cnt0 == SP_DENSE) return;  // uniform over the grid slice of this column
+    const u32 g = blockIdx.x % SP_LISTS;
+    u32* my = cnt0 + g * SP_PAD;
+    scalars += z * sstride * 2;
+    entries += (z * SP_LISTS + g) * (size_t)subcap;
+    bucket_cnt += z * nb1;
+    const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
+    const u32 lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += (size_t)gridDim.x * blockDim.x) {
+        // a list that has run full: the column is dense, what is appended from here on is thrown away by the host anyway
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > (int)subcap) return;
+        const size_t i = i0 + threadIdx.x;
+        u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < n) sp_load_canonical<SF>(scalars, tails, z, i, n, mont, w);
+        u32 carry = 0;
+        for (int j = 0; j < W; ++j) {
+            const u32 left = (w[0] | w[1] | w[2] | w[3]) | (w[4] | w[5] | w[6] | w[7]) | carry;
+            if (__ballot(left != 0) == 0ull) break;  // small values: nothing above their top digit (wave-uniform)
+            const u32 raw = (w[0] & mask) + carry;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) w[k] = (w[k] >> c) | (w[k + 1] << (32 - c));
+            w[7] >>= c;
+            u32 bucket, sign = 0;
+            if (raw > half) { bucket = (1u << c) - raw; carry = 1; sign = SIGN_BIT; }  // digit raw - 2^c
+            else { bucket = raw; carry = 0; }
+            const unsigned long long nz = __ballot(bucket != 0);
+            if (nz == 0ull) continue;
+            const int leader = __ffsll((long long)nz) - 1;
+            const u32 count = (u32)__popcll(nz);
+            u32 base = 0;
+            if ((int)lane == leader) base = atomicAdd(my, count);
+            base = (u32)__shfl((int)base, leader, 64);
+            if (base + count > subcap) continue;  // overflow: counted, not stored
+            // histogram: the lanes that share the leader's bucket go in as one atomic (a flag column: all of them, bucket 1)
+            const u32 lead_bucket = (u32)__shfl((int)bucket, leader, 64);
+            const unsigned long long same = __ballot(bucket == lead_bucket) & nz;
+            if (bucket) {
+                entries[base + (u32)__popcll(nz & below)] = ((unsigned long long)bucket << 32) | sign | (u32)((size_t)j * n + i);
+                if (bucket != lead_bucket) atomicAdd(&bucket_cnt[bucket], 1u);
+                else if ((int)lane == leader) atomicAdd(&bucket_cnt[bucket], (u32)__popcll(same));
+            }
+        }
+    }
+}
+
+// columns the host found dense after the emit (a list overflowed): their partial histogram must not reach the range scan
+__global__ void __launch_bounds__(256) msm_sparse_neutralise_kernel(const unsigned char* __restrict__ dense, u32* __restrict__ bucket_cnt, u32 nb1) {
+    const size_t z = blockIdx.y;
+    if (!dense[z]) return;
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb1) bucket_cnt[z * nb1 + b] = 0;
+}
+
+__global__ void __launch_bounds__(256) msm_sparse_scatter_kernel(const unsigned long long* __restrict__ entries, const u32* __restrict__ sp_count, const unsigned char* __restrict__ dense,
+                                                                 u32 subcap, u32* __restrict__ cursor, u32* __restrict__ sorted, size_t stride, u32 nb1) {
+    const size_t z = blockIdx.z;
+    if (dense[z]) return;
+    const u32 g = blockIdx.y;
+    const u32 count = sp_count[(z * SP_LISTS + g) * SP_PAD];
+    entries += (z * SP_LISTS + g) * (size_t)subcap;
+    cursor += z * nb1;
+    sorted += z * stride;
+    const u32 lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (u32 e0 = blockIdx.x * blockDim.x; e0 < count; e0 += gridDim.x * blockDim.x) {
+        const u32 e = e0 + threadIdx.x;
+        const bool live = e < count;
+        const unsigned long long en = live ? entries[e] : 0ull;
+        const u32 bucket = (u32)(en >> 32);  // 0 for the idle lanes of the last wave
+        const unsigned long long act = __ballot(live);
+        if (act == 0ull) continue;
+        const int leader = __ffsll((long long)act) - 1;
+        const u32 lead_bucket = (u32)__shfl((int)bucket, leader, 64);
+        const unsigned long long same = __ballot(live && bucket == lead_bucket);
+        u32 pos = 0;
+        if ((int)lane == leader) pos = atomicAdd(&cursor[lead_bucket], (u32)__popcll(same));
+        pos = (u32)__shfl((int)pos, leader, 64) + (u32)__popcll(same & below);
+        if (live && bucket != lead_bucket) pos = atomicAdd(&cursor[bucket], 1u);
+        if (live) sorted[pos] = (u32)en;
+    }
+}
+
 template <class BF> int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch);
 template <class BF> int point_sum_host_t(const u64* pts, size_t count, u64* out);
 

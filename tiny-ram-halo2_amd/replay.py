@@ -360,12 +360,18 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         blinds = synth.field_elements(seed + 0x100000 + done, b)
         e0 = ev()
         pts = params.commit_lagrange_batch(cols, blinds)
-        e1 = ev()
+        e1 = e1_commit = ev()
         for i in range(b):
             if done + i in class_first and not (done == 0 and i < 3):
                 torch.cuda.synchronize()
                 hook("commit_lagrange", dict(scalars=np.concatenate([cols[i].cpu().numpy().view(np.uint64), blinds[i][None]]), bases=gl, column_class=kinds[done + i]), pts[i])
                 checked += 1
+                e1 = None
+        if e1 is None:  # a hook ran on the host meanwhile (events measure wall time between their records: the idle gap is not the transform's)
+            commit_ms = e0.elapsed_time(e1_commit)
+            e1 = ev()
+        else:
+            commit_ms = None
         coeff = dom.lagrange_to_coeff(cols)
         e2 = ev()
         ext = dom.coeff_to_extended_blocks(coeff, D, out=ext_buf) if blocks else dom.coeff_to_extended(coeff, out=ext_buf)
@@ -377,7 +383,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
         torch.cuda.synchronize()
         times["evals"] += e3.elapsed_time(e4)
         counts["evals"] += b
-        times["commit_lagrange"] += e0.elapsed_time(e1)
+        times["commit_lagrange"] += commit_ms if commit_ms is not None else e0.elapsed_time(e1)
         times["lagrange_to_coeff"] += e1.elapsed_time(e2)
         times["coeff_to_extended"] += e2.elapsed_time(e3)
         counts["commit_lagrange"] += b
@@ -801,9 +807,11 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
             lj = api.best_multiexp(curve, p_h[half:2 * half], gp[:half])
             rj = api.best_multiexp(curve, p_h[:half], gp[half:2 * half])
             if hook is not None and j in (0, k - 1):
+                th = time.perf_counter()
                 hook("best_multiexp", dict(scalars=p_h[half:2 * half], bases=gp[:half], curve=curve), lj)
                 hook("best_multiexp", dict(scalars=p_h[:half], bases=gp[half:2 * half], curve=curve), rj)
                 checked += 2
+                t0 += time.perf_counter() - th  # the checker's time is not the opening's
     else:
         draws = iter(range(7, 10 ** 9, 13))
         p_dev = torch.from_numpy(p_h.view(np.int64)).to(dev)
@@ -828,6 +836,195 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
     return out
 
 
+def run_sharded(word_bits: int, devices, batch: int = 64, columns: str = "witness", verbose: bool = True, max_columns: int | None = None) -> dict:
+    """The per-column phase of create_proof (commit_lagrange, lagrange_to_coeff, coeff_to_extended as coset blocks, the evaluations at x)
+    COLUMN-SHARDED over a list of devices, in one process -- how a single Rust prover process (the reference proves sequentially in one
+    process, /root/reference/src/test_utils.rs:37-54) drives the GPUs of a node: per device one host thread, one libtrh context
+    (trh_ctx_create), one Params copy (bases + fixed-base tables resident on that device) and one EvaluationDomain; thread g takes the
+    contiguous columns sharded.shard_range(497, g, G), no data-path collective (SURVEY.md 8e: the columns of a proof are independent;
+    96 bytes per column come back for the transcript).  A device may be listed more than once (`--devices 0,0` on a one-GPU box: two
+    contexts, two threads, two streams on the same chip).  The commitments, gathered in column order, must equal the single-context
+    run's bit for bit; the result carries per-device times and the single-context time of the same phase."""
+    import threading
+
+    import torch
+
+    from . import sharded
+    assert columns in ("random", "witness")
+    devices = [int(d) for d in devices]
+    G = len(devices)
+    k = 2 + word_bits // 2
+    sch = schedule(k)
+    n = sch["n"]
+    D = QUOTIENT_J - 1
+    curve, field = "vesta", "fp"
+    api.init(devices[0])
+    lag_total = sch["intt_n"] if max_columns is None else min(max_columns, sch["intt_n"])
+    kinds = [(kind, blinded) for count, kind, blinded in column_classes(word_bits) for _ in range(count)]
+    x_eval = synth.field_elements(0xE7A, 1)[0]
+    seed = 0xC01
+
+    class Shard:
+        def __init__(self, g, dev_index, lo, hi):
+            self.g, self.dev_index, self.lo, self.hi = g, dev_index, lo, hi
+            self.dev = torch.device("cuda", dev_index)
+            self.ctx = api.Context(dev_index)
+            self.ms = {"commit_lagrange": 0.0, "lagrange_to_coeff": 0.0, "coeff_to_extended": 0.0, "evals": 0.0}
+            self.points, self.evals, self.err = None, None, None
+
+        def setup(self):
+            """bases, tables, domain and this shard's columns, resident on its device (untimed: once per proving key / witness)"""
+            self.ctx.bind()
+            torch.cuda.set_device(self.dev)
+            self.stream = torch.cuda.Stream(device=self.dev)
+            params = poly.Params.__new__(poly.Params)
+            params.curve, params.k, params.n = curve, k, n
+            params._g = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n + 1)
+            params._g_lagrange = api.Bases.generate(curve, synth.BASE_S0 + 77, synth.BASE_D + 2, n + 1)
+            params.w = params._g.download(n, 1)
+            params.u = None
+            for b in (params._g, params._g_lagrange):
+                b.precompute(0)
+            self.params = params
+            self.dom = poly.EvaluationDomain(field, QUOTIENT_J, k)
+            cnt = self.hi - self.lo
+            self.cols = torch.empty((cnt, n, 4), dtype=torch.int64, device=self.dev)
+            st = torch.cuda.current_stream().cuda_stream
+            i = 0
+            while i < cnt:
+                if columns == "random":
+                    j = min(cnt, i + 16)
+                    self.cols[i:j].copy_(torch.from_numpy(synth.field_elements(seed + self.lo + i, (j - i) * n).reshape(j - i, n, 4).view(np.int64)))
+                else:
+                    j = i
+                    while j < cnt and j - i < 32 and kinds[self.lo + j] == kinds[self.lo + i]:
+                        j += 1
+                    can = witness_columns(kinds[self.lo + i][0], kinds[self.lo + i][1], seed + self.lo + i, j - i, n, word_bits)
+                    d = torch.from_numpy(can.view(np.int64)).to(self.dev)
+                    api._check(api.lib().trh_field_op_dev(api.FIELD_ID[field], api.FIELD_OPS["to_mont"], api._devptr(d), None, api._devptr(d), (j - i) * n, st))
+                    torch.cuda.synchronize(self.dev)
+                    self.cols[i:j].copy_(d)
+                    del d
+                i = j
+            self.blinds = synth.field_elements(seed + 0x100000 + self.lo, max(cnt, 1))[:cnt]
+            self.ext = torch.empty((min(batch, max(cnt, 1)), D * n, 4), dtype=torch.int64, device=self.dev)
+            torch.cuda.synchronize(self.dev)
+
+        def phase(self, cols, timed=True):
+            """this shard's columns through the per-column steps, batch by batch (in place: the rows end as coefficient forms)"""
+            cnt = cols.shape[0]
+            pts, evs = np.zeros((cnt, 12), dtype=np.uint64), np.zeros((cnt, 4), dtype=np.uint64)
+            with torch.cuda.stream(self.stream):
+                def ev():
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    return e
+                done = 0
+                while done < cnt:
+                    b = min(batch, cnt - done)
+                    c = cols[done:done + b]
+                    e0 = ev()
+                    pts[done:done + b] = self.params.commit_lagrange_batch(c, self.blinds[done:done + b])
+                    e1 = ev()
+                    coeff = self.dom.lagrange_to_coeff(c)
+                    e2 = ev()
+                    self.dom.coeff_to_extended_blocks(coeff, D, out=self.ext)
+                    e3 = ev()
+                    evs[done:done + b] = api.poly_eval_batch_dev(field, coeff, n, b, x_eval, stream=self.stream.cuda_stream)
+                    e4 = ev()
+                    self.stream.synchronize()
+                    if timed:
+                        for key, (a, z) in (("commit_lagrange", (e0, e1)), ("lagrange_to_coeff", (e1, e2)), ("coeff_to_extended", (e2, e3)), ("evals", (e3, e4))):
+                            self.ms[key] += a.elapsed_time(z)
+                    done += b
+            return pts, evs
+
+        def run(self, barrier):
+            try:
+                self.ctx.bind()
+                torch.cuda.set_device(self.dev)
+                warm = self.cols[: min(batch, self.cols.shape[0])].clone()
+                self.phase(warm, timed=False)   # tables of the transforms, scratch of the MSM (sized by the batch): once per context
+                del warm
+                work = self.cols.clone()
+                torch.cuda.synchronize(self.dev)
+                barrier.wait()
+                t0 = time.perf_counter()
+                self.points, self.evals = self.phase(work)
+                torch.cuda.synchronize(self.dev)
+                self.wall_ms = (time.perf_counter() - t0) * 1e3
+            except Exception as exc:  # surfaced by the caller
+                self.err = exc
+                try:
+                    barrier.abort()
+                except Exception:
+                    pass
+            finally:
+                api.Context.unbind()
+
+    shards = []
+    for g, dv in enumerate(devices):
+        lo, hi = sharded.shard_range(lag_total, g, G)
+        shards.append(Shard(g, dv, lo, hi))
+    try:
+        for sh in shards:   # one after the other: the host-side column generation is the slow part and is not what is measured
+            sh.setup()
+            api.Context.unbind()
+        # the single-context reference: shard 0's context runs ALL columns step by step (the columns of the other shards are copied over)
+        ref = shards[0]
+        ref.ctx.bind()
+        torch.cuda.set_device(ref.dev)
+        all_cols = torch.cat([sh.cols.to(ref.dev) for sh in shards]) if G > 1 else ref.cols.clone()
+        keep_blinds, keep_ms = ref.blinds, ref.ms
+        ref.blinds = np.concatenate([sh.blinds for sh in shards])
+        ref.phase(all_cols[: min(batch, lag_total)].clone(), timed=False)
+        ref.ms = {kk: 0.0 for kk in keep_ms}
+        torch.cuda.synchronize(ref.dev)
+        t0 = time.perf_counter()
+        ref_pts, ref_evals = ref.phase(all_cols)
+        torch.cuda.synchronize(ref.dev)
+        single_wall = (time.perf_counter() - t0) * 1e3
+        single_ms = dict(ref.ms)
+        ref.blinds, ref.ms = keep_blinds, {kk: 0.0 for kk in keep_ms}
+        del all_cols
+        api.Context.unbind()
+        # the sharded run: one thread per device, started together
+        barrier = threading.Barrier(G + 1)
+        ths = [threading.Thread(target=sh.run, args=(barrier,)) for sh in shards]
+        for th in ths:
+            th.start()
+        try:
+            barrier.wait()
+        except threading.BrokenBarrierError:
+            pass
+        t0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        wall = (time.perf_counter() - t0) * 1e3
+        for sh in shards:
+            if sh.err is not None:
+                raise sh.err
+        pts = np.concatenate([sh.points for sh in shards])
+        evs = np.concatenate([sh.evals for sh in shards])
+        identical = bool((pts == ref_pts).all() and (evs == ref_evals).all())
+    finally:
+        for sh in shards:
+            for b in (getattr(getattr(sh, "params", None), "_g", None), getattr(getattr(sh, "params", None), "_g_lagrange", None)):
+                if b is not None:
+                    b.destroy()
+            sh.cols = sh.ext = None
+            sh.ctx.destroy()
+    out = {"mode": "column-sharded", "word_bits": word_bits, "columns": columns, "devices": devices, "columns_replayed": lag_total,
+           "per_device": [{"device": sh.dev_index, "columns": [sh.lo, sh.hi], "wall_ms": round(sh.wall_ms, 3), "gpu_ms": {kk: round(v, 3) for kk, v in sh.ms.items()}} for sh in shards],
+           "wall_ms": round(wall, 3), "single_context": {"wall_ms": round(single_wall, 3), "gpu_ms": {kk: round(v, 3) for kk, v in single_ms.items()}},
+           "commitments_identical_to_single_context": identical,
+           "scope": "per-column phase of ONE create_proof (commit_lagrange, lagrange_to_coeff, coeff_to_extended as 5 coset blocks, evaluations), columns resident; "
+                    "one host thread + libtrh context + Params copy per listed device, contiguous column ranges, no collective"}
+    if verbose:
+        print(json.dumps(out))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--word-bits", type=int, default=32)
@@ -840,8 +1037,12 @@ def main():
                          "trh_msm / trh_best_fft call at a time (north_star's literal integration); dropin-batched: host memory, batched host-pointer entries")
     ap.add_argument("--extended", choices=("blocks", "full"), default="blocks", help="resident mode: the extended domain as the 5 coset blocks the quotient needs, or all 2^extended_k points")
     ap.add_argument("--overlap", action="store_true", help="resident mode: also time the per-column phase with the transforms on a second context / stream / host thread")
-    ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes: replay only the first N Lagrange columns")
+    ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes / --devices: replay only the first N Lagrange columns")
+    ap.add_argument("--devices", default=None, help="comma-separated device list (a device may repeat): the per-column phase column-sharded over one context + thread per entry")
     a = ap.parse_args()
+    if a.devices is not None:
+        r = run_sharded(a.word_bits, [int(v) for v in a.devices.split(",")], a.batch, columns=a.columns, max_columns=a.max_columns)
+        sys.exit(0 if r["commitments_identical_to_single_context"] else 1)
     if a.mode != "resident":
         run_dropin(a.word_bits, {"dropin": "literal", "dropin-batched": "batched", "dropin-batched-blocks": "batched-blocks"}[a.mode], a.batch, columns=a.columns, max_columns=a.max_columns)
         return
