@@ -51,6 +51,19 @@ int main() {
             if (memcmp(dst.data(), src.data(), sz) != 0) ++bad;
         }
     }
+    // streaming-store copies (every alignment of source and destination, sizes around the 128-byte blocks)
+    for (trh::CopyPool* pool : {up, none}) {
+        for (size_t sz : {(size_t)100, (size_t)65536, (size_t)65536 + 127, (size_t)(3u << 20) + 77}) {
+            for (int ao : {0, 1, 31, 33}) {
+                std::vector<unsigned char> src(sz + 64), dst(sz + 128, 0xEE);
+                for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)(i * 131 + sz);
+                pool->copy((char*)dst.data() + 32 + ao, (const char*)src.data() + (ao ^ 1), sz, false, true);
+                if (memcmp(dst.data() + 32 + ao, src.data() + (ao ^ 1), sz) != 0) ++bad;
+                for (int g = 0; g < 32 + ao; ++g) if (dst[g] != 0xEE) { ++bad; break; }
+                for (size_t g = 32 + ao + sz; g < dst.size(); ++g) if (dst[g] != 0xEE) { ++bad; break; }
+            }
+        }
+    }
     delete up; delete down; delete none;  // the destructor stops and joins the workers (per-context pools die with their context)
     std::printf(bad ? "copypool: FAILED (%d)\n" : "copypool: ok\n", bad);
     return bad ? 1 : 0;

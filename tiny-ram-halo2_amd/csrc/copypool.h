@@ -10,7 +10,43 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define TRH_HAVE_NT_COPY 1
+#endif
+
 namespace trh {
+
+#ifdef TRH_HAVE_NT_COPY
+// dst <- src with non-temporal stores: a slot-sized copy with ordinary stores reads every destination line before it overwrites it
+// (read-for-ownership), i.e. moves 3 bytes of DRAM traffic per byte copied instead of 2 -- on a host whose memory also feeds / drains the
+// DMA engine at link rate that traffic is what the link waits for.  glibc switches to streaming stores only above ~3/4 of the shared
+// cache per call; a pool thread's share of a 16 MiB slot is below that.
+__attribute__((target("avx2"))) inline void nt_copy_avx2(char* dst, const char* src, size_t n) {
+    size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+    if (head > n) head = n;
+    memcpy(dst, src, head);
+    dst += head; src += head; n -= head;
+    const size_t blocks = n / 128;
+    for (size_t i = 0; i < blocks; ++i) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)src), b = _mm256_loadu_si256((const __m256i*)(src + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i*)(src + 64)), d = _mm256_loadu_si256((const __m256i*)(src + 96));
+        _mm256_stream_si256((__m256i*)dst, a); _mm256_stream_si256((__m256i*)(dst + 32), b);
+        _mm256_stream_si256((__m256i*)(dst + 64), c); _mm256_stream_si256((__m256i*)(dst + 96), d);
+        src += 128; dst += 128;
+    }
+    _mm_sfence();
+    memcpy(dst, src, n - blocks * 128);
+}
+#endif
+// one thread's share of a copy; nt: streaming stores where the CPU has them (the caller's choice per direction)
+inline void copy_bytes(char* dst, const char* src, size_t n, bool nt) {
+#ifdef TRH_HAVE_NT_COPY
+    static const bool have = __builtin_cpu_supports("avx2");
+    if (nt && have && n >= ((size_t)64 << 10)) { nt_copy_avx2(dst, src, n); return; }
+#endif
+    memcpy(dst, src, n);
+}
 
 // true when every byte of [p, p + bytes) is zero.  Data that is not zero answers after the first word; a zero range costs one read pass
 // (no write), which is what the zero-padded vectors of coeff_to_extended are for 7/8 of their length.
@@ -52,10 +88,11 @@ class CopyPool {
     // dst <- src, split over the pool and the calling thread; serialised per pool.
     // detect_zero: a source that is zero throughout is NOT copied and the call returns true (the caller replaces the transfer by a
     // device-side memset); parts of a mixed source that are zero are cleared in dst, the call returns false.
-    bool copy(char* dst, const char* src, size_t bytes, bool detect_zero = false) {
+    // nt: streaming stores (see nt_copy_avx2)
+    bool copy(char* dst, const char* src, size_t bytes, bool detect_zero = false, bool nt = false) {
         if (bytes < ((size_t)1 << 20) || T == 0) {
             if (detect_zero && bytes && all_zero(src, bytes)) return true;
-            memcpy(dst, src, bytes);
+            copy_bytes(dst, src, bytes, nt);
             return false;
         }
         std::lock_guard<std::mutex> call(call_mu);
@@ -63,7 +100,7 @@ class CopyPool {
         const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
         {
             std::lock_guard<std::mutex> lk(mu);
-            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per; job_detect = detect_zero;
+            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per; job_detect = detect_zero; job_nt = nt;
             zero_mask = 0;
             pending = T;
             pending_atomic.store(T, std::memory_order_release);
@@ -71,7 +108,7 @@ class CopyPool {
             gen_atomic.store(gen, std::memory_order_release);
         }
         cv_work.notify_all();
-        const bool z0 = part(0, dst, src, bytes, per, detect_zero);  // part 0 on the caller
+        const bool z0 = part(0, dst, src, bytes, per, detect_zero, nt);  // part 0 on the caller
         for (int spin = 0; spin < 20000 && pending_atomic.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
@@ -87,18 +124,18 @@ class CopyPool {
 
   private:
     // part k of the job; returns true when detect was asked and the part is zero (and was therefore NOT written)
-    static bool part(size_t k, char* dst, const char* src, size_t bytes, size_t per, bool detect) {
+    static bool part(size_t k, char* dst, const char* src, size_t bytes, size_t per, bool detect, bool nt) {
         const size_t lo = k * per;
         if (lo >= bytes) return false;
         const size_t len = lo + per < bytes ? per : bytes - lo;
         if (detect && all_zero(src + lo, len)) return true;
-        memcpy(dst + lo, src + lo, len);
+        copy_bytes(dst + lo, src + lo, len, nt);
         return false;
     }
     void worker(int id) {
         unsigned seen = 0;
         for (;;) {
-            char* dst; const char* src; size_t bytes, per; bool detect;
+            char* dst; const char* src; size_t bytes, per; bool detect, nt;
             {
                 // jobs arrive every few hundred microseconds while a transfer runs: spin briefly before sleeping (a condition-variable
                 // wake-up costs 30-50 us, a quarter of a slot's DMA time)
@@ -107,9 +144,9 @@ class CopyPool {
                 cv_work.wait(lk, [&] { return gen != seen; });
                 if (stop) return;
                 seen = gen;
-                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per; detect = job_detect;
+                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per; detect = job_detect; nt = job_nt;
             }
-            const bool z = part((size_t)id + 1, dst, src, bytes, per, detect);
+            const bool z = part((size_t)id + 1, dst, src, bytes, per, detect, nt);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (z) zero_mask |= (uint64_t)1 << (id + 1);
@@ -123,7 +160,7 @@ class CopyPool {
     std::mutex mu, call_mu;
     std::condition_variable cv_work, cv_done;
     char* job_dst = nullptr; const char* job_src = nullptr; size_t job_bytes = 0, job_per = 0;
-    bool job_detect = false, stop = false;
+    bool job_detect = false, job_nt = false, stop = false;
     uint64_t zero_mask = 0;
     unsigned gen = 0;
     int pending = 0;

@@ -94,6 +94,7 @@ struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: bat
     DevBuf heavy;        // [0] count + list of (window, bucket) ids whose pieces a whole workgroup combines
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
+    DevBuf sparse;       // sparse-column path: per item SP_LISTS list counters (one 128-byte line each), then one dense flag per item
 };
 
 struct MsmScratch {
@@ -102,6 +103,8 @@ struct MsmScratch {
     DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
+    bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped
+    void* sp_host = nullptr;    // 8 KiB pinned: the sparse path's counters as read back (4 KiB), the dense flags it sends down (from byte 4096)
     void* host_sums = nullptr;  // pinned mirror of window_sums
     size_t host_sums_cap = 0;
     // state of the enqueued-but-not-finished MSM

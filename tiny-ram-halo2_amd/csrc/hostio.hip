@@ -73,6 +73,13 @@ inline void trace_chunk(const char* what, size_t k, size_t bytes) {
     if (t_trace_t0 > 0) fprintf(stderr, "[trh io] %9.1f us    %s %zu (%zu bytes)\n", (now_s() - t_trace_t0) * 1e6, what, k, bytes);
 }
 
+// TRH_NT_COPY: bit 0 = streaming stores for the copies OUT of the download ring (into the caller's memory), bit 1 = for the copies INTO the
+// upload ring
+int nt_mode() {
+    static const int v = getenv("TRH_NT_COPY") ? atoi(getenv("TRH_NT_COPY")) : 3;
+    return v;
+}
+
 // is this host pointer already page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engine reads it directly.
 bool is_pinned(const void* p) {
     hipPointerAttribute_t attr;
@@ -158,7 +165,7 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
             if (st.up_used[sl]) TRH_HIP_TRY(hipEventSynchronize(st.up_ev[sl]));
             trace_chunk("up: slot free, copy begins", off, cur);
             char* pin = st.up + (size_t)sl * st.slot;
-            if (st.up_pool->copy(pin, (const char*)src_host + off, cur, zero_elide)) {
+            if (st.up_pool->copy(pin, (const char*)src_host + off, cur, zero_elide, (nt_mode() & 2) != 0)) {
                 // zero throughout (the padding of a zero-padded vector): cleared on the device, nothing crosses the link, the slot stays free
                 TRH_HIP_TRY(hipMemsetAsync((char*)dst_dev + off, 0, cur, s));
                 st.up_zero_bytes += (double)cur;
@@ -200,7 +207,7 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
             const int sl = (int)(k % Stage::NS);
             TRH_HIP_TRY(hipEventSynchronize(st.down_ev[sl]));
             trace_chunk("down: DMA of chunk done", k, plan[k]);
-            st.down_pool->copy((char*)dst_host + offs[k], st.down + (size_t)sl * st.slot, plan[k]);
+            st.down_pool->copy((char*)dst_host + offs[k], st.down + (size_t)sl * st.slot, plan[k], false, (nt_mode() & 1) != 0);
             trace_chunk("down: copied out", k, plan[k]);
         }
     }
@@ -357,7 +364,7 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
             if (inflight.empty()) continue;
             const Chunk ch = inflight.front();
             if (!ch.marker && hipEventSynchronize(st.down_ev[ch.slot]) != hipSuccess) { set_error("host pipeline: hipEventSynchronize failed"); fail(TRH_EHIP); cv.notify_all(); return; }
-            if (!ch.direct) st.down_pool->copy(ch.dst, st.down + (size_t)ch.slot * st.slot, ch.bytes);
+            if (!ch.direct) st.down_pool->copy(ch.dst, st.down + (size_t)ch.slot * st.slot, ch.bytes, false, (nt_mode() & 1) != 0);
             bytes_moved += (double)ch.bytes;
             inflight.pop_front();
             if (--chunks_left[ch.item] == 0) {

@@ -365,7 +365,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     u64 pt[12];
     if (fb) {  // the scalar of u is zero: the full-range (table) path
         TRH_HIP_TRY(hipMemsetAsync((char*)sp.p + (n + 1) * 32, 0, 32, s));
-        TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 2, 1, n + 2, 1, s, fb));
+        ctx().msm.dense_hint = true;  // s(X) is uniformly random: no sparse classification
+        const int rc_s = msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 2, 1, n + 2, 1, s, fb);
+        ctx().msm.dense_hint = false;
+        TRH_TRY(rc_s);
     } else
     TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
     TRH_TRY(msm_finish(curve, s, pt, 1));
@@ -434,7 +437,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             TRH_HIP_TRY(hipGetLastError());
         }
         u64 lrb[24], lr[2][12];
-        TRH_TRY(msm_enqueue(curve, round_xy, round_z, lrsc.p, n + 2, 2, stride, 1, s, fb));
+        ctx().msm.dense_hint = true;  // p' . w: full-size values on half the rows
+        const int rc_r = msm_enqueue(curve, round_xy, round_z, lrsc.p, n + 2, 2, stride, 1, s, fb);
+        ctx().msm.dense_hint = false;
+        TRH_TRY(rc_r);
         TRH_TRY(msm_finish(curve, s, lrb, 2));
         memcpy(lr[0], lrb, 96); memcpy(lr[1], lrb + 12, 96);
         tr->write_point(tr->ctx, lr[0]);

@@ -929,20 +929,21 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
 // ---------------------------------------------------------------------------------------
 // Sparse columns of a fixed-base batch (round 4).  A witness column of the reference's circuit -- flags, <= 32-bit words, even-bits
 // words, sorted small lookup values on n / 4 live rows, zero behind them, a handful of blinding rows -- has 3 * 10^4 .. 2 * 10^5
-// non-zero digits in a flat digit space of W x n = 4 * 10^6 slots.  The dense pipeline above pays for the SLOTS (recode writes them
-// all, the partition and both sort levels walk them, 0.3 ms per stage and batch of 64); the path below pays for the ENTRIES:
+// non-zero digits in a flat digit space of W x n = 4 * 10^6 slots.  The pipeline above pays for the SLOTS (recode writes them all,
+// the partition and both sort levels walk them: 0.3 ms per stage and batch of 64); the path below compacts the digits first and runs
+// the SAME pipeline over an eighth of the slots:
 //   sample    one workgroup per column looks at ~1024 rows: a column whose estimated entry count is far above the list capacity is
-//             dense and is left to the pipeline above (a full-size column never enters the kernels below)
-//   emit      one thread per scalar: canonical form, signed digits; every non-zero digit is appended to one of the column's
-//             SP_LISTS compact lists (one wave-aggregated atomic per window and wave) as bucket << 32 | sign | flat table index, and
-//             counted in the column's bucket histogram; a list that runs full marks the column dense (the dense pipeline redoes it)
-//   ranges    msm_bucket_block_sums_kernel / msm_bucket_ranges_kernel over the histogram (the kernels of the chunked passes)
-//   scatter   one thread per entry: position = cursor[bucket]++ (wave-aggregated when the lanes agree: the ~2^15 ones of a flag
-//             column all land in bucket 1), sorted[position] = index | sign
-// and from there the SAME accumulate / combine / reduce launches as every other MSM, over lists of `cap` slots per column.
-// Same group element, hence the same normalised point; which path a column takes is decided by its digits alone.
+//             dense and never enters the kernels below
+//   emit      one thread per scalar: canonical form, signed digits; every non-zero digit is appended to one of the column's SP_LISTS
+//             compact lists (ONE atomic per workgroup, window and list: device-scope atomics are executed on the memory side of the
+//             eight XCDs' L2s and same-address chains of them are slow) as a digit bucket | sign and, beside it, its flat table index;
+//             level-1 bin histogram in LDS as msm_recode_kernel has it.  A list that runs full marks the column dense.
+//   sort      msm_offsets_kernel ... msm_bucket_pass_kernel over the compact digit array (cap = W n / 8 slots per column)
+//   remap     the sorted entries name positions of the compact array: replaced by the flat table indices stored beside the digits
+// and from there the accumulate / combine / reduce launches of every other MSM.  Same group element, hence the same normalised point;
+// which path a column takes is decided by its digits alone.
 // ---------------------------------------------------------------------------------------
-constexpr int SP_LISTS = 16;              // compact lists per column: the 4096 waves of a column appending through ONE counter would serialise
+constexpr int SP_LISTS = 16;              // compact lists per column (one counter each: a single counter per column would serialise its 1025 workgroups)
 constexpr u32 SP_PAD = 32;                // u32 words between two list counters (one 128-byte line each)
 constexpr u32 SP_DENSE = 0xFFFFFFFFu;     // counter 0 of a column the sampler found dense
 
@@ -984,31 +985,36 @@ __global__ void __launch_bounds__(256) msm_sparse_sample_kernel(const uint4* __r
     if (threadIdx.x == 0 && (unsigned long long)total * step > dense_limit) sp_count[z * SP_LISTS * SP_PAD] = SP_DENSE;
 }
 
+// digits: [item][cap] compact digit array (cap = SP_LISTS * subcap; list g of item z fills [g * subcap, ...)), zero-filled by the caller;
+// flat: the flat table index (window * n + row) of every compact slot; bin_counts: [item][nbins] level-1 histogram (zeroed by the caller)
 template <class SF>
 __global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W, size_t sstride,
-                                                              const uint4* __restrict__ tails, u32* __restrict__ sp_count, unsigned long long* __restrict__ entries,
-                                                              u32 subcap, u32* __restrict__ bucket_cnt, u32 nb1) {
+                                                              const uint4* __restrict__ tails, u32* __restrict__ sp_count, u32* __restrict__ digits, u32* __restrict__ flat,
+                                                              u32 subcap, u32* __restrict__ bin_counts, int k2, u32 nbins) {
     const size_t z = blockIdx.z;
     u32* cnt0 = sp_count + z * SP_LISTS * SP_PAD;
     if (*cnt0 == SP_DENSE) return;  // uniform over the grid slice of this column
+    __shared__ u32 lhist[2048];     // nbins <= 2^11 (the partition's limit)
+    __shared__ u32 wcnt[4], base;
     const u32 g = blockIdx.x % SP_LISTS;
     u32* my = cnt0 + g * SP_PAD;
     scalars += z * sstride * 2;
-    entries += (z * SP_LISTS + g) * (size_t)subcap;
-    bucket_cnt += z * nb1;
+    digits += (z * SP_LISTS + g) * (size_t)subcap;
+    flat += (z * SP_LISTS + g) * (size_t)subcap;
+    bin_counts += z * nbins;
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) lhist[k] = 0;
     const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
-    const u32 lane = threadIdx.x & 63u;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += (size_t)gridDim.x * blockDim.x) {
-        // a list that has run full: the column is dense, what is appended from here on is thrown away by the host anyway
-        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > (int)subcap) return;
+    bool overflow = false;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n && !overflow; i0 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i0 + threadIdx.x;
         u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (i < n) sp_load_canonical<SF>(scalars, tails, z, i, n, mont, w);
         u32 carry = 0;
         for (int j = 0; j < W; ++j) {
             const u32 left = (w[0] | w[1] | w[2] | w[3]) | (w[4] | w[5] | w[6] | w[7]) | carry;
-            if (__ballot(left != 0) == 0ull) break;  // small values: nothing above their top digit (wave-uniform)
+            if (!__syncthreads_or(left != 0)) break;  // small values: nothing above their top digit (uniform over the workgroup; also the barrier that frees wcnt / base)
             const u32 raw = (w[0] & mask) + carry;
 #pragma unroll
             for (int k = 0; k < 7; ++k) w[k] = (w[k] >> c) | (w[k + 1] << (32 - c));
@@ -1017,59 +1023,45 @@ __global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __res
             if (raw > half) { bucket = (1u << c) - raw; carry = 1; sign = SIGN_BIT; }  // digit raw - 2^c
             else { bucket = raw; carry = 0; }
             const unsigned long long nz = __ballot(bucket != 0);
-            if (nz == 0ull) continue;
-            const int leader = __ffsll((long long)nz) - 1;
-            const u32 count = (u32)__popcll(nz);
-            u32 base = 0;
-            if ((int)lane == leader) base = atomicAdd(my, count);
-            base = (u32)__shfl((int)base, leader, 64);
-            if (base + count > subcap) continue;  // overflow: counted, not stored
-            // histogram: the lanes that share the leader's bucket go in as one atomic (a flag column: all of them, bucket 1)
-            const u32 lead_bucket = (u32)__shfl((int)bucket, leader, 64);
-            const unsigned long long same = __ballot(bucket == lead_bucket) & nz;
+            if (lane == 0) wcnt[wv] = (u32)__popcll(nz);
+            __syncthreads();
+            const u32 c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3], total = c0 + c1 + c2 + c3;
+            if (total == 0) continue;  // uniform
+            if (threadIdx.x == 0) base = atomicAdd(my, total);  // one atomic per workgroup and window
+            __syncthreads();
+            const u32 b0 = base;
+            if (b0 + total > subcap) { overflow = true; break; }  // uniform: the list is full, the column is dense (the host sees the counter)
             if (bucket) {
-                entries[base + (u32)__popcll(nz & below)] = ((unsigned long long)bucket << 32) | sign | (u32)((size_t)j * n + i);
-                if (bucket != lead_bucket) atomicAdd(&bucket_cnt[bucket], 1u);
-                else if ((int)lane == leader) atomicAdd(&bucket_cnt[bucket], (u32)__popcll(same));
+                const u32 pos = b0 + (wv > 0 ? c0 : 0u) + (wv > 1 ? c1 : 0u) + (wv > 2 ? c2 : 0u) + (u32)__popcll(nz & below);
+                digits[pos] = bucket | sign;
+                flat[pos] = (u32)((size_t)j * n + i);
+                atomicAdd(&lhist[(bucket - 1u) >> k2], 1u);
             }
         }
     }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const u32 v = lhist[k];
+        if (v) atomicAdd(&bin_counts[k], v);
+    }
 }
 
-// columns the host found dense after the emit (a list overflowed): their partial histogram must not reach the range scan
-__global__ void __launch_bounds__(256) msm_sparse_neutralise_kernel(const unsigned char* __restrict__ dense, u32* __restrict__ bucket_cnt, u32 nb1) {
+// columns the host found dense after the emit (a list overflowed): what they did append must not reach the sort
+__global__ void __launch_bounds__(256) msm_sparse_neutralise_kernel(const unsigned char* __restrict__ dense, u32* __restrict__ digits, size_t cap, u32* __restrict__ bin_counts, u32 nbins) {
     const size_t z = blockIdx.y;
     if (!dense[z]) return;
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb1) bucket_cnt[z * nb1 + b] = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += (size_t)gridDim.x * blockDim.x) digits[z * cap + k] = 0;
+    if (blockIdx.x == 0) for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) bin_counts[z * nbins + k] = 0;
 }
 
-__global__ void __launch_bounds__(256) msm_sparse_scatter_kernel(const unsigned long long* __restrict__ entries, const u32* __restrict__ sp_count, const unsigned char* __restrict__ dense,
-                                                                 u32 subcap, u32* __restrict__ cursor, u32* __restrict__ sorted, size_t stride, u32 nb1) {
-    const size_t z = blockIdx.z;
-    if (dense[z]) return;
-    const u32 g = blockIdx.y;
-    const u32 count = sp_count[(z * SP_LISTS + g) * SP_PAD];
-    entries += (z * SP_LISTS + g) * (size_t)subcap;
-    cursor += z * nb1;
-    sorted += z * stride;
-    const u32 lane = threadIdx.x & 63u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (u32 e0 = blockIdx.x * blockDim.x; e0 < count; e0 += gridDim.x * blockDim.x) {
-        const u32 e = e0 + threadIdx.x;
-        const bool live = e < count;
-        const unsigned long long en = live ? entries[e] : 0ull;
-        const u32 bucket = (u32)(en >> 32);  // 0 for the idle lanes of the last wave
-        const unsigned long long act = __ballot(live);
-        if (act == 0ull) continue;
-        const int leader = __ffsll((long long)act) - 1;
-        const u32 lead_bucket = (u32)__shfl((int)bucket, leader, 64);
-        const unsigned long long same = __ballot(live && bucket == lead_bucket);
-        u32 pos = 0;
-        if ((int)lane == leader) pos = atomicAdd(&cursor[lead_bucket], (u32)__popcll(same));
-        pos = (u32)__shfl((int)pos, leader, 64) + (u32)__popcll(same & below);
-        if (live && bucket != lead_bucket) pos = atomicAdd(&cursor[bucket], 1u);
-        if (live) sorted[pos] = (u32)en;
+// sorted[z][k] names a slot of the compact digit array (| sign): replace it by that slot's flat table index
+__global__ void __launch_bounds__(256) msm_sparse_remap_kernel(u32* __restrict__ sorted, const u32* __restrict__ flat, const u32* __restrict__ ends, size_t cap, u32 nbk) {
+    const size_t z = blockIdx.y;
+    const u32 total = ends[z * (nbk + 1) + nbk];
+    sorted += z * cap; flat += z * cap;
+    for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
+        const u32 e = sorted[k];
+        sorted[k] = flat[e & ~SIGN_BIT] | (e & SIGN_BIT);
     }
 }
 
@@ -1213,42 +1205,77 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
         c.attr_done |= ATTR_MSM;
     }
-    const bool timing = c.timing && batch <= chunk;  // one pass over the phases
+    // sparse-column path: fixed-base mode only (one flat bucket set per item), see msm_sparse_emit_kernel.  Lone MSMs take it as well (the
+    // literal drop-in commits one witness column per call: the classifier's synchronisation costs ~20 us, the dense pipeline's fixed
+    // costs over the W x n digit space ~0.3 ms)
+    static const int sparse_knob = getenv("TRH_SPARSE") ? atoi(getenv("TRH_SPARSE")) : 1;
+    const bool sparse_ok = sparse_knob && fb && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
+    if (sparse_ok) {
+        TRH_TRY(L.sparse.ensure((size_t)chunk * SP_LISTS * SP_PAD * 4 + chunk + 64));
+        if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, 8192, hipHostMallocDefault));
+    }
+    const bool timing = c.timing && batch <= chunk && !sparse_ok;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
 
     if (!n) {
         TRH_HIP_TRY(hipMemsetAsync(m.window_sums.p, 0, hs, s));
         if (timing) for (int k = 0; k <= 5; ++k) TRH_HIP_TRY(hipEventRecord(m.ev[k], s));
     }
-    for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
-        const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
+    // One chunk of items [b0, b0 + nb) from the digits to the window sums.
+    //   PIPE_PLAIN    recode into the W x n digit space, entry counts read back for batches (adaptive segments)
+    //   PIPE_DENSE    the same for columns the sparse classifier has found full-size (no read-back: the slot count is the entry count)
+    //   PIPE_COMPACT  the digits are already there -- msm_sparse_emit_kernel's compact arrays of `cap` slots per item with their level-1
+    //                 histogram -- and the sorted entries are remapped to flat table indices before the accumulation
+    enum { PIPE_PLAIN, PIPE_DENSE, PIPE_COMPACT };
+    const u32 sp_subcap = (u32)(ns / 8 / SP_LISTS), sp_cap = sp_subcap * SP_LISTS;  // a column with more than W n / 8 entries is dense
+    auto pipeline = [&](size_t b0, unsigned nb, int mode, size_t entry_sum, u32 entry_most) -> int {
+        const bool compact = mode == PIPE_COMPACT;
+        const size_t nse = compact ? (size_t)sp_cap : ns;  // slots per item and bucket set
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
-        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
-        unsigned gb = (unsigned)((n + 255) / 256);
-        if (gb > 2048) gb = 2048;
-        hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
-                           L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
-                           tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr, tile_flags, 14u, part_tiles);
-        static_assert(PART_TILE == 1 << 14, "tile_log of msm_recode_kernel");
+        if (!compact) {
+            TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
+            unsigned gb = (unsigned)((n + 255) / 256);
+            if (gb > 2048) gb = 2048;
+            hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
+                               L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins, recode_use_lds, stride, fb ? 1 : 0,
+                               tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr, tile_flags, 14u, part_tiles);
+            static_assert(PART_TILE == 1 << 14, "tile_log of msm_recode_kernel");
+        }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-        if (use_bin) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, use_bin ? oversize : nullptr, bin_cap,
-                           adaptive ? totals : nullptr);
+        const bool bin_sort = use_bin && !compact;  // compact lists: ~2^11 entries per bin, and a flag column has them all in one: the chunked passes
+        if (bin_sort) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, bin_sort ? oversize : nullptr, bin_cap,
+                           (adaptive && mode == PIPE_PLAIN) ? totals : nullptr);
         u32 seg_len = seg_len0, nseg = nseg0, heavy_stride = heavy_stride0;
         unsigned heavy_blocks = heavy_blocks0;
-        if (adaptive && (size_t)nb * Ws * 4 <= 4096) {
-            u32* ht = (u32*)c.pinned_land;
-            TRH_HIP_TRY(hipMemcpyAsync(ht, totals, (size_t)nb * Ws * 4, hipMemcpyDeviceToHost, s));
-            TRH_HIP_TRY(hipStreamSynchronize(s));
-            size_t sum = 0;
-            u32 most = 0;
-            for (size_t q = 0; q < (size_t)nb * Ws; ++q) { sum += ht[q]; most = ht[q] > most ? ht[q] : most; }
-            static const int target_log = getenv("TRH_ADAPTIVE_TARGET_LOG") ? atoi(getenv("TRH_ADAPTIVE_TARGET_LOG")) : 16;  // swept 15 .. 19 over the four sparse column classes at k = 18: 12.4 .. 13.8 ms per four batches, 15.5 without
+        bool resize = false;
+        if (mode == PIPE_DENSE) {  // full-size columns: the slot count is the entry count
+            seg_len = 128;
+            while (seg_len > 16 && (size_t)W * n * nb / seg_len < ((size_t)1 << 19)) seg_len >>= 1;
+            nseg = (u32)((ns + seg_len - 1) / seg_len);
+            resize = true;
+        } else if (compact || (adaptive && (size_t)nb * Ws * 4 <= 4096)) {
+            size_t sum = entry_sum;
+            u32 most = entry_most;
+            if (!compact) {
+                u32* ht = (u32*)c.pinned_land;
+                TRH_HIP_TRY(hipMemcpyAsync(ht, totals, (size_t)nb * Ws * 4, hipMemcpyDeviceToHost, s));
+                TRH_HIP_TRY(hipStreamSynchronize(s));
+                sum = 0; most = 0;
+                for (size_t q = 0; q < (size_t)nb * Ws; ++q) { sum += ht[q]; most = ht[q] > most ? ht[q] : most; }
+            }
+            // segments for >= 2^17 live threads (round 4, compact lists: 2^16 2.67 / 1.84 / 2.13 / 2.96 / 2.85 ms for the five sparse batches of the k = 18
+            // proof, 2^17 2.37 / 1.85 / 2.03 / 2.88 / 2.88, 2^18 2.34 / 1.71 / 2.06 / 2.98 / 3.05: shorter segments shorten the accumulation's chains and
+            // lengthen the combine's)
+            static const int target_log = getenv("TRH_ADAPTIVE_TARGET_LOG") ? atoi(getenv("TRH_ADAPTIVE_TARGET_LOG")) : 17;
             seg_len = 128;
             while (seg_len > 16 && sum / seg_len < ((size_t)1 << target_log)) seg_len >>= 1;
             nseg = (most + seg_len - 1) / seg_len;  // segments beyond the longest list would find nothing
             if (nseg == 0) nseg = 1;
+            resize = true;
+        }
+        if (resize) {
             const size_t mh = (size_t)Ws * nseg / HEAVY_PIECES + 1;
             heavy_stride = (u32)(mh + 1);
             heavy_blocks = (unsigned)(mh < 256 ? mh : 256);
@@ -1258,33 +1285,38 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
         }
         TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
-        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((ns + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
-                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), ns, k2, nbins, idx_bits, tile_flags);
+        hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((nse + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
+                           L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), nse, k2, nbins, idx_bits, compact ? (const unsigned char*)nullptr : tile_flags);
         {
-            const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), Ws, nb);
-            const u32* gate = use_bin ? oversize : nullptr;  // the chunked passes return at once when the bin sort did the work
-            if (use_bin)
+            const dim3 cgrid((unsigned)((nse + BS_CHUNK - 1) / BS_CHUNK), Ws, nb);
+            const u32* gate = bin_sort ? oversize : nullptr;  // the chunked passes return at once when the bin sort did the work
+            if (bin_sort)
                 hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, Ws, nb), dim3(BIN_THREADS), (size_t)bin_cap * 4, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                                   L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), ns, k2, nbins, idx_bits, nbk, oversize);
+                                   L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), nse, k2, nbins, idx_bits, nbk, oversize);
             TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk, gate);
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), nse, k2, nbins, idx_bits, nbk, gate);
             // block totals live in seg_bucket, which is only filled afterwards
             hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), nbk, gate);
             hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), L.starts.as<u32>(),
                                L.ends.as<u32>(), nbk, gate);
             hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, L.ends.as<u32>(), L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
-                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), ns, k2, nbins, idx_bits, nbk, gate);
+                               L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), nse, k2, nbins, idx_bits, nbk, gate);
+            if (compact) {
+                unsigned gr = (entry_most + 255) / 256;
+                if (gr > 512) gr = 512;
+                hipLaunchKernelGGL(msm_sparse_remap_kernel, dim3(gr ? gr : 1, nb), dim3(256), 0, s, L.sorted.as<u32>(), L.digits.as<u32>() + (size_t)chunk * sp_cap, L.ends.as<u32>(), nse, nbk);
+            }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
         if (b0 == 0 && !bases_z && !fb)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
         hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
-                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), ns, nbk, nseg, seg_len);
+                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), nse, nbk, nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         {
-            const size_t pieces = ns / ((size_t)nbk * seg_len);  // expected pieces per bucket
+            const size_t pieces = compact ? 4 : ns / ((size_t)nbk * seg_len);  // expected pieces per bucket
 #define TRH_LAUNCH_COMBINE(G)                                                                                                                          \
     hipLaunchKernelGGL((msm_combine_kernel<BF, G>), dim3((unsigned)(((size_t)nbk * G + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), \
                        L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride)
@@ -1301,9 +1333,76 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks, 1, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), L.first.as<XYZZzMem>(),
                            L.last.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
-        hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, slice, tpw);
-        hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, rblocks);
+        {
+            // compact lists: TRH_SPARSE_TPW = reduce threads per item (tuning knob).  Measured on the five sparse batches of the k = 18 proof: shorter
+            // slices make the reduction SLOWER (1024 threads per item: 0.37 - 0.64 ms per batch of 64, 2048: 0.50 - 0.75, 4096: 0.51 - 0.92, 8192:
+            // 0.45 - 1.38): it is bound by its 2 x 2^15 x 64 point additions plus one ~22-operation offset multiplication per thread, not by its depth
+            static const u32 sparse_tpw = getenv("TRH_SPARSE_TPW") ? (u32)atoi(getenv("TRH_SPARSE_TPW")) : 0u;
+            u32 r_tpw = tpw, r_slice = slice, r_blocks = rblocks;
+            if (compact && sparse_tpw >= 256 && sparse_tpw <= nbk && (sparse_tpw & (sparse_tpw - 1)) == 0 && sparse_tpw > tpw) {
+                r_tpw = sparse_tpw; r_slice = nbk / r_tpw; r_blocks = (r_tpw + 255) / 256;
+                TRH_TRY(L.partials.ensure(chunk * Ws * r_blocks * sizeof(XYZZzMem)));
+            }
+            hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(r_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, r_slice, r_tpw);
+            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks);
+        }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
+        return TRH_OK;
+    };
+
+    // Fixed-base mode (the commitments of create_proof): the sparse columns of a chunk take the compact pipeline in one pass over the whole
+    // chunk (the dense columns' lists are empty there), the dense ones the plain pipeline in runs of consecutive items, which overwrite
+    // their window sums.  One synchronisation per chunk either way (the plain path's adaptive read-back is not needed).
+    auto sparse_chunk = [&](size_t b0, unsigned nb) -> int {
+        const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
+        const uint4* tl = tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr;
+        u32* const sp_count = L.sparse.as<u32>();
+        unsigned char* const d_dense = (unsigned char*)(sp_count + (size_t)chunk * SP_LISTS * SP_PAD);
+        u32* const digits = L.digits.as<u32>();                       // [chunk][cap] compact digits, then [chunk][cap] flat table indices
+        u32* const flat = digits + (size_t)chunk * sp_cap;            // (2 x chunk x W n / 8 x 4 B: a quarter of the buffer)
+        TRH_HIP_TRY(hipMemsetAsync(sp_count, 0, (size_t)nb * SP_LISTS * SP_PAD * 4, s));
+        TRH_HIP_TRY(hipMemsetAsync(digits, 0, (size_t)nb * sp_cap * 4, s));
+        TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * nbins * 4, s));
+        hipLaunchKernelGGL((msm_sparse_sample_kernel<SF>), dim3(nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, 2 * sp_cap);
+        unsigned gbe = (unsigned)((n + 255) / 256);
+        if (gbe > 1024) gbe = 1024;
+        hipLaunchKernelGGL((msm_sparse_emit_kernel<SF>), dim3(gbe, 1, nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, digits, flat, sp_subcap, L.counts.as<u32>(), k2, nbins);
+        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_LISTS] counters, then nb dense flags at byte 4096
+        unsigned char* const hd = (unsigned char*)m.sp_host + 4096;
+        TRH_HIP_TRY(hipMemcpy2DAsync(hc, 4, sp_count, SP_PAD * 4, 4, (size_t)nb * SP_LISTS, hipMemcpyDeviceToHost, s));
+        TRH_HIP_TRY(hipStreamSynchronize(s));
+        size_t sum = 0;
+        u32 most = 0, n_sparse = 0, n_overflowed = 0;
+        for (unsigned z = 0; z < nb; ++z) {
+            const bool sampled_dense = hc[z * SP_LISTS] == SP_DENSE;
+            bool dense = sampled_dense;
+            size_t cz = 0;
+            for (int g = 0; g < SP_LISTS && !dense; ++g) { dense = hc[z * SP_LISTS + g] > sp_subcap; cz += hc[z * SP_LISTS + g]; }
+            hd[z] = dense ? 1 : 0;
+            if (dense && !sampled_dense) ++n_overflowed;
+            if (!dense) { ++n_sparse; sum += cz; most = cz > most ? (u32)cz : most; }
+        }
+        const bool any_sparse = n_sparse && most;
+        if (any_sparse) {
+            if (n_overflowed) {  // rare: a column the sampler let through filled a list; what it appended must not be sorted
+                TRH_HIP_TRY(hipMemcpyAsync(d_dense, hd, nb, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(msm_sparse_neutralise_kernel, dim3(64, nb), dim3(256), 0, s, d_dense, digits, (size_t)sp_cap, L.counts.as<u32>(), nbins);
+            }
+            TRH_TRY(pipeline(b0, nb, PIPE_COMPACT, sum, most));
+        }
+        for (unsigned z = 0; z < nb;) {  // the dense columns, in runs
+            if (!hd[z] && any_sparse) { ++z; continue; }
+            unsigned e = z + 1;
+            while (e < nb && (hd[e] || !any_sparse)) ++e;
+            TRH_TRY(pipeline(b0 + z, e - z, PIPE_DENSE, 0, 0));
+            z = e;
+        }
+        return TRH_OK;
+    };
+    for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
+        const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
+        if (sparse_ok) TRH_TRY(sparse_chunk(b0, nb));
+        else TRH_TRY(pipeline(b0, nb, PIPE_PLAIN, 0, 0));
     }
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipMemcpyAsync(m.host_sums, m.window_sums.p, hs, hipMemcpyDeviceToHost, s));
@@ -1422,7 +1521,9 @@ void msm_release() {
     m.scalars.release(); m.tails.release(); m.bases_z.release(); m.window_sums.release();
     MsmLane& L = m.lane;
     L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release(); L.bucket_cnt.release();
-    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release();
+    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release(); L.sparse.release();
+    if (m.sp_host) (void)hipHostFree(m.sp_host);
+    m.sp_host = nullptr;
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
     for (int k = 0; k < 6; ++k) if (m.ev[k]) { (void)hipEventDestroy(m.ev[k]); m.ev[k] = nullptr; }
