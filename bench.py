@@ -275,15 +275,22 @@ def e2e_replays(modes=("resident", "dropin-batched", "dropin")):
         t0 = time.perf_counter()
         try:
             if mode == "resident":
-                r = replay.run(32, batch=64, hook=hook, verbose=False, columns="witness", keygen=False)
+                # two proofs in this process, as the reference proves sequentially in one (src/test_utils.rs:37-54): the first also pays the library's
+                # one-off scratch allocations and table builds inside its timed steps and is reported beside the second; the oracle checks ride on the first
+                r1 = replay.run(32, batch=64, hook=hook, verbose=False, columns="witness", keygen=False)
+                r = replay.run(32, batch=64, hook=None, verbose=False, columns="witness", keygen=False)
                 ent = {"gpu_ms_total": r["gpu_ms_total"], "gpu_ms_total_with_real_gates": r["gpu_ms_total_with_real_gates"], "gpu_ms": r["gpu_ms"], "extended_domain": r["extended_domain"],
-                       "scope": r["scope"]}
+                       "first_proof_in_process": {"gpu_ms_total": r1["gpu_ms_total"], "gpu_ms": r1["gpu_ms"]}, "scope": r["scope"]}
             else:
                 r = replay.run_dropin(32, {"dropin": "literal", "dropin-batched": "batched"}[mode], batch=64, hook=hook, verbose=False, columns="witness")
                 pc = r["pcie"]
-                floor_ms = (pc["h2d_GB"] + pc["d2h_GB"]) / pc["link_peak_GBps_per_direction"] * 1e3  # one direction at a time at the probed pinned rate
+                # one direction at a time at the probed pinned rate: for the bytes the caller handed over, and for the bytes that really crossed
+                # (zero slots of the zero-padded vectors are cleared on the device)
+                floor_ms = (pc["h2d_GB"] + pc["d2h_GB"]) / pc["link_peak_GBps_per_direction"] * 1e3
+                cross_ms = (pc["h2d_GB"] - pc.get("h2d_zero_elided_GB", 0.0) + pc["d2h_GB"]) / pc["link_peak_GBps_per_direction"] * 1e3
                 ent = {"wall_ms_incl_pcie_total": r["wall_ms_incl_pcie_total"], "wall_ms_incl_pcie": r["wall_ms_incl_pcie"], "pcie": pc,
-                       "link_floor_ms": round(floor_ms, 1), "link_floor_frac": round(floor_ms / r["wall_ms_incl_pcie_total"], 3), "scope": r["scope"]}
+                       "link_floor_ms": round(floor_ms, 1), "link_floor_frac": round(floor_ms / r["wall_ms_incl_pcie_total"], 3),
+                       "link_floor_ms_bytes_that_crossed": round(cross_ms, 1), "link_frac_bytes_that_crossed": round(cross_ms / r["wall_ms_incl_pcie_total"], 3), "scope": r["scope"]}
             ent["checked_against_oracle"] = stat["checked"]
             ent["check"] = "oracle limb-for-limb ok" if not stat["failed"] and stat["checked"] else ("MISMATCH: " + ",".join(stat["failed"]) if stat["failed"] else "nothing checked")
         except Exception as exc:  # reported in the line, and a failed e2e fails the run

@@ -37,11 +37,13 @@ int main() {
         const size_t sizes[] = {1, 4096, (1u << 20) - 1, (1u << 20) + 1, (5u << 20) + 777, 16u << 20};
         for (size_t sz : sizes) {
             std::vector<unsigned char> src(sz, 0), dst(sz, 0xEE);
+            if (!pool->copy(nullptr, (const char*)src.data(), sz, true, false, true)) ++bad;                    // scan only: zero, no destination needed
             if (!pool->copy((char*)dst.data(), (const char*)src.data(), sz, true)) ++bad;                      // zero throughout
             for (size_t i = 0; i < sz; i += 997) if (dst[i] != 0xEE) { ++bad; break; }                           // ... and dst untouched
             for (size_t pos : {(size_t)0, sz / 2, sz - 1}) {
                 std::fill(src.begin(), src.end(), 0); std::fill(dst.begin(), dst.end(), 0xEE);
                 src[pos] = 7;
+                if (pool->copy(nullptr, (const char*)src.data(), sz, true, false, true)) ++bad;                 // scan only: not zero, nothing written
                 if (pool->copy((char*)dst.data(), (const char*)src.data(), sz, true)) ++bad;
                 if (memcmp(dst.data(), src.data(), sz) != 0) ++bad;                                                // the zero parts were cleared
             }

@@ -232,3 +232,35 @@ def test_device_block_pool_reuses_and_isolates():
     api._check(lib.trh_free(r))
     api._check(lib.trh_free(q))
     assert lib.trh_free(None) == 0
+
+
+def test_best_fft_zero_padded_vectors_and_failed_speculation():
+    """trh_best_fft on the zero-padded vector coeff_to_extended hands over (data in the first eighth): the padding is not sent -- chunks
+    that probe as zero are cleared on the device at once and read through while the device works (csrc/hostio.hip best_fft_host).
+    Against the oracle's best_fft: the plain padded vector; a vector with ONE non-zero element deep inside the padding, off every probed
+    line (the speculation must fail and the call start over); an all-zero vector; a full vector"""
+    field, log_n = "fp", 20
+    n = 1 << log_n
+    f = o.FIELDS[field]
+    w = np.array(f.limbs(f.omega(log_n)), np.uint64)
+    data = synth.field_elements(0x2E20, n // 8)
+    th = cpu_ref.hardware_threads()
+    padded = np.zeros((n, 4), dtype=np.uint64)
+    padded[: n // 8] = data
+    hidden = padded.copy()
+    hidden[5 * n // 8 + 3] = data[7]          # byte offset 20 MiB + 96: not a multiple of 64 KiB, not a chunk's first or last line
+    edge = padded.copy()
+    edge[n - 1] = data[9]                     # the very last element
+    for vec in (padded, hidden, edge, np.zeros((n, 4), dtype=np.uint64), synth.field_elements(0x2E21, n)):
+        want = cpu_ref.best_fft(field, vec, w, log_n, threads=th)
+        work = vec.copy()
+        api.io_stats(reset=True)
+        api.best_fft_inplace(field, work, w, log_n)
+        assert (work == want).all()
+    io = api.io_stats()
+    assert io["h2d_zero_bytes"] == 0          # the last vector is full: nothing elided
+    work = padded.copy()
+    api.io_stats(reset=True)
+    api.best_fft_inplace(field, work, w, log_n)
+    io = api.io_stats()
+    assert io["h2d_zero_bytes"] >= (n - n // 8 - (1 << 19)) * 32 and io["h2d_bytes"] == n * 32, io

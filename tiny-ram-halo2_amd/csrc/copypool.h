@@ -89,10 +89,11 @@ class CopyPool {
     // detect_zero: a source that is zero throughout is NOT copied and the call returns true (the caller replaces the transfer by a
     // device-side memset); parts of a mixed source that are zero are cleared in dst, the call returns false.
     // nt: streaming stores (see nt_copy_avx2)
-    bool copy(char* dst, const char* src, size_t bytes, bool detect_zero = false, bool nt = false) {
+    // scan_only (with detect_zero): nothing is written at all -- the call answers "is the source zero throughout?" with the pool's threads
+    bool copy(char* dst, const char* src, size_t bytes, bool detect_zero = false, bool nt = false, bool scan_only = false) {
         if (bytes < ((size_t)1 << 20) || T == 0) {
             if (detect_zero && bytes && all_zero(src, bytes)) return true;
-            copy_bytes(dst, src, bytes, nt);
+            if (!scan_only) copy_bytes(dst, src, bytes, nt);
             return false;
         }
         std::lock_guard<std::mutex> call(call_mu);
@@ -100,7 +101,7 @@ class CopyPool {
         const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
         {
             std::lock_guard<std::mutex> lk(mu);
-            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per; job_detect = detect_zero; job_nt = nt;
+            job_dst = dst; job_src = src; job_bytes = bytes; job_per = per; job_detect = detect_zero; job_nt = nt; job_scan = scan_only;
             zero_mask = 0;
             pending = T;
             pending_atomic.store(T, std::memory_order_release);
@@ -108,7 +109,7 @@ class CopyPool {
             gen_atomic.store(gen, std::memory_order_release);
         }
         cv_work.notify_all();
-        const bool z0 = part(0, dst, src, bytes, per, detect_zero, nt);  // part 0 on the caller
+        const bool z0 = part(0, dst, src, bytes, per, detect_zero, nt, scan_only);  // part 0 on the caller
         for (int spin = 0; spin < 20000 && pending_atomic.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
@@ -117,6 +118,7 @@ class CopyPool {
         size_t live = 0;
         for (size_t k = 0; k < parts; ++k) if (k * per < bytes) ++live;
         if (mask == (live >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << live) - 1))) return true;  // zero throughout: dst untouched
+        if (scan_only) return false;
         for (size_t k = 0; k < live; ++k)  // a mixed slot (the boundary between the data and its padding): the skipped parts are cleared
             if (mask >> k & 1) memset(dst + k * per, 0, (k + 1) * per < bytes ? per : bytes - k * per);
         return false;
@@ -124,18 +126,18 @@ class CopyPool {
 
   private:
     // part k of the job; returns true when detect was asked and the part is zero (and was therefore NOT written)
-    static bool part(size_t k, char* dst, const char* src, size_t bytes, size_t per, bool detect, bool nt) {
+    static bool part(size_t k, char* dst, const char* src, size_t bytes, size_t per, bool detect, bool nt, bool scan) {
         const size_t lo = k * per;
         if (lo >= bytes) return false;
         const size_t len = lo + per < bytes ? per : bytes - lo;
         if (detect && all_zero(src + lo, len)) return true;
-        copy_bytes(dst + lo, src + lo, len, nt);
+        if (!scan) copy_bytes(dst + lo, src + lo, len, nt);
         return false;
     }
     void worker(int id) {
         unsigned seen = 0;
         for (;;) {
-            char* dst; const char* src; size_t bytes, per; bool detect, nt;
+            char* dst; const char* src; size_t bytes, per; bool detect, nt, scan;
             {
                 // jobs arrive every few hundred microseconds while a transfer runs: spin briefly before sleeping (a condition-variable
                 // wake-up costs 30-50 us, a quarter of a slot's DMA time)
@@ -144,9 +146,9 @@ class CopyPool {
                 cv_work.wait(lk, [&] { return gen != seen; });
                 if (stop) return;
                 seen = gen;
-                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per; detect = job_detect; nt = job_nt;
+                dst = job_dst; src = job_src; bytes = job_bytes; per = job_per; detect = job_detect; nt = job_nt; scan = job_scan;
             }
-            const bool z = part((size_t)id + 1, dst, src, bytes, per, detect, nt);
+            const bool z = part((size_t)id + 1, dst, src, bytes, per, detect, nt, scan);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (z) zero_mask |= (uint64_t)1 << (id + 1);
@@ -160,7 +162,7 @@ class CopyPool {
     std::mutex mu, call_mu;
     std::condition_variable cv_work, cv_done;
     char* job_dst = nullptr; const char* job_src = nullptr; size_t job_bytes = 0, job_per = 0;
-    bool job_detect = false, job_nt = false, stop = false;
+    bool job_detect = false, job_nt = false, job_scan = false, stop = false;
     uint64_t zero_mask = 0;
     unsigned gen = 0;
     int pending = 0;

@@ -15,6 +15,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/trh.h"
@@ -210,12 +211,17 @@ void stage_release(Ctx& c);
 // (part_of_batch: more uploads follow at once -- full slots throughout, the next call's copy overlaps this one's DMA; otherwise the
 //  transfer starts and ends with short chunks; head_only: short chunks at the start only -- the first of a run of uploads)
 // (zero_elide: slots whose source is zero throughout become a hipMemsetAsync -- the zero-padded vectors of coeff_to_extended)
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch = false, bool zero_elide = false, bool head_only = false);
+// (speculate: chunks whose PROBE -- one 64-byte line per 64 KiB, the first and the last -- is zero are cleared on the device at once and
+//  listed as (offset, length) instead of being read through; the caller must verify every listed range before it relies on the result)
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch = false, bool zero_elide = false, bool head_only = false,
+              std::vector<std::pair<size_t, size_t>>* speculate = nullptr);
 // src (device src_device, ordered behind src_stream) -> dst on dstc's device WITHOUT peer access: slots of dstc's pinned download ring carry
 // the bytes (D2H on src_stream, H2D on dst_stream), everything stream-ordered, no host synchronisation
 int stage_d2d_via_host(Ctx& dstc, void* dst_dev, hipStream_t dst_stream, const void* src_dev, int src_device, hipStream_t src_stream, size_t bytes);
-// src_dev -> dst_host through the download ring, ordered behind the work queued on s; returns when dst_host is complete
-int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
+// src_dev -> dst_host through the download ring, ordered behind the work queued on s; returns when dst_host is complete.
+// before_copy_out (optional) runs once after the first DMAs into the ring were issued and before anything is written to dst_host; a
+// non-zero return stops the download with that code (dst_host untouched, the DMAs already issued only touch the ring)
+int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s, const std::function<int()>* before_copy_out = nullptr);
 // Batch pipeline over `count` items (each a group of host buffers): upload (caller thread, stage.us) -> compute(item, in, out,
 // stage.cs) -> download (helper thread, stage.ds), over a ring of device buffers.  in_bytes / out_bytes: device bytes per item;
 // upload(item, dev_in) issues the stage_h2d calls of one item; segments(item, dev_out, list) names where its results go -- the helper

@@ -80,6 +80,18 @@ int nt_mode() {
     return v;
 }
 
+// one 64-byte line per 64 KiB, the first and the last: zero?  (a hint, never a proof: stage_h2d's `speculate`)
+bool probe_zero(const char* p, size_t bytes) {
+    const uint64_t* first = (const uint64_t*)p;
+    const uint64_t* last = (const uint64_t*)(p + ((bytes - 64) & ~(size_t)7));
+    for (int k = 0; k < 8; ++k) if (first[k] | last[k]) return false;
+    for (size_t o = (size_t)64 << 10; o + 64 <= bytes; o += (size_t)64 << 10) {
+        const uint64_t* w = (const uint64_t*)(p + o);
+        if (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) return false;
+    }
+    return true;
+}
+
 // is this host pointer already page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engine reads it directly.
 bool is_pinned(const void* p) {
     hipPointerAttribute_t attr;
@@ -147,7 +159,8 @@ void stage_release(Ctx& c) {
     st.slot = 0;
 }
 
-int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch, bool zero_elide, bool head_only) {
+int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s, bool part_of_batch, bool zero_elide, bool head_only,
+              std::vector<std::pair<size_t, size_t>>* speculate) {
     if (!bytes) return TRH_OK;
     TRH_TRY(stage_ensure(c));
     Stage& st = c.stage;
@@ -161,6 +174,14 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
         chunk_plan(bytes, st.slot, !part_of_batch, !part_of_batch && !head_only, plan);
         size_t off = 0;
         for (const size_t cur : plan) {
+            if (speculate && cur >= ((size_t)1 << 20) && probe_zero((const char*)src_host + off, cur)) {
+                // looks like padding: cleared on the device NOW, read through LATER (the caller verifies the range while the device works)
+                TRH_HIP_TRY(hipMemsetAsync((char*)dst_dev + off, 0, cur, s));
+                speculate->push_back({off, cur});
+                st.up_zero_bytes += (double)cur;
+                off += cur;
+                continue;
+            }
             const int sl = (int)(st.up_next % Stage::NS);
             if (st.up_used[sl]) TRH_HIP_TRY(hipEventSynchronize(st.up_ev[sl]));
             trace_chunk("up: slot free, copy begins", off, cur);
@@ -183,12 +204,13 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
     return TRH_OK;
 }
 
-int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s) {
+int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s, const std::function<int()>* before_copy_out) {
     if (!bytes) return TRH_OK;
     TRH_TRY(stage_ensure(c));
     Stage& st = c.stage;
     const double t0 = now_s();
     if (is_pinned(dst_host)) {
+        if (before_copy_out) { const int rc = (*before_copy_out)(); if (rc != TRH_OK) return rc; }
         TRH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
     } else {
@@ -203,6 +225,11 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
                 const int sl = (int)(issued % Stage::NS);
                 TRH_HIP_TRY(hipMemcpyAsync(st.down + (size_t)sl * st.slot, (const char*)src_dev + offs[issued], plan[issued], hipMemcpyDeviceToHost, s));
                 TRH_HIP_TRY(hipEventRecord(st.down_ev[sl], s));
+            }
+            if (k == 0 && before_copy_out) {  // the first DMAs are on their way into the ring; nothing has been written to dst_host yet
+                const int rc = (*before_copy_out)();
+                trace_chunk("down: before-copy-out hook returned", (size_t)rc, 0);
+                if (rc != TRH_OK) { (void)hipStreamSynchronize(s); return rc; }
             }
             const int sl = (int)(k % Stage::NS);
             TRH_HIP_TRY(hipEventSynchronize(st.down_ev[sl]));
@@ -424,16 +451,36 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     IoTrace tr;
     TRH_TRY(c.io.ensure(bytes));
     tr.mark("begin, bytes", bytes);
-    // zero slots are not sent (coeff_to_extended hands over a vector that is zero beyond its first 2^k entries: 7/8 of the upload)
-    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true));
-    tr.mark("upload issued");
+    // Zero slots are not sent (coeff_to_extended hands over a vector that is zero beyond its first 2^k entries: 7/8 of the upload).  Reading
+    // 56 MiB of zeros to be SURE they are zeros takes the host 0.5 ms, and nothing else could start before it: so chunks that look like
+    // padding (a sparse probe) are cleared on the device at once, the transform and the first downloads are queued, and the padding is
+    // read through while the device works -- before anything is written back into `a` (the transform is in place: until then `a` still
+    // holds the input).  If a probed chunk turns out not to be zero the speculative result is dropped and the call starts over plainly.
+    static const int spec_knob = getenv("TRH_FFT_SPECULATE") ? atoi(getenv("TRH_FFT_SPECULATE")) : 1;
+    std::vector<std::pair<size_t, size_t>> spec;
+    const bool speculative = spec_knob && bytes >= ((size_t)8 << 20) && !is_pinned(a);
+    TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true, false, speculative ? &spec : nullptr));
+    tr.mark("upload issued; speculated ranges", spec.size());
     TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
     tr.mark("transform queued");
-    TRH_TRY(stage_d2h(c, a, c.io.p, bytes, s));
+    const std::function<int()> verify = [&]() -> int {
+        for (const auto& r : spec)
+            if (!c.stage.up_pool->copy(nullptr, (const char*)a + r.first, r.second, true, false, true)) return TRH_EBUSY;  // (any non-zero code: handled below)
+        return TRH_OK;
+    };
+    int rc = stage_d2h(c, a, c.io.p, bytes, s, spec.empty() ? nullptr : &verify);
+    if (rc == TRH_EBUSY && !spec.empty()) {  // a chunk that probed as zero was not: `a` is untouched, do it again without guessing
+        tr.mark("speculation failed: plain pass");
+        TRH_HIP_TRY(hipStreamSynchronize(s));
+        TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true));
+        TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
+        rc = stage_d2h(c, a, c.io.p, bytes, s);
+    }
+    TRH_TRY(rc);
     tr.mark("download complete");
-    const int rc = scope.finish();
+    const int rc_end = scope.finish();
     tr.mark("end");
-    return rc;
+    return rc_end;
 }
 
 static int best_fft_batch_host(int field, uint64_t* const* a, size_t count, const uint64_t* omega, uint32_t log_n) {

@@ -1205,11 +1205,12 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
         c.attr_done |= ATTR_MSM;
     }
-    // sparse-column path: fixed-base mode only (one flat bucket set per item), see msm_sparse_emit_kernel.  Lone MSMs take it as well (the
-    // literal drop-in commits one witness column per call: the classifier's synchronisation costs ~20 us, the dense pipeline's fixed
-    // costs over the W x n digit space ~0.3 ms)
+    // sparse-column path: fixed-base BATCHES only (one flat bucket set per item), see msm_sparse_emit_kernel.  A lone MSM does not take it:
+    // measured at k = 18 per value class (tools/lone_sparse_probe.py), the classifier's two launches and its synchronisation cost a lone
+    // commitment 0.02 - 0.10 ms more than the compaction saves (flag 0.735 vs 0.719 ms, word 0.651 vs 0.625, even-bits 0.791 vs 0.691, full-size
+    // 0.679 vs 0.637): a lone MSM's time is its latency chain, not the digit slots
     static const int sparse_knob = getenv("TRH_SPARSE") ? atoi(getenv("TRH_SPARSE")) : 1;
-    const bool sparse_ok = sparse_knob && fb && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
+    const bool sparse_ok = sparse_knob && fb && batch >= 8 && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
     if (sparse_ok) {
         TRH_TRY(L.sparse.ensure((size_t)chunk * SP_LISTS * SP_PAD * 4 + chunk + 64));
         if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, 8192, hipHostMallocDefault));

@@ -825,6 +825,9 @@ def run_dropin(word_bits: int, level: str = "literal", batch: int = 64, hook=Non
     out = {"mode": "dropin-" + level + ("-blocks" if blocks_level else ""), "word_bits": word_bits, "columns": columns, "schedule": sch, "counts": counts,
            "wall_ms_incl_pcie": {kk: round(v * 1e3, 3) for kk, v in wall.items()}, "wall_ms_incl_pcie_total": round(in_calls * 1e3, 3),
            "pcie": {"h2d_GB": round(io["h2d_bytes"] / 1e9, 3), "d2h_GB": round(io["d2h_bytes"] / 1e9, 3),
+                    # of h2d_GB: pinned slots that were zero throughout (the padding of the zero-padded 2^extended_k vectors) and were cleared on the
+                    # device instead of crossing the link
+                    "h2d_zero_elided_GB": round(io.get("h2d_zero_bytes", 0.0) / 1e9, 3),
                     "h2d_GBps_in_copies": round(io["h2d_bytes"] / max(io["h2d_seconds"], 1e-9) / 1e9, 2),
                     "d2h_GBps_in_copies": round(io["d2h_bytes"] / max(io["d2h_seconds"], 1e-9) / 1e9, 2),
                     "GBps_over_call_time": round((io["h2d_bytes"] + io["d2h_bytes"]) / max(in_calls, 1e-9) / 1e9, 2),
