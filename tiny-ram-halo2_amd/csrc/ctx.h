@@ -95,6 +95,7 @@ struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: bat
     DevBuf heavy;        // [0] count + list of (window, bucket) ids whose pieces a whole workgroup combines
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
+    DevBuf reduce2l;     // two-level reduction (TRH_REDUCE_2L): row and column sums per window
     DevBuf sparse;       // sparse-column path: per item SP_LISTS list counters (one 128-byte line each), then one dense flag per item
 };
 

@@ -862,6 +862,79 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZzMem* __restr
     if (threadIdx.x == 0) store_raw(&partials[(size_t)j * gridDim.x + blockIdx.x], sh[0]);
 }
 
+// ---------------------------------------------------------------------------------------
+// 5'. the same window sum in the two-level row / column form (round 4: built to be measured against the slices above):
+//     bucket id - 1 = r * C + q with C = 256 columns: sum_b b B_b = C * sum_r r * Row_r + sum_q (q + 1) * Col_q with
+//     Row_r = sum_q B_{r,q}, Col_q = sum_r B_{r,q}.
+//       sums   one workgroup per row (256 buckets -> Row_r) and one per column (R buckets -> Col_q): LDS trees, 8 levels
+//       final  two workgroups per window: sum_q (q + 1) Col_q and sum_r r Row_r as the sum of the suffix sums (a Hillis-Steele suffix scan,
+//              8 levels, then a tree, 8 levels), the row part doubled 8 times (x C); msm_window_sum_kernel adds the two
+//     Depth: 8 + 16 (+ 8 doublings) + 1 point operations against 2 * slice + ~22 + 8 + 4 of the slice form; the work is the same 2 N additions.
+//     MEASURED (profiles/r04_reduce_ab.txt): it loses by a factor of two -- reduction + window sum of a lone MSM 0.31 -> 0.70 ms at 2^20, 0.34 ->
+//     0.79 at 2^22, 0.44 -> 0.95 at 2^24, the k = 18 opening unchanged (15.1 / 15.0 ms).  Every level of the scan and of the trees is a full
+//     lazy addition per thread with two LDS round trips of 144 bytes, and the column sums gather 144-byte records 36 KiB apart; the slice form's
+//     running sums and offset multiplication stay in registers.  Kept behind TRH_REDUCE_2L=1 as the record of the experiment, off by default.
+// ---------------------------------------------------------------------------------------
+constexpr u32 R2L_COLS = 256;
+template <class BF>
+__global__ void __launch_bounds__(256) msm_reduce2l_sums_kernel(const XYZZzMem* __restrict__ buckets, XYZZzMem* __restrict__ sums /* [item][window][R + C] */, u32 nbk) {
+    const size_t z = blockIdx.z;
+    const u32 R = nbk / R2L_COLS;
+    buckets += (z * gridDim.y + blockIdx.y) * (size_t)nbk;
+    sums += (z * gridDim.y + blockIdx.y) * (size_t)(R + R2L_COLS);
+    __shared__ XYZZz<BF> sh[256];
+    XYZZz<BF> v = xyzzz_identity<BF>();
+    if (blockIdx.x < R) {  // row r: buckets r * C .. r * C + 255 (coalesced)
+        v = load_raw<BF>(&buckets[(size_t)blockIdx.x * R2L_COLS + threadIdx.x]);
+    } else {               // column q: buckets q, C + q, 2 C + q, ...
+        const u32 q = blockIdx.x - R;
+        for (u32 r = threadIdx.x; r < R; r += 256) v = xyzzz_add(v, load_raw<BF>(&buckets[(size_t)r * R2L_COLS + q]));
+    }
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    int top = 128;
+    if (blockIdx.x >= R) while (top > 1 && (u32)top >= R) top >>= 1;  // a column holds R <= 256 values
+    for (int st = top; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_raw(&sums[blockIdx.x], sh[0]);
+}
+template <class BF>
+__global__ void __launch_bounds__(256) msm_reduce2l_final_kernel(const XYZZzMem* __restrict__ sums, XYZZzMem* __restrict__ partials /* [item][window][2] */, u32 nbk) {
+    const size_t z = blockIdx.z;
+    const u32 R = nbk / R2L_COLS;
+    sums += (z * gridDim.y + blockIdx.y) * (size_t)(R + R2L_COLS);
+    partials += (z * gridDim.y + blockIdx.y) * 2;
+    __shared__ XYZZz<BF> sh[256];
+    const bool rows = blockIdx.x == 1;
+    const u32 count = rows ? R : R2L_COLS, t = threadIdx.x;
+    // x_t: Col_t (weight t + 1) or Row_t (weight t).  sum_t w_t x_t = sum over the suffix sums S_t = x_t + x_{t+1} + ... of all t >= t0, with
+    // t0 = 0 for the columns (weight t + 1: S_0 .. S_t each hold x_t once) and t0 = 1 for the rows (weight t)
+    sh[t] = t < count ? load_raw<BF>(&sums[rows ? t : R + t]) : xyzzz_identity<BF>();
+    __syncthreads();
+    for (u32 off = 1; off < count; off <<= 1) {  // suffix scan
+        XYZZz<BF> o = xyzzz_identity<BF>();
+        if (t + off < count) o = sh[t + off];
+        __syncthreads();
+        if (t + off < count) sh[t] = xyzzz_add(sh[t], o);
+        __syncthreads();
+    }
+    if (rows && t == 0) sh[0] = xyzzz_identity<BF>();  // weight 0
+    __syncthreads();
+    int top = 128;
+    while (top > 1 && (u32)top >= count) top >>= 1;
+    for (int st = top; st > 0; st >>= 1) {
+        if ((int)t < st) sh[t] = xyzzz_add(sh[t], sh[t + st]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        XYZZz<BF> v = sh[0];
+        if (rows) for (u32 k = 1; k < R2L_COLS; k <<= 1) v = xyzzz_dbl(v);  // x C
+        store_raw(&partials[blockIdx.x], v);
+    }
+}
+
 // one block per window: sum `count` partials, hand the window sum over in the canonical form
 template <class BF>
 __global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
@@ -1344,8 +1417,19 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                 r_tpw = sparse_tpw; r_slice = nbk / r_tpw; r_blocks = (r_tpw + 255) / 256;
                 TRH_TRY(L.partials.ensure(chunk * Ws * r_blocks * sizeof(XYZZzMem)));
             }
+            // TRH_REDUCE_2L=1: the two-level row / column form for small launches (a lone MSM, an IPA round), see msm_reduce2l_sums_kernel
+            static const int two_level = getenv("TRH_REDUCE_2L") ? atoi(getenv("TRH_REDUCE_2L")) : 0;
+            if (two_level && nbk >= 2 * R2L_COLS && nbk <= 256 * R2L_COLS && (size_t)Ws * nb <= 64) {  // (R <= 256 rows: one workgroup scans them)
+                const u32 R = nbk / R2L_COLS;
+                TRH_TRY(L.reduce2l.ensure((size_t)chunk * Ws * (R + R2L_COLS) * sizeof(XYZZzMem)));
+                TRH_TRY(L.partials.ensure((size_t)chunk * Ws * 2 * sizeof(XYZZzMem)));
+                hipLaunchKernelGGL((msm_reduce2l_sums_kernel<BF>), dim3(R + R2L_COLS, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.reduce2l.as<XYZZzMem>(), nbk);
+                hipLaunchKernelGGL((msm_reduce2l_final_kernel<BF>), dim3(2, Ws, nb), dim3(256), 0, s, L.reduce2l.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk);
+                hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, 2u);
+            } else {
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(r_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, r_slice, r_tpw);
             hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks);
+            }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
         return TRH_OK;
@@ -1522,7 +1606,7 @@ void msm_release() {
     m.scalars.release(); m.tails.release(); m.bases_z.release(); m.window_sums.release();
     MsmLane& L = m.lane;
     L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release(); L.bucket_cnt.release();
-    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release(); L.sparse.release();
+    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release(); L.sparse.release(); L.reduce2l.release();
     if (m.sp_host) (void)hipHostFree(m.sp_host);
     m.sp_host = nullptr;
     if (m.host_sums) (void)hipHostFree(m.host_sums);
