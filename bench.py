@@ -207,7 +207,7 @@ def spawn_ranks(args) -> int:
         if first_fail is None and any(rc not in (None, 0) for rc in rcs):
             first_fail = time.time()
         # a rank that died leaves the others in a rendezvous or a collective: give them a minute, then end OUR children by pid
-        if (first_fail is not None and time.time() - first_fail > 60) or time.time() > deadline:
+        if (first_fail is not None and time.time() - first_fail > float(os.environ.get("TRH_BENCH_SPAWN_GRACE", "60"))) or time.time() > deadline:
             for p in procs:
                 if p.poll() is None:
                     p.kill()

@@ -14,7 +14,10 @@
 // /root/reference/src/test_utils.rs:23-25) and the polynomial side of poly::multiopen::create_proof (x1 fold per point set, kate
 // divisions, x2 fold, q' commitment, evaluations at x3, x4 fold) in front of the IPA opening.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstring>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -304,6 +307,174 @@ int run_dropin(int word_bits, size_t batch, bool witness, bool batched, int max_
 
 }  // namespace
 
+// --devices d0,d1,...: the per-column phase of create_proof (commit_lagrange, lagrange_to_coeff, coeff_to_extended as coset blocks, the
+// evaluations at x) COLUMN-SHARDED over the listed devices from this one process -- per entry one host thread, one trh::Context, one Params
+// copy and one EvaluationDomain on that device; thread g takes the contiguous columns [lo_g, hi_g) (the split of sharded.shard_range), no
+// data-path collective.  A device may be listed twice (two contexts on one chip).  The commitments gathered in column order must equal the
+// single-context run's bit for bit (exit code 1 otherwise); per-device times and the single-context time of the same phase are printed.
+// The reference proves in one process (/root/reference/src/test_utils.rs:37-54): this is what that process does with a node's GPUs.
+int run_sharded(int word_bits, size_t batch, bool witness, const std::vector<int>& devices, int max_columns) {
+    init(devices[0]);
+    const uint32_t k = 2 + word_bits / 2;
+    const size_t n = (size_t)1 << k;
+    const Curve curve = Curve::Vesta;
+    const Field field = scalar_field(curve);
+    int lag_total = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS;
+    if (max_columns > 0 && max_columns < lag_total) lag_total = max_columns;
+    std::vector<std::pair<Kind, bool>> kinds;
+    for (const ColumnClass& c : WITNESS_CLASSES) for (int i = 0; i < c.count; ++i) kinds.push_back({c.kind, c.blinded});
+    const size_t G = devices.size();
+    const Limbs x_eval = SplitMix{0xe7a}.element();
+    struct Shard {
+        int device = 0, lo = 0, hi = 0;
+        std::unique_ptr<Context> ctx;
+        std::unique_ptr<Params> params;
+        std::unique_ptr<EvaluationDomain> dom;
+        std::unique_ptr<DeviceBuffer> cols, work, ext;
+        std::vector<Limbs> blinds;
+        std::vector<Point> points;
+        std::vector<Limbs> evals;
+        double ms[4] = {0, 0, 0, 0}, wall_ms = 0;
+        std::string err;
+    };
+    std::vector<Shard> sh(G);
+    const int base = lag_total / (int)G, extra = lag_total % (int)G;
+    for (size_t g = 0; g < G; ++g) {
+        sh[g].device = devices[g];
+        sh[g].lo = (int)g * base + std::min((int)g, extra);
+        sh[g].hi = sh[g].lo + base + ((int)g < extra ? 1 : 0);
+    }
+    // the per-column steps over `count` columns of `buf` (in place), batch by batch, on the bound context's stream
+    auto phase = [&](Shard& s, DeviceBuffer& buf, size_t count, const Limbs* blinds, std::vector<Point>& pts, std::vector<Limbs>& evals, double* ms) {
+        void* st = s.ctx->stream();
+        const uint32_t D = s.dom->quotient_blocks();
+        pts.clear(); evals.clear();
+        for (size_t done = 0; done < count; done += batch) {
+            const size_t b = std::min(batch, count - done);
+            void* c0 = buf.at(done * n * 32);
+            double t0 = now_ms();
+            std::vector<Point> p(b);
+            check(trh_commit_batch_dev(s.params->g_lagrange().handle(), c0, n, b, (const uint64_t*)(blinds + done), st, (uint64_t*)p.data()), "commit_batch");
+            double t1 = now_ms();
+            s.dom->lagrange_to_coeff(c0, b, st);
+            check(trh_stream_synchronize(st), "sync");
+            double t2 = now_ms();
+            s.dom->coeff_to_extended_blocks(c0, s.ext->data(), b, D, st);
+            check(trh_stream_synchronize(st), "sync");
+            double t3 = now_ms();
+            const std::vector<Limbs> e = eval_polynomials(field, c0, n, b, x_eval, st);
+            double t4 = now_ms();
+            if (ms) { ms[0] += t1 - t0; ms[1] += t2 - t1; ms[2] += t3 - t2; ms[3] += t4 - t3; }
+            pts.insert(pts.end(), p.begin(), p.end());
+            evals.insert(evals.end(), e.begin(), e.end());
+        }
+    };
+    auto setup = [&](Shard& s) {
+        s.ctx.reset(new Context(s.device));
+        s.ctx->bind();
+        s.params.reset(new Params(curve, k, 0x1234567, 0x89abcdef, true));
+        s.dom.reset(new EvaluationDomain(field, QUOTIENT_J, k));
+        const size_t cnt = (size_t)(s.hi - s.lo);
+        s.cols.reset(new DeviceBuffer(std::max<size_t>(cnt, 1) * n * 32));
+        s.work.reset(new DeviceBuffer(std::max<size_t>(cnt, 1) * n * 32));
+        s.ext.reset(new DeviceBuffer(std::min(batch, std::max<size_t>(cnt, 1)) * s.dom->quotient_blocks() * n * 32));
+        std::vector<Limbs> host(n);
+        for (size_t c = 0; c < cnt; ++c) {  // every column has its own generator state: the single-context run rebuilds exactly these
+            SplitMix rng{0xc01 + (uint64_t)(s.lo + (int)c) * 7919};
+            if (witness) fill_witness_column(kinds[s.lo + c].first, kinds[s.lo + c].second, rng, word_bits, n, host.data());
+            else for (size_t i = 0; i < n; ++i) host[i] = rng.element();
+            s.cols->upload(host.data(), n * 32, c * n * 32);
+        }
+        if (witness && cnt) check(trh_field_op_dev((int)field, 6 /* to_montgomery */, s.cols->data(), nullptr, s.cols->data(), cnt * n, nullptr), "to_mont");
+        check(trh_stream_synchronize(nullptr), "sync");
+        s.blinds.resize(cnt);
+        for (size_t c = 0; c < cnt; ++c) s.blinds[c] = SplitMix{0xb11d + (uint64_t)(s.lo + (int)c)}.element();
+        Context::unbind();
+    };
+    auto copy_cols = [&](Shard& s) {  // work <- cols (one kernel per column: the ABI's copy helpers would bounce over the host)
+        const std::vector<Limbs> unit(1, host::one(field));
+        for (int c = 0; c < s.hi - s.lo; ++c) lincomb(field, s.cols->at((size_t)c * n * 32), n, unit, s.work->at((size_t)c * n * 32), s.ctx->stream());
+        check(trh_stream_synchronize(s.ctx->stream()), "sync");
+    };
+    for (Shard& s : sh) setup(s);
+    // single-context reference: shard 0's context takes every column, step by step (the other shards' columns are rebuilt on its device)
+    std::vector<Point> ref_pts;
+    std::vector<Limbs> ref_evals;
+    double single_ms[4] = {0, 0, 0, 0}, single_wall = 0;
+    {
+        Shard& r = sh[0];
+        r.ctx->bind();
+        DeviceBuffer all((size_t)lag_total * n * 32);
+        std::vector<Limbs> host(n), blinds(lag_total);
+        for (int c = 0; c < lag_total; ++c) {
+            SplitMix rng{0xc01 + (uint64_t)c * 7919};
+            if (witness) fill_witness_column(kinds[c].first, kinds[c].second, rng, word_bits, n, host.data());
+            else for (size_t i = 0; i < n; ++i) host[i] = rng.element();
+            all.upload(host.data(), n * 32, (size_t)c * n * 32);
+            blinds[c] = SplitMix{0xb11d + (uint64_t)c}.element();
+        }
+        if (witness) check(trh_field_op_dev((int)field, 6, all.data(), nullptr, all.data(), (size_t)lag_total * n, nullptr), "to_mont");
+        check(trh_stream_synchronize(nullptr), "sync");
+        {   // warm-up at the real batch size (scratch, tables)
+            DeviceBuffer warm(std::min(batch, (size_t)lag_total) * n * 32);
+            const std::vector<Limbs> unit(1, host::one(field));
+            for (size_t c = 0; c < std::min(batch, (size_t)lag_total); ++c) lincomb(field, all.at(c * n * 32), n, unit, warm.at(c * n * 32), r.ctx->stream());
+            std::vector<Point> p; std::vector<Limbs> e;
+            phase(r, warm, std::min(batch, (size_t)lag_total), blinds.data(), p, e, nullptr);
+        }
+        const double t0 = now_ms();
+        phase(r, all, (size_t)lag_total, blinds.data(), ref_pts, ref_evals, single_ms);
+        single_wall = now_ms() - t0;
+        Context::unbind();
+    }
+    // the sharded run: one thread per device, started together
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> ths;
+    for (size_t g = 0; g < G; ++g) ths.emplace_back([&, g] {
+        Shard& s = sh[g];
+        try {
+            s.ctx->bind();
+            const size_t cnt = (size_t)(s.hi - s.lo);
+            copy_cols(s);
+            { std::vector<Point> p; std::vector<Limbs> e; phase(s, *s.work, std::min(batch, cnt), s.blinds.data(), p, e, nullptr); }  // warm-up
+            copy_cols(s);
+            ready.fetch_add(1);
+            while (!go.load()) std::this_thread::yield();
+            const double t0 = now_ms();
+            phase(s, *s.work, cnt, s.blinds.data(), s.points, s.evals, s.ms);
+            s.wall_ms = now_ms() - t0;
+            Context::unbind();
+        } catch (const std::exception& e) { s.err = e.what(); ready.fetch_add(1); }
+    });
+    while (ready.load() < (int)G) std::this_thread::yield();
+    const double t0 = now_ms();
+    go.store(true);
+    for (auto& t : ths) t.join();
+    const double wall = now_ms() - t0;
+    bool identical = true;
+    for (Shard& s : sh) {
+        if (!s.err.empty()) { std::fprintf(stderr, "shard on device %d failed: %s\n", s.device, s.err.c_str()); return 2; }
+        for (int c = s.lo; c < s.hi; ++c) {
+            identical = identical && std::memcmp(&s.points[c - s.lo], &ref_pts[c], sizeof(Point)) == 0 && s.evals[c - s.lo] == ref_evals[c];
+        }
+    }
+    std::printf("{\"mode\": \"column-sharded\", \"k\": %u, \"columns\": \"%s\", \"devices\": [", k, witness ? "witness" : "random");
+    for (size_t g = 0; g < G; ++g) std::printf("%s%d", g ? ", " : "", devices[g]);
+    std::printf("], \"columns_replayed\": %d, \"per_device\": [", lag_total);
+    for (size_t g = 0; g < G; ++g)
+        std::printf("%s{\"device\": %d, \"columns\": [%d, %d], \"wall_ms\": %.3f, \"ms\": {\"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f}}",
+                    g ? ", " : "", sh[g].device, sh[g].lo, sh[g].hi, sh[g].wall_ms, sh[g].ms[0], sh[g].ms[1], sh[g].ms[2], sh[g].ms[3]);
+    std::printf("], \"wall_ms\": %.3f, \"single_context\": {\"wall_ms\": %.3f, \"ms\": {\"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f}}, "
+                "\"commitments_identical_to_single_context\": %s}\n", wall, single_wall, single_ms[0], single_ms[1], single_ms[2], single_ms[3], identical ? "true" : "false");
+    for (Shard& s : sh) {  // everything a shard owns lives on its context's device: released while it is bound
+        s.ctx->bind();
+        s.ext.reset(); s.work.reset(); s.cols.reset(); s.dom.reset(); s.params.reset();
+        Context::unbind();
+    }
+    return identical ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     int word_bits = 32;
     size_t batch = 64;
@@ -311,6 +482,7 @@ int main(int argc, char** argv) {
     std::string mode = "resident";
     int max_columns = 0;
     bool overlap = false, pinned = false;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--overlap") { overlap = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--pinned") { pinned = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -319,8 +491,10 @@ int main(int argc, char** argv) {
         else if (std::string(argv[i]) == "--columns") witness = std::string(argv[i + 1]) == "witness";
         else if (std::string(argv[i]) == "--mode") mode = argv[i + 1];
         else if (std::string(argv[i]) == "--max-columns") max_columns = std::atoi(argv[i + 1]);
+        else if (std::string(argv[i]) == "--devices") { for (const char* q = argv[i + 1]; *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
     }
     try {
+        if (!devices.empty()) return run_sharded(word_bits, batch, witness, devices, max_columns);
         if (mode == "dropin" || mode == "dropin-batched") return run_dropin(word_bits, batch, witness, mode == "dropin-batched", max_columns, pinned);
         init(0);
         const uint32_t k = 2 + word_bits / 2;

@@ -552,5 +552,22 @@ private:
 
 inline void init(int device = 0) { check(trh_init(device), "trh_init"); }
 
+// An independent libtrh context on one device (own scratch, own lock, own stream): one per host thread that should overlap with others, one
+// per GPU of a node.  bind() makes it the calling thread's context until unbind(); objects created while it is bound (Bases, Params,
+// EvaluationDomain, DeviceBuffer) live on its device.
+class Context {
+public:
+    explicit Context(int device = 0) { check(trh_ctx_create(device, &c_), "trh_ctx_create"); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ~Context() { if (c_) trh_ctx_destroy(c_); }
+    void bind() const { check(trh_ctx_set_current(c_), "trh_ctx_set_current"); }
+    static void unbind() { check(trh_ctx_set_current(nullptr), "trh_ctx_set_current"); }
+    void* stream() const { return trh_ctx_stream(c_); }
+    int device() const { return trh_ctx_device(c_); }
+private:
+    trh_ctx_t c_ = nullptr;
+};
+
 }  // namespace trh
 #endif  // TRH_HPP

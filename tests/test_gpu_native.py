@@ -51,3 +51,54 @@ def test_bench_two_ranks_on_one_device():
     assert out["config"]["pairs_total"] == 2 << 20
     assert out["strong"]["check"] == "closed-form ok" and out["strong"]["scaling"] == "strong"
     assert out["single_process"].get("check") == "closed-form ok", out["single_process"]
+
+
+@pytest.mark.parametrize("args", [["--word-bits", "16", "--batch", "32", "--devices", "0,0"], ["--word-bits", "32", "--batch", "32", "--max-columns", "120", "--devices", "0,0,0"]])
+def test_native_replay_column_sharded(args):
+    """examples/replay --devices: the per-column phase column-sharded over one thread + trh::Context + Params copy per listed device from
+    one compiled process; exit code 0 = the commitments and evaluations equal the single-context run's bit for bit"""
+    exe = os.path.join(ROOT, "examples", "replay")
+    r = subprocess.run([exe, "--columns", "witness", *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["mode"] == "column-sharded" and out["commitments_identical_to_single_context"] is True
+    n_dev = len(args[-1].split(","))
+    assert len(out["per_device"]) == n_dev and out["per_device"][0]["columns"][0] == 0 and out["per_device"][-1]["columns"][1] == out["columns_replayed"]
+    assert all(d["wall_ms"] > 0 for d in out["per_device"]) and out["single_context"]["wall_ms"] > 0
+    print(out)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's command): the parent starts the two ranks itself before it
+    touches a GPU, relays rank 0's line; the line names the backend that carried the partials, the world size it proved with an all-reduce
+    and the devices.  gloo with the ranks folded onto the one GPU of the box; the driver's scaling runs use RCCL"""
+    import sys
+    env = dict(os.environ, TRH_BENCH_BACKEND="gloo", TRH_BENCH_SINGLE_PROCESS="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "18", "--ntt-log-n", "14", "--no-sweep"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["check"] == "closed-form ok" and out["config"]["pairs_total"] == 2 << 18
+    c = out["collective"]
+    assert c["ok"] is True and c["backend"] == "gloo" and c["world"] == 2 and c["all_reduce_of_ones"] == 2 and len(c["devices"]) == 2
+    assert "gloo" in out["config"]["parallelism"] and "RCCL" not in out["config"]["parallelism"]
+
+
+def test_bench_reports_a_collective_that_did_not_come_up():
+    """the same command with the real backend on a box that has ONE GPU: rank 1 cannot bind its device, the collective never forms -- the
+    run must say so in its line ("ok": false) and exit non-zero; it must not fall back to another backend or print a rate"""
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = dict(os.environ, TRH_BENCH_SPAWN_GRACE="5", TRH_BENCH_INIT_TIMEOUT="20")
+    for k in ("WORLD_SIZE", "RANK", "TRH_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-n", "16", "--no-sweep"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, r.stdout + r.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["collective"]["ok"] is False and out["value"] is None and out["n_gpus"] == 2
