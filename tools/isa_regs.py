@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Register counts of every kernel of libtrh as the ISA declares them (.vgpr_count / .sgpr_count / scratch / LDS of the code objects'
+metadata notes), for the profile summaries: rocprofv3's `vgpr_count` column is an allocation-granule count on gfx950 (80 for a kernel
+whose ISA says 160), which VERDICT r03 asked to print beside the real figure.
+    tools/isa_regs.py            -> profiles/isa_registers.json  {kernel<Field>: {"vgpr": .., "sgpr": .., "scratch": .., "lds": ..}}
+Runs in the build container (llvm tools of /opt/rocm); the extracted bundles go to a temporary directory."""
+import glob, json, os, re, shutil, subprocess, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)\b", name)
+    if m:
+        t = re.search(r"<trh::(\w+)Params", name)
+        return m.group(1) + (f"<{t.group(1)}>" if t else "")
+    return name.split("(")[0][-60:]
+
+
+def main():
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in sorted(glob.glob(os.path.join(ROOT, "tiny-ram-halo2_amd", "csrc", "*.o"))):
+            local = os.path.join(tmp, os.path.basename(obj))
+            shutil.copy(obj, local)
+            subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], capture_output=True)
+            for co in glob.glob(local + ".*amdgcn*"):
+                notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+                cur = {}
+                for line in notes.splitlines():
+                    m = re.match(r"\s+\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\S+)", line)
+                    if not m:
+                        continue
+                    key, val = m.group(1), m.group(2)
+                    if key == "name":
+                        cur = {"mangled": val}
+                        dem = subprocess.run(["c++filt", val], capture_output=True, text=True).stdout.strip()
+                        cur["short"] = short(dem)
+                    else:
+                        cur[key] = int(val)
+                    if all(k in cur for k in ("short", "vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")):
+                        prev = out.get(cur["short"])
+                        ent = {"vgpr": cur["vgpr_count"], "sgpr": cur["sgpr_count"], "scratch": cur["private_segment_fixed_size"], "lds": cur["group_segment_fixed_size"]}
+                        if prev is None or ent["vgpr"] > prev["vgpr"]:
+                            out[cur["short"]] = ent  # template instances that share a short name: the largest
+                        cur = {}
+    path = os.path.join(ROOT, "profiles", "isa_registers.json")
+    json.dump(dict(sorted(out.items())), open(path, "w"), indent=1)
+    print(f"{len(out)} kernels -> {path}")
+    for k in ("msm_accumulate_seg_kernel<Fp>", "ntt_passy_kernel", "msm_reduce_kernel<Fp>"):
+        print(k, out.get(k))
+
+
+if __name__ == "__main__":
+    main()

@@ -39,11 +39,17 @@ def main():
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
              "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-check --no-sweep`",
              "(2 warm-up + 8 timed 2^%d Pallas MSMs, then the 2^%d Fp NTT loop).  Durations in microseconds." % (msm_log_n, ntt_log_n), "",
-             "| kernel | calls | total us | avg us | min us | max us | % | VGPR | SGPR | LDS B | scratch | grid | wg |",
-             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+             "`VGPR (ISA)` is the kernel's .vgpr_count from the code object (tools/isa_regs.py -> profiles/isa_registers.json); `VGPR (rocprofv3)` is the",
+             "trace's own column, an allocation-granule count on gfx950 (half the ISA figure for the kernels here).", "",
+             "| kernel | calls | total us | avg us | min us | max us | % | VGPR (ISA) | VGPR (rocprofv3) | SGPR | LDS B | scratch | grid | wg |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    try:
+        isa = json.load(open(os.path.join(out_dir, "isa_registers.json")))
+    except Exception:
+        isa = {}
     for r in rows:
         lines.append(f"| {short(r[0])} | {r[1]} | {r[2]/1e3:.1f} | {r[3]/1e3:.1f} | {r[4]/1e3:.1f} | {r[5]/1e3:.1f} | {100*r[2]/total:.1f} | "
-                     f"{r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]}x{r[11]} | {r[12]} |")
+                     f"{(isa.get(short(r[0])) or isa.get(short(r[0]) + '<Fp>') or {}).get('vgpr', '')} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]}x{r[11]} | {r[12]} |")
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))
