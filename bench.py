@@ -277,8 +277,8 @@ def e2e_replays(modes=("resident", "dropin-batched", "dropin")):
             if mode == "resident":
                 # two proofs in this process, as the reference proves sequentially in one (src/test_utils.rs:37-54): the first also pays the library's
                 # one-off scratch allocations and table builds inside its timed steps and is reported beside the second; the oracle checks ride on the first
-                r1 = replay.run(32, batch=64, hook=hook, verbose=False, columns="witness", keygen=False)
-                r = replay.run(32, batch=64, hook=None, verbose=False, columns="witness", keygen=False)
+                r1 = replay.run(32, batch=64, hook=hook, verbose=False, columns="witness", keygen=False, gates_dir=os.path.join(ROOT, "tests", "golden"))
+                r = replay.run(32, batch=64, hook=None, verbose=False, columns="witness", keygen=False, gates_dir=os.path.join(ROOT, "tests", "golden"))
                 ent = {"gpu_ms_total": r["gpu_ms_total"], "gpu_ms_total_with_real_gates": r["gpu_ms_total_with_real_gates"], "gpu_ms": r["gpu_ms"], "extended_domain": r["extended_domain"],
                        "first_proof_in_process": {"gpu_ms_total": r1["gpu_ms_total"], "gpu_ms": r1["gpu_ms"]}, "scope": r["scope"]}
             else:

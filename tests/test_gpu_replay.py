@@ -8,6 +8,8 @@ import pasta as o
 from tiny_ram_halo2_amd import expr, replay
 
 pytestmark = pytest.mark.gpu
+import os
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def to_tuple(e):
@@ -106,7 +108,7 @@ def test_replay_k10_matches_oracle(columns):
             want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert [f.from_limbs(r) for r in np.asarray(out).reshape(-1, 4)] == want, kind
 
-    res = replay.run(16, batch=32, hook=hook, verbose=False, columns=columns)
+    res = replay.run(16, batch=32, hook=hook, verbose=False, columns=columns, gates_dir=GOLDEN)
     assert res["schedule"]["k"] == 10 and res["schedule"]["msm_n_plus_1"] == 504 and res["columns"] == columns
     assert res["counts"]["multiopen_folds"] == 4 and res["keygen_gpu_ms"]["columns"] == {"fixed": 25, "sigma": 188, "l0_l_blind_l_last": 3}
     assert res["counts"]["commit_lagrange"] == 497 and res["counts"]["coeff_to_extended"] == 497
@@ -130,7 +132,7 @@ def test_replay_k10_full_extended_domain_matches_oracle():
         want = dom.coeff_to_extended(a) if kind == "coeff_to_extended" else dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
 
-    res = replay.run(16, batch=32, hook=hook, verbose=False, columns="witness", keygen=False, extended="full")
+    res = replay.run(16, batch=32, hook=hook, verbose=False, columns="witness", keygen=False, extended="full", gates_dir=GOLDEN)
     assert res["extended_domain"] == "all 2^13 points" and seen["coeff_to_extended"] == 3 and seen["divide_and_extended_to_coeff"] == 1 and seen["h_eval"] == 2
 
 
@@ -214,7 +216,7 @@ def test_replay_k18_matches_oracle():
             want = dom.extended_to_coeff(dom.divide_by_vanishing_poly(a))
         assert (np.asarray(out).reshape(-1, 4) == want).all(), kind
 
-    res = replay.run(32, batch=32, hook=hook, verbose=False, columns="witness", keygen=True)
+    res = replay.run(32, batch=32, hook=hook, verbose=False, columns="witness", keygen=True, gates_dir=GOLDEN)
     assert res["schedule"]["k"] == 18 and res["schedule"]["extended_k"] == 21 and res["schedule"]["msm_n_plus_1"] == 504
     # one commitment per value class beyond the first three columns: unblinded flags are the first columns, then
     # unblinded words, blinded flags / words / even-bits words, the sorted lookup columns and the full-size ones

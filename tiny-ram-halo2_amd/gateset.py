@@ -10,7 +10,8 @@ that carry the same name in two fixtures (pc, flag, reg0..7, s_trace, value) are
 
 What this is NOT: the assembled constraint system.  Which selector enables which chip on which row is the circuit's `configure` /
 assignment code and stays on the Rust side; for the TIMING of the gate evaluator only the polynomials' shapes (degrees, the columns and
-rotations they read) matter.  The fixtures are data files of the test tree; `reference_gates()` returns None when they are not there.
+rotations they read) matter.  The fixtures are data files of the test tree: the caller names their directory (argument or TRH_GATES_DIR); `reference_gates()` returns
+None when it is not given or the files are not there.
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ import os
 
 from . import expr
 
-_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GATES_DIR_ENV = "TRH_GATES_DIR"  # where the caller keeps the two fixture files; the package itself knows no path outside itself
 WORD_BITS = 16
 N_EVEN_BITS_CONFIGS = 14
 N_SIGNED_CONFIGS = 3
@@ -58,8 +59,12 @@ def _from_json(j, names, sel_names, cols, rename):
 
 
 def reference_gates(golden_dir: str | None = None):
-    """-> (gates, info) or None.  gates: list of Expression over Advice / Selector columns numbered by `info["advice"]` / ["selectors"]"""
-    gd = golden_dir or _GOLDEN
+    """-> (gates, info) or None.  gates: list of Expression over Advice / Selector columns numbered by `info["advice"]` / ["selectors"].
+    golden_dir: the directory that holds exe_tempvar_gates.json and chip_gates.json (the repository keeps them under tests/golden/; the
+    replay's callers pass it, or set TRH_GATES_DIR); without one there is no reference gate set and the replay times the synthetic one only"""
+    gd = golden_dir or os.environ.get(GATES_DIR_ENV)
+    if not gd:
+        return None
     paths = [os.path.join(gd, "exe_tempvar_gates.json"), os.path.join(gd, "chip_gates.json")]
     if not all(os.path.exists(p) for p in paths):
         return None

@@ -203,7 +203,7 @@ def _column_loop_two_contexts(params, dom, batches, blinds, ext_buf, D, blocks, 
 
 
 def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bool = True, precompute: bool = True, columns: str = "random",
-        keygen: bool = True, extended: str = "blocks", overlap: bool = False) -> dict:
+        keygen: bool = True, extended: str = "blocks", overlap: bool = False, gates_dir: str | None = None) -> dict:
     import torch
 
     from . import multiopen
@@ -461,7 +461,7 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     # extended column (copies of this batch's), so the evaluator's reads are the real set's reads.  Reported beside the synthetic figure.
     real = None
     from . import gateset
-    ref_gates = gateset.reference_gates()
+    ref_gates = gateset.reference_gates(gates_dir)  # the fixtures' directory is the caller's to name (tests/golden in this repository)
     if ref_gates is not None:
         rgates, rinfo = ref_gates
         rprog = expr.compile_gates(field, rgates, y=0x5EED)
@@ -1047,6 +1047,9 @@ def main():
     ap.add_argument("--extended", choices=("blocks", "full"), default="blocks", help="resident mode: the extended domain as the 5 coset blocks the quotient needs, or all 2^extended_k points")
     ap.add_argument("--overlap", action="store_true", help="resident mode: also time the per-column phase with the transforms on a second context / stream / host thread")
     ap.add_argument("--max-columns", type=int, default=None, help="drop-in modes / --devices: replay only the first N Lagrange columns")
+    repo_golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")  # the command line's default, not the package's
+    ap.add_argument("--gates-dir", default=repo_golden if os.path.isdir(repo_golden) else None,
+                    help="directory with exe_tempvar_gates.json / chip_gates.json: h(X) is then also timed on the reference's gate polynomials")
     ap.add_argument("--devices", default=None, help="comma-separated device list (a device may repeat): the per-column phase column-sharded over one context + thread per entry")
     a = ap.parse_args()
     if a.devices is not None:
@@ -1055,7 +1058,7 @@ def main():
     if a.mode != "resident":
         run_dropin(a.word_bits, {"dropin": "literal", "dropin-batched": "batched", "dropin-batched-blocks": "batched-blocks"}[a.mode], a.batch, columns=a.columns, max_columns=a.max_columns)
         return
-    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended, overlap=a.overlap)
+    run(a.word_bits, a.batch, precompute=not a.no_precompute, columns=a.columns, keygen=not a.no_keygen, extended=a.extended, overlap=a.overlap, gates_dir=a.gates_dir)
 
 
 if __name__ == "__main__":
