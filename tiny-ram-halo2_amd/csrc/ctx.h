@@ -106,7 +106,7 @@ struct MsmScratch {
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
     bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped
-    void* sp_host = nullptr;    // 8 KiB pinned: the sparse path's counters as read back (4 KiB), the dense flags it sends down (from byte 4096)
+    void* sp_host = nullptr;    // pinned: the sparse path's list counters as read back, then the dense flags it sends down
     void* host_sums = nullptr;  // pinned mirror of window_sums
     size_t host_sums_cap = 0;
     // state of the enqueued-but-not-finished MSM

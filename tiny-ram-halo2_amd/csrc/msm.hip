@@ -1019,6 +1019,7 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
 constexpr int SP_LISTS = 16;              // compact lists per column (one counter each: a single counter per column would serialise its 1025 workgroups)
 constexpr u32 SP_PAD = 32;                // u32 words between two list counters (one 128-byte line each)
 constexpr u32 SP_DENSE = 0xFFFFFFFFu;     // counter 0 of a column the sampler found dense
+constexpr size_t SP_MAX_CHUNK = 256;      // items per launch set the pinned read-back area is sized for
 
 // scalar i of item z (the commitment blind for the last one) as canonical words
 template <class SF>
@@ -1205,9 +1206,13 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     size_t chunk = batch;
     {
         const size_t per_item = (size_t)W * n * 12 + 1;  // digits + parted + sorted dominate
-        const size_t cap = ((size_t)4 << 30) / per_item;
+        // TRH_MSM_CHUNK / TRH_MSM_CHUNK_GB: items per launch set and the scratch budget behind it (defaults 64 items, 4 GiB per digit array set)
+        static const size_t chunk_max = getenv("TRH_MSM_CHUNK") ? (size_t)atol(getenv("TRH_MSM_CHUNK")) : 64;
+        static const size_t chunk_gb = getenv("TRH_MSM_CHUNK_GB") ? (size_t)atol(getenv("TRH_MSM_CHUNK_GB")) : 4;
+        const size_t cap = (chunk_gb << 30) / per_item;
         if (chunk > cap) chunk = cap ? cap : 1;
-        if (chunk > 64) chunk = 64;
+        if (chunk > chunk_max && chunk_max >= 1 && chunk_max <= SP_MAX_CHUNK) chunk = chunk_max;
+        if (chunk > SP_MAX_CHUNK) chunk = SP_MAX_CHUNK;
     }
     // reduce geometry: each thread owns a slice of buckets and pays one short scalar multiplication for
     // the slice offset, so long slices do less work per bucket but are a long serial chain: a lone MSM
@@ -1246,7 +1251,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // histogram scan (one synchronisation per chunk, ~20 us) and the segment length is sized to the entries that exist.
     static const int adaptive_knob = getenv("TRH_ADAPTIVE_SEG") ? atoi(getenv("TRH_ADAPTIVE_SEG")) : 1;
     const bool adaptive = adaptive_knob && batch >= 8 && !getenv("TRH_SEG_LEN");
-    if (adaptive && !c.pinned_land) TRH_HIP_TRY(hipHostMalloc(&c.pinned_land, 4096, hipHostMallocDefault));
+    if (adaptive && !c.pinned_land) TRH_HIP_TRY(hipHostMalloc(&c.pinned_land, 4096, hipHostMallocDefault));  // (>= SP_MAX_CHUNK x 16 windows x 4 B)
     // LDS bin sort when the bins are big enough to fill a 1024-thread workgroup and fit with 6 % + 512 entries of slack
     // (uniform digits: the largest of 8192 bins of 2^15 entries is 4.5 sigma = 800 entries above the mean)
     const size_t avg_bin = ns / nbins;
@@ -1286,7 +1291,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const bool sparse_ok = sparse_knob && fb && batch >= 8 && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
     if (sparse_ok) {
         TRH_TRY(L.sparse.ensure((size_t)chunk * SP_LISTS * SP_PAD * 4 + chunk + 64));
-        if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, 8192, hipHostMallocDefault));
+        if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, SP_MAX_CHUNK * SP_LISTS * 4 + SP_MAX_CHUNK + 64, hipHostMallocDefault));
     }
     const bool timing = c.timing && batch <= chunk && !sparse_ok;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
@@ -1452,8 +1457,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         unsigned gbe = (unsigned)((n + 255) / 256);
         if (gbe > 1024) gbe = 1024;
         hipLaunchKernelGGL((msm_sparse_emit_kernel<SF>), dim3(gbe, 1, nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, digits, flat, sp_subcap, L.counts.as<u32>(), k2, nbins);
-        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_LISTS] counters, then nb dense flags at byte 4096
-        unsigned char* const hd = (unsigned char*)m.sp_host + 4096;
+        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_LISTS] counters, then nb dense flags
+        unsigned char* const hd = (unsigned char*)m.sp_host + SP_MAX_CHUNK * SP_LISTS * 4;
         TRH_HIP_TRY(hipMemcpy2DAsync(hc, 4, sp_count, SP_PAD * 4, 4, (size_t)nb * SP_LISTS, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
         size_t sum = 0;
