@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 import torch
 from tiny_ram_halo2_amd import api, permutation, poly, synth
 MOD = {"fp": poly._MODULUS["fp"], "fq": poly._MODULUS["fq"]}
-KINDS = ["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products"]
+KINDS = ["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products", "sparse", "padded", "sharded"]
+GROUP = 8  # the suite's device group is [0] * 8 (trh_init_multi accepts only the list it was first given)
 rng = random.Random(1)  # re-seeded by run()
 cpu_ref = None          # the oracle module when a test hands it over
 
@@ -128,6 +129,128 @@ def trial(which, fails):
         if not ok:
             fails.append(which)
             print("BLOCKS MISMATCH", field, k, j, batch, nb, flush=True)
+    elif which == "sparse":
+        # round 4: a batch of commitments whose columns mix the witness's value classes with full-size ones in random order (sparse-column path,
+        # dense runs of every length) against the same columns committed one at a time (a lone MSM takes the plain pipeline)
+        curve = rng.choice(["pallas", "vesta"])
+        sf = api.SCALAR_FIELD[curve]
+        k = rng.randrange(12, 17)
+        n = 1 << k
+        b = rng.randrange(8, 25)
+        bases = api.Bases.generate(curve, rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30), n + 1)
+        try:
+            bases.precompute(0)
+        except api.TrhError:
+            pass
+        cols = np.zeros((b, n, 4), dtype=np.uint64)
+        live = max(1, n // rng.choice([1, 2, 4, 8]))
+        for i in range(b):
+            kind = rng.choice(["flag", "word", "byte", "full", "full", "zero", "ones", "hidden", "edge"])
+            raw = synth.splitmix64_stream(rng.randrange(1 << 30), 0, live)
+            if kind == "flag":
+                cols[i, :live, 0] = raw & np.uint64(1)
+            elif kind == "word":
+                cols[i, :live, 0] = raw & np.uint64((1 << 32) - 1)
+            elif kind == "byte":
+                cols[i, :live, 0] = raw & np.uint64(255)
+            elif kind == "full":
+                cols[i] = scalars(sf, n, "uniform")
+            elif kind == "ones":
+                cols[i, :, 0] = 1
+            elif kind == "hidden":  # full-size everywhere except on the rows the sampler reads
+                cols[i] = scalars(sf, n, "uniform")
+                cols[i, :: max(1, n // 1024)] = 0
+            elif kind == "edge":    # a fraction of full-size rows around the list capacity
+                step = rng.choice([4, 8, 16, 32])
+                cols[i, ::step] = scalars(sf, (n + step - 1) // step, "uniform")
+            if kind in ("flag", "word", "byte", "ones"):  # small canonical integers -> Montgomery form, a few full-size blinding rows at the end
+                d0 = torch.from_numpy(cols[i].view(np.int64)).cuda()
+                api._check(api.lib().trh_field_op_dev(api.FIELD_ID[sf], api.FIELD_OPS["to_mont"], api._devptr(d0), None, api._devptr(d0), n, None))
+                torch.cuda.synchronize()
+                cols[i] = d0.cpu().numpy().view(np.uint64)
+                if rng.random() < 0.7:
+                    cols[i, n - 6:] = scalars(sf, 6, "uniform")
+        blinds = synth.field_elements(rng.randrange(1 << 30), b)
+        d = torch.from_numpy(cols.view(np.int64)).cuda()
+        got = bases.commit_batch_dev(d, n, b, blinds)
+        ok = True
+        for i in rng.sample(range(b), min(b, 6)):
+            one = torch.from_numpy(np.concatenate([cols[i], blinds[i][None]]).view(np.int64)).cuda()
+            ok = ok and (bases.msm_dev(one, n + 1) == got[i]).all()
+        if cpu_ref is not None:
+            i = rng.randrange(b)
+            want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([cols[i], blinds[i][None]]), bases.download(), threads=cpu_ref.hardware_threads()))
+            ok = ok and (np.asarray(got[i])[:8] == want).all()
+            _ORACLE_COUNT[0] += 1
+        bases.destroy()
+        if not ok:
+            fails.append(which)
+            print("SPARSE MISMATCH", curve, k, b, flush=True)
+    elif which == "padded":
+        # round 4: trh_best_fft on zero-padded host vectors (slots that are zero throughout are not sent; probed padding is cleared at once and
+        # verified later) with non-zero elements dropped at random places of the padding, against the resident transform of the same vector
+        field = rng.choice(["fp", "fq"])
+        k = rng.randrange(16, 22)
+        n = 1 << k
+        dom = poly.EvaluationDomain(field, 3, k)
+        w = dom._w["omega"]
+        a = np.zeros((n, 4), dtype=np.uint64)
+        data = n >> rng.randrange(0, 5)
+        a[:data] = synth.field_elements(rng.randrange(1 << 30), data)
+        for _ in range(rng.choice([0, 0, 1, 3])):
+            a[rng.randrange(n)] = synth.field_elements(rng.randrange(1 << 30), 1)[0]
+        d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        api.ntt_dev(field, d, k, w)
+        torch.cuda.synchronize()
+        work = a.copy()
+        api.best_fft_inplace(field, work, w, k)
+        ok = (work == d.cpu().numpy().view(np.uint64)).all()
+        if cpu_ref is not None and k <= 18:
+            ok = ok and (work == cpu_ref.best_fft(field, a, np.asarray(w, dtype=np.uint64), k, threads=cpu_ref.hardware_threads())).all()
+            _ORACLE_COUNT[0] += 1
+        if not ok:
+            fails.append(which)
+            print("PADDED MISMATCH", field, k, data, flush=True)
+    elif which == "sharded":
+        # round 4: a base set range-sharded over the device group: host scalars (one uploader thread per shard), page-locked host scalars,
+        # device scalars with and without the forced no-peer hand-over, random sub-ranges -- against the same MSM on one context
+        if api.group_size() != GROUP:
+            try:
+                api.init_multi([0] * GROUP)
+            except api.TrhError:
+                return  # another group shape is active in this process: nothing to test here
+        curve = rng.choice(["pallas", "vesta"])
+        sf = api.SCALAR_FIELD[curve]
+        n = rng.randrange(1 << 13, 1 << 18)
+        s0, dd = rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30)
+        sc = scalars(sf, n, rng.choice(["uniform", "uniform", "small", "edge"]))
+        api.set_shard_min(1 << 62)
+        one = api.Bases.generate(curve, s0, dd, n)
+        api.set_shard_min(1 << 12)
+        try:
+            sh = api.Bases.generate(curve, s0, dd, n)
+            lo = rng.randrange(0, n - 1)
+            cnt = rng.randrange(1, n - lo + 1)
+            if rng.random() < 0.5:
+                lo, cnt = 0, n
+            part = np.ascontiguousarray(sc[lo:lo + cnt])
+            want = one.msm(part, offset=lo)
+            ok = (sh.msm(part, offset=lo) == want).all()
+            pinned = torch.from_numpy(part.view(np.int64)).pin_memory()
+            ok = ok and (sh.msm(pinned.numpy().view(np.uint64), offset=lo) == want).all()
+            dsc = torch.from_numpy(part.view(np.int64)).cuda()
+            ok = ok and (sh.msm_dev(dsc, cnt, offset=lo) == want).all()
+            os.environ["TRH_FORCE_NO_PEER"] = "1"
+            ok = ok and (sh.msm_dev(dsc, cnt, offset=lo) == want).all()
+            del os.environ["TRH_FORCE_NO_PEER"]
+            sh.destroy()
+        finally:
+            os.environ.pop("TRH_FORCE_NO_PEER", None)
+            api.set_shard_min(1 << 62)
+        one.destroy()
+        if not ok:
+            fails.append(which)
+            print("SHARDED MISMATCH", curve, n, lo, cnt, flush=True)
     elif which == "hostio":
         # host-pointer entries against the device-resident ones (round 3): batch FFT, batched commitments, range-tiled host MSMs
         field = rng.choice(["fp", "fq"])
