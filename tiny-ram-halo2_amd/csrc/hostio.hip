@@ -277,7 +277,8 @@ int stage_d2d_via_host(Ctx& dstc, void* dst_dev, hipStream_t dst_stream, const v
         const int sl = (int)(k % Stage::NS);
         char* pin = st.down + (size_t)sl * st.slot;
         hipError_t e = hipSetDevice(src_device);
-        if (e == hipSuccess && k >= (size_t)Stage::NS) e = hipStreamWaitEvent(src_stream, st.down_ev[sl], 0);  // the H2D that read this slot last
+        // the transfer that used this slot last (an earlier chunk's H2D, an earlier hand-over's, a download's DMA); an event never recorded does not wait
+        if (e == hipSuccess) e = hipStreamWaitEvent(src_stream, st.down_ev[sl], 0);
         if (e == hipSuccess) e = hipMemcpyAsync(pin, (const char*)src_dev + off, cur, hipMemcpyDeviceToHost, src_stream);
         if (e == hipSuccess) e = hipEventRecord(filled[sl], src_stream);
         if (e == hipSuccess) e = hipSetDevice(dstc.device);
