@@ -5,7 +5,7 @@ product columns, and round 4's paths: batches that mix sparse and full-size colu
 stray non-zero elements in the padding, range-sharded MSMs over the device group with host / page-locked / device scalars and the forced
 no-peer hand-over.  Different code paths of libtrh must agree bit for bit, and the MSM (n <= 2^16) and NTT (k <= 18) trials are also
 compared with the oracle's best_multiexp / best_fft (/root/reference reaches them through src/test_utils.rs:41-49).
-The seed is fixed and printed; TRH_SOAK_SEED / TRH_SOAK_SECONDS override it for a longer run."""
+The seed is fixed and printed; TRH_SOAK_SEED / TRH_SOAK_SECONDS / TRH_SOAK_KINDS override it for a longer or narrower run."""
 import os
 import sys
 
@@ -22,9 +22,10 @@ def test_bounded_soak():
     import soak
     seed = int(os.environ.get("TRH_SOAK_SEED", "20261003"))
     seconds = float(os.environ.get("TRH_SOAK_SECONDS", "90"))
-    stats, fails = soak.run(seconds, seed, oracle=cpu_ref)
+    kinds = [k for k in os.environ.get("TRH_SOAK_KINDS", "").split(",") if k] or None  # e.g. TRH_SOAK_KINDS=sparse: one kind of trial only
+    stats, fails = soak.run(seconds, seed, oracle=cpu_ref, kinds=kinds)
     print("soak:", stats, "failures:", fails)
     assert not fails, f"seed {seed}: mismatches in {fails} ({stats})"
     # every kind of trial ran, and the oracle saw a share of them
-    assert all(stats[k] > 0 for k in ("msm", "ntt", "lookup", "blocks", "hostio", "products", "sparse", "padded", "sharded")), (seed, stats)
+    assert all(stats[k] > 0 for k in (kinds or ("msm", "ntt", "lookup", "blocks", "hostio", "products", "sparse", "padded", "sharded"))), (seed, stats)
     assert stats["vs_oracle"] > 0

@@ -109,3 +109,54 @@ def test_witness_classes_k18():
         sc = torch.from_numpy(np.concatenate([colsm[j], bl[j][None]]).view(np.int64)).cuda()
         assert (bases.msm_dev(sc, n + 1) == got[i]).all(), i
     bases.destroy()
+
+
+def test_unit_digits_and_tiny_columns_k14():
+    """a chunk whose sampled rows show nothing but 0 / +-1 digits takes the unit path: digits equal to +-1 are summed from the table directly
+    and a column with at most 256 other digits skips the sort (msm_unit_sum_kernel, msm_unit_final_kernel); columns with more digits than the
+    sampler saw go through the compact pipeline and get their unit sums added.  +-1 digits in every window (2^16 j, 2^16 j - 1 -> -1 then a carry), all-ones, flags with 0 / a few / exactly
+    as many / one more than the tiny limit of other digits, chunks without any general column (no pipeline launch at all) and chunks that
+    mix all three classes, repeated and identity bases under the ones"""
+    k, n = 14, 1 << 14
+    def flags(seed, density=0.5):
+        f = np.zeros((1, n, 4), dtype=np.uint64)
+        f[0, : n // 4, 0] = (np.random.default_rng(seed).random(n // 4) < density).astype(np.uint64)
+        return f
+    ones = np.zeros((1, n, 4), dtype=np.uint64); ones[:, :, 0] = 1
+    zero = np.zeros((1, n, 4), dtype=np.uint64)
+    # powers of two at window boundaries and just below them, for every plausible window width: +1 digits in high windows, -1 with a carry
+    pw = np.zeros((1, n, 4), dtype=np.uint64)
+    vals = []
+    for w in range(10, 18):
+        for j in range(1, 6):
+            vals += [1 << (w * j), (1 << (w * j)) - 1, (1 << (w * j)) + 1, (1 << (w * j)) - 2]
+    for t, v in enumerate(vals):
+        for limb in range(4):
+            pw[0, 3 * t + 1, limb] = (v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF
+    def with_big(base, count, seed):
+        """`count` full-size scalars (about W other digits each) on rows the sampler does NOT read (it reads every 16th row at k = 14): the
+        chunk still votes for the unit path and the column's class is decided by its real digit count (tiny up to 256 entries, general above)"""
+        col = base.copy()
+        if count:
+            rows = 16 * np.random.default_rng(seed).choice(n // 16, size=count, replace=False) + 5
+            col[0, rows] = full_size(seed, count)
+        return col
+    f0 = flags(1)
+    cases = [f0, with_big(f0, 3, 2), with_big(f0, 14, 3), with_big(f0, 15, 4), with_big(f0, 16, 5), with_big(f0, 17, 6), with_big(f0, 40, 7),
+             ones, zero, pw, with_big(ones, 5, 8), flags(9, 0.02), flags(10, 1.0)]
+    word = replay.witness_columns("word", True, 11, 2, n, 32)
+    full = replay.witness_columns("full", True, 12, 2, n, 32)
+    for order in (cases[:8],                                           # tiny (and nearly tiny) columns only
+                  [ones, zero, pw, f0, f0, f0, f0, f0],                # nothing but unit entries and a handful of digits: no pipeline launch
+                  cases + [word[0:1], full[0:1], word[1:2], full[1:2]]):  # all three classes in one chunk
+        cols = np.concatenate(order)
+        commit_and_check("vesta", k, cols, synth.field_elements(0xB7 + cols.shape[0], cols.shape[0]))
+    # zero blinds as well: a column of zeros then commits to the identity, whichever path it takes (batch: the direct sum; lone: the buckets)
+    cols = np.concatenate([zero, f0, zero, ones, zero, zero, f0, zero])
+    got = commit_and_check("pallas", k, cols, np.zeros((8, 4), dtype=np.uint64), check_idx=[1, 3, 6])
+    bases = api.Bases.generate("pallas", synth.BASE_S0 + k, synth.BASE_D, n + 1)
+    bases.precompute(0)
+    lone = bases.msm_dev(torch.zeros((n + 1, 4), dtype=torch.int64, device="cuda"), n + 1)
+    for i in (0, 2, 4, 5, 7):
+        assert (got[i] == lone).all(), i
+    bases.destroy()

@@ -1015,9 +1015,20 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
 //   remap     the sorted entries name positions of the compact array: replaced by the flat table indices stored beside the digits
 // and from there the accumulate / combine / reduce launches of every other MSM.  Same group element, hence the same normalised point;
 // which path a column takes is decided by its digits alone.
+//   units     digits equal to +-1 never reach a bucket: the term is +-T[window][row] itself, so the emit appends the flat table index to
+//             the column's UNIT lists and msm_unit_sum_kernel adds the listed table entries up (a flag column -- 3 * 10^4 ones -- is
+//             nothing else; through the buckets they were one heavy bucket behind the whole sort / range / combine / reduce chain)
+//   tiny      what a flag column has beyond its ones are the ~100 digits of its blinding rows: a column with <= SP_TINY digit entries
+//             skips the sort as well (digit * T[..] by a short double-and-add per entry, one workgroup per column); a chunk of such
+//             columns launches no pipeline at all.  msm_unit_final_kernel adds the partial sums (and the pipeline's sum of a column that
+//             went through it) into the window sum.
 // ---------------------------------------------------------------------------------------
 constexpr int SP_LISTS = 16;              // compact lists per column (one counter each: a single counter per column would serialise its 1025 workgroups)
+constexpr int SP_CNT = 2 * SP_LISTS;      // counters per column: the SP_LISTS digit lists, then the SP_LISTS unit lists
 constexpr u32 SP_PAD = 32;                // u32 words between two list counters (one 128-byte line each)
+constexpr u32 SP_TINY = 256;              // a column with at most this many digit entries is summed directly (no sort, no buckets)
+constexpr int SP_PARTS = SP_LISTS + 1;    // partial sums per column: one per unit list, one for the digit entries of a tiny column
+constexpr u32 SP_VOTES = 2;               // sp_count[SP_VOTES] (a spare word of the first counter line): columns of the chunk that vote for the unit path
 constexpr u32 SP_DENSE = 0xFFFFFFFFu;     // counter 0 of a column the sampler found dense
 constexpr size_t SP_MAX_CHUNK = 256;      // items per launch set the pinned read-back area is sized for
 
@@ -1040,7 +1051,7 @@ __global__ void __launch_bounds__(256) msm_sparse_sample_kernel(const uint4* __r
     __syncthreads();
     const size_t samples = n < 1024 ? n : 1024, step = n / samples;
     const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
-    u32 mine = 0;
+    u32 mine = 0;  // non-zero digits, and (<< 16) those among them that are not +-1
     for (size_t q = threadIdx.x; q < samples; q += 256) {
         u32 w[8];
         sp_load_canonical<SF>(scalars, tails, z, q * step, n, mont, w);
@@ -1051,12 +1062,18 @@ __global__ void __launch_bounds__(256) msm_sparse_sample_kernel(const uint4* __r
             for (int k = 0; k < 7; ++k) w[k] = (w[k] >> c) | (w[k + 1] << (32 - c));
             w[7] >>= c;
             carry = raw > half ? 1u : 0u;
-            mine += (raw != 0 && raw != (1u << c)) ? 1u : 0u;  // digit raw - 2^c of raw == 2^c is zero with a carry
+            const bool nonzero = raw != 0 && raw != (1u << c);  // digit raw - 2^c of raw == 2^c is zero with a carry
+            mine += (nonzero ? 1u : 0u) + ((nonzero && raw != 1u && raw != (1u << c) - 1u) ? 0x10000u : 0u);
         }
     }
-    atomicAdd(&total, mine);
+    atomicAdd(&total, mine);  // (at most 1024 x 16 digits: the halves cannot run into each other... 2^14 < 2^16)
     __syncthreads();
-    if (threadIdx.x == 0 && (unsigned long long)total * step > dense_limit) sp_count[z * SP_LISTS * SP_PAD] = SP_DENSE;
+    if (threadIdx.x == 0) {
+        const bool dense = (unsigned long long)(total & 0xFFFFu) * step > dense_limit;
+        if (dense) sp_count[z * SP_CNT * SP_PAD] = SP_DENSE;
+        // the chunk's vote for the unit path (msm_sparse_emit_kernel): every column that is not dense shows nothing but 0 / +-1 digits
+        if (dense || (total >> 16) == 0) atomicAdd(&sp_count[SP_VOTES], 1u);
+    }
 }
 
 // digits: [item][cap] compact digit array (cap = SP_LISTS * subcap; list g of item z fills [g * subcap, ...)), zero-filled by the caller;
@@ -1064,22 +1081,25 @@ __global__ void __launch_bounds__(256) msm_sparse_sample_kernel(const uint4* __r
 template <class SF>
 __global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __restrict__ scalars, size_t n, int mont, int c, int W, size_t sstride,
                                                               const uint4* __restrict__ tails, u32* __restrict__ sp_count, u32* __restrict__ digits, u32* __restrict__ flat,
-                                                              u32 subcap, u32* __restrict__ bin_counts, int k2, u32 nbins) {
+                                                              u32* __restrict__ units, u32 subcap, u32* __restrict__ bin_counts, int k2, u32 nbins) {
     const size_t z = blockIdx.z;
-    u32* cnt0 = sp_count + z * SP_LISTS * SP_PAD;
+    u32* cnt0 = sp_count + z * SP_CNT * SP_PAD;
     if (*cnt0 == SP_DENSE) return;  // uniform over the grid slice of this column
     __shared__ u32 lhist[2048];     // nbins <= 2^11 (the partition's limit)
-    __shared__ u32 wcnt[4], base;
+    __shared__ u32 wcnt[4], ucnt[4], base, ubase;
     const u32 g = blockIdx.x % SP_LISTS;
     u32* my = cnt0 + g * SP_PAD;
+    u32* myu = cnt0 + (SP_LISTS + g) * SP_PAD;
     scalars += z * sstride * 2;
     digits += (z * SP_LISTS + g) * (size_t)subcap;
     flat += (z * SP_LISTS + g) * (size_t)subcap;
+    units += (z * SP_LISTS + g) * (size_t)subcap;
     bin_counts += z * nbins;
     for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) lhist[k] = 0;
     const u32 mask = (1u << c) - 1u, half = 1u << (c - 1);
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
+    const bool unit_mode = sp_count[SP_VOTES] == gridDim.z;  // uniform over the grid: the sampler's votes are complete before this launch
     bool overflow = false;
     for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n && !overflow; i0 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i0 + threadIdx.x;
@@ -1096,20 +1116,29 @@ __global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __res
             u32 bucket, sign = 0;
             if (raw > half) { bucket = (1u << c) - raw; carry = 1; sign = SIGN_BIT; }  // digit raw - 2^c
             else { bucket = raw; carry = 0; }
-            const unsigned long long nz = __ballot(bucket != 0);
-            if (lane == 0) wcnt[wv] = (u32)__popcll(nz);
+            const bool is_unit = unit_mode && bucket == 1u;          // +-1: the table entry itself
+            const unsigned long long nz = __ballot(bucket != 0 && !is_unit);  // digits that need a bucket
+            const unsigned long long nu = __ballot(is_unit);
+            if (lane == 0) { wcnt[wv] = (u32)__popcll(nz); ucnt[wv] = (u32)__popcll(nu); }
             __syncthreads();
             const u32 c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3], total = c0 + c1 + c2 + c3;
-            if (total == 0) continue;  // uniform
-            if (threadIdx.x == 0) base = atomicAdd(my, total);  // one atomic per workgroup and window
+            const u32 u0 = ucnt[0], u1 = ucnt[1], u2 = ucnt[2], u3 = ucnt[3], utotal = u0 + u1 + u2 + u3;
+            if ((total | utotal) == 0) continue;  // uniform
+            if (threadIdx.x == 0) {  // one atomic per workgroup, window and kind
+                if (total) base = atomicAdd(my, total);
+                if (utotal) ubase = atomicAdd(myu, utotal);
+            }
             __syncthreads();
-            const u32 b0 = base;
-            if (b0 + total > subcap) { overflow = true; break; }  // uniform: the list is full, the column is dense (the host sees the counter)
-            if (bucket) {
+            const u32 b0 = total ? base : 0u, ub0 = utotal ? ubase : 0u;
+            if (b0 + total > subcap || ub0 + utotal > subcap) { overflow = true; break; }  // uniform: a list is full, the column is dense (the host sees the counter)
+            if (bucket != 0 && !is_unit) {
                 const u32 pos = b0 + (wv > 0 ? c0 : 0u) + (wv > 1 ? c1 : 0u) + (wv > 2 ? c2 : 0u) + (u32)__popcll(nz & below);
                 digits[pos] = bucket | sign;
                 flat[pos] = (u32)((size_t)j * n + i);
                 atomicAdd(&lhist[(bucket - 1u) >> k2], 1u);
+            } else if (is_unit) {
+                const u32 pos = ub0 + (wv > 0 ? u0 : 0u) + (wv > 1 ? u1 : 0u) + (wv > 2 ? u2 : 0u) + (u32)__popcll(nu & below);
+                units[pos] = (u32)((size_t)j * n + i) | sign;
             }
         }
     }
@@ -1120,12 +1149,125 @@ __global__ void __launch_bounds__(256) msm_sparse_emit_kernel(const uint4* __res
     }
 }
 
-// columns the host found dense after the emit (a list overflowed): what they did append must not reach the sort
-__global__ void __launch_bounds__(256) msm_sparse_neutralise_kernel(const unsigned char* __restrict__ dense, u32* __restrict__ digits, size_t cap, u32* __restrict__ bin_counts, u32 nbins) {
+// what a column's counters say after the emit -- the same rule on the host (sparse_chunk) and in the kernels below:
+//   dense    the sampler said so, or a list ran full: the plain pipeline recodes the column from its scalars, nothing emitted counts
+//   tiny     at most SP_TINY digit entries: summed directly, never sorted
+//   general  through the compact pipeline
+enum { SP_CLASS_GENERAL = 0, SP_CLASS_DENSE = 1, SP_CLASS_TINY = 2 };
+__host__ __device__ inline int sp_classify(const u32* cnt, u32 stride, u32 subcap) {  // cnt[k * stride], k < SP_CNT
+    if (cnt[0] == SP_DENSE) return SP_CLASS_DENSE;
+    size_t entries = 0;
+    for (int k = 0; k < SP_CNT; ++k) {
+        if (cnt[(size_t)k * stride] > subcap) return SP_CLASS_DENSE;
+        if (k < SP_LISTS) entries += cnt[(size_t)k * stride];
+    }
+    return entries <= SP_TINY ? SP_CLASS_TINY : SP_CLASS_GENERAL;
+}
+// Tiny columns exist only on the unit path (`unit_mode`: the chunk's vote, known to the kernels and -- after the read-back -- to the host)
+__host__ __device__ inline int sp_classify(const u32* cnt, u32 stride, u32 subcap, int unit_mode) {
+    const int cls = sp_classify(cnt, stride, subcap);
+    return (cls == SP_CLASS_TINY && !unit_mode) ? (int)SP_CLASS_GENERAL : cls;
+}
+
+// columns that do not go through the compact pipeline although they emitted something (a list overflowed: dense; on the unit path: few
+// digits, summed directly): what they appended must not reach the sort
+__global__ void __launch_bounds__(256) msm_sparse_neutralise_kernel(const u32* __restrict__ sp_count, u32 subcap, u32* __restrict__ digits, size_t cap, u32* __restrict__ bin_counts, u32 nbins) {
     const size_t z = blockIdx.y;
-    if (!dense[z]) return;
+    const int unit_mode = sp_count[SP_VOTES] == gridDim.y;
+    if (sp_classify(sp_count + z * SP_CNT * SP_PAD, SP_PAD, subcap, unit_mode) == SP_CLASS_GENERAL) return;  // uniform
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += (size_t)gridDim.x * blockDim.x) digits[z * cap + k] = 0;
     if (blockIdx.x == 0) for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) bin_counts[z * nbins + k] = 0;
+}
+
+// table record `flat` (x, and y or -y) as a lazy affine point; all-zero = identity
+template <class BF>
+__device__ __forceinline__ AffineZ<BF> sp_load_entry(const uint4* __restrict__ table, u32 entry) {
+    const uint4* bp = table + (size_t)(entry & ~SIGN_BIT) * (ZREC / 16);
+    const uint4* yp = bp + 2 + ((entry >> 31) << 1);
+    const uint4 a = bp[0], b = bp[1], c = yp[0], d = yp[1], t = bp[6];
+    AffineZ<BF> p;
+    p.x.l[0] = (i32)a.x; p.x.l[1] = (i32)a.y; p.x.l[2] = (i32)a.z; p.x.l[3] = (i32)a.w;
+    p.x.l[4] = (i32)b.x; p.x.l[5] = (i32)b.y; p.x.l[6] = (i32)b.z; p.x.l[7] = (i32)b.w; p.x.l[8] = (i32)t.x;
+    p.y.l[0] = (i32)c.x; p.y.l[1] = (i32)c.y; p.y.l[2] = (i32)c.z; p.y.l[3] = (i32)c.w;
+    p.y.l[4] = (i32)d.x; p.y.l[5] = (i32)d.y; p.y.l[6] = (i32)d.z; p.y.l[7] = (i32)d.w; p.y.l[8] = (i32)((entry >> 31) ? t.z : t.y);
+    return p;
+}
+
+// Unit path only (the kernel returns at once otherwise).  part[z][g], g < SP_LISTS: the sum of the table entries named by unit list g of
+// column z (every thread a contiguous run of the list, LDS tree); part[z][SP_LISTS]: the sum of digit * entry over ALL digit entries of a
+// tiny column (one entry per thread and round: a double-and-add over the <= 15 bits of the digit), the identity for a general column.
+// Dense columns: untouched (never read).
+template <class BF>
+__global__ void __launch_bounds__(256) msm_unit_sum_kernel(const uint4* __restrict__ table, const u32* __restrict__ sp_count, const u32* __restrict__ units,
+                                                           const u32* __restrict__ digits, const u32* __restrict__ flat, u32 subcap, XYZZzMem* __restrict__ part) {
+    if (sp_count[SP_VOTES] != gridDim.y) return;  // not on the unit path: nothing was diverted
+    const size_t z = blockIdx.y;
+    const u32 g = blockIdx.x;
+    const u32* cnt = sp_count + z * SP_CNT * SP_PAD;
+    __shared__ XYZZz<BF> sh[256];
+    __shared__ int cls_s;
+    if (threadIdx.x == 0) cls_s = sp_classify(cnt, SP_PAD, subcap, 1);
+    __syncthreads();
+    const int cls = cls_s;
+    if (cls == SP_CLASS_DENSE) return;
+    XYZZz<BF> acc = xyzzz_identity<BF>();
+    if (g < (u32)SP_LISTS) {
+        const u32 count = cnt[(SP_LISTS + g) * SP_PAD];
+        const u32* lst = units + (z * SP_LISTS + g) * (size_t)subcap;
+        const u32 per = (count + 255u) / 256u;
+        const u32 lo = threadIdx.x * per, hi = lo + per < count ? lo + per : count;
+        for (u32 k = lo; k < hi; ++k) xyzzz_madd(acc, sp_load_entry<BF>(table, lst[k]));
+    } else if (cls == SP_CLASS_TINY) {
+        for (int sub = 0; sub < SP_LISTS; ++sub) {
+            const u32 count = cnt[sub * SP_PAD];
+            const size_t off = (z * SP_LISTS + sub) * (size_t)subcap;
+            for (u32 k = threadIdx.x; k < count; k += 256) {
+                const u32 d = digits[off + k], bucket = d & ~SIGN_BIT;
+                const AffineZ<BF> p = sp_load_entry<BF>(table, flat[off + k] | (d & SIGN_BIT));
+                XYZZz<BF> r = xyzzz_identity<BF>();
+                for (int i = 31 - __clz(bucket); i >= 0; --i) {  // bucket >= 2
+                    r = xyzzz_dbl(r);
+                    if ((bucket >> i) & 1u) xyzzz_madd(r, p);
+                }
+                acc = xyzzz_add(acc, r);
+            }
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_raw(&part[z * SP_PARTS + g], sh[0]);
+}
+
+// window sum of a sparse column.  Unit path: its SP_PARTS partial sums (+ what the compact pipeline left there for a general column).
+// Otherwise the kernel only runs for a chunk whose sparse columns are all empty (no pipeline launched): the identity.
+template <class BF>
+__global__ void __launch_bounds__(64) msm_unit_final_kernel(const u32* __restrict__ sp_count, u32 subcap, const XYZZzMem* __restrict__ part, XYZZMem* __restrict__ window_sums,
+                                                            int pipeline_ran) {
+    const size_t z = blockIdx.x;
+    const int unit_mode = sp_count[SP_VOTES] == gridDim.x;
+    __shared__ XYZZz<BF> sh[32];
+    __shared__ int cls_s;
+    if (threadIdx.x == 0) cls_s = sp_classify(sp_count + z * SP_CNT * SP_PAD, SP_PAD, subcap, unit_mode);
+    __syncthreads();
+    const int cls = cls_s;
+    if (cls == SP_CLASS_DENSE) return;  // the plain pipeline writes this column's sum
+    const u32 t = threadIdx.x;
+    if (t < 32) {
+        XYZZz<BF> v = xyzzz_identity<BF>();
+        if (t < (u32)SP_PARTS) { if (unit_mode) v = load_raw<BF>(&part[z * SP_PARTS + t]); }
+        else if (t == (u32)SP_PARTS) { if (pipeline_ran && cls == SP_CLASS_GENERAL) v = xyzzz_from_canonical(load_xyzz<BF>(&window_sums[z])); }
+        sh[t] = v;
+    }
+    __syncthreads();
+    for (int st = 16; st > 0; st >>= 1) {
+        if ((int)t < st) sh[t] = xyzzz_add(sh[t], sh[t + st]);
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz(&window_sums[z], xyzzz_to_canonical(sh[0]));
 }
 
 // sorted[z][k] names a slot of the compact digit array (| sign): replace it by that slot's flat table index
@@ -1290,8 +1432,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     static const int sparse_knob = getenv("TRH_SPARSE") ? atoi(getenv("TRH_SPARSE")) : 1;
     const bool sparse_ok = sparse_knob && fb && batch >= 8 && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
     if (sparse_ok) {
-        TRH_TRY(L.sparse.ensure((size_t)chunk * SP_LISTS * SP_PAD * 4 + chunk + 64));
-        if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, SP_MAX_CHUNK * SP_LISTS * 4 + SP_MAX_CHUNK + 64, hipHostMallocDefault));
+        // [counters: chunk x SP_CNT lines][partial sums: chunk x SP_PARTS raw points]
+        TRH_TRY(L.sparse.ensure((size_t)chunk * SP_CNT * SP_PAD * 4 + (size_t)chunk * SP_PARTS * sizeof(XYZZzMem) + 64));
+        if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, SP_MAX_CHUNK * SP_CNT * 4 + 4 + SP_MAX_CHUNK + 64, hipHostMallocDefault));
     }
     const bool timing = c.timing && batch <= chunk && !sparse_ok;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
@@ -1447,43 +1590,55 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         const uint4* tl = tails_dev ? (const uint4*)tails_dev + 2 * b0 : nullptr;
         u32* const sp_count = L.sparse.as<u32>();
-        unsigned char* const d_dense = (unsigned char*)(sp_count + (size_t)chunk * SP_LISTS * SP_PAD);
-        u32* const digits = L.digits.as<u32>();                       // [chunk][cap] compact digits, then [chunk][cap] flat table indices
-        u32* const flat = digits + (size_t)chunk * sp_cap;            // (2 x chunk x W n / 8 x 4 B: a quarter of the buffer)
-        TRH_HIP_TRY(hipMemsetAsync(sp_count, 0, (size_t)nb * SP_LISTS * SP_PAD * 4, s));
+        XYZZzMem* const part = (XYZZzMem*)(sp_count + (size_t)chunk * SP_CNT * SP_PAD);
+        u32* const digits = L.digits.as<u32>();                       // [chunk][cap] compact digits, [chunk][cap] flat table indices, [chunk][cap] unit entries
+        u32* const flat = digits + (size_t)chunk * sp_cap;            // (3 x chunk x W n / 8 x 4 B: three eighths of the buffer)
+        u32* const units = flat + (size_t)chunk * sp_cap;
+        TRH_HIP_TRY(hipMemsetAsync(sp_count, 0, (size_t)nb * SP_CNT * SP_PAD * 4, s));
         TRH_HIP_TRY(hipMemsetAsync(digits, 0, (size_t)nb * sp_cap * 4, s));
         TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * nbins * 4, s));
         hipLaunchKernelGGL((msm_sparse_sample_kernel<SF>), dim3(nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, 2 * sp_cap);
         unsigned gbe = (unsigned)((n + 255) / 256);
         if (gbe > 1024) gbe = 1024;
-        hipLaunchKernelGGL((msm_sparse_emit_kernel<SF>), dim3(gbe, 1, nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, digits, flat, sp_subcap, L.counts.as<u32>(), k2, nbins);
-        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_LISTS] counters, then nb dense flags
-        unsigned char* const hd = (unsigned char*)m.sp_host + SP_MAX_CHUNK * SP_LISTS * 4;
-        TRH_HIP_TRY(hipMemcpy2DAsync(hc, 4, sp_count, SP_PAD * 4, 4, (size_t)nb * SP_LISTS, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL((msm_sparse_emit_kernel<SF>), dim3(gbe, 1, nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, digits, flat, units, sp_subcap, L.counts.as<u32>(), k2, nbins);
+        // unit path: the lists (and the digit entries of tiny columns) are summed while the host reads the counters; the kernel reads the
+        // chunk's vote and classifies the columns by the same rule as the host below
+        hipLaunchKernelGGL((msm_unit_sum_kernel<BF>), dim3(SP_PARTS, nb), dim3(256), 0, s, bz, sp_count, units, digits, flat, sp_subcap, part);
+        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_CNT] counters, the chunk's votes, then nb class bytes
+        u32* const hvotes = hc + SP_MAX_CHUNK * SP_CNT;
+        unsigned char* const hd = (unsigned char*)(hvotes + 1);
+        TRH_HIP_TRY(hipMemcpy2DAsync(hc, 4, sp_count, SP_PAD * 4, 4, (size_t)nb * SP_CNT, hipMemcpyDeviceToHost, s));
+        TRH_HIP_TRY(hipMemcpyAsync(hvotes, sp_count + SP_VOTES, 4, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
+        const int unit_mode = *hvotes == nb;
         size_t sum = 0;
-        u32 most = 0, n_sparse = 0, n_overflowed = 0;
+        u32 most = 0, n_general = 0, n_neutral = 0, n_dense = 0;
         for (unsigned z = 0; z < nb; ++z) {
-            const bool sampled_dense = hc[z * SP_LISTS] == SP_DENSE;
-            bool dense = sampled_dense;
+            const int cls = sp_classify(hc + (size_t)z * SP_CNT, 1, sp_subcap, unit_mode);
+            hd[z] = (unsigned char)cls;
             size_t cz = 0;
-            for (int g = 0; g < SP_LISTS && !dense; ++g) { dense = hc[z * SP_LISTS + g] > sp_subcap; cz += hc[z * SP_LISTS + g]; }
-            hd[z] = dense ? 1 : 0;
-            if (dense && !sampled_dense) ++n_overflowed;
-            if (!dense) { ++n_sparse; sum += cz; most = cz > most ? (u32)cz : most; }
-        }
-        const bool any_sparse = n_sparse && most;
-        if (any_sparse) {
-            if (n_overflowed) {  // rare: a column the sampler let through filled a list; what it appended must not be sorted
-                TRH_HIP_TRY(hipMemcpyAsync(d_dense, hd, nb, hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(msm_sparse_neutralise_kernel, dim3(64, nb), dim3(256), 0, s, d_dense, digits, (size_t)sp_cap, L.counts.as<u32>(), nbins);
+            for (int g = 0; g < SP_LISTS; ++g) cz += hc[(size_t)z * SP_CNT + g];
+            if (cls == SP_CLASS_DENSE) {
+                ++n_dense;
+                if (hc[(size_t)z * SP_CNT] != SP_DENSE) ++n_neutral;  // it emitted until a list ran full
+            } else if (cls == SP_CLASS_TINY) {
+                if (cz) ++n_neutral;
+            } else {
+                ++n_general; sum += cz; most = cz > most ? (u32)cz : most;
             }
+        }
+        const bool run_compact = n_general != 0 && most != 0;
+        if (run_compact) {
+            if (n_neutral)  // what the columns that stay out of the compact pipeline appended must not be sorted
+                hipLaunchKernelGGL(msm_sparse_neutralise_kernel, dim3(64, nb), dim3(256), 0, s, sp_count, sp_subcap, digits, (size_t)sp_cap, L.counts.as<u32>(), nbins);
             TRH_TRY(pipeline(b0, nb, PIPE_COMPACT, sum, most));
         }
+        if (n_dense < nb && (unit_mode || !run_compact))
+            hipLaunchKernelGGL((msm_unit_final_kernel<BF>), dim3(nb), dim3(64), 0, s, sp_count, sp_subcap, part, m.window_sums.as<XYZZMem>() + b0, run_compact ? 1 : 0);
         for (unsigned z = 0; z < nb;) {  // the dense columns, in runs
-            if (!hd[z] && any_sparse) { ++z; continue; }
+            if (hd[z] != SP_CLASS_DENSE) { ++z; continue; }
             unsigned e = z + 1;
-            while (e < nb && (hd[e] || !any_sparse)) ++e;
+            while (e < nb && hd[e] == SP_CLASS_DENSE) ++e;
             TRH_TRY(pipeline(b0 + z, e - z, PIPE_DENSE, 0, 0));
             z = e;
         }

@@ -144,8 +144,11 @@ def trial(which, fails):
             pass
         cols = np.zeros((b, n, 4), dtype=np.uint64)
         live = max(1, n // rng.choice([1, 2, 4, 8]))
+        # a third of the trials draw only from the classes whose sampled rows show nothing but 0 / 1: such a chunk takes the unit path (ones
+        # summed from the table, tiny columns summed directly, the others -- "flagbig" with many scalars -- through the compact pipeline)
+        palette = ["flag", "word", "byte", "full", "full", "zero", "ones", "hidden", "edge"] if rng.random() < 0.65 else ["flag", "flag", "flagbig", "zero", "ones", "hidden"]
         for i in range(b):
-            kind = rng.choice(["flag", "word", "byte", "full", "full", "zero", "ones", "hidden", "edge"])
+            kind = rng.choice(palette)
             raw = synth.splitmix64_stream(rng.randrange(1 << 30), 0, live)
             if kind == "flag":
                 cols[i, :live, 0] = raw & np.uint64(1)
@@ -163,13 +166,21 @@ def trial(which, fails):
             elif kind == "edge":    # a fraction of full-size rows around the list capacity
                 step = rng.choice([4, 8, 16, 32])
                 cols[i, ::step] = scalars(sf, (n + step - 1) // step, "uniform")
-            if kind in ("flag", "word", "byte", "ones"):  # small canonical integers -> Montgomery form, a few full-size blinding rows at the end
+            elif kind == "flagbig":  # flags plus full-size scalars on rows the sampler skips: few (tiny) or many (general on the unit path)
+                cols[i, :live, 0] = raw & np.uint64(1)
+            if kind in ("flag", "word", "byte", "ones", "flagbig"):  # small canonical integers -> Montgomery form, a few full-size blinding rows at the end
                 d0 = torch.from_numpy(cols[i].view(np.int64)).cuda()
                 api._check(api.lib().trh_field_op_dev(api.FIELD_ID[sf], api.FIELD_OPS["to_mont"], api._devptr(d0), None, api._devptr(d0), n, None))
                 torch.cuda.synchronize()
                 cols[i] = d0.cpu().numpy().view(np.uint64)
                 if rng.random() < 0.7:
                     cols[i, n - 6:] = scalars(sf, 6, "uniform")
+                if kind == "flagbig":
+                    step = max(1, n // 1024)
+                    cnt = rng.choice([1, 9, 10, 11, 12, 40, 200])
+                    if step > 1:
+                        rows = [step * rng.randrange(n // step) + 1 + rng.randrange(step - 1) for _ in range(cnt)]
+                        cols[i, rows] = scalars(sf, cnt, "uniform")
         blinds = synth.field_elements(rng.randrange(1 << 30), b)
         d = torch.from_numpy(cols.view(np.int64)).cuda()
         got = bases.commit_batch_dev(d, n, b, blinds)
