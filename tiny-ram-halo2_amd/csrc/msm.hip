@@ -1594,19 +1594,29 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         u32* const digits = L.digits.as<u32>();                       // [chunk][cap] compact digits, [chunk][cap] flat table indices, [chunk][cap] unit entries
         u32* const flat = digits + (size_t)chunk * sp_cap;            // (3 x chunk x W n / 8 x 4 B: three eighths of the buffer)
         u32* const units = flat + (size_t)chunk * sp_cap;
+        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_CNT] counters, the chunk's votes, then nb class bytes
+        u32* const hvotes = hc + SP_MAX_CHUNK * SP_CNT;
+        unsigned char* const hd = (unsigned char*)(hvotes + 1);
         TRH_HIP_TRY(hipMemsetAsync(sp_count, 0, (size_t)nb * SP_CNT * SP_PAD * 4, s));
+        hipLaunchKernelGGL((msm_sparse_sample_kernel<SF>), dim3(nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, 2 * sp_cap);
+        // Measured on the k = 18 proof, chunk by chunk on one box: the compact pipeline alone is no faster than the plain one (word columns
+        // 2.93 against 2.55 ms, sorted / even-bits 2.92 against 3.08, mixed 2.42 against 2.37); what pays is the unit path (flag chunks 0.64 /
+        // 0.96 against 1.64 / 1.82 ms).  So the sampler's vote is read first (one short synchronisation) and a chunk that is not flag-like
+        // goes through the plain pipeline as if the path did not exist; TRH_SPARSE=2 sends it through the compact pipeline (A/B).
+        static const int compact_all = sparse_knob == 2;
+        if (!compact_all) {
+            TRH_HIP_TRY(hipMemcpyAsync(hvotes, sp_count + SP_VOTES, 4, hipMemcpyDeviceToHost, s));
+            TRH_HIP_TRY(hipStreamSynchronize(s));
+            if (*hvotes != nb) return pipeline(b0, nb, PIPE_PLAIN, 0, 0);
+        }
         TRH_HIP_TRY(hipMemsetAsync(digits, 0, (size_t)nb * sp_cap * 4, s));
         TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * nbins * 4, s));
-        hipLaunchKernelGGL((msm_sparse_sample_kernel<SF>), dim3(nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, 2 * sp_cap);
         unsigned gbe = (unsigned)((n + 255) / 256);
         if (gbe > 1024) gbe = 1024;
         hipLaunchKernelGGL((msm_sparse_emit_kernel<SF>), dim3(gbe, 1, nb), dim3(256), 0, s, sc, n, mont, cb, W, stride, tl, sp_count, digits, flat, units, sp_subcap, L.counts.as<u32>(), k2, nbins);
         // unit path: the lists (and the digit entries of tiny columns) are summed while the host reads the counters; the kernel reads the
         // chunk's vote and classifies the columns by the same rule as the host below
         hipLaunchKernelGGL((msm_unit_sum_kernel<BF>), dim3(SP_PARTS, nb), dim3(256), 0, s, bz, sp_count, units, digits, flat, sp_subcap, part);
-        u32* const hc = (u32*)m.sp_host;                       // [nb][SP_CNT] counters, the chunk's votes, then nb class bytes
-        u32* const hvotes = hc + SP_MAX_CHUNK * SP_CNT;
-        unsigned char* const hd = (unsigned char*)(hvotes + 1);
         TRH_HIP_TRY(hipMemcpy2DAsync(hc, 4, sp_count, SP_PAD * 4, 4, (size_t)nb * SP_CNT, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipMemcpyAsync(hvotes, sp_count + SP_VOTES, 4, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
