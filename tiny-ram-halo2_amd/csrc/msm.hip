@@ -1000,28 +1000,28 @@ __global__ void __launch_bounds__(256) msm_table_kernel(const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// Sparse columns of a fixed-base batch (round 4).  A witness column of the reference's circuit -- flags, <= 32-bit words, even-bits
+// Flag-like chunks of a fixed-base batch (round 4).  A witness column of the reference's circuit -- flags, <= 32-bit words, even-bits
 // words, sorted small lookup values on n / 4 live rows, zero behind them, a handful of blinding rows -- has 3 * 10^4 .. 2 * 10^5
-// non-zero digits in a flat digit space of W x n = 4 * 10^6 slots.  The pipeline above pays for the SLOTS (recode writes them all,
-// the partition and both sort levels walk them: 0.3 ms per stage and batch of 64); the path below compacts the digits first and runs
-// the SAME pipeline over an eighth of the slots:
+// non-zero digits in a flat digit space of W x n = 4 * 10^6 slots, and a FLAG column's digits are all +1: its commitment is a plain sum
+// of table entries, which the bucket pipeline computes as one heavy bucket behind the whole sort / range / combine / reduce chain
+// (1.6 - 2.5 ms per chunk of 64 such columns at k = 18, 0.1 ms of which is additions).
 //   sample    one workgroup per column looks at ~1024 rows: a column whose estimated entry count is far above the list capacity is
-//             dense and never enters the kernels below
-//   emit      one thread per scalar: canonical form, signed digits; every non-zero digit is appended to one of the column's SP_LISTS
-//             compact lists (ONE atomic per workgroup, window and list: device-scope atomics are executed on the memory side of the
-//             eight XCDs' L2s and same-address chains of them are slow) as a digit bucket | sign and, beside it, its flat table index;
-//             level-1 bin histogram in LDS as msm_recode_kernel has it.  A list that runs full marks the column dense.
-//   sort      msm_offsets_kernel ... msm_bucket_pass_kernel over the compact digit array (cap = W n / 8 slots per column)
-//   remap     the sorted entries name positions of the compact array: replaced by the flat table indices stored beside the digits
-// and from there the accumulate / combine / reduce launches of every other MSM.  Same group element, hence the same normalised point;
-// which path a column takes is decided by its digits alone.
-//   units     digits equal to +-1 never reach a bucket: the term is +-T[window][row] itself, so the emit appends the flat table index to
-//             the column's UNIT lists and msm_unit_sum_kernel adds the listed table entries up (a flag column -- 3 * 10^4 ones -- is
-//             nothing else; through the buckets they were one heavy bucket behind the whole sort / range / combine / reduce chain)
+//             dense; a column votes for the UNIT PATH when it is dense or shows nothing but 0 / +-1 digits.  The host reads the vote:
+//             a chunk that is not unanimous runs the plain pipeline (sparse_chunk: the compact pipeline below measured no faster)
+//   emit      one thread per scalar: canonical form, signed digits.  A digit +-1 never reaches a bucket -- the term is +-T[window][row]
+//             itself -- and is appended to one of the column's SP_LISTS UNIT lists (flat table index | sign); every other non-zero
+//             digit goes to one of its SP_LISTS compact digit lists as bucket | sign with its flat table index beside it (ONE atomic per
+//             workgroup, window, kind and list: device-scope atomics are executed on the memory side of the eight XCDs' L2s and
+//             same-address chains of them are slow); level-1 bin histogram in LDS as msm_recode_kernel has it.  A list that runs full
+//             marks the column dense (the plain pipeline then recodes it from its scalars).
+//   units     msm_unit_sum_kernel adds the listed table entries up (every thread a run of a list, an LDS tree per list)
 //   tiny      what a flag column has beyond its ones are the ~100 digits of its blinding rows: a column with <= SP_TINY digit entries
-//             skips the sort as well (digit * T[..] by a short double-and-add per entry, one workgroup per column); a chunk of such
-//             columns launches no pipeline at all.  msm_unit_final_kernel adds the partial sums (and the pipeline's sum of a column that
-//             went through it) into the window sum.
+//             skips the sort as well (digit * T[..] by a short double-and-add per entry); a chunk of such columns launches no pipeline
+//   general   a column with more digits than the sampler saw: msm_offsets_kernel ... msm_bucket_pass_kernel over the compact digit
+//             arrays (cap = W n / 8 slots per column), msm_sparse_remap_kernel replaces the sorted entries by the flat table indices
+//             stored beside the digits, and from there the accumulate / combine / reduce launches of every other MSM
+//   final     msm_unit_final_kernel: window sum = the partial sums of the lists (+ the tiny column's digit sum, + the pipeline's sum)
+// Same group element, hence the same normalised point; which path a chunk or a column takes is decided by its digits alone.
 // ---------------------------------------------------------------------------------------
 constexpr int SP_LISTS = 16;              // compact lists per column (one counter each: a single counter per column would serialise its 1025 workgroups)
 constexpr int SP_CNT = 2 * SP_LISTS;      // counters per column: the SP_LISTS digit lists, then the SP_LISTS unit lists
