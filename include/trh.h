@@ -160,8 +160,9 @@ int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_de
                         int scalars_are_montgomery, void* stream);
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);
 /* batch of MSMs over the same bases (one per column): scalars_dev holds batch x n x 4 u64.  Batches of >= 8 items run in chunks
- * of <= 64 and synchronise `stream` once per chunk (the entry counts of the chunk are read back to size the accumulation's segments
- * for sparse -- witness-shaped -- columns), so the call is not fully asynchronous even before the final hand-over of the points. */
+ * of <= 64 and synchronise `stream` once or twice per chunk (a sampler's vote decides whether the chunk is flag-like and its +-1 digits
+ * are summed straight from the table; the entry counts of the chunk are read back to size the accumulation's segments for sparse --
+ * witness-shaped -- columns), so the call is not fully asynchronous even before the final hand-over of the points. */
 int trh_msm_batch_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n, size_t batch,
                       int scalars_are_montgomery, void* stream, uint64_t* out_xyz /* batch x 12 */);
 /* Params::commit / commit_lagrange for `batch` polynomials already in device memory (batch x n x 4 u64, back to back):
