@@ -151,7 +151,18 @@ def test_unit_digits_and_tiny_columns_k14():
                   cases + [word[0:1], full[0:1], word[1:2], full[1:2]]):  # all three classes in one chunk
         cols = np.concatenate(order)
         commit_and_check("vesta", k, cols, synth.field_elements(0xB7 + cols.shape[0], cols.shape[0]))
-    # zero blinds as well: a column of zeros then commits to the identity, whichever path it takes (batch: the direct sum; lone: the buckets)
+    # a lone commitment is a chunk of one (trh_msm_dev over the tabled set): every case on its own against the oracle
+    bases = api.Bases.generate("vesta", synth.BASE_S0 + k, synth.BASE_D, n + 1)
+    bases.precompute(0)
+    xy = bases.download()
+    blind = synth.field_elements(0xB9, 1)
+    for i, col in enumerate(cases):
+        sc = np.concatenate([mont("fp", col)[0], blind])
+        got1 = bases.msm_dev(torch.from_numpy(sc.view(np.int64)).cuda(), n + 1)
+        want = cpu_ref.to_affine("vesta", cpu_ref.best_multiexp("vesta", sc, xy, threads=cpu_ref.hardware_threads()))
+        assert (np.asarray(got1)[:8] == want).all(), i
+    bases.destroy()
+    # zero blinds as well: a column of zeros then commits to the identity, whichever path it takes
     cols = np.concatenate([zero, f0, zero, ones, zero, zero, f0, zero])
     got = commit_and_check("pallas", k, cols, np.zeros((8, 4), dtype=np.uint64), check_idx=[1, 3, 6])
     bases = api.Bases.generate("pallas", synth.BASE_S0 + k, synth.BASE_D, n + 1)

@@ -1425,12 +1425,15 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
         c.attr_done |= ATTR_MSM;
     }
-    // sparse-column path: fixed-base BATCHES only (one flat bucket set per item), see msm_sparse_emit_kernel.  A lone MSM does not take it:
-    // measured at k = 18 per value class (tools/lone_sparse_probe.py), the classifier's two launches and its synchronisation cost a lone
-    // commitment 0.02 - 0.10 ms more than the compaction saves (flag 0.735 vs 0.719 ms, word 0.651 vs 0.625, even-bits 0.791 vs 0.691, full-size
-    // 0.679 vs 0.637): a lone MSM's time is its latency chain, not the digit slots
+    // unit path (see msm_sparse_emit_kernel): fixed-base mode only (one flat bucket set per item).  Lone commitments ask the sampler too
+    // (tools/lone_sparse_probe.py at k = 18, device scalars: a flag column 0.716 -> 0.417 ms; the vote -- one 12 us kernel and a short
+    // synchronisation -- costs the others 0.02 - 0.06 ms: word 0.629 -> 0.650, even-bits 0.689 -> 0.723, full-size 0.646 -> 0.710; over the
+    // 497 single-call commitments of the literal k = 18 replay 515 -> 460 ms).  TRH_SPARSE_LONE=0 keeps batches of < 8 items out; the IPA's
+    // round MSMs never ask (dense_hint).  The compact pipeline without the unit path loses on a lone commitment (round 4, first half: flag
+    // 0.735 vs 0.719 ms, even-bits 0.791 vs 0.691): a lone MSM's time is its latency chain, not the digit slots
     static const int sparse_knob = getenv("TRH_SPARSE") ? atoi(getenv("TRH_SPARSE")) : 1;
-    const bool sparse_ok = sparse_knob && fb && batch >= 8 && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
+    static const int sparse_lone = getenv("TRH_SPARSE_LONE") ? atoi(getenv("TRH_SPARSE_LONE")) : 1;
+    const bool sparse_ok = sparse_knob && fb && (batch >= 8 || sparse_lone) && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
     if (sparse_ok) {
         // [counters: chunk x SP_CNT lines][partial sums: chunk x SP_PARTS raw points]
         TRH_TRY(L.sparse.ensure((size_t)chunk * SP_CNT * SP_PAD * 4 + (size_t)chunk * SP_PARTS * sizeof(XYZZzMem) + 64));
