@@ -61,7 +61,7 @@ def main():
         wtotal = sum(r[2] for r in wrows) or 1
         wl = [f"# rocprofv3 --kernel-trace --stats: k = 18 create_proof replay over WITNESS-SHAPED columns ({tag})", "",
               "Command: `rocprofv3 --kernel-trace --stats -- python3 tools/replay_probe.py 32 witness` (= python -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --no-keygen)",
-              "(flags / 32-bit words on the n / 4 live rows, zero padding, blinding rows: almost every pair of a commitment falls into a handful of buckets, so the",
+              "(flags / 32-bit words on the n / 4 live rows, zero padding, blinding rows: a flag column is a plain sum of table entries (msm_unit_sum_kernel); the other classes fall into few buckets, where the",
               "chunked bucket passes (msm_bucket_pass_kernel) and the heavy-bucket combine (msm_combine_heavy_kernel) carry the commitments).  Durations in microseconds.", "",
               "| kernel | calls | total us | avg us | max us | % |", "|---|---|---|---|---|---|"]
         for r in wrows[:40]:
