@@ -155,7 +155,11 @@ int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_
                 int scalars_are_montgomery, void* stream, uint64_t out_xyz[12]);
 /* asynchronous halves of trh_msm_dev: enqueue leaves the per-window sums on the device,
  * finish synchronises, folds the windows on the host and returns the point.  One MSM in flight per
- * context (TRH_EBUSY otherwise); finish must name the base set and be called on the context of its enqueue. */
+ * context (TRH_EBUSY otherwise); finish must name the base set and be called on the context of its enqueue.
+ * Over a base set WITH fixed-base tables (trh_bases_precompute) the enqueue is not fully asynchronous: a sampler reads ~1024 scalars
+ * and votes on the flag-like unit path, which synchronises `stream` once (everything queued on it before the call completes first);
+ * TRH_SPARSE_LONE=0 (or a set without tables) keeps the enqueue free of host synchronisations.  With trh_set_timing(1) such an MSM
+ * reports zero phase times (trh_last_timing): the sampler's paths are not timed phase by phase.                                  */
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
                         int scalars_are_montgomery, void* stream);
 int trh_msm_dev_finish(trh_bases_t bases, void* stream, uint64_t out_xyz[12]);

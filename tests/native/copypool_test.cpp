@@ -66,6 +66,25 @@ int main() {
             }
         }
     }
+    // chunk_plan: every chunk fits a ring slot for every slot size TRH_STAGE_SLOT_MB admits (1 ... 256 MiB), the chunks
+    // add up to the transfer, and a graded head / tail only appears where it is shorter than a slot
+    {
+        const size_t MiB = (size_t)1 << 20;
+        const size_t sizes[] = {1, MiB - 1, MiB, 2 * MiB, 4 * MiB, 4 * MiB + 1, 5 * MiB + 3, 8 * MiB, 14 * MiB + 5, 16 * MiB, 33 * MiB + 7, 128 * MiB, 600 * MiB + 11};
+        std::vector<size_t> plan;
+        for (size_t slot_mb = 1; slot_mb <= 256; ++slot_mb)
+            for (size_t bytes : sizes)
+                for (int ht = 0; ht < 4; ++ht) {
+                    trh::chunk_plan(bytes, slot_mb * MiB, (ht & 1) != 0, (ht & 2) != 0, plan);
+                    size_t sum = 0;
+                    for (size_t cur : plan) { sum += cur; if (!cur || cur > slot_mb * MiB) ++bad; }
+                    if (sum != bytes) ++bad;
+                }
+        trh::chunk_plan(0, 16 * MiB, true, true, plan);
+        if (!plan.empty()) ++bad;
+        trh::chunk_plan(128 * MiB, 16 * MiB, true, true, plan);  // the default ring: 2, 6, full slots, 6, 2
+        if (plan.size() < 5 || plan[0] != 2 * MiB || plan[1] != 6 * MiB || plan[plan.size() - 2] != 6 * MiB || plan.back() != 2 * MiB) ++bad;
+    }
     delete up; delete down; delete none;  // the destructor stops and joins the workers (per-context pools die with their context)
     std::printf(bad ? "copypool: FAILED (%d)\n" : "copypool: ok\n", bad);
     return bad ? 1 : 0;

@@ -100,3 +100,85 @@ def test_point_sum_host_combine(curve):
     assert [int(v) for v in got[8:]] == f.limbs(1)
     assert (api.point_sum(curve, np.array(rows[5:7], np.uint64)) == 0).all()
     assert (api.point_sum(curve, np.zeros((0, 12), np.uint64)) == 0).all()
+
+
+# ---- INTEGRATION.md's Rust binding vs include/trh.h -------------------------------------------------------------
+
+def _split_args(s):
+    """top-level comma split (function-pointer arguments carry their own parentheses)"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [a.strip() for a in out]
+
+
+def _c_prototypes():
+    """name -> (return class, [argument classes]) from include/trh.h; classes: 'ptr', 'int' (any integer scalar), 'void'"""
+    text = open(os.path.join(ROOT, "include", "trh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    protos = {}
+    i = 0
+    for m in re.finditer(r"\b(trh_[a-z0-9_]+)\s*\(", text):
+        name = m.group(1)
+        # the return type: what stands between the previous ';' / '}' / '{' and the name
+        start = max(text.rfind(";", 0, m.start()), text.rfind("}", 0, m.start()), text.rfind("{", 0, m.start())) + 1
+        ret = text[start:m.start()].strip()
+        if not ret or "typedef" in ret or "(" in ret:
+            continue  # a function-pointer typedef or a use inside another declaration
+        depth, j = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[j], 0)
+            j += 1
+        args = _split_args(text[m.end():j - 1])
+        if args == ["void"]:
+            args = []
+        cls = lambda d: "ptr" if ("*" in d or "[" in d or "(" in d or re.search(r"\btrh_\w+_t\b|\btrh_\w+_fn\b|\btrh_\w+_cb\b", d)) else "int"
+        protos[name] = ("void" if ret == "void" else cls(ret + " "), [cls(a) for a in args])
+    return protos
+
+
+def _rust_prototypes():
+    """every `fn trh_*` inside an extern "C" block of INTEGRATION.md"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    protos = {}
+    for blk in re.finditer(r'extern\s+"C"\s*\{(.*?)\n\}', text, flags=re.S):
+        body = re.sub(r"//[^\n]*", "", blk.group(1))
+        for m in re.finditer(r"fn\s+(trh_[a-z0-9_]+)\s*\(", body):
+            depth, j = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(body[j], 0)
+                j += 1
+            args = _split_args(body[m.end():j - 1])
+            tail = body[j:body.index(";", j)]
+            ret = tail.split("->")[1].strip() if "->" in tail else ""
+            rcls = lambda t: "ptr" if (t.startswith("*") or "extern" in t or "fn(" in t or t.startswith("Option<")) else "int"
+            protos.setdefault(name := m.group(1), ("void" if not ret else rcls(ret), [rcls(a.split(":", 1)[1].strip()) for a in args]))
+    return protos
+
+
+def test_integration_md_rust_block_matches_the_header():
+    """the source-only Rust shim of INTEGRATION.md declares libtrh's entry points by hand; nothing compiles it here (no Rust toolchain), so
+    this test is its only guard: every `fn trh_*` of every extern "C" block exists in include/trh.h with the same number of arguments,
+    pointer vs integer scalar argument by argument, and the same kind of return value"""
+    c, rust = _c_prototypes(), _rust_prototypes()
+    assert len(rust) >= 30, sorted(rust)
+    # the header parser sees what the symbol test sees
+    assert set(_declared_symbols()) <= set(c) | {"trh_version"} | set(_declared_symbols()) - set(c) and len(c) >= 90
+    for name, (rret, rargs) in sorted(rust.items()):
+        assert name in c, f"INTEGRATION.md declares {name}, include/trh.h does not"
+        cret, cargs = c[name]
+        assert len(rargs) == len(cargs), f"{name}: {len(rargs)} arguments in INTEGRATION.md, {len(cargs)} in trh.h"
+        assert rargs == cargs, f"{name}: argument kinds {rargs} in INTEGRATION.md vs {cargs} in trh.h"
+        assert rret == cret, f"{name}: returns {rret} in INTEGRATION.md, {cret} in trh.h"

@@ -570,9 +570,15 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
                 if (hipMemcpyPeerAsync(sc->msm.scalars.p, sc->device, rg[g].src, src_device, rg[g].cnt * 32, sc->own_stream) != hipSuccess) { set_error("msm[sharded]: peer copy failed: %s", hipGetErrorString(hipGetLastError())); rc = TRH_EHIP; }
             }
         }
-        if (rc == TRH_OK)
+        if (rc == TRH_OK) {
+            // no sparse vote on a shard: the sampler ends in a host synchronisation behind this shard's upload / hand-over, which
+            // would hold back the enqueues of the later shards; a range-sharded MSM is a full-size one
+            const bool hint = sc->msm.dense_hint;
+            sc->msm.dense_hint = true;
             rc = msm_enqueue(B->curve, (const char*)sh->d_xy + rg[g].local * 64, lazy_bases(sh, rg[g].local, sc->own_stream), sc->msm.scalars.p, rg[g].cnt, 1, rg[g].cnt, mont, sc->own_stream,
                              fixed_base(sh, rg[g].local, rg[g].cnt));
+            sc->msm.dense_hint = hint;
+        }
         if (rc != TRH_OK) { join_all(); return rc; }
     }
     size_t cntp = 0;

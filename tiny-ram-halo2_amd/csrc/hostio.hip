@@ -43,21 +43,6 @@ int copy_threads() {
     return n;
 }
 
-// Chunk sizes of ONE transfer through a slot ring.  Full slots in the middle; a short head (2 MiB, then 6) when the transfer's first
-// bytes gate the pipeline (an upload: nothing moves until the first chunk sits in pinned memory) and a short tail (6, then 2) when its
-// last bytes do (a download: the caller waits for the copy out of the last chunk; an upload whose host copies are the slower side).
-// The fill / drain of a 16 MiB ring cost 0.25 ms each on a 128 MiB best_fft; uniformly small slots lose to the per-slot hand-over.
-void chunk_plan(size_t bytes, size_t slot, bool head, bool tail, std::vector<size_t>& out) {
-    out.clear();
-    const size_t small = (size_t)2 << 20, mid = (size_t)6 << 20;
-    size_t left = bytes;
-    std::vector<size_t> back;
-    if (head && left > 2 * small) { out.push_back(small); left -= small; if (slot > mid && left > mid + small) { out.push_back(mid); left -= mid; } }
-    if (tail && left > 2 * small) { back.push_back(small); left -= small; if (slot > mid && left > mid + small) { back.push_back(mid); left -= mid; } }
-    while (left) { const size_t cur = left < slot ? left : slot; out.push_back(cur); left -= cur; }
-    for (size_t i = back.size(); i-- > 0;) out.push_back(back[i]);
-}
-
 // TRH_IO_TRACE=1: the single-call host entries print their timeline (microseconds since the call began) to stderr
 thread_local double t_trace_t0 = 0;   // > 0 while a traced call is running on this thread: the staging loops then report every chunk
 struct IoTrace {
@@ -257,7 +242,12 @@ int stage_d2d_via_host(Ctx& dstc, void* dst_dev, hipStream_t dst_stream, const v
     auto it = st.xfer_ev.find(src_device);
     if (it == st.xfer_ev.end()) {
         std::array<hipEvent_t, Stage::NS> evs{};
-        TRH_HIP_TRY(hipSetDevice(src_device));
+        if (hipSetDevice(src_device) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipSetDevice(cur_dev);  // every exit leaves the caller's device current
+            set_error("hand-over through the host: hipSetDevice(%d) failed", src_device);
+            return TRH_EHIP;
+        }
         for (int i = 0; i < Stage::NS; ++i) {
             const hipError_t e = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming);
             if (e != hipSuccess) {
@@ -460,19 +450,25 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     static const int spec_knob = getenv("TRH_FFT_SPECULATE") ? atoi(getenv("TRH_FFT_SPECULATE")) : 1;
     std::vector<std::pair<size_t, size_t>> spec;
     const bool speculative = spec_knob && bytes >= ((size_t)8 << 20) && !is_pinned(a);
+    const double up_bytes0 = c.stage.up_bytes, up_zero0 = c.stage.up_zero_bytes;
     TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true, false, speculative ? &spec : nullptr));
     tr.mark("upload issued; speculated ranges", spec.size());
     TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
     tr.mark("transform queued");
+    // the hook's own verdict travels in a flag, not in a public error code: a TRH_EBUSY out of stage_d2h stays what it says
+    bool guess_wrong = false;
     const std::function<int()> verify = [&]() -> int {
         for (const auto& r : spec)
-            if (!c.stage.up_pool->copy(nullptr, (const char*)a + r.first, r.second, true, false, true)) return TRH_EBUSY;  // (any non-zero code: handled below)
+            if (!c.stage.up_pool->copy(nullptr, (const char*)a + r.first, r.second, true, false, true)) { guess_wrong = true; return TRH_EINVAL; }
         return TRH_OK;
     };
     int rc = stage_d2h(c, a, c.io.p, bytes, s, spec.empty() ? nullptr : &verify);
-    if (rc == TRH_EBUSY && !spec.empty()) {  // a chunk that probed as zero was not: `a` is untouched, do it again without guessing
+    if (guess_wrong) {  // a chunk that probed as zero was not: `a` is untouched, do it again without guessing
         tr.mark("speculation failed: plain pass");
         TRH_HIP_TRY(hipStreamSynchronize(s));
+        // trh_io_stats counts the call's bytes once: the dropped first pass leaves the counters (its host seconds stay -- they were spent)
+        c.stage.up_bytes = up_bytes0;
+        c.stage.up_zero_bytes = up_zero0;
         TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true));
         TRH_TRY(ntt_device(field, c.io.p, log_n, omega, 1, s));
         rc = stage_d2h(c, a, c.io.p, bytes, s);

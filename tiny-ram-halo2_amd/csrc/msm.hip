@@ -1701,6 +1701,11 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
         TRH_HIP_TRY(hipEventElapsedTime(&tt, m.ev[0], m.ev[4]));
         c.last.total_ms = tt; c.last.digits_ms = t01; c.last.sort_ms = t12; c.last.accumulate_ms = t23; c.last.reduce_ms = t34;
     }
+    else if (c.timing) {
+        // timing was asked for but this MSM was not timed phase by phase (a tabled set through the sampler, a batch beyond one chunk):
+        // zeros, not the previous MSM's figures
+        c.last.total_ms = c.last.digits_ms = c.last.sort_ms = c.last.accumulate_ms = c.last.reduce_ms = c.last.accumulate_kernel_ms = 0;
+    }
     c.last.window_bits = m.pending_c;
     c.last.windows = m.pending_windows;
     if (m.tile_sum_valid && !m.in_tile) {  // last tile of a tiled MSM: add the earlier tiles

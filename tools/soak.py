@@ -131,17 +131,21 @@ def trial(which, fails):
             print("BLOCKS MISMATCH", field, k, j, batch, nb, flush=True)
     elif which == "sparse":
         # round 4: a batch of commitments whose columns mix the witness's value classes with full-size ones in random order (sparse-column path,
-        # dense runs of every length) against the same columns committed one at a time (a lone MSM takes the plain pipeline)
+        # dense runs of every length) against the same columns committed one at a time over an UNTABLED copy of the base set (plain windowed pipeline)
         curve = rng.choice(["pallas", "vesta"])
         sf = api.SCALAR_FIELD[curve]
         k = rng.randrange(12, 17)
         n = 1 << k
         b = rng.randrange(8, 25)
-        bases = api.Bases.generate(curve, rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30), n + 1)
+        seed_a, seed_b = rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30)
+        bases = api.Bases.generate(curve, seed_a, seed_b, n + 1)
         try:
             bases.precompute(0)
         except api.TrhError:
             pass
+        # the reference for the lone commitments: the same points WITHOUT tables -- a lone MSM over a tabled set asks the sampler as well
+        # (TRH_SPARSE_LONE=1) and would compare the unit path with itself; without tables it is the plain windowed pipeline
+        plain = api.Bases.generate(curve, seed_a, seed_b, n + 1)
         cols = np.zeros((b, n, 4), dtype=np.uint64)
         live = max(1, n // rng.choice([1, 2, 4, 8]))
         # a third of the trials draw only from the classes whose sampled rows show nothing but 0 / 1: such a chunk takes the unit path (ones
@@ -187,13 +191,15 @@ def trial(which, fails):
         ok = True
         for i in rng.sample(range(b), min(b, 6)):
             one = torch.from_numpy(np.concatenate([cols[i], blinds[i][None]]).view(np.int64)).cuda()
-            ok = ok and (bases.msm_dev(one, n + 1) == got[i]).all()
+            ref = plain.msm_dev(one, n + 1)
+            ok = ok and (ref == got[i]).all() and (bases.msm_dev(one, n + 1) == ref).all()  # batch == plain lone == tabled lone
         if cpu_ref is not None:
             i = rng.randrange(b)
             want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, np.concatenate([cols[i], blinds[i][None]]), bases.download(), threads=cpu_ref.hardware_threads()))
             ok = ok and (np.asarray(got[i])[:8] == want).all()
             _ORACLE_COUNT[0] += 1
         bases.destroy()
+        plain.destroy()
         if not ok:
             fails.append(which)
             print("SPARSE MISMATCH", curve, k, b, flush=True)
