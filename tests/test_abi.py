@@ -175,7 +175,7 @@ def test_integration_md_rust_block_matches_the_header():
     c, rust = _c_prototypes(), _rust_prototypes()
     assert len(rust) >= 30, sorted(rust)
     # the header parser sees what the symbol test sees
-    assert set(_declared_symbols()) <= set(c) | {"trh_version"} | set(_declared_symbols()) - set(c) and len(c) >= 90
+    assert set(_declared_symbols()) == set(c) and len(c) >= 90
     for name, (rret, rargs) in sorted(rust.items()):
         assert name in c, f"INTEGRATION.md declares {name}, include/trh.h does not"
         cret, cargs = c[name]
