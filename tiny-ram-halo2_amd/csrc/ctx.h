@@ -169,6 +169,7 @@ struct Ctx {
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;
     void* lookup_scratch = nullptr;  // lookup.hip's buffers (opaque here)
+    int cu_count = 0;                // compute units of the device (persistent kernels size their grids by it); 0: not asked yet
     unsigned attr_done = 0;          // hipFuncSetAttribute is per device: bit per kernel family already configured for this context's device
     hipStream_t own_stream = nullptr;  // the multi-device MSM driver enqueues this context's shard here
     // scratch is shared by every stream that enters this context: a call on another stream than the previous one waits for it

@@ -822,6 +822,206 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     }
 }
 
+// ---- persistent, software-pipelined form of the signed pass (round 5) ---------------------------------------------------------------
+// ntt_passy_kernel pays ~30 % of its time for memory it has nothing to overlap with: every workgroup starts by waiting for its own
+// loads and ends behind its own stores (NOTEBOOK "(f)": 2^22 0.470 ms, 0.319 with no memory operations).  Here a workgroup stays
+// resident and walks over tiles w = blockIdx.x, + gridDim.x, ...; while the LAST round of tile t computes, tile t + 1 is already on its way:
+//   * the elements by LDS-DMA (global_load_lds_dwordx4: no VGPRs) straight into the exchange buffer, which is free from the moment
+//     every wave has made the last exchange read of tile t.  The DMA puts global row r of the tile at LDS row bitrev_s(r): exactly the
+//     slots thread (m, c) owns in round 0 (rows (bitrev(m) << 2) + u), so round 0 reads its four elements from LDS instead of HBM and
+//     writes its results back to the same slots -- no extra exchange;
+//   * the per-element factor (inter-pass twiddle of passes >= 1, or the coset-block table of coeff_to_extended_blocks on pass 0) into
+//     36 registers by ordinary loads, issued at the same point (the last round holds four elements + these + a product's temporaries,
+//     the same pressure the non-persistent kernel has in its round 0);
+//   * the stores of tile t are issued after the barrier that publishes tile t + 1's DMA and drain under round 0 of tile t + 1.
+// The in-tile twiddle table is built once per workgroup instead of once per tile.  Not taken here (ntt_passy_kernel keeps them):
+// zero-padded inputs, the packed periodic factors (pre / post), passes without a direct table, s < 4.
+struct NttPipeArgs {
+    const uint4* in; uint4* out;
+    int log_n, s, log_ns, last, words_in, raw_out;
+    const uint4* fac;        // factor table in the three-plane balanced form (null: none)
+    unsigned long long fac_M;  // its entries per plane
+    u32 fac_blocks;          // 0: inter-pass table, entry (r << log_ns) + k; > 0: coset-block table, entry ((t % blocks) << log_n) + index
+    u32 in_div;              // word-form input: transform t reads row t / in_div (the blocks of one polynomial share its coefficients)
+    const uint4* post_blocks; u32 blocks;
+    u32 nb; int batch_major;
+    const uint4* tile_tab; const uint4* z_lo; const uint4* z_hi; int lo_bits;
+};
+// 16 bytes per lane from global address sbase + voff (sbase wave-uniform in SGPRs, voff the lane's 32-bit byte offset) to LDS byte address
+// lds_dst + lane * 16 (lds_dst wave-uniform, through M0)
+__device__ __forceinline__ void glds16(const void* sbase, u32 voff, u32 lds_dst) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// MODE bit 0: word-form input (pass 0); bit 1: a factor table; bit 2: coset-block factors on the final store (post_blocks); bit 3: raw output
+template <class F, int TWM, int MODE>
+__global__ void __launch_bounds__(TILE >> 2) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_passp_kernel(const NttPipeArgs p) {
+    constexpr int LG = 2, G = 4, T = TILE, TLOG = TILE_LOG;
+    constexpr bool WORDS_IN = (MODE & 1) != 0, HAS_FAC = (MODE & 2) != 0, POSTB = (MODE & 4) != 0, RAW_OUT = (MODE & 8) != 0;
+#ifndef TRH_NTT_PF
+#define TRH_NTT_PF 1
+#endif
+#ifndef TRH_NTT_PFMODE
+#define TRH_NTT_PFMODE 0  // 1: the other factor rows are requested before the tile's stores; 0: at the start of the next tile
+#endif
+    constexpr int PF = TRH_NTT_PF;  // factor rows fetched a round ahead (the others at the start of the tile)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = p.s, log_n = p.log_n, log_ns = p.log_ns;
+    const int R = 1 << s;
+    const int log_c = TLOG - s;
+    const int C = 1 << log_c;
+    uint4* pa = (uint4*)smem;
+    uint4* pb = pa + T;
+    const int tw_n = TWM == 2 ? (R >> 2) : (R >> 1);
+    uint4* tw_lo = pb + T;
+    uint4* tw_hi = tw_lo + tw_n;
+    u32* pc = (u32*)(tw_hi + tw_n);
+    const TileTwiddlesY<F, TWM> tw{tw_lo, tw_hi, pc + T, p.tile_tab, R >> 1};
+    const size_t N = (size_t)1 << log_n;
+    const int tid = threadIdx.x;
+    const u32 c0 = tid & (C - 1), m0 = tid >> log_c;
+    const size_t row_stride = N >> s;
+    const u32 tiles_log = (u32)(log_n - TLOG);
+    const u32 total = p.nb << tiles_log;
+    const u32 lds_a = (u32)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const u32 lds_b = lds_a + T * 16, lds_c = lds_a + 2 * T * 16 + 2 * (u32)tw_n * 16;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6), lane = (u32)tid & 63u;
+
+    auto coords = [&](u32 w, u32& bx, u32& by) {
+        if (p.batch_major) { bx = w / p.nb; by = w - bx * p.nb; }
+        else { by = w >> tiles_log; bx = w & ((1u << tiles_log) - 1u); }
+    };
+    // a tile's DMA: the lane offsets (row bitrev_s(slot row), column) are the same for every tile; the tile and the transform move the
+    // wave-uniform base
+    auto issue_dma = [&](u32 bx, u32 by) {
+        const char* src = WORDS_IN ? (const char*)(p.in + (size_t)(by / p.in_div) * N * 2) : (const char*)p.in + (size_t)by * N * 36;
+        src += ((size_t)bx << log_c) * (WORDS_IN ? 32 : 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 e0 = (wv * 4 + (u32)i) * 64u;  // wave-uniform first slot of this instruction
+            const u32 e = e0 + lane;
+            const u32 rho = e >> log_c, cc = e & (u32)(C - 1);
+            const u32 r = __brev(rho) >> (32 - s);
+            const u32 g = cc + r * (u32)row_stride;
+            const u32 da = (u32)__builtin_amdgcn_readfirstlane((int)(lds_a + e0 * 16u)), db = (u32)__builtin_amdgcn_readfirstlane((int)(lds_b + e0 * 16u));
+            if constexpr (WORDS_IN) { glds16(src, g * 32u, da); glds16(src + 16, g * 32u, db); }
+            else { glds16(src, g * 16u, da); glds16(src + N * 16, g * 16u, db); }
+        }
+        if constexpr (!WORDS_IN) {  // the 4-byte plane: four consecutive elements of a row (C >= 4) per lane
+            const u32 e0 = wv * 256u;
+            const u32 e = e0 + lane * 4u;
+            const u32 rho = e >> log_c, cc = e & (u32)(C - 1);
+            const u32 r = __brev(rho) >> (32 - s);
+            const u32 g = cc + r * (u32)row_stride;
+            glds16(src + N * 32 - ((size_t)bx << log_c) * 12, g * 4u, (u32)__builtin_amdgcn_readfirstlane((int)(lds_c + e0 * 4u)));
+        }
+    };
+    // factor of the element x[u] holds (row m + bitrev2(u) R / 4 of the tile).  Rows u = 0, 1 are fetched a round ahead (18 registers beside the
+    // last round's four elements); rows 2, 3 at the start of the tile, under the products of rows 0, 1 (36 more would spill)
+    auto load_fac = [&](u32 bx, u32 by, int u, u32 m, u32 c) -> Fy<F> {
+        const u32 j = (bx << log_c) + c;
+        const u32 r = m + (u32)(((u & 1) << 1) | (u >> 1)) * (u32)(R >> LG);
+        const size_t idx = p.fac_blocks ? ((size_t)(by % p.fac_blocks) << log_n) + (size_t)j + (size_t)r * row_stride : ((size_t)r << log_ns) + (j & ((1u << log_ns) - 1u));
+        return load_direct_y<F>(p.fac, (size_t)p.fac_M, idx);
+    };
+
+    u32 w = blockIdx.x, bx = 0, by = 0;
+    Fy<F> f0 = fy_zero<F>(), f1 = fy_zero<F>(), f2 = fy_zero<F>(), f3 = fy_zero<F>();
+    if (w < total) {
+        coords(w, bx, by);
+        issue_dma(bx, by);
+        if constexpr (HAS_FAC) { f0 = load_fac(bx, by, 0, m0, c0); f1 = load_fac(bx, by, 1, m0, c0); f2 = load_fac(bx, by, 2, m0, c0); f3 = load_fac(bx, by, 3, m0, c0); }
+    }
+    if constexpr (TWM == 2) {
+        for (int i = tid; i < tw_n; i += (T >> LG)) lds_store_limbs_y<F>(tw_lo, tw_hi, pc + T, i, load_direct_y<F>(p.tile_tab, (size_t)(R >> 1), (size_t)(2 * i)));
+    } else {
+        for (int i = tid; i < tw_n; i += (T >> LG)) tw.put(i, twiddle_y<F>(p.z_lo, p.z_hi, (u32)i << (log_n - s), p.lo_bits));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    while (w < total) {
+        // (m, c) pass through an empty asm statement once per tile: otherwise the compiler keeps the dozen 64-bit factor / output addresses that
+        // depend on them alone live across the whole loop and spills them (76 - 96 bytes of scratch per thread, reloaded behind vmcnt(0))
+        u32 m = m0, c = c0;
+        asm volatile("" : "+v"(m), "+v"(c));
+        const u32 j = (bx << log_c) + c;
+        const u32 k = j & ((1u << log_ns) - 1u);
+        const size_t blk = (POSTB && p.blocks) ? by % p.blocks : 0u;
+        uint4* out_a = RAW_OUT ? (uint4*)((char*)p.out + (size_t)by * N * 36) : p.out + (size_t)by * N * 2;
+        u32 base = (__brev(m) >> (32 - (s - LG))) << LG;
+        Fy<F> x[G];
+        // round 0: the thread's own four slots, filled by the DMA
+        auto own = [&](int u) -> Fy<F> {
+            const int idx = (int)(((base + (u32)u) << log_c) | c);
+            if constexpr (WORDS_IN) { const uint4 a = pa[idx], b = pb[idx]; return fy_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
+            else return lds_load_limbs_y<F>(pa, pb, pc, idx);
+        };
+        if constexpr (HAS_FAC && TRH_NTT_PFMODE == 0) { if constexpr (PF < 2) f1 = load_fac(bx, by, 1, m, c); f2 = load_fac(bx, by, 2, m, c); f3 = load_fac(bx, by, 3, m, c); }
+        x[0] = own(0); x[1] = own(1);
+        if constexpr (HAS_FAC) { x[0] = fy_mul(x[0], f0); x[1] = fy_mul(x[1], f1); }
+        x[2] = own(2); x[3] = own(3);
+        if constexpr (HAS_FAC) { x[2] = fy_mul(x[2], f2); x[3] = fy_mul(x[3], f3); }
+        round0_stage_y<F, LG, 0, true>(x, tw, s);
+        round0_stage_y<F, LG, 1, true>(x, tw, s);
+        const u32 wn = w + gridDim.x;
+        const bool has_next = wn < total;
+        u32 nbx = 0, nby = 0;
+        if (has_next) coords(wn, nbx, nby);
+        u32 L = 0;
+        int stl = 0, vb = 0;
+        for (int st = LG; st < s; st += LG) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) lds_store_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
+            __syncthreads();
+            stl = st + LG <= s ? st : s - LG;
+            vb = st - stl;
+            L = m & ((1u << stl) - 1u);
+            base = L | ((m >> stl) << (stl + LG));
+#pragma unroll
+            for (int u = 0; u < G; ++u) x[u] = lds_load_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
+            if (st + LG >= s) {  // the last exchange read: once every wave has made it the buffer takes the next tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (has_next) {
+                    issue_dma(nbx, nby);
+                    if constexpr (HAS_FAC) { f0 = load_fac(nbx, nby, 0, m, c); if constexpr (PF >= 2) f1 = load_fac(nbx, nby, 1, m, c); }
+                }
+            }
+            if (0 >= vb) round_stage_y<F, LG, 0, true>(x, tw, L, stl, s, false, true);
+            if (1 >= vb) round_stage_y<F, LG, 1, true>(x, tw, L, stl, s, false, vb == 1);
+        }
+        // the next tile's elements have landed (this wave's; the barrier makes it every wave's) before the stores go out: they drain
+        // under the next tile's round 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // the remaining factor rows of the next tile go out BEFORE the stores: the memory counter retires in order, so a load issued behind
+        // the stores could not be waited for without waiting for them
+        if constexpr (HAS_FAC && TRH_NTT_PFMODE == 1) {
+            if (has_next) { if constexpr (PF < 2) f1 = load_fac(nbx, nby, 1, m, c); f2 = load_fac(nbx, nby, 2, m, c); f3 = load_fac(nbx, nby, 3, m, c); }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const u32 rr = base + ((u32)u << stl);
+            const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
+            if constexpr (RAW_OUT) {
+                out_a[dst] = make_uint4((u32)x[u].l[0], (u32)x[u].l[1], (u32)x[u].l[2], (u32)x[u].l[3]);
+                out_a[N + dst] = make_uint4((u32)x[u].l[4], (u32)x[u].l[5], (u32)x[u].l[6], (u32)x[u].l[7]);
+                ((u32*)(out_a + 2 * N))[dst] = (u32)x[u].l[8];
+            } else {
+                Fy<F> y;
+                if (POSTB && p.post_blocks && p.last) y = fy_mul(x[u], load_direct_y<F>(p.post_blocks, (size_t)p.blocks << log_n, (blk << log_n) + dst));
+                else y = fy_norm(x[u]);
+                u32 wd[8];
+                fy_canonical_words(y, wd);
+                out_a[2 * dst] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                out_a[2 * dst + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+            }
+        }
+        w = wn; bx = nbx; by = nby;
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t rows, size_t row_len, size_t active_len,
                                                                    const uint4* __restrict__ factors, u32 period) {
@@ -1032,6 +1232,42 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
                 const size_t ldh = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 2));
                 const uint4* tile_tab = (sp == 9 && t->tile9.p) ? t->tile9.as<uint4>() : nullptr;
+                // persistent software-pipelined form (ntt_passp_kernel) for the shapes it takes: TRH_NTT_PIPE=1.  Off by default -- measured
+                // (profiles/r05_ntt_pipeline_ab.txt): 2^22 0.437 vs 0.439 ms, 2^24 +2 %, 320 x 2^18 +10 %, coset blocks +8 %; the waves wait less
+                // (SQ_WAIT_ANY -20 %) and the pass takes as long: what bounds it is VALU issue, not the load / store phases
+                static const int pipe_knob = getenv("TRH_NTT_PIPE") ? atoi(getenv("TRH_NTT_PIPE")) : 0;
+                static const int pipe_wg = getenv("TRH_NTT_PIPE_WG") ? atoi(getenv("TRH_NTT_PIPE_WG")) : 2;  // resident workgroups per CU
+                const bool pipe_ok = pipe_knob && log_n <= 26 && sp >= 4 && (sp <= 8 || tile_tab) && !kf.pre && !kf.post && (!kf.in_dev || kf.in_log == log_n) && (p == 0 || direct) &&
+                                     (N >> TILE_LOG) * nb < ((size_t)1 << 31);
+                if (pipe_ok) {
+                    NttPipeArgs pa;
+                    pa.in = (p == 0 && kf.in_dev) ? (const uint4*)kf.in_dev : src;
+                    pa.out = dst;
+                    pa.log_n = (int)log_n; pa.s = sp; pa.log_ns = log_ns; pa.last = (int)(p == P - 1); pa.words_in = (int)(p == 0); pa.raw_out = (int)(p < P - 1);
+                    pa.fac = p > 0 ? direct : (const uint4*)kf.pre_blocks;
+                    pa.fac_M = p > 0 ? (unsigned long long)1 << (log_ns + sp) : (unsigned long long)kf.blocks << log_n;
+                    pa.fac_blocks = (p == 0 && kf.pre_blocks) ? kf.blocks : 0u;
+                    pa.in_div = (p == 0 && kf.pre_blocks) ? kf.blocks : 1u;
+                    pa.post_blocks = (const uint4*)kf.post_blocks; pa.blocks = kf.blocks;
+                    pa.nb = (u32)nb; pa.batch_major = batch_major;
+                    pa.tile_tab = tile_tab; pa.z_lo = t->zlo.as<uint4>(); pa.z_hi = t->zhi.as<uint4>(); pa.lo_bits = t->lo_bits;
+                    if (!c.cu_count) TRH_HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, c.device));
+                    const size_t total = (N >> TILE_LOG) * nb, resident = (size_t)c.cu_count * (size_t)(pipe_wg > 0 ? pipe_wg : 2);
+                    const dim3 pgrid((unsigned)(total < resident ? total : resident));
+                    const size_t lds = sp <= 8 ? ldl : ldh;
+                    const int mode = (p == 0 ? 1 : 0) | (pa.fac ? 2 : 0) | ((p == P - 1 && kf.post_blocks) ? 4 : 0) | (p < P - 1 ? 8 : 0);
+#define TRH_LAUNCH_PASSP(TWM, MODE) hipLaunchKernelGGL((ntt_passp_kernel<F, TWM, MODE>), pgrid, dim3(TILE >> 2), lds, s, pa)
+#define TRH_LAUNCH_PASSP_MODES(TWM)                                                                                                                      \
+    do {                                                                                                                                                 \
+        if (mode == 9) TRH_LAUNCH_PASSP(TWM, 9); else if (mode == 11) TRH_LAUNCH_PASSP(TWM, 11); else if (mode == 10) TRH_LAUNCH_PASSP(TWM, 10);          \
+        else if (mode == 2) TRH_LAUNCH_PASSP(TWM, 2); else TRH_LAUNCH_PASSP(TWM, 6);                                                                     \
+    } while (0)
+                    if (sp <= 8) TRH_LAUNCH_PASSP_MODES(1); else TRH_LAUNCH_PASSP_MODES(2);
+#undef TRH_LAUNCH_PASSP_MODES
+#undef TRH_LAUNCH_PASSP
+                    log_ns += sp;
+                    continue;
+                }
 #define TRH_LAUNCH_PASSY(TWM, FUSE, LDS)                                                                                                       \
     hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWM, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
                        t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major, tile_tab)
@@ -1144,6 +1380,11 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_PASSY_ATTR(FqParams, 1, false); TRH_PASSY_ATTR(FqParams, 1, true); TRH_PASSY_ATTR(FqParams, 0, false); TRH_PASSY_ATTR(FqParams, 0, true);
         TRH_PASSY_ATTR(FpParams, 2, false); TRH_PASSY_ATTR(FpParams, 2, true); TRH_PASSY_ATTR(FqParams, 2, false); TRH_PASSY_ATTR(FqParams, 2, true);
 #undef TRH_PASSY_ATTR
+#define TRH_PASSP_ATTR(FIELD, TWM, MODE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passp_kernel<FIELD, TWM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
+#define TRH_PASSP_ATTRS(FIELD, TWM) TRH_PASSP_ATTR(FIELD, TWM, 9); TRH_PASSP_ATTR(FIELD, TWM, 11); TRH_PASSP_ATTR(FIELD, TWM, 10); TRH_PASSP_ATTR(FIELD, TWM, 2); TRH_PASSP_ATTR(FIELD, TWM, 6)
+        TRH_PASSP_ATTRS(FpParams, 1); TRH_PASSP_ATTRS(FpParams, 2); TRH_PASSP_ATTRS(FqParams, 1); TRH_PASSP_ATTRS(FqParams, 2);
+#undef TRH_PASSP_ATTRS
+#undef TRH_PASSP_ATTR
         ctx().attr_done |= ATTR_NTT;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu, scale);
