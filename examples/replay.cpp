@@ -509,6 +509,12 @@ int main(int argc, char** argv) {
         Timer t_setup;
         Params params(curve, k, 0x1234567, 0x89abcdef, true);
         const double setup_ms = t_setup.stop();
+        // HBM of the fixed-base tables the three resident sets carry (W windows x points x 128-byte records each)
+        double tables_gb = 0;
+        for (const Bases* b : {&params.g(), &params.g_lagrange(), &params.ipa_bases()}) {
+            const int c = trh_bases_precomputed_window_bits(b->handle());
+            if (c > 0 && (b != &params.ipa_bases() || b->handle() != params.g().handle())) tables_gb += (double)(255 / c + 1) * (double)trh_bases_len(b->handle()) * 128.0 / 1e9;
+        }
 
         const int lag_total = N_INSTANCE + N_ADVICE + 3 * N_LOOKUPS + N_PERM_PRODUCTS;
         if (batch > (size_t)lag_total) batch = lag_total;
@@ -911,10 +917,10 @@ int main(int argc, char** argv) {
         }
 
         const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_multiopen + ms_ipa;
-        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"extended_domain\": \"5 of 8 coset blocks\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"keygen_ms\": %.3f, "
+        std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"extended_domain\": \"5 of 8 coset blocks\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"setup_tables_GB\": %.3f, \"keygen_ms\": %.3f, "
                     "\"ms\": {\"lookup_permute\": %.3f, \"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
                     "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f, \"column_loop_ms\": {\"step_by_step\": %.3f, \"two_contexts_overlapped\": %.3f}}\n",
-                    word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total,
+                    word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, tables_gb, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total,
                     loop_seq_ms, loop_ovl_ms);
         trh_shutdown();
     } catch (const std::exception& e) {

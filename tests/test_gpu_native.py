@@ -102,3 +102,23 @@ def test_bench_reports_a_collective_that_did_not_come_up():
     assert lines, r.stdout + r.stderr[-2000:]
     out = json.loads(lines[-1])
     assert out["collective"]["ok"] is False and out["value"] is None and out["n_gpus"] == 2
+
+
+def test_bench_one_rank_rccl_first_contact():
+    """first-contact insurance for the driver's 8-GPU run: bench.py under a launcher's environment with ONE rank and the real
+    backend -- init_process_group("nccl", device_id=...) = RCCL on this MI355X, the all-reduce-of-ones on a device tensor and
+    sharded.all_gather_points on a device tensor -- everything the N > 1 path calls except a second device"""
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRH_BENCH_BACKEND="nccl",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-sweep", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    c = out["collective"]
+    assert c["backend"] == "nccl" and c["ok"] is True and c["world"] == 1 and c["all_reduce_of_ones"] == 1, c
+    assert c["all_gather_points"] == "ok" and out["check"] == "closed-form ok", (c, out["check"])
