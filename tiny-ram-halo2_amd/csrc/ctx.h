@@ -21,7 +21,7 @@
 #include "../../include/trh.h"
 #include "curve.h"
 
-namespace trh { class CopyPool; }
+namespace trh { class CopyPool; class Prefaulter; }
 
 namespace trh {
 
@@ -144,6 +144,7 @@ struct Stage {
     // pipeline's download helper never queue behind each other, and per CONTEXT, so that the GPUs of a device group are fed in parallel
     CopyPool* up_pool = nullptr;
     CopyPool* down_pool = nullptr;
+    Prefaulter* prefault = nullptr;  // populates the pages of download destinations while uploads and kernels run (TRH_PREFAULT=0: off)
     std::map<int, std::array<hipEvent_t, NS>> xfer_ev;  // stage_d2d_via_host: "slot filled" events on the source device, per source device
 };
 

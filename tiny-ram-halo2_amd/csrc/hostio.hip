@@ -92,6 +92,10 @@ int stage_ensure(Ctx& c) {
     if (st.up) return TRH_OK;
     if (!st.up_pool) st.up_pool = new CopyPool(copy_threads());
     if (!st.down_pool) st.down_pool = new CopyPool(copy_threads());
+    // off by default: measured no gain (profiles/r05_prefault_probe.txt -- reused destinations have their pages, and for fresh ones one
+    // populating thread is no faster than the copy threads that take the same faults in parallel)
+    static const int prefault_knob = getenv("TRH_PREFAULT") ? atoi(getenv("TRH_PREFAULT")) : 0;
+    if (!st.prefault && prefault_knob) st.prefault = new Prefaulter();
     size_t slot = (size_t)16 << 20;  // x NS = 4 slots per direction; smaller slots lose to the per-slot hand-over (measured: 16 MiB 32 ms, 8 MiB 39 ms, 4 MiB 45 ms for the 1.6 GB of a 2^24 best_multiexp)
     if (const char* e = getenv("TRH_STAGE_SLOT_MB")) { const long v = atol(e); if (v >= 1 && v <= 256) slot = (size_t)v << 20; }
     hipError_t e = hipHostMalloc((void**)&st.up, slot * Stage::NS, hipHostMallocDefault);
@@ -119,7 +123,9 @@ int stage_ensure(Ctx& c) {
 void stage_release(Ctx& c) {
     Stage& st = c.stage;
     delete st.up_pool; delete st.down_pool;  // stops and joins this context's copy threads
+    delete st.prefault;
     st.up_pool = st.down_pool = nullptr;
+    st.prefault = nullptr;
     if (st.up) (void)hipHostFree(st.up);
     if (st.down) (void)hipHostFree(st.down);
     st.up = st.down = nullptr;
@@ -199,6 +205,7 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
         TRH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
     } else {
+        if (st.prefault) st.prefault->request(dst_host, bytes);  // (a no-op walk over pages that are there already)
         std::vector<size_t> plan, offs;
         chunk_plan(bytes, st.slot, false, true, plan);  // short LAST chunks: the caller waits for the copy out of the last one
         size_t o = 0;
@@ -402,6 +409,11 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
             cv.wait(lk, [&] { return downloaded + D > i || abort; });
             if (abort) return helper_rc;
         }
+        if (st.prefault) {  // this item's destinations, an upload and a kernel ahead of the first byte that lands in them
+            std::vector<HostPipe::Seg> dsts;
+            p.segments(i, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p, dsts);
+            for (const HostPipe::Seg& sg : dsts) if (sg.bytes && !is_pinned(sg.dst)) st.prefault->request(sg.dst, sg.bytes);
+        }
         TRH_TRY(p.upload(i, st.ring_in[slot].p));
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
         TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
@@ -442,6 +454,9 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     IoTrace tr;
     TRH_TRY(c.io.ensure(bytes));
     tr.mark("begin, bytes", bytes);
+    // the transform is in place, but a zero-padded vector's padding is typically untouched (references to the zero page): the download's
+    // first store into each page would fault.  Populate while the upload and the transform run
+    if (c.stage.prefault && !is_pinned(a)) c.stage.prefault->request(a, bytes);
     // Zero slots are not sent (coeff_to_extended hands over a vector that is zero beyond its first 2^k entries: 7/8 of the upload).  Reading
     // 56 MiB of zeros to be SURE they are zeros takes the host 0.5 ms, and nothing else could start before it: so chunks that look like
     // padding (a sparse probe) are cleared on the device at once, the transform and the first downloads are queued, and the padding is
