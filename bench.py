@@ -116,8 +116,11 @@ def cpu_baseline_ntt(field: str, log_n: int):
              "sample": f"{reps} x 2^{log_n} Fp best_fft (oracle/cpu_ref.cpp, {threads} threads), {dt:.2f} s"}, last)
 
 
-TRAFFIC_SOURCE = ("profiles/traffic.json: HBM bytes per launch from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over this same command "
-                  "(tools/profile.sh, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); read from the file, NOT measured in this run")
+TRAFFIC_SOURCE = ("profiles/traffic.json: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from committed rocprofv3 --pmc passes, one counter per pass "
+                  "(headline sizes: tools/profile.sh over this same command; sweep sizes: tools/pmc_sweep.sh -> profiles/r05_pmc_sweep.md).  Factor 2 on FETCH_SIZE: "
+                  "every fabric read request is a 128-byte line tallied at 64 bytes -- MI355X_MICROARCH.md's streaming calibration, measured to hold for this library's "
+                  "16-byte-per-lane gathers out of random 128-byte records as well (profiles/r05_gather_calibration.txt: gather80 whole-lines / reported = 1.994, "
+                  "TCC_EA0_RDREQ_32B = 0); WRITE_SIZE as reported.  Read from the file, NOT measured in this run")
 
 
 def load_traffic(name: str):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# FETCH_SIZE / WRITE_SIZE of the dominant kernels at every size of bench.py's sweep (no roofline with traffic None):
+#   tools/pmc_sweep.sh <tag>   -> gpurun_out/pmc_sweep_<tag>/{msm20,msm22,msm26,ntt20,ntt24}_{fetch,write}/ ; then, back in the repo,
+#   python3 tools/summarize_sweep_pmc.py gpurun_out/pmc_sweep_<tag> <tag>   -> profiles/<tag>_pmc_sweep.md + profiles/traffic.json
+# One counter per pass, kernel trace only beside it.
+set -u
+TAG=${1:-r05}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/pmc_sweep_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+for lg in 20 22 26; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    d=$OUT/msm${lg}_$( [ $c = FETCH_SIZE ] && echo fetch || echo write )
+    rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python3 $REPO/tools/msm_probe.py $lg pallas 0 0 > $d.log 2>&1
+  done
+done
+for lg in 20 24; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    d=$OUT/ntt${lg}_$( [ $c = FETCH_SIZE ] && echo fetch || echo write )
+    rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python3 $REPO/tools/ntt_probe.py $lg 5 > $d.log 2>&1
+  done
+done
+ls $OUT
