@@ -387,8 +387,8 @@ int trh_point_fft_dev(int curve, void* points_dev, uint32_t log_n, const uint64_
 /* ---- element-wise field / group ops on device memory (parity tests of the device arithmetic;
  *      op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv, 6 to_mont, 7 from_mont) ------------------ */
 int trh_field_op_dev(int field, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);
-/* op: 0 out = p + q (both Jacobian 12 x u64), 1 out = p + q (q affine 8 x u64), 2 out = 2p;
- * out Jacobian normalised */
+/* op: 0 out = p + q (both Jacobian 12 x u64), 1 out = p + q (q affine 8 x u64), 2 out = 2p; 3 / 4: p + q / 2p through the quad-lane
+ * arithmetic of the small MSMs' bucket reduction (csrc/curve_q4.h); out Jacobian normalised */
 int trh_point_op_dev(int curve, int op, const void* p_dev, const void* q_dev, void* out_dev, size_t n, void* stream);
 
 /* ---- plain device memory helpers so that non-HIP hosts (Rust, ctypes) can stage buffers ----

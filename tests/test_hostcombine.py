@@ -46,7 +46,10 @@ def test_host_side_under_sanitizers():
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     with tempfile.TemporaryDirectory() as tmp:
         for name, inc, banner in (("hostcombine_test", [], "hostcombine: ok"), ("trh_hpp_host_test", ["-I" + os.path.join(ROOT, "include")], "trh.hpp host side: ok"),
-                                  ("lazy29_test", [], "lazy29: ok")):
+                                  ("lazy29_test", [], "lazy29: ok"),
+                                  # the quad-lane group law of csrc/curve_q4.h as a lane-by-lane CPU model (which lane multiplies what, and the
+                                  # magnitude bounds of every intermediate) against curve.h's xyzzz_add / xyzzz_dbl
+                                  ("q4_model_test", [], "q4 model: ok")):
             exe = os.path.join(tmp, name + "_san")
             subprocess.check_call(["g++", *flags, *inc, os.path.join(ROOT, "tests", "native", name + ".cpp"), "-o", exe])
             r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)

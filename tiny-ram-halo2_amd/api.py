@@ -32,7 +32,7 @@ FIELD_ID = {"fp": FP, "fq": FQ}
 SCALAR_FIELD = {"pallas": "fq", "vesta": "fp"}
 BASE_FIELD = {"pallas": "fp", "vesta": "fq"}
 FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "inv": 5, "to_mont": 6, "from_mont": 7}
-POINT_OPS = {"add": 0, "madd": 1, "dbl": 2}
+POINT_OPS = {"add": 0, "madd": 1, "dbl": 2, "q4_add": 3, "q4_dbl": 4}  # q4_*: the quad-lane arithmetic of csrc/curve_q4.h
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _vp = ctypes.c_void_p

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "ctx.h"
+#include "curve_q4.h"
 #include "devpool.h"
 
 #ifndef TRH_BUILD_ID
@@ -243,6 +244,23 @@ __global__ void __launch_bounds__(64) point_op_kernel(int op, const JacobianMem*
         r = xyzz_dbl(a);
     }
     jac_store(jac_from_affine(xyzz_to_affine(r)), out[i]);
+}
+
+// ops 3 / 4: the same addition / doubling through the quad-lane arithmetic of curve_q4.h (four lanes per pair: lane q carries coordinate q in
+// the lazy domain), so that the golden vectors and the edge cases (identity operands, P + P, P - P) test it directly
+template <class F>
+__global__ void __launch_bounds__(64) point_op_q4_kernel(int op, const JacobianMem* __restrict__ p, const void* __restrict__ q_in, JacobianMem* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
+    if (i >= n) return;  // n is padded to whole quads by construction: the four lanes of a pair share i
+    auto coord = [&](const XYZZz<F>& v) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.zz : v.zzz; };
+    const Fy<F> a = coord(xyzzz_from_canonical(xyzz_from_jacobian(jac_load<F>(p[i]))));
+    Fy<F> r;
+    if (op == 3) r = q4_add(a, coord(xyzzz_from_canonical(xyzz_from_jacobian(jac_load<F>(((const JacobianMem*)q_in)[i])))), q);
+    else r = q4_dbl(a, q);
+    XYZZz<F> full;
+    full.x = q4_perm<F, 0, 0, 0, 0>(r); full.y = q4_perm<F, 1, 1, 1, 1>(r); full.zz = q4_perm<F, 2, 2, 2, 2>(r); full.zzz = q4_perm<F, 3, 3, 3, 3>(r);
+    if (q == 0) jac_store(jac_from_affine(xyzz_to_affine(xyzzz_to_canonical(full))), out[i]);
 }
 
 int check_curve(int curve) {
@@ -1019,6 +1037,13 @@ int trh_point_op_dev(int curve, int op, const void* p, const void* q, void* out,
     TRH_TRY(check_curve(curve));
     TRH_ENTER(stream);
     if (!n) return TRH_OK;
+    if (op == 3 || op == 4) {
+        const unsigned gq = (unsigned)((n * 4 + 63) / 64);
+        if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_q4_kernel<FpParams>), dim3(gq), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
+        else hipLaunchKernelGGL((point_op_q4_kernel<FqParams>), dim3(gq), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
+        TRH_HIP_TRY(hipGetLastError());
+        return TRH_OK;
+    }
     const unsigned gb = (unsigned)((n + 63) / 64);
     if (curve == TRH_PALLAS) hipLaunchKernelGGL((point_op_kernel<FpParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);
     else hipLaunchKernelGGL((point_op_kernel<FqParams>), dim3(gb), dim3(64), 0, (hipStream_t)stream, op, (const JacobianMem*)p, q, (JacobianMem*)out, n);

@@ -173,8 +173,12 @@ __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __rest
 
 // The two tail scalars of both round MSMs without a trip to the host: [rand] W comes from the staged draws, [value z] U from the
 // inner products' partial sums (the host never needs `value`).  Block `side` writes row `side` of the scalar matrix.
+// (the round's constants travel as kernel arguments: a staged copy is a blit kernel and ~20 us of queue idle per round on the trace)
+struct IpaConsts { uint4 w[6]; };
 template <class F>
-__global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const uint4* __restrict__ consts /* rand_l, rand_r, z */,
+__device__ __forceinline__ Fe<F> ipa_const(const IpaConsts& c, int k) { return fe_load<F>(c.w[2 * k].x, c.w[2 * k].y, c.w[2 * k].z, c.w[2 * k].w, c.w[2 * k + 1].x, c.w[2 * k + 1].y, c.w[2 * k + 1].z, c.w[2 * k + 1].w); }
+template <class F>
+__global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const IpaConsts consts /* rand_l, rand_r, z */,
                                                               uint4* __restrict__ lrsc, size_t n, size_t stride) {
     __shared__ Fe<F> sh[256];
     const u32 side = blockIdx.x;
@@ -188,21 +192,21 @@ __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        st<F>(lrsc + 2 * (side * stride + n), ld<F>(consts + 2 * side));
-        st<F>(lrsc + 2 * (side * stride + n + 1), fe_mul(sh[0], ld<F>(consts + 4)));
+        st<F>(lrsc + 2 * (side * stride + n), side ? ipa_const<F>(consts, 1) : ipa_const<F>(consts, 0));
+        st<F>(lrsc + 2 * (side * stride + n + 1), fe_mul(sh[0], ipa_const<F>(consts, 2)));
     }
 }
 // the folds of a round in one launch: p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] (i < half) and the generators' weights
 // (x u where bit log2(half) of the index is set); consts = (u^-1, u)
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_update_kernel(uint4* __restrict__ p, uint4* __restrict__ b, uint4* __restrict__ wgt, size_t n, size_t half, u32 bit,
-                                                               const uint4* __restrict__ consts) {
+                                                               const IpaConsts consts) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const Fe<F> u = ld<F>(consts + 2);
+    const Fe<F> u = ipa_const<F>(consts, 1);
     if ((idx >> bit) & 1u) st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), u));
     if (idx < half) {
-        st<F>(p + 2 * idx, fe_add(ld<F>(p + 2 * idx), fe_mul(ld<F>(p + 2 * (half + idx)), ld<F>(consts))));
+        st<F>(p + 2 * idx, fe_add(ld<F>(p + 2 * idx), fe_mul(ld<F>(p + 2 * (half + idx)), ipa_const<F>(consts, 0))));
         st<F>(b + 2 * idx, fe_add(ld<F>(b + 2 * idx), fe_mul(ld<F>(b + 2 * (half + idx)), u)));
     }
 }
@@ -431,9 +435,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             uint4* partial = ctx().io.as<uint4>();
             hipLaunchKernelGGL((inner_product2_kernel<SF>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)pph, (const uint4*)b.p, (const uint4*)pp.p, (const uint4*)bh, half, partial);
             FeMem cst[3] = {stm(rnd[0]), stm(rnd[1]), zm};
-            void* d_cst;
-            TRH_TRY(stage_constant(cst, sizeof(cst), s, &d_cst));  // through the pinned ring: no synchronisation
-            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, (const uint4*)d_cst, (uint4*)lrsc.p, n, stride);
+            IpaConsts kc;
+            memcpy(&kc, cst, sizeof(cst));
+            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, kc, (uint4*)lrsc.p, n, stride);
             TRH_HIP_TRY(hipGetLastError());
         }
         u64 lrb[24], lr[2][12];
@@ -451,9 +455,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const Fe<SF> u_inv = fe_inv(u_j);
         {
             FeMem cst[2] = {stm(u_inv), stm(u_j)};
-            void* d_cst;
-            TRH_TRY(stage_constant(cst, sizeof(cst), s, &d_cst));
-            hipLaunchKernelGGL((ipa_round_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)pp.p, (uint4*)b.p, (uint4*)wgt.p, n, half, bit, (const uint4*)d_cst);
+            IpaConsts kc{};
+            memcpy(&kc, cst, sizeof(cst));
+            hipLaunchKernelGGL((ipa_round_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)pp.p, (uint4*)b.p, (uint4*)wgt.p, n, half, bit, kc);
             TRH_HIP_TRY(hipGetLastError());
         }
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "ctx.h"
+#include "curve_q4.h"
 #include "hostcombine.h"
 
 namespace trh {
@@ -935,6 +936,76 @@ __global__ void __launch_bounds__(256) msm_reduce2l_final_kernel(const XYZZzMem*
     }
 }
 
+// ---- the same reduction with every point operation spread over a DPP quad (curve_q4.h): for launches that are ONE latency chain ----------
+// (a lone fixed-base commitment, an IPA round, a small MSM).  Quad t of a window owns the slice of m buckets the thread t of
+// msm_reduce_kernel owns; the chain is the same (running sums, slice offset by double-and-add, workgroup tree over the 64 quads) at five /
+// four multiplication steps per addition / doubling instead of fourteen / nine.  4 x the lanes for ~0.45 x the chain: only where lanes are idle.
+template <class BF>
+__global__ void __launch_bounds__(256) msm_reduce_q4_kernel(const XYZZzMem* __restrict__ buckets, XYZZzMem* __restrict__ partials, u32 nbk, u32 m, u32 quads_per_window) {
+    const size_t z = blockIdx.z;  // batch item
+    buckets += z * (size_t)gridDim.y * nbk; partials += z * (size_t)gridDim.y * gridDim.x;
+    __shared__ Fy<BF> sh[256];  // coordinate q of quad Qi at [4 Qi + q]
+    const int j = blockIdx.y;
+    const int q = threadIdx.x & 3, Qi = threadIdx.x >> 2;
+    const u32 t = blockIdx.x * 64u + (u32)Qi;
+    Fy<BF> total = fy_zero<BF>();
+    if (t < quads_per_window) {
+        const XYZZzMem* bk = buckets + (size_t)j * nbk + (size_t)t * m;
+        Fy<BF> run = fy_zero<BF>(), acc = fy_zero<BF>();
+        for (int k = (int)m - 1; k >= 0; --k) {
+            run = q4_add(run, q4_load<BF>(&bk[k], q), q);
+            acc = q4_add(acc, run, q);
+        }
+        const u32 off = t * m;  // acc = sum (k + 1) B[k]; the slice starts at global bucket id t m + 1
+        if (off) {
+            Fy<BF> sc = fy_zero<BF>();
+            for (int i = 31 - __clz(off); i >= 0; --i) {
+                sc = q4_dbl(sc, q);
+                if ((off >> i) & 1u) sc = q4_add(sc, run, q);
+            }
+            acc = q4_add(acc, sc, q);
+        }
+        total = acc;
+    }
+    sh[threadIdx.x] = total;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if (Qi < s) {  // reads [s, 2 s), writes [0, s): disjoint within a level
+            total = q4_add(total, sh[((Qi + s) << 2) | q], q);
+            sh[threadIdx.x] = total;
+        }
+        __syncthreads();
+    }
+    if (Qi == 0) q4_store(&partials[(size_t)j * gridDim.x + blockIdx.x], q, total);
+}
+// one block per window: the sum of `count` partials as 64 quads, handed over in the canonical form (lane q converts and stores coordinate q)
+template <class BF>
+__global__ void __launch_bounds__(256) msm_window_sum_q4_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+    const size_t z = blockIdx.z;
+    partials += z * (size_t)gridDim.x * count; window_sums += z * (size_t)gridDim.x;
+    __shared__ Fy<BF> sh[256];
+    const int j = blockIdx.x;
+    const int q = threadIdx.x & 3, Qi = threadIdx.x >> 2;
+    Fy<BF> v = fy_zero<BF>();
+    for (u32 k = (u32)Qi; k < count; k += 64) v = q4_add(v, q4_load<BF>(&partials[(size_t)j * count + k], q), q);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    int top = 32;
+    while (top > 1 && (u32)top >= count) top >>= 1;
+    for (int s = top; s > 0; s >>= 1) {
+        if (Qi < s) {
+            v = q4_add(v, sh[((Qi + s) << 2) | q], q);
+            sh[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    if (Qi == 0) {
+        const bool id = q4_is_identity(v);
+        const Fe<BF> c = id ? fe_zero<BF>() : fy_to_fe(v);
+        store_fe4((uint4*)&window_sums[j] + 2 * q, c);
+    }
+}
+
 // one block per window: sum `count` partials, hand the window sum over in the canonical form
 template <class BF>
 __global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
@@ -1578,8 +1649,25 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                 hipLaunchKernelGGL((msm_reduce2l_final_kernel<BF>), dim3(2, Ws, nb), dim3(256), 0, s, L.reduce2l.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk);
                 hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, 2u);
             } else {
+            // quad-lane form (curve_q4.h) when the launch is ONE latency chain -- at most TRH_REDUCE_Q4_SETS bucket sets (default 8: a lone
+            // fixed-base commitment, an IPA round, a small fixed-base batch) and four lanes per slice within 2^TRH_REDUCE_Q4_LANES_LOG lanes
+            // (default 2^16 = one wave per SIMD).  Measured (profiles/r05_q4_reduce_ab.txt): IPA k = 18 14.9 -> 13.0 ms, a lone 2^18 commitment
+            // 0.71 -> 0.61 ms; with 16 windows the quads crowd each other out (2^24: reduction 0.43 -> 0.52 ms) and 2^17 lanes lose to 2^16
+            // (IPA 13.9 against 13.0 ms).  TRH_REDUCE_Q4=0 keeps the one-thread-per-slice kernels everywhere
+            static const int q4_knob = getenv("TRH_REDUCE_Q4") ? atoi(getenv("TRH_REDUCE_Q4")) : 1;
+            static const int q4_lanes_log = getenv("TRH_REDUCE_Q4_LANES_LOG") ? atoi(getenv("TRH_REDUCE_Q4_LANES_LOG")) : 16;
+            static const int q4_sets = getenv("TRH_REDUCE_Q4_SETS") ? atoi(getenv("TRH_REDUCE_Q4_SETS")) : 8;
+            u32 q4_tpw = r_tpw;
+            while (q4_tpw > 1024 && (size_t)q4_tpw * 4 * Ws * nb > ((size_t)1 << q4_lanes_log)) q4_tpw >>= 1;
+            if (q4_knob && !compact && (size_t)Ws * nb <= (size_t)q4_sets && q4_tpw >= 64 && (size_t)q4_tpw * 4 * Ws * nb <= ((size_t)1 << q4_lanes_log) && nbk % q4_tpw == 0) {
+                const u32 q4_blocks = (q4_tpw + 63) / 64;
+                TRH_TRY(L.partials.ensure((size_t)chunk * Ws * q4_blocks * sizeof(XYZZzMem)));
+                hipLaunchKernelGGL((msm_reduce_q4_kernel<BF>), dim3(q4_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, nbk / q4_tpw, q4_tpw);
+                hipLaunchKernelGGL((msm_window_sum_q4_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, q4_blocks);
+            } else {
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(r_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, r_slice, r_tpw);
             hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks);
+            }
             }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
