@@ -11,6 +11,8 @@
 // power vector b = (1, x, x^2, ...).
 #include <string.h>
 
+#include <chrono>
+
 #include "ctx.h"
 
 namespace trh {
@@ -418,7 +420,12 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // block (no host synchronisation before the MSM: the host never needs value_l / value_r), the MSM, the transcript, then ONE
     // launch for the three folds.  (The first version had 14 small operations and two synchronisations per round.)
     FeMem zm = stm(z);
+    // TRH_IPA_TRACE=1: where the host's part of a round goes (averages over the rounds, microseconds, to stderr)
+    static const bool ipa_trace = getenv("TRH_IPA_TRACE") && atoi(getenv("TRH_IPA_TRACE"));
+    double tr_acc[6] = {0, 0, 0, 0, 0, 0};
+    auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (uint32_t j = 0; j < k; ++j) {
+        const double t_round0 = ipa_trace ? tnow() : 0;
         const size_t half = (size_t)1 << (k - j - 1);
         const u32 bit = k - j - 1;
         char* pph = (char*)pp.p + half * 32;
@@ -445,11 +452,14 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const int rc_r = msm_enqueue(curve, round_xy, round_z, lrsc.p, n + 2, 2, stride, 1, s, fb);
         ctx().msm.dense_hint = false;
         TRH_TRY(rc_r);
+        const double t_enq = ipa_trace ? tnow() : 0;
         TRH_TRY(msm_finish(curve, s, lrb, 2));
+        const double t_fin = ipa_trace ? tnow() : 0;
         memcpy(lr[0], lrb, 96); memcpy(lr[1], lrb + 12, 96);
         tr->write_point(tr->ctx, lr[0]);
         tr->write_point(tr->ctx, lr[1]);
         tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
+        const double t_tr = ipa_trace ? tnow() : 0;
         const Fe<SF> u_j = fe_load<SF>(tmp);
         if (fe_is_zero(u_j)) { set_error("ipa_create_proof: round %u challenge is zero (the Rust prover's u_j.invert().unwrap() panics here)", j); return TRH_EINVAL; }
         const Fe<SF> u_inv = fe_inv(u_j);
@@ -461,7 +471,14 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             TRH_HIP_TRY(hipGetLastError());
         }
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
+        if (ipa_trace) {
+            const double t_end = tnow();
+            tr_acc[0] += t_enq - t_round0; tr_acc[1] += t_fin - t_enq; tr_acc[2] += t_tr - t_fin; tr_acc[3] += t_end - t_tr; tr_acc[4] += t_end - t_round0;
+        }
     }
+    if (ipa_trace)
+        fprintf(stderr, "[trh ipa] k = %u, per round (us): enqueue %.1f, wait for the MSM (sync + host combine) %.1f, transcript callbacks %.1f, inversion + update launch %.1f, round %.1f\n",
+                k, tr_acc[0] / k, tr_acc[1] / k, tr_acc[2] / k, tr_acc[3] / k, tr_acc[4] / k);
     TRH_HIP_TRY(hipStreamSynchronize(s));
     TRH_HIP_TRY(hipMemcpy(&tmp, pp.p, 32, hipMemcpyDeviceToHost));
     FeMem fm = stm(f);
