@@ -3,6 +3,7 @@
 // width the MSM uses, identity / doubling / cancellation cases.  Built and run by tests/test_hostcombine.py (g++ only).
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include "../../tiny-ram-halo2_amd/csrc/curve.h"
 #include "../../tiny-ram-halo2_amd/csrc/hostcombine.h"
 using namespace trh;
@@ -55,6 +56,25 @@ static int run(const char* name) {
         reference<BF>(ws, W, cb, want);
         hostcombine::combine_windows<BF>((const uint64_t*)ws, W, cb, (uint64_t*)got);
         if (memcmp(want, got, 96) != 0) { ++bad; std::printf("%s: mismatch at trial %d (c = %d)\n", name, trial, cb); }
+    }
+    // the batch form (one inversion for all items): W = 1 (fixed-base mode) and W = 16, batches around the chunk boundary, identities sprinkled in
+    for (int W : {1, 16}) {
+        for (size_t batch : {(size_t)1, (size_t)2, (size_t)3, (size_t)64, (size_t)255, (size_t)256, (size_t)257, (size_t)600}) {
+            const int cb = 16;
+            std::vector<XYZZMem> ws(batch * W);
+            XYZZ<BF> p = xyzz_from_affine(G);
+            for (size_t i = 0; i < batch * W; ++i) {
+                p = xyzz_dbl(p); if (next() & 1) xyzz_madd(p, G);
+                XYZZ<BF> v = p;
+                if (next() % 7 == 0) v = xyzz_identity<BF>();
+                xyzz_store(v, ws[i]);
+            }
+            if (batch >= 3) for (int j = 0; j < W; ++j) xyzz_store(xyzz_identity<BF>(), ws[(batch - 2) * W + j]);  // one item is the identity altogether
+            std::vector<u64> got(batch * 12), want(batch * 12);
+            for (size_t i = 0; i < batch; ++i) reference<BF>(ws.data() + i * W, W, cb, want.data() + 12 * i);
+            hostcombine::combine_windows_batch<BF>((const uint64_t*)ws.data(), W, cb, batch, (uint64_t*)got.data());
+            if (memcmp(want.data(), got.data(), batch * 96) != 0) { ++bad; std::printf("%s: batch mismatch (W = %d, batch = %zu)\n", name, W, batch); }
+        }
     }
     return bad;
 }

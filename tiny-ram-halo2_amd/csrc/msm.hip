@@ -936,6 +936,43 @@ __global__ void __launch_bounds__(256) msm_reduce2l_final_kernel(const XYZZzMem*
     }
 }
 
+// The combine with a DPP quad per bucket (curve_q4.h): the quad adds the bucket's pieces one after the other at five multiplication steps each.
+// The four-lanes-per-bucket form of msm_combine_kernel (G = 4) runs ceil(pieces / 4) + 2 FULL additions on every lane -- five for the three or
+// four pieces a bucket of a lone commitment or an IPA round has --, the quad form pieces - 1 quad additions: the same lanes, a third of the work.
+template <class BF>
+__global__ void __launch_bounds__(256) msm_combine_q4_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
+                                                             const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
+                                                             const XYZZzMem* __restrict__ direct, XYZZzMem* __restrict__ buckets,
+                                                             u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride) {
+    const size_t z = blockIdx.z;  // batch item
+    {
+        const size_t Wz = gridDim.y;
+        starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
+        direct += z * Wz * (nbk + 1); buckets += z * Wz * nbk; heavy += z * heavy_stride;
+    }
+    const u32 gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 b = gt / 4 + 1;
+    const int q = threadIdx.x & 3;
+    const int j = blockIdx.y;
+    if (b > nbk) return;  // (nbk and the block size are multiples of four: a quad is never split by the bound)
+    const u32 nb1 = nbk + 1;
+    const u32 S = starts[(size_t)j * nb1 + b], E = ends[(size_t)j * nb1 + b];
+    Fy<BF> acc = fy_zero<BF>();
+    if (E > S) {
+        const u32 t_lo = S / seg_len, t_hi = (E - 1) / seg_len;
+        if (t_hi - t_lo > HEAVY_PIECES) {  // skewed bucket: a whole workgroup adds its pieces (msm_combine_heavy_kernel)
+            if (q == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)j * nb1 + b;
+            return;  // uniform over the quad
+        }
+        const XYZZzMem* fj = first + (size_t)j * nseg;
+        if (S == t_lo * seg_len) acc = q4_load<BF>(fj + t_lo, q);
+        else if (E <= (t_lo + 1) * seg_len) acc = q4_load<BF>(direct + (size_t)j * nb1 + b, q);
+        else acc = q4_load<BF>(last + (size_t)j * nseg + t_lo, q);
+        for (u32 t = t_lo + 1; t <= t_hi; ++t) acc = q4_add(acc, q4_load<BF>(fj + t, q), q);
+    }
+    q4_store(&buckets[(size_t)j * nbk + (b - 1)], q, acc);  // stays in the lazy domain for the reduction; an empty bucket is all zeros
+}
+
 // ---- the same reduction with every point operation spread over a DPP quad (curve_q4.h): for launches that are ONE latency chain ----------
 // (a lone fixed-base commitment, an IPA round, a small MSM).  Quad t of a window owns the slice of m buckets the thread t of
 // msm_reduce_kernel owns; the chain is the same (running sums, slice offset by double-and-add, workgroup tree over the 64 quads) at five /
@@ -1622,7 +1659,15 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // 256 buckets of 512 entries = 32 pieces each, added one after the other by one thread: 1.6 ms per batch) while most groups find an
             // empty bucket and leave at once -- a quarter wave per bucket
             // (16 lanes per bucket for these: 2^15 buckets x 64 columns x 16 lanes of mostly empty groups cost more than the chains: 3.4 -> 5.4 ms)
-            if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
+            // quad form only where the caller vouches for uniformly full-size scalars (dense_hint: the IPA's rounds, three or four pieces per bucket):
+            // opening 12.8 -> 12.4 ms; on a lone even-bits column (256 buckets of 32 pieces, which four lanes share better than one quad walks)
+            // it measured 0.52 -> 0.58 ms, full-size and word columns the same.  TRH_COMBINE_Q4=0: the shuffle form everywhere, 2: the quad form
+            // for every small launch (A/B)
+            static const int q4c_knob = getenv("TRH_COMBINE_Q4") ? atoi(getenv("TRH_COMBINE_Q4")) : 1;
+            if (pieces >= 3 && nbk >= 4 && !compact && (q4c_knob == 2 || (q4c_knob == 1 && m.dense_hint)) && (size_t)Ws * nb <= 8)
+                hipLaunchKernelGGL((msm_combine_q4_kernel<BF>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(),
+                                   L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
+            else if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
             else TRH_LAUNCH_COMBINE(1);
 #undef TRH_LAUNCH_COMBINE
         }
@@ -1777,7 +1822,7 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     m.pending_curve = -1;  // whatever happens below, the context is free for the next MSM
     TRH_HIP_TRY(hipStreamSynchronize(s));
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
-    for (size_t bi = 0; bi < batch; ++bi) combine_windows_host<BF>(ws + bi * m.pending_windows, m.pending_windows, m.pending_c, out_xyz + 12 * bi);
+    hostcombine::combine_windows_batch<BF>((const uint64_t*)ws, m.pending_windows, m.pending_c, batch, (uint64_t*)out_xyz);  // one inversion for the whole batch
     if (m.ev_valid) {
         float t01, t12, t23, t34, tt, t25;
         TRH_HIP_TRY(hipEventElapsedTime(&t25, m.ev[2], m.ev[5]));
