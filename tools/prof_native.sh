@@ -1,21 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the native driver: tools/prof_native.sh <tag> [driver args]
+# rocprofv3 kernel trace of the compiled replay driver: tools/prof_native.sh <tag> [replay args...]  -> gpurun_out/trace_native_<tag>/
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/trace_$TAG
+OUT=$REPO/gpurun_out/trace_native_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export LD_LIBRARY_PATH=$REPO/tiny-ram-halo2_amd:${LD_LIBRARY_PATH:-}
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $REPO/examples/replay "$@" > $OUT/log.txt 2>&1
-tail -1 $OUT/log.txt
-python3 - <<PY
-import sqlite3, glob, re
-for p in glob.glob("$OUT/*.db"):
-    db = sqlite3.connect(p)
-    rows = db.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc").fetchall()
-    tot = sum(r[2] for r in rows)
-    for r in rows[:10]:
-        m = re.search(r"(\w+_kernel)", r[0])
-        print(f"{(m.group(1) if m else r[0][:40]):36s} calls {r[1]:5d}  total {r[2]/1e6:9.3f} ms  avg {r[3]/1e3:9.1f} us  {100*r[2]/tot:5.1f}%")
-PY
+tail -1 $OUT/log.txt | cut -c1-400
