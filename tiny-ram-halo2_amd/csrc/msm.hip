@@ -115,6 +115,15 @@ __global__ void __launch_bounds__(256) msm_recode_kernel(const uint4* __restrict
     }
 }
 
+// up to four ranges cleared by ONE launch (a small MSM's pipeline cleared its counters with four hipMemsetAsync fill kernels of ~4.5 us each)
+struct ZeroRanges { uint4* p[4]; u32 n16[4]; };
+__global__ void __launch_bounds__(256) msm_zero_ranges_kernel(const ZeroRanges z) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n16[k]; i += gridDim.x * blockDim.x) z.p[k][i] = zero;
+}
+
 // ---------------------------------------------------------------------------------------
 // 2. exclusive scan per window of cnt[0..len) -> starts; cnt becomes the running cursor
 // ---------------------------------------------------------------------------------------
@@ -1491,7 +1500,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // L.counts: [bin counts][fixed-base mode: one byte per (item, partition tile)][oversize-bin flags of the LDS bin sort][entry totals per item and window]
     const u32 part_tiles = (u32)((ns + PART_TILE - 1) / PART_TILE);
     const size_t flag_bytes = fb ? ((size_t)chunk * part_tiles + 3) / 4 * 4 : 0;
-    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + flag_bytes + 2 * chunk * Ws * 4));
+    TRH_TRY(L.counts.ensure(chunk * Ws * nbins * 4 + flag_bytes + 2 * chunk * Ws * 4 + 16));
     unsigned char* const tile_flags = fb ? (unsigned char*)(L.counts.as<u32>() + chunk * Ws * nbins) : nullptr;
     u32* const oversize = (u32*)((char*)L.counts.p + chunk * Ws * nbins * 4 + flag_bytes);
     u32* const totals = oversize + chunk * Ws;
@@ -1509,14 +1518,14 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     const bool use_bin = avg_bin >= 4096 && bin_cap <= BIN_CAP_MAX && !getenv("TRH_NO_BIN_SORT");
     TRH_TRY(L.bin_starts.ensure(chunk * Ws * nbins * 4));
     TRH_TRY(L.starts.ensure(chunk * Ws * nb1 * 4));
-    TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4));
+    TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4 + 16));
     TRH_TRY(L.ends.ensure(chunk * Ws * nb1 * 4));
     const unsigned range_blocks = (nb1 + RANGE_BLOCK - 1) / RANGE_BLOCK;  // <= 2^17 / 1024 + 1 = 129 < RANGE_BLOCK threads
     TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg0 > range_blocks ? nseg0 : range_blocks) * 4 + 16));
     TRH_TRY(L.first.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
     TRH_TRY(L.last.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
     TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
-    TRH_TRY(L.heavy.ensure(chunk * heavy_stride0 * 4));
+    TRH_TRY(L.heavy.ensure(chunk * heavy_stride0 * 4 + 16));
     TRH_TRY(L.buckets.ensure(chunk * Ws * nbk * sizeof(XYZZzMem)));
     TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZzMem)));
     if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * ZREC + ZREC));
@@ -1566,8 +1575,24 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         const size_t nse = compact ? (size_t)sp_cap : ns;  // slots per item and bucket set
         const uint4* sc = (const uint4*)((const char*)scalars_dev + b0 * stride * 32);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
+        // small launches (a lone MSM, an IPA round): counts, oversize flags, heavy list and bucket counters cleared by one launch up front instead
+        // of four fill kernels along the way (none of them is written before the kernel that the old memset preceded; adaptive batches keep
+        // the memsets: their heavy list is sized after the read-back)
+        const bool zero_fused = !compact && batch < 8 && mode != PIPE_DENSE;
+        if (zero_fused) {
+            auto up16 = [](size_t b) { return (u32)((b + 15) / 16); };
+            ZeroRanges zr{};
+            // range 0 is the whole counts buffer: bin counts, tile flags, oversize flags, entry totals (the buffers below are allocated 16 bytes
+            // longer than their contents, so that the 16-byte granules of this kernel never leave them)
+            zr.p[0] = (uint4*)L.counts.p; zr.n16[0] = up16((size_t)chunk * Ws * nbins * 4 + flag_bytes + 2 * (size_t)chunk * Ws * 4);
+            zr.p[1] = nullptr; zr.n16[1] = 0u;
+            zr.p[2] = (uint4*)L.heavy.p; zr.n16[2] = up16((size_t)nb * heavy_stride0 * 4);
+            zr.p[3] = (uint4*)L.bucket_cnt.p; zr.n16[3] = up16((size_t)nb * Ws * nb1 * 4);
+            const u32 most = zr.n16[3] > zr.n16[0] ? zr.n16[3] : zr.n16[0];
+            hipLaunchKernelGGL(msm_zero_ranges_kernel, dim3((most + 255) / 256 < 512 ? (most + 255) / 256 : 512), dim3(256), 0, s, zr);
+        }
         if (!compact) {
-            TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
+            if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
             unsigned gb = (unsigned)((n + 255) / 256);
             if (gb > 2048) gb = 2048;
             hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, nb), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W,
@@ -1577,7 +1602,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
         const bool bin_sort = use_bin && !compact;  // compact lists: ~2^11 entries per bin, and a flag column has them all in one: the chunked passes
-        if (bin_sort) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
+        if (bin_sort && !zero_fused) TRH_HIP_TRY(hipMemsetAsync(oversize, 0, (size_t)chunk * Ws * 4, s));
         hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, nb), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, bin_sort ? oversize : nullptr, bin_cap,
                            (adaptive && mode == PIPE_PLAIN) ? totals : nullptr);
         u32 seg_len = seg_len0, nseg = nseg0, heavy_stride = heavy_stride0;
@@ -1617,7 +1642,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
             TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
         }
-        TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
+        if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((nse + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), nse, k2, nbins, idx_bits, compact ? (const unsigned char*)nullptr : tile_flags);
         {
@@ -1626,7 +1651,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             if (bin_sort)
                 hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, Ws, nb), dim3(BIN_THREADS), (size_t)bin_cap * 4, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                    L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), nse, k2, nbins, idx_bits, nbk, oversize);
-            TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
+            if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), nse, k2, nbins, idx_bits, nbk, gate);
             // block totals live in seg_bucket, which is only filled afterwards

@@ -14,7 +14,7 @@ n = 1 << k
 api.init(0)
 curve, field = "vesta", "fp"
 gl = api.Bases.generate(curve, synth.BASE_S0 + 77, synth.BASE_D + 2, n + 1)
-gl.precompute(0)
+gl.precompute(int(os.environ.get("TRH_PROBE_TABLE_C", "0")))
 can = replay.witness_columns(kind, blinded, 0xC01, batch, n, 2 * (k - 2))
 d = torch.from_numpy(can.view(np.int64)).cuda()
 st = torch.cuda.current_stream().cuda_stream
