@@ -54,7 +54,8 @@ extern "C" {
 #define TRH_ENODEV (-2)   /* no HIP device / trh_init not called */
 #define TRH_EHIP (-3)     /* HIP runtime error */
 #define TRH_ENOMEM (-4)
-#define TRH_EBUSY (-5)    /* the context already has an MSM in flight */
+#define TRH_EBUSY (-5)    /* the context already has an MSM in flight; trh_set_option while a context exists */
+#define TRH_ESELFTEST (-6) /* trh_init: the known-answer self-test of the device arithmetic failed (trh_last_error() names the primitive) */
 
 #define TRH_PALLAS 0
 #define TRH_VESTA 1
@@ -67,6 +68,15 @@ void trh_shutdown(void);             /* destroys the default context / the devic
 const char* trh_last_error(void);
 int trh_device_count(void);
 const char* trh_version(void);       /* "trh <version> (gfx950, build <hash of the sources>)" */
+/* The library's switches.  Each has an environment variable TRH_<NAME IN UPPER CASE> that is read ONCE (at the first trh_init /
+ * trh_set_option); trh_set_option overrides it for hosts that must not touch the environment (a multi-threaded prover: getenv racing a
+ * setenv elsewhere in the process is undefined behaviour, so no entry point of this library calls getenv after that).  Options are
+ * process-wide and fixed while any context exists: call before trh_init, or after trh_shutdown (TRH_EBUSY otherwise).  Values are
+ * decimal integers.  Names (defaults): pool_mb (4096), stage_slot_mb (16), copy_threads (-1 = by core count), bases_cache (0),
+ * force_no_peer (0), roctx (1), trace (0; bit 0 host-pointer entries, bit 1 IPA rounds), msm_chunk_gb (4), sparse (1), reduce_q4 (1),
+ * bin_sort (1), selftest (1) -- see DESIGN.md section 8.                                                                            */
+int trh_set_option(const char* name, const char* value);
+int trh_get_option(const char* name, long* value);
 
 /* ---- device group: the MSM range-sharded over the GPUs of one node (one host process, as the reference's prover is:
  * /root/reference/src/test_utils.rs:37-54).  devices[0] becomes the process default, exactly as trh_init(devices[0]);
@@ -158,7 +168,7 @@ int trh_msm_dev(trh_bases_t bases, size_t offset, const void* scalars_dev, size_
  * context (TRH_EBUSY otherwise); finish must name the base set and be called on the context of its enqueue.
  * Over a base set WITH fixed-base tables (trh_bases_precompute) the enqueue is not fully asynchronous: a sampler reads ~1024 scalars
  * and votes on the flag-like unit path, which synchronises `stream` once (everything queued on it before the call completes first);
- * TRH_SPARSE_LONE=0 (or a set without tables) keeps the enqueue free of host synchronisations.  With trh_set_timing(1) such an MSM
+ * option sparse = 0 (or a set without tables) keeps the enqueue free of host synchronisations.  With trh_set_timing(1) such an MSM
  * reports zero phase times (trh_last_timing): the sampler's paths are not timed phase by phase.                                  */
 int trh_msm_dev_enqueue(trh_bases_t bases, size_t offset, const void* scalars_dev, size_t n,
                         int scalars_are_montgomery, void* stream);
@@ -393,7 +403,7 @@ int trh_point_op_dev(int curve, int op, const void* p_dev, const void* q_dev, vo
 
 /* ---- plain device memory helpers so that non-HIP hosts (Rust, ctypes) can stage buffers ----
  * trh_free keeps freed blocks for reuse by trh_malloc (per device, by rounded size; it returns when the device has drained, as
- * hipFree does): at most TRH_POOL_MB MiB (environment, default 4096; 0 switches the pool off), evicting the device's largest idle
+ * hipFree does): at most `pool_mb` MiB (trh_set_option / TRH_POOL_MB, default 4096; 0 switches the pool off), evicting the device's largest idle
  * blocks first.  The idle blocks are invisible to any other allocator in the process (torch's caching allocator, say): libtrh
  * returns them when one of its own allocations fails, and trh_pool_trim() returns them on request.  Freeing a block twice is
  * reported (TRH_EINVAL) while it still waits in the pool. */

@@ -86,39 +86,6 @@ int main() {
         trh::chunk_plan(128 * MiB, 16 * MiB, true, true, plan);  // the default ring: 2, 6, full slots, 6, 2
         if (plan.size() < 5 || plan[0] != 2 * MiB || plan[1] != 6 * MiB || plan[plan.size() - 2] != 6 * MiB || plan.back() != 2 * MiB) ++bad;
     }
-    // Prefaulter: an untouched anonymous mapping gets its pages (content stays zero), a buffer with content keeps it while a reader and a
-    // writer work on it, short and unaligned ranges are fine, requests after the owner is gone do not happen (destructor joins)
-    {
-        const size_t len = (size_t)24 << 20;
-        std::vector<unsigned char> buf(len + 4096);
-        unsigned char* p = buf.data() + 123;
-        for (size_t i = 0; i < len; ++i) p[i] = (unsigned char)(i * 7 + 1);
-        std::vector<unsigned char> zeros_src(len, 0);
-        trh::Prefaulter* pf = new trh::Prefaulter();
-        pf->request(p, len);
-        pf->request(nullptr, len);
-        pf->request(p, 100);  // below the threshold: ignored
-        std::thread writer([&] { for (size_t i = 0; i < len; i += 4099) __atomic_store_n(&p[i], (unsigned char)(i * 7 + 1), __ATOMIC_RELAXED); });
-        size_t wrong = 0;
-        for (size_t i = 0; i < len; i += 4093) wrong += __atomic_load_n(&p[i], __ATOMIC_RELAXED) != (unsigned char)(i * 7 + 1);
-        writer.join();
-        pf->drain();
-        for (size_t i = 0; i < len; ++i) wrong += p[i] != (unsigned char)(i * 7 + 1);
-        if (wrong || pf->skipped_bytes() != len || pf->populated_bytes() != 0) ++bad;  // a written buffer is resident: sampled and left alone
-        void* q = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);  // no page-table entries: the shape of a prover's fresh Vec
-        if (q == MAP_FAILED) ++bad;
-        else {
-            pf->request(q, len);
-            pf->drain();
-            if (pf->populated_bytes() < len) ++bad;
-            for (size_t i = 0; i < len; i += 4096) if (((unsigned char*)q)[i]) ++bad;
-            pf->request(q, len);  // populated now: skipped
-            pf->drain();
-            if (pf->skipped_bytes() != 2 * len) ++bad;
-            munmap(q, len);
-        }
-        delete pf;
-    }
     delete up; delete down; delete none;  // the destructor stops and joins the workers (per-context pools die with their context)
     std::printf(bad ? "copypool: FAILED (%d)\n" : "copypool: ok\n", bad);
     return bad ? 1 : 0;

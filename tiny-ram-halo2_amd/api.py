@@ -70,6 +70,8 @@ _SIGNATURES = {
     "trh_last_error": ([], ctypes.c_char_p),
     "trh_device_count": ([], ctypes.c_int),
     "trh_version": ([], ctypes.c_char_p),
+    "trh_set_option": ([ctypes.c_char_p, ctypes.c_char_p], ctypes.c_int),
+    "trh_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)], ctypes.c_int),
     "trh_init_multi": ([ctypes.POINTER(ctypes.c_int), ctypes.c_int], ctypes.c_int),
     "trh_group_size": ([], ctypes.c_int),
     "trh_group_peer_access": ([], ctypes.c_int),
@@ -193,6 +195,17 @@ def _check(rc: int):
 
 def init(device: int = 0):
     _check(lib().trh_init(device))
+
+
+def set_option(name: str, value) -> None:
+    """trh_set_option: a library switch; only while no context exists (before init / after shutdown)"""
+    _check(lib().trh_set_option(name.encode(), str(int(value)).encode()))
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_long(0)
+    _check(lib().trh_get_option(name.encode(), ctypes.byref(v)))
+    return int(v.value)
 
 
 def init_multi(devices):

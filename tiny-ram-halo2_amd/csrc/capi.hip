@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -27,6 +28,47 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- options (ctx.h Options): environment once, then trh_set_option while no context exists ------------------------------
+namespace {
+Options g_opt;
+std::once_flag g_opt_once;
+std::mutex g_opt_mu;                 // serialises trh_set_option calls; readers need none (nothing writes while a context is alive)
+std::atomic<int> g_live_ctx{0};      // contexts alive: while > 0 the options are fixed
+struct OptField { const char* name; int kind; void* p; long lo, hi; };  // kind 0: int, 1: long
+const OptField* opt_fields(size_t* count) {
+    static const OptField f[] = {
+        {"pool_mb", 1, &g_opt.pool_mb, 0, 1 << 20},          {"stage_slot_mb", 1, &g_opt.stage_slot_mb, 1, 256}, {"copy_threads", 0, &g_opt.copy_threads, -1, 64},
+        {"bases_cache", 0, &g_opt.bases_cache, 0, 1},        {"force_no_peer", 0, &g_opt.force_no_peer, 0, 1},   {"roctx", 0, &g_opt.roctx, 0, 1},
+        {"trace", 0, &g_opt.trace, 0, 3},                    {"msm_chunk_gb", 1, &g_opt.msm_chunk_gb, 1, 256},   {"sparse", 0, &g_opt.sparse, 0, 1},
+        {"reduce_q4", 0, &g_opt.reduce_q4, 0, 1},            {"bin_sort", 0, &g_opt.bin_sort, 0, 1},             {"selftest", 0, &g_opt.selftest, 0, 1},
+    };
+    *count = sizeof(f) / sizeof(f[0]);
+    return f;
+}
+bool opt_assign(const OptField& f, const char* value) {
+    char* end = nullptr;
+    const long v = strtol(value, &end, 10);
+    if (end == value || *end != 0 || v < f.lo || v > f.hi) return false;
+    if (f.kind == 0) *(int*)f.p = (int)v; else *(long*)f.p = v;
+    return true;
+}
+void opt_load_env() {  // TRH_<NAME> for every field; a value out of range is ignored (the default stays)
+    size_t n = 0;
+    const OptField* f = opt_fields(&n);
+    for (size_t i = 0; i < n; ++i) {
+        char env[64] = "TRH_";
+        size_t k = 4;
+        for (const char* q = f[i].name; *q && k + 1 < sizeof(env); ++q) env[k++] = (char)(*q >= 'a' && *q <= 'z' ? *q - 32 : *q);
+        env[k] = 0;
+        if (const char* e = getenv(env)) (void)opt_assign(f[i], e);
+    }
+}
+}  // namespace
+const Options& opt() {
+    std::call_once(g_opt_once, opt_load_env);
+    return g_opt;
 }
 
 // ---- context registry ------------------------------------------------------------------------------------------------
@@ -101,7 +143,7 @@ roctx_push_fn g_roctx_push = nullptr;
 roctx_pop_fn g_roctx_pop = nullptr;
 std::once_flag g_roctx_once;
 void roctx_resolve() {
-    if (const char* e = getenv("TRH_ROCTX")) if (atoi(e) == 0) return;
+    if (!opt().roctx) return;
     void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return;
@@ -137,6 +179,7 @@ static int create_ctx(int device, Ctx** out) {
     if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     if (e1 != hipSuccess || e2 != hipSuccess) { delete h; set_error("context creation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return TRH_EHIP; }
     c->inited = true;
+    g_live_ctx.fetch_add(1);
     *out = c;
     return TRH_OK;
 }
@@ -146,10 +189,7 @@ struct DevPool : DevPoolIndex {  // devpool.h: live / idle maps and the eviction
     std::mutex mu;
 };
 DevPool g_pool;
-size_t pool_cap() {
-    static const size_t cap = (size_t)(getenv("TRH_POOL_MB") ? atoll(getenv("TRH_POOL_MB")) : 4096) << 20;
-    return cap;
-}
+size_t pool_cap() { return (size_t)opt().pool_mb << 20; }
 size_t pool_round(size_t bytes) { return DevPoolIndex::round(bytes); }
 void pool_release_idle() {  // g_pool.mu held
     for (auto& kv : g_pool.idle) {
@@ -195,6 +235,7 @@ static void destroy_ctx(Ctx* c) {
     c->inited = false;
     if (t_bound == c) t_bound = nullptr;
     delete static_cast<trh_ctx*>(c);
+    g_live_ctx.fetch_sub(1);
 }
 
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s);
@@ -339,10 +380,8 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
     Stage& st = c.stage;
     // range boundaries
     std::vector<size_t> cut(1, 0);
-    size_t forced = 0;
-    if (const char* e = getenv("TRH_HOST_TILE_LOG")) { const int v = atoi(e); if (v >= 10 && v <= 26) forced = (size_t)1 << v; }
-    if (forced || (bases_host && n > ((size_t)1 << 21))) {  // equal ranges
-        const size_t want = forced ? forced : (size_t)1 << 20, nt = (n + want - 1) / want, len = (n + nt - 1) / nt;
+    if (bases_host && n > ((size_t)1 << 21)) {  // equal ranges
+        const size_t want = (size_t)1 << 20, nt = (n + want - 1) / want, len = (n + nt - 1) / nt;
         for (size_t o = len; o < n; o += len) cut.push_back(o);
     } else if (!bases_host && n > ((size_t)3 << 21)) {
         // growing ranges: 2^21, 2^22, then the rest -- the first upload is short, every later one hides under the range before it
@@ -391,8 +430,7 @@ int best_multiexp_host(int curve, const uint64_t* coeffs, const uint64_t* bases,
     if (!out || (n && (!coeffs || !bases))) { set_error("best_multiexp: null pointer"); return TRH_EINVAL; }
     if (n >= ((size_t)1 << 31)) { set_error("best_multiexp: n too large"); return TRH_EINVAL; }
     if (n == 0) { memset(out, 0, 96); return TRH_OK; }  // the empty sum: the identity (an empty Rust slice may carry any pointer)
-    static const int cache_on = getenv("TRH_BASES_CACHE") ? atoi(getenv("TRH_BASES_CACHE")) : 0;
-    if (cache_on && n >= 1024) {
+    if (opt().bases_cache && n >= 1024) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         const uint64_t fp = bases_fingerprint(bases, n);
         BasesCacheEntry* hit = nullptr;
@@ -488,10 +526,7 @@ int sharded_create(int curve, const uint64_t* xy_host, uint64_t s0, uint64_t d, 
 // TRH_FORCE_NO_PEER=1: the group behaves as if no pair of devices had peer access -- trh_init_multi enables none, and device-resident
 // scalars reach EVERY shard (the one on the source device included) through the pinned-host hand-over that a box without peer access
 // takes.  For exercising that path on a one-GPU box ({0, 0} groups).
-bool force_no_peer() {  // read per call: a test flips it between two MSMs of one process
-    const char* e = getenv("TRH_FORCE_NO_PEER");
-    return e && atoi(e);
-}
+bool force_no_peer() { return opt().force_no_peer != 0; }
 
 int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_on_host, size_t n, int mont, hipStream_t caller_stream, uint64_t* out) {
     Range range("trh_msm[sharded]");
@@ -591,11 +626,12 @@ int msm_sharded(trh_bases* B, size_t offset, const void* scalars, bool scalars_o
         if (rc == TRH_OK) {
             // no sparse vote on a shard: the sampler ends in a host synchronisation behind this shard's upload / hand-over, which
             // would hold back the enqueues of the later shards; a range-sharded MSM is a full-size one
-            const bool hint = sc->msm.dense_hint;
-            sc->msm.dense_hint = true;
+            // (its own flag: dense_hint also selects the quad-lane combine, which is for callers that vouch for full-size scalars -- ADVICE r05)
+            const bool keep = sc->msm.no_sparse_vote;
+            sc->msm.no_sparse_vote = true;
             rc = msm_enqueue(B->curve, (const char*)sh->d_xy + rg[g].local * 64, lazy_bases(sh, rg[g].local, sc->own_stream), sc->msm.scalars.p, rg[g].cnt, 1, rg[g].cnt, mont, sc->own_stream,
                              fixed_base(sh, rg[g].local, rg[g].cnt));
-            sc->msm.dense_hint = hint;
+            sc->msm.no_sparse_vote = keep;
         }
         if (rc != TRH_OK) { join_all(); return rc; }
     }
@@ -620,6 +656,32 @@ extern "C" {
 
 const char* trh_version(void) { return "trh 0.2.0 (gfx950, build " TRH_BUILD_ID ")"; }
 const char* trh_last_error(void) { return g_err; }
+
+int trh_set_option(const char* name, const char* value) {
+    if (!name || !value) { set_error("trh_set_option: null pointer"); return TRH_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    (void)opt();  // the environment first: an explicit call overrides it
+    if (g_live_ctx.load() > 0) { set_error("trh_set_option(%s): options are fixed while a context exists (call it before trh_init, or after trh_shutdown)", name); return TRH_EBUSY; }
+    size_t n = 0;
+    const OptField* f = opt_fields(&n);
+    for (size_t i = 0; i < n; ++i)
+        if (strcmp(f[i].name, name) == 0) {
+            if (!opt_assign(f[i], value)) { set_error("trh_set_option(%s): value '%s' is not an integer in [%ld, %ld]", name, value, f[i].lo, f[i].hi); return TRH_EINVAL; }
+            return TRH_OK;
+        }
+    set_error("trh_set_option: unknown option '%s'", name);
+    return TRH_EINVAL;
+}
+int trh_get_option(const char* name, long* value) {
+    if (!name || !value) { set_error("trh_get_option: null pointer"); return TRH_EINVAL; }
+    (void)opt();
+    size_t n = 0;
+    const OptField* f = opt_fields(&n);
+    for (size_t i = 0; i < n; ++i)
+        if (strcmp(f[i].name, name) == 0) { *value = f[i].kind == 0 ? (long)*(int*)f[i].p : *(long*)f[i].p; return TRH_OK; }
+    set_error("trh_get_option: unknown option '%s'", name);
+    return TRH_EINVAL;
+}
 
 int trh_device_count(void) {
     int n = 0;

@@ -194,100 +194,4 @@ inline void chunk_plan(size_t bytes, size_t slot, bool head, bool tail, std::vec
     for (size_t i = back.size(); i-- > 0;) out.push_back(back[i]);
 }
 
-// Pre-faulting of download destinations: the prover hands over freshly allocated vectors -- calloc'ed padding is a run of
-// references to the kernel's zero page, a fresh Vec is not mapped at all -- and the first store into each 4 KiB page then takes a page fault in
-// the middle of the copy out of the pinned ring (measured: downloads into untouched pages at 27 - 32 GB/s against 53 - 57 into touched ones).
-// One background thread per context populates the pages of requested ranges (madvise(MADV_POPULATE_WRITE), Linux >= 5.14; otherwise an atomic
-// `or 0` on one byte per page) while the upload and the kernels run.  Content is never changed; a range may be read or written by others
-// meanwhile (populating is what the first store would have done); whatever the thread has not reached is faulted by the copy itself as before.
-class Prefaulter {
-public:
-    Prefaulter() : th([this] { run(); }) {}
-    ~Prefaulter() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
-        th.join();
-    }
-    void request(void* p, size_t bytes) {
-        if (!p || bytes < ((size_t)1 << 20)) return;  // short ranges: the faults cost less than the hand-over
-        if (looks_resident(p, bytes)) { skipped.fetch_add(bytes, std::memory_order_relaxed); return; }
-        { std::lock_guard<std::mutex> lk(mu); jobs.push_back({(char*)p, bytes}); }
-        cv.notify_one();
-    }
-    // Eight sample pages, all mapped?  Then the range has been written before (a reused buffer) and populating it would only walk the page
-    // tables -- measured on the k = 18 literal replay, whose buffers are reused: 1.79 - 1.86 s without, 1.96 - 2.01 s with an unconditional
-    // populate (2.5 ms of walking per 64 MiB vector).  A fresh calloc / Vec has no page-table entries beyond its first stores.
-    static bool looks_resident(const void* p, size_t bytes) {
-#if defined(__linux__)
-        const size_t page = 4096;
-        const uintptr_t lo = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), hi = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
-        if (hi <= lo + 8 * page) return true;
-        const size_t pages = (hi - lo) / page;
-        for (int i = 0; i < 8; ++i) {
-            unsigned char v = 0;
-            const uintptr_t a = lo + ((pages - 1) * (size_t)i / 7) * page;
-            if (::mincore((void*)a, page, &v) != 0) return true;  // cannot tell: leave the range alone
-            if (!(v & 1)) return false;
-        }
-        return true;
-#else
-        (void)p; (void)bytes;
-        return true;
-#endif
-    }
-    // the thread is idle and the queue empty (tests; nothing in the library waits for it)
-    void drain() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_idle.wait(lk, [this] { return jobs.empty() && !busy; });
-    }
-    size_t populated_bytes() const { return done.load(std::memory_order_relaxed); }
-    size_t skipped_bytes() const { return skipped.load(std::memory_order_relaxed); }
-    bool used_madvise() const { return madvise_ok.load(std::memory_order_relaxed); }
-
-private:
-    struct Job { char* p; size_t bytes; };
-    void run() {
-        const size_t page = 4096, step = (size_t)4 << 20;
-        for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                busy = false;
-                cv_idle.notify_all();
-                cv.wait(lk, [this] { return stop || !jobs.empty(); });
-                if (stop) return;
-                j = jobs.front();
-                jobs.erase(jobs.begin());
-                busy = true;
-            }
-            uintptr_t lo = (uintptr_t)j.p & ~(uintptr_t)(page - 1), hi = ((uintptr_t)j.p + j.bytes + page - 1) & ~(uintptr_t)(page - 1);
-            for (uintptr_t a = lo; a < hi; a += step) {
-                const size_t len = hi - a < step ? hi - a : step;
-                bool ok = false;
-#if defined(__linux__)
-                if (madvise_ok.load(std::memory_order_relaxed)) {
-                    ok = ::madvise((void*)a, len, 23 /* MADV_POPULATE_WRITE */) == 0;
-                    if (!ok && errno == EINVAL) madvise_ok.store(false, std::memory_order_relaxed);  // kernel without it: touch instead, from now on
-                }
-#endif
-                if (!ok) {
-                    // only bytes INSIDE the caller's range are touched (the rounded-out edges may belong to someone else's read-only page)
-                    uintptr_t b = a < (uintptr_t)j.p ? (uintptr_t)j.p : a;
-                    const uintptr_t e = a + len < (uintptr_t)j.p + j.bytes ? a + len : (uintptr_t)j.p + j.bytes;
-                    for (; b < e; b = (b & ~(uintptr_t)(page - 1)) + page) __atomic_fetch_or((unsigned char*)b, 0, __ATOMIC_RELAXED);
-                }
-                done.fetch_add(len, std::memory_order_relaxed);
-                { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
-            }
-        }
-    }
-    std::mutex mu;
-    std::condition_variable cv, cv_idle;
-    std::vector<Job> jobs;
-    bool stop = false, busy = false;
-    std::atomic<size_t> done{0}, skipped{0};
-    std::atomic<bool> madvise_ok{true};
-    std::thread th;  // last: started when everything above exists
-};
-
 }  // namespace trh

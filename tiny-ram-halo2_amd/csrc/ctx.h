@@ -21,11 +21,30 @@
 #include "../../include/trh.h"
 #include "curve.h"
 
-namespace trh { class CopyPool; class Prefaulter; }
+namespace trh { class CopyPool; }
 
 namespace trh {
 
 void set_error(const char* fmt, ...);
+
+// The library's switches.  Parsed ONCE -- the environment variables TRH_<NAME> when the first option is needed, then
+// whatever trh_set_option(name, value) overrides while no context exists -- into this struct, which nothing writes once a context is alive:
+// no getenv on any call path (a host that runs libtrh from rayon workers while another thread calls setenv would race it).
+struct Options {
+    long pool_mb = 4096;     // TRH_POOL_MB        idle device blocks trh_malloc / trh_free keep per process (MiB)
+    long stage_slot_mb = 16; // TRH_STAGE_SLOT_MB  pinned slot size of the host-pointer entries' rings (x 4 slots x 2 directions per context)
+    int copy_threads = -1;   // TRH_COPY_THREADS   host threads per staging direction and context (-1: by core count)
+    int bases_cache = 0;     // TRH_BASES_CACHE    1: trh_best_multiexp_* keeps base sets it has seen twice (full-content hash)
+    int force_no_peer = 0;   // TRH_FORCE_NO_PEER  1: the device group hands device-resident scalars over through pinned host memory
+    int roctx = 1;           // TRH_ROCTX          0: no roctx ranges around the primitives
+    int trace = 0;           // TRH_TRACE          bit 0: timeline of the single-call host entries, bit 1: host side of the IPA's rounds (stderr)
+    long msm_chunk_gb = 4;   // TRH_MSM_CHUNK_GB   scratch budget of one chunk of a batched MSM (GiB per digit array set)
+    int sparse = 1;          // TRH_SPARSE         0: flag-like chunks of a fixed-base batch take the plain pipeline (no unit path)
+    int reduce_q4 = 1;       // TRH_REDUCE_Q4      0: bucket reductions of small launches stay one thread per slice (no DPP-quad group law)
+    int bin_sort = 1;        // TRH_BIN_SORT       0: the chunked bucket passes for every MSM (the path skewed scalars take anyway)
+    int selftest = 1;        // TRH_SELFTEST       0: trh_init skips the known-answer self-test
+};
+const Options& opt();
 
 #define TRH_HIP_TRY(expr)                                                                    \
     do {                                                                                     \
@@ -95,7 +114,6 @@ struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: bat
     DevBuf heavy;        // [0] count + list of (window, bucket) ids whose pieces a whole workgroup combines
     DevBuf buckets;      // W x NB XYZZ
     DevBuf partials;     // W x blocks XYZZ
-    DevBuf reduce2l;     // two-level reduction (TRH_REDUCE_2L): row and column sums per window
     DevBuf sparse;       // sparse-column path: per item SP_LISTS list counters (one 128-byte line each), then one dense flag per item
 };
 
@@ -105,7 +123,8 @@ struct MsmScratch {
     DevBuf bases_z;      // n affine bases converted to the lazy domain
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
-    bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped
+    bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped, the combine takes the quad form
+    bool no_sparse_vote = false;  // the sparse classifier is skipped and nothing else changes (the shards of a range-sharded MSM: its host synchronisation would hold back the other shards)
     void* sp_host = nullptr;    // pinned: the sparse path's list counters as read back, then the dense flags it sends down
     void* host_sums = nullptr;  // pinned mirror of window_sums
     size_t host_sums_cap = 0;
@@ -119,6 +138,14 @@ struct MsmScratch {
     u64 tile_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    // window-group pipeline of a lone large MSM (msm.hip): the sort of group g + 1 and the reduction of group g - 1 run on their own
+    // streams beside the accumulation of group g
+    static constexpr int MAX_GROUPS = 8;
+    hipStream_t g_sort = nullptr, g_tail = nullptr;
+    hipEvent_t g_front = nullptr, g_done = nullptr;
+    hipEvent_t g_sorted[MAX_GROUPS] = {}, g_acc[MAX_GROUPS] = {};
+    hipEvent_t g_t0[MAX_GROUPS] = {}, g_t1[MAX_GROUPS] = {};  // timing: around each group's accumulation launch
+    int g_timed = 0;                                          // groups of the last timed MSM (0: the single-stream pipeline)
 };
 
 // Host <-> device staging of the host-pointer entry points (hostio.hip): pinned slot rings + three streams.  Measured on the
@@ -144,7 +171,6 @@ struct Stage {
     // pipeline's download helper never queue behind each other, and per CONTEXT, so that the GPUs of a device group are fed in parallel
     CopyPool* up_pool = nullptr;
     CopyPool* down_pool = nullptr;
-    Prefaulter* prefault = nullptr;  // populates the pages of download destinations while uploads and kernels run (TRH_PREFAULT=0: off)
     std::map<int, std::array<hipEvent_t, NS>> xfer_ev;  // stage_d2d_via_host: "slot filled" events on the source device, per source device
 };
 

@@ -34,21 +34,19 @@ namespace {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int copy_threads() {
-    static const int n = [] {
-        if (const char* e = getenv("TRH_COPY_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v; }
-        const unsigned hw = std::thread::hardware_concurrency();
-        // one memcpy thread moves 24-36 GB/s on the box, five (four workers + the caller) 60-85: above the 57 GB/s of the link
-        return hw >= 16 ? 4 : hw >= 8 ? 2 : hw >= 4 ? 1 : 0;
-    }();
-    return n;
+    const int v = opt().copy_threads;
+    if (v >= 0 && v <= 64) return v;
+    const unsigned hw = std::thread::hardware_concurrency();
+    // one memcpy thread moves 24-36 GB/s on the box, five (four workers + the caller) 60-85: above the 57 GB/s of the link
+    return hw >= 16 ? 4 : hw >= 8 ? 2 : hw >= 4 ? 1 : 0;
 }
 
-// TRH_IO_TRACE=1: the single-call host entries print their timeline (microseconds since the call began) to stderr
+// TRH_TRACE bit 0: the single-call host entries print their timeline (microseconds since the call began) to stderr
 thread_local double t_trace_t0 = 0;   // > 0 while a traced call is running on this thread: the staging loops then report every chunk
 struct IoTrace {
     bool on;
     double t0;
-    IoTrace() : on(getenv("TRH_IO_TRACE") && atoi(getenv("TRH_IO_TRACE"))), t0(now_s()) { if (on) t_trace_t0 = t0; }
+    IoTrace() : on((opt().trace & 1) != 0), t0(now_s()) { if (on) t_trace_t0 = t0; }
     ~IoTrace() { t_trace_t0 = 0; }
     void mark(const char* what, size_t bytes = 0) const {
         if (on) fprintf(stderr, "[trh io] %9.1f us  %s %zu\n", (now_s() - t0) * 1e6, what, bytes);
@@ -58,12 +56,9 @@ inline void trace_chunk(const char* what, size_t k, size_t bytes) {
     if (t_trace_t0 > 0) fprintf(stderr, "[trh io] %9.1f us    %s %zu (%zu bytes)\n", (now_s() - t_trace_t0) * 1e6, what, k, bytes);
 }
 
-// TRH_NT_COPY: bit 0 = streaming stores for the copies OUT of the download ring (into the caller's memory), bit 1 = for the copies INTO the
-// upload ring
-int nt_mode() {
-    static const int v = getenv("TRH_NT_COPY") ? atoi(getenv("TRH_NT_COPY")) : 3;
-    return v;
-}
+// streaming stores for the copies out of the download ring (into the caller's memory, bit 0) and into the upload ring (bit 1): both on
+// (measured in round 4; the cached forms were the A/B)
+constexpr int nt_mode() { return 3; }
 
 // one 64-byte line per 64 KiB, the first and the last: zero?  (a hint, never a proof: stage_h2d's `speculate`)
 bool probe_zero(const char* p, size_t bytes) {
@@ -92,12 +87,9 @@ int stage_ensure(Ctx& c) {
     if (st.up) return TRH_OK;
     if (!st.up_pool) st.up_pool = new CopyPool(copy_threads());
     if (!st.down_pool) st.down_pool = new CopyPool(copy_threads());
-    // off by default: measured no gain (profiles/r05_prefault_probe.txt -- reused destinations have their pages, and for fresh ones one
-    // populating thread is no faster than the copy threads that take the same faults in parallel)
-    static const int prefault_knob = getenv("TRH_PREFAULT") ? atoi(getenv("TRH_PREFAULT")) : 0;
-    if (!st.prefault && prefault_knob) st.prefault = new Prefaulter();
-    size_t slot = (size_t)16 << 20;  // x NS = 4 slots per direction; smaller slots lose to the per-slot hand-over (measured: 16 MiB 32 ms, 8 MiB 39 ms, 4 MiB 45 ms for the 1.6 GB of a 2^24 best_multiexp)
-    if (const char* e = getenv("TRH_STAGE_SLOT_MB")) { const long v = atol(e); if (v >= 1 && v <= 256) slot = (size_t)v << 20; }
+    // x NS = 4 slots per direction; smaller slots lose to the per-slot hand-over (measured: 16 MiB 32 ms, 8 MiB 39 ms, 4 MiB 45 ms for the 1.6 GB of a 2^24 best_multiexp)
+    size_t slot = (size_t)16 << 20;
+    if (opt().stage_slot_mb >= 1 && opt().stage_slot_mb <= 256) slot = (size_t)opt().stage_slot_mb << 20;
     hipError_t e = hipHostMalloc((void**)&st.up, slot * Stage::NS, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st.down, slot * Stage::NS, hipHostMallocDefault);
     for (int i = 0; i < Stage::NS && e == hipSuccess; ++i) {
@@ -123,9 +115,7 @@ int stage_ensure(Ctx& c) {
 void stage_release(Ctx& c) {
     Stage& st = c.stage;
     delete st.up_pool; delete st.down_pool;  // stops and joins this context's copy threads
-    delete st.prefault;
     st.up_pool = st.down_pool = nullptr;
-    st.prefault = nullptr;
     if (st.up) (void)hipHostFree(st.up);
     if (st.down) (void)hipHostFree(st.down);
     st.up = st.down = nullptr;
@@ -205,7 +195,6 @@ int stage_d2h(Ctx& c, void* dst_host, const void* src_dev, size_t bytes, hipStre
         TRH_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         TRH_HIP_TRY(hipStreamSynchronize(s));
     } else {
-        if (st.prefault) st.prefault->request(dst_host, bytes);  // (a no-op walk over pages that are there already)
         std::vector<size_t> plan, offs;
         chunk_plan(bytes, st.slot, false, true, plan);  // short LAST chunks: the caller waits for the copy out of the last one
         size_t o = 0;
@@ -409,11 +398,6 @@ int host_pipeline(Ctx& c, const HostPipe& p) {
             cv.wait(lk, [&] { return downloaded + D > i || abort; });
             if (abort) return helper_rc;
         }
-        if (st.prefault) {  // this item's destinations, an upload and a kernel ahead of the first byte that lands in them
-            std::vector<HostPipe::Seg> dsts;
-            p.segments(i, p.in_place ? st.ring_in[slot].p : st.ring_out[slot].p, dsts);
-            for (const HostPipe::Seg& sg : dsts) if (sg.bytes && !is_pinned(sg.dst)) st.prefault->request(sg.dst, sg.bytes);
-        }
         TRH_TRY(p.upload(i, st.ring_in[slot].p));
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
         TRH_HIP_TRY(hipStreamWaitEvent(st.cs, st.ev_up[slot], 0));
@@ -454,17 +438,13 @@ int best_fft_host(int field, uint64_t* a, const uint64_t* omega, uint32_t log_n)
     IoTrace tr;
     TRH_TRY(c.io.ensure(bytes));
     tr.mark("begin, bytes", bytes);
-    // the transform is in place, but a zero-padded vector's padding is typically untouched (references to the zero page): the download's
-    // first store into each page would fault.  Populate while the upload and the transform run
-    if (c.stage.prefault && !is_pinned(a)) c.stage.prefault->request(a, bytes);
     // Zero slots are not sent (coeff_to_extended hands over a vector that is zero beyond its first 2^k entries: 7/8 of the upload).  Reading
     // 56 MiB of zeros to be SURE they are zeros takes the host 0.5 ms, and nothing else could start before it: so chunks that look like
     // padding (a sparse probe) are cleared on the device at once, the transform and the first downloads are queued, and the padding is
     // read through while the device works -- before anything is written back into `a` (the transform is in place: until then `a` still
     // holds the input).  If a probed chunk turns out not to be zero the speculative result is dropped and the call starts over plainly.
-    static const int spec_knob = getenv("TRH_FFT_SPECULATE") ? atoi(getenv("TRH_FFT_SPECULATE")) : 1;
     std::vector<std::pair<size_t, size_t>> spec;
-    const bool speculative = spec_knob && bytes >= ((size_t)8 << 20) && !is_pinned(a);
+    const bool speculative = bytes >= ((size_t)8 << 20) && !is_pinned(a);
     const double up_bytes0 = c.stage.up_bytes, up_zero0 = c.stage.up_zero_bytes;
     TRH_TRY(stage_h2d(c, c.io.p, a, bytes, s, false, true, false, speculative ? &spec : nullptr));
     tr.mark("upload issued; speculated ranges", spec.size());

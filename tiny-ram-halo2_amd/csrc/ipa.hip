@@ -420,8 +420,8 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // block (no host synchronisation before the MSM: the host never needs value_l / value_r), the MSM, the transcript, then ONE
     // launch for the three folds.  (The first version had 14 small operations and two synchronisations per round.)
     FeMem zm = stm(z);
-    // TRH_IPA_TRACE=1: where the host's part of a round goes (averages over the rounds, microseconds, to stderr)
-    static const bool ipa_trace = getenv("TRH_IPA_TRACE") && atoi(getenv("TRH_IPA_TRACE"));
+    // TRH_TRACE bit 1: where the host's part of a round goes (averages over the rounds, microseconds, to stderr)
+    const bool ipa_trace = (opt().trace & 2) != 0;
     double tr_acc[6] = {0, 0, 0, 0, 0, 0};
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (uint32_t j = 0; j < k; ++j) {

@@ -249,6 +249,76 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
     }
 }
 
+// The same partition with a small footprint (512 threads, the digits read twice -- the second time from the L2 -- instead of kept in
+// registers): a workgroup fits beside two waves per SIMD of the accumulation (window-group pipeline, msm_enqueue_t)
+constexpr int PARTL_THREADS = 512;
+__global__ void __launch_bounds__(PARTL_THREADS) msm_partition_lean_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor, u32* __restrict__ parted, size_t n,
+                                                                           int k2, u32 nbins, int idx_bits) {
+    extern __shared__ u32 lds[];
+    u32* stage = lds;
+    u32* cnt = lds + PART_TILE;
+    u32* lbase = cnt + nbins;
+    u32* gbase = lbase + nbins;
+    __shared__ u32 scan[PARTL_THREADS];
+    const int j = blockIdx.y;
+    const size_t t0 = (size_t)blockIdx.x * PART_TILE;
+    const size_t t1 = t0 + PART_TILE < n ? t0 + PART_TILE : n;
+    const u32* dg = digits + (size_t)j * n;
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    constexpr int PER = PART_TILE / PARTL_THREADS;
+#pragma unroll 8
+    for (int q = 0; q < PER; ++q) {
+        const size_t i = t0 + threadIdx.x + (size_t)q * PARTL_THREADS;
+        const u32 b = (i < t1 ? dg[i] : 0u) & ~SIGN_BIT;
+        if (b) atomicAdd(&cnt[(b - 1u) >> k2], 1u);
+    }
+    __syncthreads();
+    {
+        const u32 per = (nbins + PARTL_THREADS - 1) / PARTL_THREADS;
+        const u32 lo = threadIdx.x * per < nbins ? threadIdx.x * per : nbins, hi = lo + per < nbins ? lo + per : nbins;
+        u32 sum = 0;
+        for (u32 k = lo; k < hi; ++k) sum += cnt[k];
+        scan[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < PARTL_THREADS; off <<= 1) {
+            const u32 v = ((int)threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        u32 run = scan[threadIdx.x] - sum;
+        for (u32 k = lo; k < hi; ++k) {
+            const u32 v = cnt[k];
+            lbase[k] = run;
+            gbase[k] = v ? atomicAdd(&bin_cursor[(size_t)j * nbins + k], v) : 0u;
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const u32 low_mask = (1u << k2) - 1u;
+#pragma unroll 8
+    for (int q = 0; q < PER; ++q) {
+        const size_t i = t0 + threadIdx.x + (size_t)q * PARTL_THREADS;
+        const u32 e = i < t1 ? dg[i] : 0u;
+        const u32 b = e & ~SIGN_BIT;
+        if (b) {
+            const u32 bm = b - 1u, bin = bm >> k2;
+            const u32 r = atomicAdd(&cnt[bin], 1u);
+            stage[lbase[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
+        }
+    }
+    __syncthreads();
+    u32* out = parted + (size_t)j * n;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (u32 bin = wave; bin < nbins; bin += PARTL_THREADS / 64) {
+        const u32 c = cnt[bin], lb = lbase[bin], gb = gbase[bin];
+        for (u32 k = lane; k < c; k += 64) out[gb + k] = stage[lb + k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 3b. bucket sort, chunk-parallel: the bin-grouped list is cut into fixed chunks of BS_CHUNK entries
 //     whatever the bin sizes (witness-like scalars put millions of entries into one bin), and every
@@ -429,6 +499,63 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __
     for (u32 i = threadIdx.x; i < count; i += BIN_THREADS) dst[i] = bstage[i];
 }
 
+// The whole-bin sort with a small footprint (512 threads, the bin read twice instead of held in registers), see msm_partition_lean_kernel
+constexpr int BINL_THREADS = 512;
+__global__ void __launch_bounds__(BINL_THREADS) msm_bin_sort_lean_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts, const u32* __restrict__ bin_ends,
+                                                                         u32* __restrict__ sorted, u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2, u32 nbins,
+                                                                         int idx_bits, u32 nbk, const u32* __restrict__ oversize) {
+    if (oversize[blockIdx.y] != 0u) return;
+    extern __shared__ u32 bstage[];
+    __shared__ u32 cnt[128], tbase[128], wave0_total;
+    const int j = blockIdx.y;
+    const u32 bin = blockIdx.x;
+    const size_t wrow = j;
+    const u32 lo = bin_starts[wrow * nbins + bin], hi = bin_ends[wrow * nbins + bin];
+    const u32 count = hi - lo;
+    const u32 nsub = 1u << k2, low_mask = nsub - 1u, idx_mask = (1u << idx_bits) - 1u;
+    const u32* src = parted + wrow * n + lo;
+    u32* dst = sorted + wrow * n + lo;
+    const u32 lane = threadIdx.x & 63u;
+    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll 8
+    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) atomicAdd(&cnt[(src[i] >> idx_bits) & low_mask], 1u);
+    __syncthreads();
+    u32 v = 0, x = 0;
+    if (threadIdx.x < 128) {
+        v = threadIdx.x < nsub ? cnt[threadIdx.x] : 0u;
+        x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if ((int)lane >= off) x += y;
+        }
+        if (threadIdx.x == 63) wave0_total = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const u32 excl = x - v + (threadIdx.x >= 64 ? wave0_total : 0u);
+        tbase[threadIdx.x] = excl;
+        cnt[threadIdx.x] = 0;
+        if (threadIdx.x < nsub) {
+            const size_t b = wrow * (nbk + 1) + ((size_t)bin << k2) + threadIdx.x + 1u;
+            starts[b] = lo + excl;
+            ends[b] = lo + excl + v;
+        }
+        if (bin == 0 && threadIdx.x == 0) { starts[wrow * (nbk + 1)] = 0; ends[wrow * (nbk + 1)] = 0; }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) {
+        const u32 e = src[i];
+        const u32 sub = (e >> idx_bits) & low_mask;
+        const u32 r = atomicAdd(&cnt[sub], 1u);
+        bstage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) dst[i] = bstage[i];
+}
+
 // per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts).  Two launches over
 // 1024-bucket blocks (coalesced): block totals, then every block adds the totals before it to its own LDS scan -- one
 // workgroup per window walking 64 buckets per thread was a 0.18 ms latency chain at 2^16 buckets.
@@ -598,10 +725,10 @@ __device__ __forceinline__ XYZZz<BF> load_raw(const XYZZzMem* src) {
 }
 
 template <class BF>
-__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
-                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
-                                                                 XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
-                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+__device__ __forceinline__ void msm_accumulate_seg_body(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
+                                                        const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                                                        XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
+                                                        XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
     const size_t z = blockIdx.z;  // batch item
     {
         const size_t Wz = gridDim.y;
@@ -711,6 +838,23 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     if (is_first) store_raw(my_first, acc);
     else if (cur_end == stop) store_raw(direct + (size_t)j * nb1 + B, acc);
     else store_raw(last + (size_t)j * nseg + t, acc);
+}
+template <class BF>
+__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
+                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                                                                 XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
+                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+    msm_accumulate_seg_body<BF>(bases_z, sorted, ends, seg_bucket, first, last, direct, n, nbk, nseg, seg_len);
+}
+// The same accumulation held to TWO waves per SIMD (the register allocation is padded so that a third does not fit): it issues at the
+// rate of three (measured: 14.24 against 14.20 ms at 2^24) and leaves a third of every SIMD's registers and the whole LDS to the sort
+// and reduction kernels of the neighbouring window groups (msm_enqueue_t, window-group pipeline).
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+msm_accumulate_seg2_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted, const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                           XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last, XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+    asm volatile("" ::: "v175");  // next free VGPR = 176: three waves would need 528 of the SIMD's 512 registers (the attribute alone stops at 164 -> 168 allocated, which fits three)
+    msm_accumulate_seg_body<BF>(bases_z, sorted, ends, seg_bucket, first, last, direct, n, nbk, nseg, seg_len);
 }
 
 constexpr u32 HEAVY_PIECES = 64;
@@ -870,79 +1014,6 @@ __global__ void __launch_bounds__(256) msm_reduce_kernel(const XYZZzMem* __restr
         __syncthreads();
     }
     if (threadIdx.x == 0) store_raw(&partials[(size_t)j * gridDim.x + blockIdx.x], sh[0]);
-}
-
-// ---------------------------------------------------------------------------------------
-// 5'. the same window sum in the two-level row / column form (round 4: built to be measured against the slices above):
-//     bucket id - 1 = r * C + q with C = 256 columns: sum_b b B_b = C * sum_r r * Row_r + sum_q (q + 1) * Col_q with
-//     Row_r = sum_q B_{r,q}, Col_q = sum_r B_{r,q}.
-//       sums   one workgroup per row (256 buckets -> Row_r) and one per column (R buckets -> Col_q): LDS trees, 8 levels
-//       final  two workgroups per window: sum_q (q + 1) Col_q and sum_r r Row_r as the sum of the suffix sums (a Hillis-Steele suffix scan,
-//              8 levels, then a tree, 8 levels), the row part doubled 8 times (x C); msm_window_sum_kernel adds the two
-//     Depth: 8 + 16 (+ 8 doublings) + 1 point operations against 2 * slice + ~22 + 8 + 4 of the slice form; the work is the same 2 N additions.
-//     MEASURED (profiles/r04_reduce_ab.txt): it loses by a factor of two -- reduction + window sum of a lone MSM 0.31 -> 0.70 ms at 2^20, 0.34 ->
-//     0.79 at 2^22, 0.44 -> 0.95 at 2^24, the k = 18 opening unchanged (15.1 / 15.0 ms).  Every level of the scan and of the trees is a full
-//     lazy addition per thread with two LDS round trips of 144 bytes, and the column sums gather 144-byte records 36 KiB apart; the slice form's
-//     running sums and offset multiplication stay in registers.  Kept behind TRH_REDUCE_2L=1 as the record of the experiment, off by default.
-// ---------------------------------------------------------------------------------------
-constexpr u32 R2L_COLS = 256;
-template <class BF>
-__global__ void __launch_bounds__(256) msm_reduce2l_sums_kernel(const XYZZzMem* __restrict__ buckets, XYZZzMem* __restrict__ sums /* [item][window][R + C] */, u32 nbk) {
-    const size_t z = blockIdx.z;
-    const u32 R = nbk / R2L_COLS;
-    buckets += (z * gridDim.y + blockIdx.y) * (size_t)nbk;
-    sums += (z * gridDim.y + blockIdx.y) * (size_t)(R + R2L_COLS);
-    __shared__ XYZZz<BF> sh[256];
-    XYZZz<BF> v = xyzzz_identity<BF>();
-    if (blockIdx.x < R) {  // row r: buckets r * C .. r * C + 255 (coalesced)
-        v = load_raw<BF>(&buckets[(size_t)blockIdx.x * R2L_COLS + threadIdx.x]);
-    } else {               // column q: buckets q, C + q, 2 C + q, ...
-        const u32 q = blockIdx.x - R;
-        for (u32 r = threadIdx.x; r < R; r += 256) v = xyzzz_add(v, load_raw<BF>(&buckets[(size_t)r * R2L_COLS + q]));
-    }
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    int top = 128;
-    if (blockIdx.x >= R) while (top > 1 && (u32)top >= R) top >>= 1;  // a column holds R <= 256 values
-    for (int st = top; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) store_raw(&sums[blockIdx.x], sh[0]);
-}
-template <class BF>
-__global__ void __launch_bounds__(256) msm_reduce2l_final_kernel(const XYZZzMem* __restrict__ sums, XYZZzMem* __restrict__ partials /* [item][window][2] */, u32 nbk) {
-    const size_t z = blockIdx.z;
-    const u32 R = nbk / R2L_COLS;
-    sums += (z * gridDim.y + blockIdx.y) * (size_t)(R + R2L_COLS);
-    partials += (z * gridDim.y + blockIdx.y) * 2;
-    __shared__ XYZZz<BF> sh[256];
-    const bool rows = blockIdx.x == 1;
-    const u32 count = rows ? R : R2L_COLS, t = threadIdx.x;
-    // x_t: Col_t (weight t + 1) or Row_t (weight t).  sum_t w_t x_t = sum over the suffix sums S_t = x_t + x_{t+1} + ... of all t >= t0, with
-    // t0 = 0 for the columns (weight t + 1: S_0 .. S_t each hold x_t once) and t0 = 1 for the rows (weight t)
-    sh[t] = t < count ? load_raw<BF>(&sums[rows ? t : R + t]) : xyzzz_identity<BF>();
-    __syncthreads();
-    for (u32 off = 1; off < count; off <<= 1) {  // suffix scan
-        XYZZz<BF> o = xyzzz_identity<BF>();
-        if (t + off < count) o = sh[t + off];
-        __syncthreads();
-        if (t + off < count) sh[t] = xyzzz_add(sh[t], o);
-        __syncthreads();
-    }
-    if (rows && t == 0) sh[0] = xyzzz_identity<BF>();  // weight 0
-    __syncthreads();
-    int top = 128;
-    while (top > 1 && (u32)top >= count) top >>= 1;
-    for (int st = top; st > 0; st >>= 1) {
-        if ((int)t < st) sh[t] = xyzzz_add(sh[t], sh[t + st]);
-        __syncthreads();
-    }
-    if (t == 0) {
-        XYZZz<BF> v = sh[0];
-        if (rows) for (u32 k = 1; k < R2L_COLS; k <<= 1) v = xyzzz_dbl(v);  // x C
-        store_raw(&partials[blockIdx.x], v);
-    }
 }
 
 // The combine with a DPP quad per bucket (curve_q4.h): the quad adds the bucket's pieces one after the other at five multiplication steps each.
@@ -1454,7 +1525,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     while (((size_t)1 << idx_bits) < ns) ++idx_bits;
     int k2 = cb - 1 < 7 ? cb - 1 : 7;
     if (k2 > 31 - idx_bits) k2 = 31 - idx_bits;
-    if (const char* e = getenv("TRH_K2")) { int v = atoi(e); if (v >= 1 && v <= k2 && cb - 1 - v <= 11) k2 = v; }  // tuning knob
     const int k1 = cb - 1 - k2;
     const u32 nbins = 1u << k1;
     const size_t recode_lds = (size_t)Ws * nbins * 4;
@@ -1465,13 +1535,11 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     size_t chunk = batch;
     {
         const size_t per_item = (size_t)W * n * 12 + 1;  // digits + parted + sorted dominate
-        // TRH_MSM_CHUNK / TRH_MSM_CHUNK_GB: items per launch set and the scratch budget behind it (defaults 64 items, 4 GiB per digit array set)
-        static const size_t chunk_max = getenv("TRH_MSM_CHUNK") ? (size_t)atol(getenv("TRH_MSM_CHUNK")) : 64;
-        static const size_t chunk_gb = getenv("TRH_MSM_CHUNK_GB") ? (size_t)atol(getenv("TRH_MSM_CHUNK_GB")) : 4;
-        const size_t cap = (chunk_gb << 30) / per_item;
+        // at most 64 items per launch set, inside the scratch budget (option msm_chunk_gb, default 4 GiB per digit array set)
+        const size_t cap = ((size_t)opt().msm_chunk_gb << 30) / per_item;
         if (chunk > cap) chunk = cap ? cap : 1;
-        if (chunk > chunk_max && chunk_max >= 1 && chunk_max <= SP_MAX_CHUNK) chunk = chunk_max;
-        if (chunk > SP_MAX_CHUNK) chunk = SP_MAX_CHUNK;
+        if (chunk > 64) chunk = 64;
+        static_assert(64 <= SP_MAX_CHUNK, "chunk size against the pinned read-back area");
     }
     // reduce geometry: each thread owns a slice of buckets and pays one short scalar multiplication for
     // the slice offset, so long slices do less work per bucket but are a long serial chain: a lone MSM
@@ -1479,7 +1547,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     u32 tpw = nbk >= (1u << 15) ? 4096 : 2048;  // slices of >= 8 buckets (measured: 2^20..2^24 pairs gain 0.07-0.16 ms, 2^18 loses with 4096)
     if (fb) tpw = 16384;  // one flat window per item: slices of 2 buckets while the batch is small (the cap below takes over for batches) -- the
                           // opening's rounds are two such items each: reduce 240 -> 190 us per round, k = 18 opening 15.4 -> 14.6 ms
-    if (const char* e = getenv("TRH_REDUCE_TPW")) { int v = atoi(e); if (v >= 256 && v <= 65536 && (v & (v - 1)) == 0) tpw = (u32)v; }  // tuning knob
     while (tpw > 256 && (size_t)Ws * tpw * chunk > ((size_t)1 << 16)) tpw >>= 1;  // 2^16 threads = one wave per SIMD (batch of 64 commits: 0.79 -> 0.62 ms)
     if (tpw > nbk) tpw = nbk;
     const u32 slice = nbk / tpw;
@@ -1487,7 +1554,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 128 entries each
     u32 seg_len0 = 128;
     while (seg_len0 > 16 && (size_t)W * n * chunk / seg_len0 < ((size_t)1 << 19)) seg_len0 >>= 1;  // W * n == Ws * ns
-    if (const char* e = getenv("TRH_SEG_LEN")) { int v = atoi(e); if (v >= 8 && v <= 1024) seg_len0 = (u32)v; }  // tuning knob
     const u32 nseg0 = (u32)((ns + seg_len0 - 1) / seg_len0);
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
     const size_t max_heavy = (size_t)Ws * nseg0 / HEAVY_PIECES + 1;
@@ -1508,14 +1574,13 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // leave the sorted lists almost empty, and fixed 128-entry segments then mean a few hundred threads each walking a serial chain of 128
     // mixed additions (3 ms per batch of 64 flag columns at k = 18, the chip idle).  For batches the entry counts are read back after the
     // histogram scan (one synchronisation per chunk, ~20 us) and the segment length is sized to the entries that exist.
-    static const int adaptive_knob = getenv("TRH_ADAPTIVE_SEG") ? atoi(getenv("TRH_ADAPTIVE_SEG")) : 1;
-    const bool adaptive = adaptive_knob && batch >= 8 && !getenv("TRH_SEG_LEN");
+    const bool adaptive = batch >= 8;
     if (adaptive && !c.pinned_land) TRH_HIP_TRY(hipHostMalloc(&c.pinned_land, 4096, hipHostMallocDefault));  // (>= SP_MAX_CHUNK x 16 windows x 4 B)
     // LDS bin sort when the bins are big enough to fill a 1024-thread workgroup and fit with 6 % + 512 entries of slack
     // (uniform digits: the largest of 8192 bins of 2^15 entries is 4.5 sigma = 800 entries above the mean)
     const size_t avg_bin = ns / nbins;
     u32 bin_cap = (u32)(((avg_bin + avg_bin / 16 + 512 + 1023) / 1024) * 1024);
-    const bool use_bin = avg_bin >= 4096 && bin_cap <= BIN_CAP_MAX && !getenv("TRH_NO_BIN_SORT");
+    const bool use_bin = avg_bin >= 4096 && bin_cap <= BIN_CAP_MAX && opt().bin_sort;
     TRH_TRY(L.bin_starts.ensure(chunk * Ws * nbins * 4));
     TRH_TRY(L.starts.ensure(chunk * Ws * nb1 * 4));
     TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4 + 16));
@@ -1545,12 +1610,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // unit path (see msm_sparse_emit_kernel): fixed-base mode only (one flat bucket set per item).  Lone commitments ask the sampler too
     // (tools/lone_sparse_probe.py at k = 18, device scalars: a flag column 0.716 -> 0.417 ms; the vote -- one 12 us kernel and a short
     // synchronisation -- costs the others 0.02 - 0.06 ms: word 0.629 -> 0.650, even-bits 0.689 -> 0.723, full-size 0.646 -> 0.710; over the
-    // 497 single-call commitments of the literal k = 18 replay 515 -> 460 ms).  TRH_SPARSE_LONE=0 keeps batches of < 8 items out; the IPA's
-    // round MSMs never ask (dense_hint).  The compact pipeline without the unit path loses on a lone commitment (round 4, first half: flag
+    // 497 single-call commitments of the literal k = 18 replay 515 -> 460 ms).  The IPA's round MSMs never ask (dense_hint).  The compact pipeline without the unit path loses on a lone commitment (round 4, first half: flag
     // 0.735 vs 0.719 ms, even-bits 0.791 vs 0.691): a lone MSM's time is its latency chain, not the digit slots
-    static const int sparse_knob = getenv("TRH_SPARSE") ? atoi(getenv("TRH_SPARSE")) : 1;
-    static const int sparse_lone = getenv("TRH_SPARSE_LONE") ? atoi(getenv("TRH_SPARSE_LONE")) : 1;
-    const bool sparse_ok = sparse_knob && fb && (batch >= 8 || sparse_lone) && !m.dense_hint && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
+    const bool sparse_ok = opt().sparse && fb && !m.dense_hint && !m.no_sparse_vote && n >= 4096 && ns / 8 / SP_LISTS >= 1024 && c.window_override == 0;
     if (sparse_ok) {
         // [counters: chunk x SP_CNT lines][partial sums: chunk x SP_PARTS raw points]
         TRH_TRY(L.sparse.ensure((size_t)chunk * SP_CNT * SP_PAD * 4 + (size_t)chunk * SP_PARTS * sizeof(XYZZzMem) + 64));
@@ -1590,6 +1652,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             zr.p[3] = (uint4*)L.bucket_cnt.p; zr.n16[3] = up16((size_t)nb * Ws * nb1 * 4);
             const u32 most = zr.n16[3] > zr.n16[0] ? zr.n16[3] : zr.n16[0];
             hipLaunchKernelGGL(msm_zero_ranges_kernel, dim3((most + 255) / 256 < 512 ? (most + 255) / 256 : 512), dim3(256), 0, s, zr);
+            TRH_HIP_TRY(hipGetLastError());
         }
         if (!compact) {
             if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, fb ? (size_t)chunk * Ws * nbins * 4 + flag_bytes : (size_t)nb * Ws * nbins * 4, s));  // counts (+ the tile flags behind them)
@@ -1626,7 +1689,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // segments for >= 2^17 live threads (round 4, compact lists: 2^16 2.67 / 1.84 / 2.13 / 2.96 / 2.85 ms for the five sparse batches of the k = 18
             // proof, 2^17 2.37 / 1.85 / 2.03 / 2.88 / 2.88, 2^18 2.34 / 1.71 / 2.06 / 2.98 / 3.05: shorter segments shorten the accumulation's chains and
             // lengthen the combine's)
-            static const int target_log = getenv("TRH_ADAPTIVE_TARGET_LOG") ? atoi(getenv("TRH_ADAPTIVE_TARGET_LOG")) : 17;
+            constexpr int target_log = 17;
             seg_len = 128;
             while (seg_len > 16 && sum / seg_len < ((size_t)1 << target_log)) seg_len >>= 1;
             nseg = (most + seg_len - 1) / seg_len;  // segments beyond the longest list would find nothing
@@ -1642,6 +1705,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
             TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
         }
+        // the fused zeroing cleared nb * heavy_stride0 words up front: it must not be combined with a resized heavy list
+        if (zero_fused && (resize || heavy_stride != heavy_stride0)) { set_error("msm: internal error: fused zeroing with resized segments"); return TRH_EINVAL; }
         if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.heavy.p, 0, (size_t)nb * heavy_stride * 4, s));
         hipLaunchKernelGGL(msm_partition_kernel, dim3((unsigned)((nse + PART_TILE - 1) / PART_TILE), Ws, nb), dim3(PART_THREADS), (size_t)PART_TILE * 4 + (size_t)nbins * 12, s,
                            L.digits.as<u32>(), L.counts.as<u32>(), L.parted.as<u32>(), nse, k2, nbins, idx_bits, compact ? (const unsigned char*)nullptr : tile_flags);
@@ -1670,7 +1735,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
         if (b0 == 0 && !bases_z && !fb)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
+        static const size_t exp_acc_lds = getenv("TRH_EXP_ACC_LDS") ? (size_t)atol(getenv("TRH_EXP_ACC_LDS")) : 0;  // EXPERIMENT: dynamic LDS caps the accumulation's workgroups per CU
+        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), exp_acc_lds, s, bz, L.sorted.as<u32>(),
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), nse, nbk, nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         {
@@ -1686,10 +1752,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // (16 lanes per bucket for these: 2^15 buckets x 64 columns x 16 lanes of mostly empty groups cost more than the chains: 3.4 -> 5.4 ms)
             // quad form only where the caller vouches for uniformly full-size scalars (dense_hint: the IPA's rounds, three or four pieces per bucket):
             // opening 12.8 -> 12.4 ms; on a lone even-bits column (256 buckets of 32 pieces, which four lanes share better than one quad walks)
-            // it measured 0.52 -> 0.58 ms, full-size and word columns the same.  TRH_COMBINE_Q4=0: the shuffle form everywhere, 2: the quad form
-            // for every small launch (A/B)
-            static const int q4c_knob = getenv("TRH_COMBINE_Q4") ? atoi(getenv("TRH_COMBINE_Q4")) : 1;
-            if (pieces >= 3 && nbk >= 4 && !compact && (q4c_knob == 2 || (q4c_knob == 1 && m.dense_hint)) && (size_t)Ws * nb <= 8)
+            // it measured 0.52 -> 0.58 ms, full-size and word columns the same
+            if (pieces >= 3 && nbk >= 4 && !compact && opt().reduce_q4 && m.dense_hint && (size_t)Ws * nb <= 8)
                 hipLaunchKernelGGL((msm_combine_q4_kernel<BF>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(),
                                    L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
             else if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
@@ -1700,33 +1764,17 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                            L.last.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), (u32)Ws, heavy_stride);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[3], s));
         {
-            // compact lists: TRH_SPARSE_TPW = reduce threads per item (tuning knob).  Measured on the five sparse batches of the k = 18 proof: shorter
-            // slices make the reduction SLOWER (1024 threads per item: 0.37 - 0.64 ms per batch of 64, 2048: 0.50 - 0.75, 4096: 0.51 - 0.92, 8192:
-            // 0.45 - 1.38): it is bound by its 2 x 2^15 x 64 point additions plus one ~22-operation offset multiplication per thread, not by its depth
-            static const u32 sparse_tpw = getenv("TRH_SPARSE_TPW") ? (u32)atoi(getenv("TRH_SPARSE_TPW")) : 0u;
-            u32 r_tpw = tpw, r_slice = slice, r_blocks = rblocks;
-            if (compact && sparse_tpw >= 256 && sparse_tpw <= nbk && (sparse_tpw & (sparse_tpw - 1)) == 0 && sparse_tpw > tpw) {
-                r_tpw = sparse_tpw; r_slice = nbk / r_tpw; r_blocks = (r_tpw + 255) / 256;
-                TRH_TRY(L.partials.ensure(chunk * Ws * r_blocks * sizeof(XYZZzMem)));
-            }
-            // TRH_REDUCE_2L=1: the two-level row / column form for small launches (a lone MSM, an IPA round), see msm_reduce2l_sums_kernel
-            static const int two_level = getenv("TRH_REDUCE_2L") ? atoi(getenv("TRH_REDUCE_2L")) : 0;
-            if (two_level && nbk >= 2 * R2L_COLS && nbk <= 256 * R2L_COLS && (size_t)Ws * nb <= 64) {  // (R <= 256 rows: one workgroup scans them)
-                const u32 R = nbk / R2L_COLS;
-                TRH_TRY(L.reduce2l.ensure((size_t)chunk * Ws * (R + R2L_COLS) * sizeof(XYZZzMem)));
-                TRH_TRY(L.partials.ensure((size_t)chunk * Ws * 2 * sizeof(XYZZzMem)));
-                hipLaunchKernelGGL((msm_reduce2l_sums_kernel<BF>), dim3(R + R2L_COLS, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.reduce2l.as<XYZZzMem>(), nbk);
-                hipLaunchKernelGGL((msm_reduce2l_final_kernel<BF>), dim3(2, Ws, nb), dim3(256), 0, s, L.reduce2l.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk);
-                hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, 2u);
-            } else {
-            // quad-lane form (curve_q4.h) when the launch is ONE latency chain -- at most TRH_REDUCE_Q4_SETS bucket sets (default 8: a lone
-            // fixed-base commitment, an IPA round, a small fixed-base batch) and four lanes per slice within 2^TRH_REDUCE_Q4_LANES_LOG lanes
-            // (default 2^16 = one wave per SIMD).  Measured (profiles/r05_q4_reduce_ab.txt): IPA k = 18 14.9 -> 13.0 ms, a lone 2^18 commitment
-            // 0.71 -> 0.61 ms; with 16 windows the quads crowd each other out (2^24: reduction 0.43 -> 0.52 ms) and 2^17 lanes lose to 2^16
-            // (IPA 13.9 against 13.0 ms).  TRH_REDUCE_Q4=0 keeps the one-thread-per-slice kernels everywhere
-            static const int q4_knob = getenv("TRH_REDUCE_Q4") ? atoi(getenv("TRH_REDUCE_Q4")) : 1;
-            static const int q4_lanes_log = getenv("TRH_REDUCE_Q4_LANES_LOG") ? atoi(getenv("TRH_REDUCE_Q4_LANES_LOG")) : 16;
-            static const int q4_sets = getenv("TRH_REDUCE_Q4_SETS") ? atoi(getenv("TRH_REDUCE_Q4_SETS")) : 8;
+            // compact lists keep the geometry of the plain ones (round 4: shorter slices made their reduction SLOWER -- 1024 threads per item
+            // 0.37 - 0.64 ms per batch of 64, 8192: 0.45 - 1.38: it is bound by its 2 x 2^15 x 64 point additions, not by its depth)
+            const u32 r_tpw = tpw, r_slice = slice, r_blocks = rblocks;
+            // quad-lane form (curve_q4.h) when the launch is ONE latency chain -- at most 8 bucket sets (a lone fixed-base commitment, an IPA
+            // round, a small fixed-base batch) and four lanes per slice within 2^16 lanes (one wave per SIMD).  Measured
+            // (profiles/r05_q4_reduce_ab.txt): IPA k = 18 14.9 -> 13.0 ms, a lone 2^18 commitment 0.71 -> 0.61 ms; with 16 windows the quads
+            // crowd each other out (2^24: reduction 0.43 -> 0.52 ms) and 2^17 lanes lose to 2^16 (IPA 13.9 against 13.0 ms).  Option
+            // reduce_q4 = 0 keeps the one-thread-per-slice kernels everywhere
+            const int q4_knob = opt().reduce_q4;
+            static const int q4_lanes_log = getenv("TRH_EXP_Q4_LANES_LOG") ? atoi(getenv("TRH_EXP_Q4_LANES_LOG")) : 16;  // EXPERIMENT
+            static const int q4_sets = getenv("TRH_EXP_Q4_SETS") ? atoi(getenv("TRH_EXP_Q4_SETS")) : 8;
             u32 q4_tpw = r_tpw;
             while (q4_tpw > 1024 && (size_t)q4_tpw * 4 * Ws * nb > ((size_t)1 << q4_lanes_log)) q4_tpw >>= 1;
             if (q4_knob && !compact && (size_t)Ws * nb <= (size_t)q4_sets && q4_tpw >= 64 && (size_t)q4_tpw * 4 * Ws * nb <= ((size_t)1 << q4_lanes_log) && nbk % q4_tpw == 0) {
@@ -1738,9 +1786,135 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(r_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, r_slice, r_tpw);
             hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks);
             }
-            }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
+        return TRH_OK;
+    };
+
+    // Window-group pipeline of a lone large MSM.  The windows are cut into G groups; the sort of group g + 1 (lean 512-thread forms of the
+    // partition and the bin sort) and the combine / reduction of group g - 1 (quad-lane forms, 115 - 121 registers) run on two
+    // high-priority streams beside the accumulation of group g, which is held to two waves per SIMD (msm_accumulate_seg2_kernel) so that
+    // a third of every SIMD's registers and the whole LDS stay free for them.  Exposed: the recode, the first group's sort, the last
+    // group's reduction.
+    const bool b0_convert_needed = !bases_z && !fb;
+    auto pipeline_groups = [&](const int* bounds, int G) -> int {
+        static const int exp_acc2 = getenv("TRH_EXP_ACC2") ? atoi(getenv("TRH_EXP_ACC2")) : 1;      // EXPERIMENT knobs
+        static const int exp_lean = getenv("TRH_EXP_LEAN") ? atoi(getenv("TRH_EXP_LEAN")) : 1;
+        static const int exp_tailq4 = getenv("TRH_EXP_TAILQ4") ? atoi(getenv("TRH_EXP_TAILQ4")) : 1;
+        static const int exp_prio = getenv("TRH_EXP_PRIO") ? atoi(getenv("TRH_EXP_PRIO")) : 1;
+        if (!m.g_sort) {
+            int lo_p = 0, hi_p = 0;
+            TRH_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            TRH_HIP_TRY(hipStreamCreateWithPriority(&m.g_sort, hipStreamNonBlocking, exp_prio ? hi_p : lo_p));
+            TRH_HIP_TRY(hipStreamCreateWithPriority(&m.g_tail, hipStreamNonBlocking, exp_prio ? hi_p : lo_p));
+            TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_front, hipEventDisableTiming));
+            TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_done, hipEventDisableTiming));
+            for (int g = 0; g < MsmScratch::MAX_GROUPS; ++g) {
+                TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_sorted[g], hipEventDisableTiming));
+                TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_acc[g], hipEventDisableTiming));
+                TRH_HIP_TRY(hipEventCreate(&m.g_t0[g]));
+                TRH_HIP_TRY(hipEventCreate(&m.g_t1[g]));
+            }
+            TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_bin_sort_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_CAP_MAX * 4));
+            TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
+        }
+        hipStream_t ss = m.g_sort, ts = m.g_tail;
+        const uint4* sc = (const uint4*)scalars_dev;
+        const u32 seg_len = seg_len0, nseg = nseg0, heavy_stride = heavy_stride0;
+        // reduction geometry of the quad-lane tails: the slices of the one-thread form
+        u32 q4_tpw = tpw;
+        while (q4_tpw > 64 && nbk % q4_tpw != 0) q4_tpw >>= 1;
+        const u32 q4_blocks = (q4_tpw + 63) / 64;
+        TRH_TRY(L.partials.ensure((size_t)Ws * (q4_blocks > rblocks ? q4_blocks : rblocks) * sizeof(XYZZzMem)));
+        TRH_TRY(L.heavy.ensure((size_t)G * heavy_stride * 4 + 16));
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
+        {
+            auto up16 = [](size_t b) { return (u32)((b + 15) / 16); };
+            ZeroRanges zr{};
+            zr.p[0] = (uint4*)L.counts.p; zr.n16[0] = up16((size_t)Ws * nbins * 4 + 2 * (size_t)Ws * 4);
+            zr.p[1] = nullptr; zr.n16[1] = 0u;
+            zr.p[2] = (uint4*)L.heavy.p; zr.n16[2] = up16((size_t)G * heavy_stride * 4);
+            zr.p[3] = (uint4*)L.bucket_cnt.p; zr.n16[3] = up16((size_t)Ws * nb1 * 4);
+            const u32 most = zr.n16[3] > zr.n16[0] ? zr.n16[3] : zr.n16[0];
+            hipLaunchKernelGGL(msm_zero_ranges_kernel, dim3((most + 255) / 256 < 512 ? (most + 255) / 256 : 512), dim3(256), 0, s, zr);
+        }
+        unsigned gb = (unsigned)((n + 255) / 256);
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, 1), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W, L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins,
+                           recode_use_lds, stride, 0, tails_dev ? (const uint4*)tails_dev : nullptr, (unsigned char*)nullptr, 14u, part_tiles);
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, 1), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, oversize, bin_cap, (u32*)nullptr);
+        if (b0_convert_needed) hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
+        TRH_HIP_TRY(hipEventRecord(m.g_front, s));
+        TRH_HIP_TRY(hipStreamWaitEvent(ss, m.g_front, 0));
+        TRH_HIP_TRY(hipStreamWaitEvent(ts, m.g_front, 0));
+        const size_t part_lds = (size_t)PART_TILE * 4 + (size_t)nbins * 12;
+        const unsigned ptiles = (unsigned)((ns + PART_TILE - 1) / PART_TILE);
+        for (int g = 0; g < G; ++g) {
+            const size_t j0 = (size_t)bounds[g];
+            const unsigned wg = (unsigned)(bounds[g + 1] - bounds[g]);
+            u32* digits_g = L.digits.as<u32>() + j0 * n; u32* parted_g = L.parted.as<u32>() + j0 * n; u32* sorted_g = L.sorted.as<u32>() + j0 * n;
+            u32* counts_g = L.counts.as<u32>() + j0 * nbins; u32* bstarts_g = L.bin_starts.as<u32>() + j0 * nbins;
+            u32* starts_g = L.starts.as<u32>() + j0 * nb1; u32* ends_g = L.ends.as<u32>() + j0 * nb1; u32* bcnt_g = L.bucket_cnt.as<u32>() + j0 * nb1;
+            u32* segb_g = L.seg_bucket.as<u32>() + j0 * nseg; u32* over_g = oversize + j0;
+            XYZZzMem* first_g = L.first.as<XYZZzMem>() + j0 * nseg; XYZZzMem* last_g = L.last.as<XYZZzMem>() + j0 * nseg;
+            XYZZzMem* direct_g = L.direct.as<XYZZzMem>() + j0 * nb1; XYZZzMem* buckets_g = L.buckets.as<XYZZzMem>() + j0 * nbk;
+            u32* heavy_g = L.heavy.as<u32>() + (size_t)g * heavy_stride;
+            // ---- sort of group g
+            if (exp_lean) {
+                hipLaunchKernelGGL(msm_partition_lean_kernel, dim3(ptiles, wg, 1), dim3(PARTL_THREADS), part_lds, ss, digits_g, counts_g, parted_g, ns, k2, nbins, idx_bits);
+                hipLaunchKernelGGL(msm_bin_sort_lean_kernel, dim3(nbins, wg, 1), dim3(BINL_THREADS), (size_t)bin_cap * 4, ss, parted_g, bstarts_g, counts_g, sorted_g, starts_g, ends_g, ns, k2,
+                                   nbins, idx_bits, nbk, over_g);
+            } else {
+                hipLaunchKernelGGL(msm_partition_kernel, dim3(ptiles, wg, 1), dim3(PART_THREADS), part_lds, ss, digits_g, counts_g, parted_g, ns, k2, nbins, idx_bits, (const unsigned char*)nullptr);
+                hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, wg, 1), dim3(BIN_THREADS), (size_t)bin_cap * 4, ss, parted_g, bstarts_g, counts_g, sorted_g, starts_g, ends_g, ns, k2,
+                                   nbins, idx_bits, nbk, over_g);
+            }
+            {   // the chunked passes: return at once unless a bin of the window was too large for the LDS
+                const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), wg, 1);
+                hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, ss, parted_g, bstarts_g, counts_g, bcnt_g, sorted_g, ns, k2, nbins, idx_bits, nbk, over_g);
+                hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, wg, 1), dim3(RANGE_BLOCK), 0, ss, bcnt_g, segb_g, nbk, over_g);
+                hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, wg, 1), dim3(RANGE_BLOCK), 0, ss, bcnt_g, segb_g, starts_g, ends_g, nbk, over_g);
+                hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, ss, ends_g, segb_g, nbk, nseg, seg_len);
+                hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, ss, parted_g, bstarts_g, counts_g, bcnt_g, sorted_g, ns, k2, nbins, idx_bits, nbk, over_g);
+            }
+            TRH_HIP_TRY(hipEventRecord(m.g_sorted[g], ss));
+            // ---- accumulation of group g
+            TRH_HIP_TRY(hipStreamWaitEvent(s, m.g_sorted[g], 0));
+            if (timing) TRH_HIP_TRY(hipEventRecord(m.g_t0[g], s));
+            if (exp_acc2)
+                hipLaunchKernelGGL((msm_accumulate_seg2_kernel<BF>), dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, s, bz, sorted_g, ends_g, segb_g, first_g, last_g, direct_g, ns, nbk, nseg, seg_len);
+            else
+                hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, s, bz, sorted_g, ends_g, segb_g, first_g, last_g, direct_g, ns, nbk, nseg, seg_len);
+            if (timing) TRH_HIP_TRY(hipEventRecord(m.g_t1[g], s));
+            TRH_HIP_TRY(hipEventRecord(m.g_acc[g], s));
+            // ---- combine / reduction of group g
+            TRH_HIP_TRY(hipStreamWaitEvent(ts, m.g_acc[g], 0));
+            const size_t pieces = ns / ((size_t)nbk * seg_len);
+            if (exp_tailq4 && nbk >= 4)
+                hipLaunchKernelGGL((msm_combine_q4_kernel<BF>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
+                                   nseg, seg_len, heavy_g, heavy_stride);
+            else if (pieces >= 3 && nbk >= 4)
+                hipLaunchKernelGGL((msm_combine_kernel<BF, 4>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
+                                   nseg, seg_len, heavy_g, heavy_stride);
+            else
+                hipLaunchKernelGGL((msm_combine_kernel<BF, 1>), dim3((unsigned)(((size_t)nbk + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
+                                   nseg, seg_len, heavy_g, heavy_stride);
+            hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks0, 1, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, buckets_g, nbk, nseg, seg_len, heavy_g, wg, heavy_stride);
+            if (exp_tailq4 && q4_tpw >= 64) {
+                XYZZzMem* partials_g = L.partials.as<XYZZzMem>() + j0 * q4_blocks;
+                hipLaunchKernelGGL((msm_reduce_q4_kernel<BF>), dim3(q4_blocks, wg, 1), dim3(256), 0, ts, buckets_g, partials_g, nbk, nbk / q4_tpw, q4_tpw);
+                hipLaunchKernelGGL((msm_window_sum_q4_kernel<BF>), dim3(wg, 1, 1), dim3(256), 0, ts, partials_g, m.window_sums.as<XYZZMem>() + j0, q4_blocks);
+            } else {
+                XYZZzMem* partials_g = L.partials.as<XYZZzMem>() + j0 * rblocks;
+                hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, wg, 1), dim3(256), 0, ts, buckets_g, partials_g, nbk, slice, tpw);
+                hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(wg, 1, 1), dim3(256), 0, ts, partials_g, m.window_sums.as<XYZZMem>() + j0, rblocks);
+            }
+        }
+        TRH_HIP_TRY(hipEventRecord(m.g_done, ts));
+        TRH_HIP_TRY(hipStreamWaitEvent(s, m.g_done, 0));
+        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
+        m.g_timed = timing ? G : 0;
         return TRH_OK;
     };
 
@@ -1763,13 +1937,10 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         // Measured on the k = 18 proof, chunk by chunk on one box: the compact pipeline alone is no faster than the plain one (word columns
         // 2.93 against 2.55 ms, sorted / even-bits 2.92 against 3.08, mixed 2.42 against 2.37); what pays is the unit path (flag chunks 0.64 /
         // 0.96 against 1.64 / 1.82 ms).  So the sampler's vote is read first (one short synchronisation) and a chunk that is not flag-like
-        // goes through the plain pipeline as if the path did not exist; TRH_SPARSE=2 sends it through the compact pipeline (A/B).
-        static const int compact_all = sparse_knob == 2;
-        if (!compact_all) {
-            TRH_HIP_TRY(hipMemcpyAsync(hvotes, sp_count + SP_VOTES, 4, hipMemcpyDeviceToHost, s));
-            TRH_HIP_TRY(hipStreamSynchronize(s));
-            if (*hvotes != nb) return pipeline(b0, nb, PIPE_PLAIN, 0, 0);
-        }
+        // goes through the plain pipeline as if the path did not exist.
+        TRH_HIP_TRY(hipMemcpyAsync(hvotes, sp_count + SP_VOTES, 4, hipMemcpyDeviceToHost, s));
+        TRH_HIP_TRY(hipStreamSynchronize(s));
+        if (*hvotes != nb) return pipeline(b0, nb, PIPE_PLAIN, 0, 0);
         TRH_HIP_TRY(hipMemsetAsync(digits, 0, (size_t)nb * sp_cap * 4, s));
         TRH_HIP_TRY(hipMemsetAsync(L.counts.p, 0, (size_t)nb * nbins * 4, s));
         unsigned gbe = (unsigned)((n + 255) / 256);
@@ -1815,9 +1986,28 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         }
         return TRH_OK;
     };
+    m.g_timed = 0;
+    int gbounds[MsmScratch::MAX_GROUPS + 1];
+    int G = 0;
+    if (!fb && batch == 1 && n && use_bin && Ws >= 4) {  // EXPERIMENT knob: TRH_EXP_GROUPS = number of groups, or explicit cut points "3,7,11"
+        if (const char* e = getenv("TRH_EXP_GROUPS")) {
+            if (strchr(e, ',')) {
+                gbounds[0] = 0; G = 1;
+                for (const char* q = e; *q && G < MsmScratch::MAX_GROUPS;) { gbounds[G++] = atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+                gbounds[G] = Ws;
+                for (int g = 0; g < G; ++g) if (gbounds[g + 1] <= gbounds[g]) G = 0;
+            } else {
+                G = atoi(e);
+                if (G > MsmScratch::MAX_GROUPS) G = MsmScratch::MAX_GROUPS;
+                if (G > Ws) G = Ws;
+                for (int g = 0; g <= G; ++g) gbounds[g] = (int)((size_t)Ws * g / G);
+            }
+        }
+    }
     for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
         const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
         if (sparse_ok) TRH_TRY(sparse_chunk(b0, nb));
+        else if (G >= 2) TRH_TRY(pipeline_groups(gbounds, G));
         else TRH_TRY(pipeline(b0, nb, PIPE_PLAIN, 0, 0));
     }
     TRH_HIP_TRY(hipGetLastError());
@@ -1848,7 +2038,18 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     TRH_HIP_TRY(hipStreamSynchronize(s));
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     hostcombine::combine_windows_batch<BF>((const uint64_t*)ws, m.pending_windows, m.pending_c, batch, (uint64_t*)out_xyz);  // one inversion for the whole batch
-    if (m.ev_valid) {
+    if (m.ev_valid && m.g_timed > 0) {  // window-group pipeline: sort = the exposed head, accumulate = first launch .. last launch, kernel = the sum of the launches
+        float t01 = 0, th = 0, ta = 0, tr = 0, tt = 0, ksum = 0;
+        const int G = m.g_timed;
+        TRH_HIP_TRY(hipEventElapsedTime(&t01, m.ev[0], m.ev[1]));
+        TRH_HIP_TRY(hipEventElapsedTime(&th, m.ev[1], m.g_t0[0]));
+        TRH_HIP_TRY(hipEventElapsedTime(&ta, m.g_t0[0], m.g_t1[G - 1]));
+        TRH_HIP_TRY(hipEventElapsedTime(&tr, m.g_t1[G - 1], m.ev[4]));
+        TRH_HIP_TRY(hipEventElapsedTime(&tt, m.ev[0], m.ev[4]));
+        for (int g = 0; g < G; ++g) { float t = 0; TRH_HIP_TRY(hipEventElapsedTime(&t, m.g_t0[g], m.g_t1[g])); ksum += t; }
+        c.last.total_ms = tt; c.last.digits_ms = t01; c.last.sort_ms = th; c.last.accumulate_ms = ta; c.last.reduce_ms = tr; c.last.accumulate_kernel_ms = ksum;
+    }
+    else if (m.ev_valid) {
         float t01, t12, t23, t34, tt, t25;
         TRH_HIP_TRY(hipEventElapsedTime(&t25, m.ev[2], m.ev[5]));
         c.last.accumulate_kernel_ms = t25;
@@ -1942,12 +2143,22 @@ void msm_release() {
     m.scalars.release(); m.tails.release(); m.bases_z.release(); m.window_sums.release();
     MsmLane& L = m.lane;
     L.digits.release(); L.parted.release(); L.sorted.release(); L.counts.release(); L.bin_starts.release(); L.starts.release(); L.ends.release(); L.bucket_cnt.release();
-    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release(); L.sparse.release(); L.reduce2l.release();
+    L.seg_bucket.release(); L.first.release(); L.last.release(); L.direct.release(); L.heavy.release(); L.buckets.release(); L.partials.release(); L.sparse.release();
     if (m.sp_host) (void)hipHostFree(m.sp_host);
     m.sp_host = nullptr;
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
     for (int k = 0; k < 6; ++k) if (m.ev[k]) { (void)hipEventDestroy(m.ev[k]); m.ev[k] = nullptr; }
+    if (m.g_sort) { (void)hipStreamDestroy(m.g_sort); m.g_sort = nullptr; }
+    if (m.g_tail) { (void)hipStreamDestroy(m.g_tail); m.g_tail = nullptr; }
+    if (m.g_front) { (void)hipEventDestroy(m.g_front); m.g_front = nullptr; }
+    if (m.g_done) { (void)hipEventDestroy(m.g_done); m.g_done = nullptr; }
+    for (int g = 0; g < MsmScratch::MAX_GROUPS; ++g) {
+        if (m.g_sorted[g]) { (void)hipEventDestroy(m.g_sorted[g]); m.g_sorted[g] = nullptr; }
+        if (m.g_acc[g]) { (void)hipEventDestroy(m.g_acc[g]); m.g_acc[g] = nullptr; }
+        if (m.g_t0[g]) { (void)hipEventDestroy(m.g_t0[g]); m.g_t0[g] = nullptr; }
+        if (m.g_t1[g]) { (void)hipEventDestroy(m.g_t1[g]); m.g_t1[g] = nullptr; }
+    }
 }
 
 }  // namespace trh

@@ -88,14 +88,13 @@ __global__ void __launch_bounds__(256) ntt_tables_kernel(const uint4* __restrict
         store_fe<F>(t_hi + 2 * (size_t)i, r);
     }
 }
-// the same tables in the lazy domain's Montgomery form (x 2^270 unsigned / x 2^261 signed), values < 2 m
-template <class F, bool SIGNED>
+// the same tables in the signed lazy domain's Montgomery form (x 2^261), non-negative, below m (1 + 2^-7)
+template <class F>
 __global__ void __launch_bounds__(256) ntt_tables_lazy_kernel(const uint4* __restrict__ t, uint4* __restrict__ z, u32 cnt) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
     u32 w[8];
-    if (SIGNED) fy_store(fy_from_fe(load_fe<F>(t + 2 * (size_t)i)), w);  // non-negative, below m (1 + 2^-7)
-    else fz_store(fz_from_fe(load_fe<F>(t + 2 * (size_t)i)), w);
+    fy_store(fy_from_fe(load_fe<F>(t + 2 * (size_t)i)), w);
     z[2 * (size_t)i] = make_uint4(w[0], w[1], w[2], w[3]);
     z[2 * (size_t)i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
@@ -255,261 +254,6 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passg_kernel(const uint
         const u32 rr = base + ((u32)u << stl);
         const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
         store_fe<F>(out + 2 * dst, x[u]);
-    }
-}
-
-// ---- lazy-domain pass (the default for full tiles) -------------------------------------------
-// Same schedule as ntt_passg_kernel, but the values stay unreduced nine-limb residues (Fz) for the
-// whole pass: the input words x R (canonical Montgomery, or < 2 m from a previous pass) are taken as
-// they are, every twiddle is held in the 2^270 Montgomery form so that fz_mul(v, W) = v w carries the
-// element's own 2^256 factor through, and a butterfly is one fz_mul + one carry chain each for
-// a + t and a + K m - t: no conditional subtraction, no 16-bit round, and the LDS exchange moves the
-// nine limbs as they are (two 16-byte planes + one 4-byte plane: no pack / unpack).
-// Bounds (in units of m, inputs < 2): round 0 does stages 0..LG-1 with the trivial twiddle left out,
-// so stage v sees operands < 2^(v+1) and leaves < 2^(v+2); every later stage multiplies (t < 2) and
-// adds 2.  After s <= 9 stages the values are < 2^(LG+1) + 2 (s - LG) <= 30 (LG = 3: 28), far below the 256 m
-// that fz_mul tolerates against a twiddle < 2 m, and nine limbs hold 2^16 m.  The pass ends with
-// v - max(floor(v / 2^254) - 1, 0) m in [0, 2 m) and, on the last pass, the conditional subtraction.
-template <class F>
-__device__ __forceinline__ Fz<F> load_fz(const uint4* __restrict__ p) {
-    uint4 a = p[0], b = p[1];
-    return fz_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
-}
-template <class F>
-__device__ __forceinline__ Fz<F> lds_load_words(const uint4* lo, const uint4* hi, int idx) {
-    uint4 a = lo[idx], b = hi[idx];
-    return fz_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
-}
-template <class F>
-__device__ __forceinline__ void lds_store_words(uint4* lo, uint4* hi, int idx, const Fz<F>& v) {
-    u32 w[8];
-    fz_store(v, w);
-    lo[idx] = make_uint4(w[0], w[1], w[2], w[3]);
-    hi[idx] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-template <class F>
-__device__ __forceinline__ Fz<F> lds_load_limbs(const uint4* pa, const uint4* pb, const u32* pc, int idx) {
-    const uint4 a = pa[idx], b = pb[idx];
-    Fz<F> r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = pc[idx];
-    return r;
-}
-template <class F>
-__device__ __forceinline__ void lds_store_limbs(uint4* pa, uint4* pb, u32* pc, int idx, const Fz<F>& v) {
-    pa[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    pb[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    pc[idx] = v.l[8];
-}
-template <class F>
-__device__ __forceinline__ Fz<F> twiddle_z(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, u32 e, int lo_bits) {
-    const u32 el = e & ((1u << lo_bits) - 1u), eh = e >> lo_bits;
-    Fz<F> w = load_fz<F>(z_lo + 2 * (size_t)el);
-    if (eh) w = fz_mul(w, load_fz<F>(z_hi + 2 * (size_t)eh));
-    return w;
-}
-// (a, b) -> (a + b, a + K m - b), bound(b) <= K m
-template <class F, u32 K>
-__device__ __forceinline__ void bfly_z(Fz<F>& a, Fz<F>& b) {
-    const Fz<F> t = fz_add(a, b);
-    b = fz_sub<F, K>(a, b);
-    a = t;
-}
-// v < 2^6 m  ->  [0, 2 m), then [0, m) when `canonical`
-template <class F>
-__device__ __forceinline__ void fz_finish(Fz<F>& v, bool canonical) {
-    const u32 q = v.l[8] >> 14;  // floor(v / 2^254) >= floor(v / m) >= q - 1
-    const u32 qq = q ? q - 1u : 0u;
-    u64 c = 0;
-    i32 br = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        c += (u64)qq * mod_limb<F>(i);
-        const i32 d = (i32)v.l[i] - (i32)((u32)c & LIMB_MASK) + br;
-        v.l[i] = (u32)d & LIMB_MASK;
-        br = d >> 30;
-        c >>= 30;
-    }
-    if (canonical) {
-        Fe<F> t;
-#pragma unroll
-        for (int i = 0; i < NLIMBS; ++i) t.l[i] = v.l[i];
-        fe_cond_sub(t);
-#pragma unroll
-        for (int i = 0; i < NLIMBS; ++i) v.l[i] = t.l[i];
-    }
-}
-
-// inter-pass twiddles of one pass laid out as the pass reads them: d[r * Ns + k] = omega^((k r) << tw_shift), lazy form
-template <class F>
-__global__ void __launch_bounds__(256) ntt_direct_table_kernel(const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, uint4* __restrict__ d,
-                                                               int log_ns, int s, int tw_shift) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((size_t)1 << (log_ns + s))) return;
-    const u32 k = (u32)i & ((1u << log_ns) - 1u), r = (u32)(i >> log_ns);
-    Fz<F> w = twiddle_z<F>(z_lo, z_hi, (k * r) << tw_shift, lo_bits);
-    u32 o[8];
-    fz_store(w, o);
-    d[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
-    d[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-}
-
-// stage V of round 0 (rows u, u | 2^V of the thread's G = 2^LG registers)
-template <class F, int LG, int V, class TW>
-__device__ __forceinline__ void round0_stage_z(Fz<F> (&x)[1 << LG], const TW& tw, int s) {
-    const int sh = s - 1 - V;
-#pragma unroll
-    for (int u = 0; u < (1 << LG); ++u) {
-        if (u & (1 << V)) continue;
-        const u32 ul = (u32)(u & ((1 << V) - 1));
-        if (ul) {
-            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], tw((int)(ul << sh)));
-            bfly_z<F, 2>(x[u], x[u | (1 << V)]);
-        } else {
-            bfly_z<F, (2u << V)>(x[u], x[u | (1 << V)]);
-        }
-    }
-}
-
-// in-tile twiddle table in LDS: nine limbs as they are (TWL, fits next to the data for s <= 8) or the eight memory words
-template <class F, bool TWL>
-struct TileTwiddles {
-    uint4* a;
-    uint4* b;
-    u32* c;
-    __device__ __forceinline__ Fz<F> operator()(int idx) const {
-        if constexpr (TWL) return lds_load_limbs<F>(a, b, c, idx);
-        else return lds_load_words<F>(a, b, idx);
-    }
-    __device__ __forceinline__ void put(int idx, const Fz<F>& v) const {
-        if constexpr (TWL) lds_store_limbs<F>(a, b, c, idx, v);
-        else lds_store_words<F>(a, b, idx, v);
-    }
-};
-
-// stage V of a later round: rows u, u | 2^V of the thread's registers, twiddle index (L + (u mod 2^V) << stl) << sh
-template <class F, int LG, int V, class TW>
-__device__ __forceinline__ void round_stage_z(Fz<F> (&x)[1 << LG], const TW& tw, u32 L, int stl, int s, bool partner_zero) {
-    const int sh = s - 1 - stl - V;
-#pragma unroll
-    for (int u = 0; u < (1 << LG); ++u) {
-        if (u & (1 << V)) continue;
-        if (partner_zero) {
-            x[u | (1 << V)] = x[u];  // a + w * 0 = a - w * 0
-        } else {
-            const u32 idx = (L + ((u32)(u & ((1 << V) - 1)) << stl)) << sh;
-            x[u | (1 << V)] = fz_mul(x[u | (1 << V)], tw((int)idx));  // idx 0 holds the lazy one
-            bfly_z<F, 2>(x[u], x[u | (1 << V)]);
-        }
-    }
-}
-
-template <class F, int LG, int TLOG, bool TWL, bool FUSE>
-__global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passz_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int log_n, int s, int log_ns,
-                                                               const uint4* __restrict__ z_lo, const uint4* __restrict__ z_hi, int lo_bits, int last,
-                                                               const uint4* __restrict__ direct, NttFusion fu) {
-    constexpr int G = 1 << LG, T = 1 << TLOG, THREADS = T >> LG;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int R = 1 << s;
-    const int log_c = TLOG - s;
-    const int C = 1 << log_c;
-    uint4* pa = (uint4*)smem;
-    uint4* pb = pa + T;
-    uint4* tw_lo = pb + T;
-    uint4* tw_hi = tw_lo + (R >> 1);
-    u32* pc = (u32*)(tw_hi + (R >> 1));
-    const TileTwiddles<F, TWL> tw{tw_lo, tw_hi, pc + T};  // word form at s = 9: exactly 80 KiB per workgroup, two per CU
-
-    const size_t N = (size_t)1 << log_n;
-    const size_t batch_off = (size_t)blockIdx.y * N * 2;
-    const bool padded = FUSE && fu.in_dev;
-    const size_t in_len = padded ? (size_t)1 << fu.in_log : N;  // pass 0 of a zero-padded transform reads a shorter row
-    in = padded ? (const uint4*)fu.in_dev + (size_t)blockIdx.y * in_len * 2 : in + batch_off;
-    out += batch_off;
-    const int tid = threadIdx.x;
-    const u32 c = tid & (C - 1), m = tid >> log_c;
-    const u32 j = (blockIdx.x << log_c) + c;
-    const u32 k = j & ((1u << log_ns) - 1u);
-    const size_t row_stride = N >> s;
-    // zero-padded input: rows r >= in_len / row_stride are zero.  With at most R/4 live rows a thread's rows 1..3 are
-    // zero and round 0 is a broadcast; with at most R/8 the third stage is one as well (uniform over the grid)
-    const u32 live_rows = (u32)(in_len / row_stride ? in_len / row_stride : 1);
-    const bool bcast0 = padded && LG == 2 && s > LG && live_rows <= (u32)(R >> 2);
-    const bool bcast2 = bcast0 && s >= 2 * LG && live_rows <= (u32)(R >> 3);
-
-    Fz<F> x[G];
-    const int tw_shift = log_n - log_ns - s;
-    // element v of the thread (row m + v R/G) lands in the bit-reversed slot; one call per compile-time v keeps x[] in registers
-    auto load_row = [&](const int v) -> Fz<F> {
-        const u32 r = m + (u32)v * (u32)(R >> LG);
-        const size_t idx = (size_t)j + (size_t)r * row_stride;
-        Fz<F> val = fz_zero<F>();
-        if (!(bcast0 && v) && idx < in_len) {
-            val = load_fz<F>(in + 2 * idx);
-            if (FUSE && fu.pre) val = fz_mul(val, load_fz<F>((const uint4*)fu.pre + 2 * (idx % fu.pre_period)));
-            if (log_ns > 0) {
-                const u32 ex = (k * r) << tw_shift;
-                if (ex) val = fz_mul(val, direct ? load_fz<F>(direct + 2 * (((size_t)r << log_ns) + k)) : twiddle_z<F>(z_lo, z_hi, ex, lo_bits));
-            }
-        }
-        return val;
-    };
-    if constexpr (LG == 2) {
-        x[0] = load_row(0); x[2] = load_row(1); x[1] = load_row(2); x[3] = load_row(3);
-    } else {
-        x[0] = load_row(0); x[4] = load_row(1); x[2] = load_row(2); x[6] = load_row(3);
-        x[1] = load_row(4); x[5] = load_row(5); x[3] = load_row(6); x[7] = load_row(7);
-    }
-    for (int i = tid; i < (R >> 1); i += THREADS) tw.put(i, twiddle_z<F>(z_lo, z_hi, (u32)i << (log_n - s), lo_bits));
-    __syncthreads();
-
-    u32 base = (s > LG) ? ((__brev(m) >> (32 - (s - LG))) << LG) : 0u;
-    u32 L = 0;
-    int stl = 0, vb = 0;
-    // round 0: compile-time twiddles 1, w4, w8, w8^3 (index 0 is left out: operand bounds 2^(v+1))
-    if (bcast0) {
-#pragma unroll
-        for (int u = 1; u < G; ++u) x[u] = x[0];  // a + w * 0 = a - w * 0 = a in both stages
-    } else {
-        round0_stage_z<F, LG, 0>(x, tw, s);
-        if constexpr (LG > 1) round0_stage_z<F, LG, 1>(x, tw, s);
-        if constexpr (LG > 2) round0_stage_z<F, LG, 2>(x, tw, s);
-    }
-    for (int st = LG; st < s; st += LG) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) lds_store_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
-        __syncthreads();
-        stl = st + LG <= s ? st : s - LG;
-        vb = st - stl;
-        L = m & ((1u << stl) - 1u);
-        base = L | ((m >> stl) << (stl + LG));
-#pragma unroll
-        for (int u = 0; u < G; ++u) x[u] = lds_load_limbs<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
-        const bool partner_zero = bcast2 && st == LG;  // third stage of a zero-padded input
-        if (0 >= vb) round_stage_z<F, LG, 0>(x, tw, L, stl, s, partner_zero);
-        if constexpr (LG > 1) { if (1 >= vb) round_stage_z<F, LG, 1>(x, tw, L, stl, s, false); }
-        if constexpr (LG > 2) { if (2 >= vb) round_stage_z<F, LG, 2>(x, tw, L, stl, s, false); }
-    }
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-        const u32 rr = base + ((u32)u << stl);
-        const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
-        if (FUSE && fu.post && last) {
-            Fe<F> t;
-            const Fz<F> y = fz_mul(x[u], load_fz<F>((const uint4*)fu.post + 2 * (dst % fu.post_period)));  // < m (1 + 2^-8)
-#pragma unroll
-            for (int i = 0; i < NLIMBS; ++i) t.l[i] = y.l[i];
-            fe_cond_sub(t);
-#pragma unroll
-            for (int i = 0; i < NLIMBS; ++i) x[u].l[i] = t.l[i];
-        } else {
-            fz_finish(x[u], last != 0);
-        }
-        u32 w[8];
-        fz_store(x[u], w);
-        out[2 * dst] = make_uint4(w[0], w[1], w[2], w[3]);
-        out[2 * dst + 1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
 
@@ -822,206 +566,6 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     }
 }
 
-// ---- persistent, software-pipelined form of the signed pass (round 5) ---------------------------------------------------------------
-// ntt_passy_kernel pays ~30 % of its time for memory it has nothing to overlap with: every workgroup starts by waiting for its own
-// loads and ends behind its own stores (NOTEBOOK "(f)": 2^22 0.470 ms, 0.319 with no memory operations).  Here a workgroup stays
-// resident and walks over tiles w = blockIdx.x, + gridDim.x, ...; while the LAST round of tile t computes, tile t + 1 is already on its way:
-//   * the elements by LDS-DMA (global_load_lds_dwordx4: no VGPRs) straight into the exchange buffer, which is free from the moment
-//     every wave has made the last exchange read of tile t.  The DMA puts global row r of the tile at LDS row bitrev_s(r): exactly the
-//     slots thread (m, c) owns in round 0 (rows (bitrev(m) << 2) + u), so round 0 reads its four elements from LDS instead of HBM and
-//     writes its results back to the same slots -- no extra exchange;
-//   * the per-element factor (inter-pass twiddle of passes >= 1, or the coset-block table of coeff_to_extended_blocks on pass 0) into
-//     36 registers by ordinary loads, issued at the same point (the last round holds four elements + these + a product's temporaries,
-//     the same pressure the non-persistent kernel has in its round 0);
-//   * the stores of tile t are issued after the barrier that publishes tile t + 1's DMA and drain under round 0 of tile t + 1.
-// The in-tile twiddle table is built once per workgroup instead of once per tile.  Not taken here (ntt_passy_kernel keeps them):
-// zero-padded inputs, the packed periodic factors (pre / post), passes without a direct table, s < 4.
-struct NttPipeArgs {
-    const uint4* in; uint4* out;
-    int log_n, s, log_ns, last, words_in, raw_out;
-    const uint4* fac;        // factor table in the three-plane balanced form (null: none)
-    unsigned long long fac_M;  // its entries per plane
-    u32 fac_blocks;          // 0: inter-pass table, entry (r << log_ns) + k; > 0: coset-block table, entry ((t % blocks) << log_n) + index
-    u32 in_div;              // word-form input: transform t reads row t / in_div (the blocks of one polynomial share its coefficients)
-    const uint4* post_blocks; u32 blocks;
-    u32 nb; int batch_major;
-    const uint4* tile_tab; const uint4* z_lo; const uint4* z_hi; int lo_bits;
-};
-// 16 bytes per lane from global address sbase + voff (sbase wave-uniform in SGPRs, voff the lane's 32-bit byte offset) to LDS byte address
-// lds_dst + lane * 16 (lds_dst wave-uniform, through M0)
-__device__ __forceinline__ void glds16(const void* sbase, u32 voff, u32 lds_dst) {
-    u32 keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-// MODE bit 0: word-form input (pass 0); bit 1: a factor table; bit 2: coset-block factors on the final store (post_blocks); bit 3: raw output
-template <class F, int TWM, int MODE>
-__global__ void __launch_bounds__(TILE >> 2) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_passp_kernel(const NttPipeArgs p) {
-    constexpr int LG = 2, G = 4, T = TILE, TLOG = TILE_LOG;
-    constexpr bool WORDS_IN = (MODE & 1) != 0, HAS_FAC = (MODE & 2) != 0, POSTB = (MODE & 4) != 0, RAW_OUT = (MODE & 8) != 0;
-#ifndef TRH_NTT_PF
-#define TRH_NTT_PF 1
-#endif
-#ifndef TRH_NTT_PFMODE
-#define TRH_NTT_PFMODE 0  // 1: the other factor rows are requested before the tile's stores; 0: at the start of the next tile
-#endif
-    constexpr int PF = TRH_NTT_PF;  // factor rows fetched a round ahead (the others at the start of the tile)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = p.s, log_n = p.log_n, log_ns = p.log_ns;
-    const int R = 1 << s;
-    const int log_c = TLOG - s;
-    const int C = 1 << log_c;
-    uint4* pa = (uint4*)smem;
-    uint4* pb = pa + T;
-    const int tw_n = TWM == 2 ? (R >> 2) : (R >> 1);
-    uint4* tw_lo = pb + T;
-    uint4* tw_hi = tw_lo + tw_n;
-    u32* pc = (u32*)(tw_hi + tw_n);
-    const TileTwiddlesY<F, TWM> tw{tw_lo, tw_hi, pc + T, p.tile_tab, R >> 1};
-    const size_t N = (size_t)1 << log_n;
-    const int tid = threadIdx.x;
-    const u32 c0 = tid & (C - 1), m0 = tid >> log_c;
-    const size_t row_stride = N >> s;
-    const u32 tiles_log = (u32)(log_n - TLOG);
-    const u32 total = p.nb << tiles_log;
-    const u32 lds_a = (u32)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const u32 lds_b = lds_a + T * 16, lds_c = lds_a + 2 * T * 16 + 2 * (u32)tw_n * 16;
-    const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6), lane = (u32)tid & 63u;
-
-    auto coords = [&](u32 w, u32& bx, u32& by) {
-        if (p.batch_major) { bx = w / p.nb; by = w - bx * p.nb; }
-        else { by = w >> tiles_log; bx = w & ((1u << tiles_log) - 1u); }
-    };
-    // a tile's DMA: the lane offsets (row bitrev_s(slot row), column) are the same for every tile; the tile and the transform move the
-    // wave-uniform base
-    auto issue_dma = [&](u32 bx, u32 by) {
-        const char* src = WORDS_IN ? (const char*)(p.in + (size_t)(by / p.in_div) * N * 2) : (const char*)p.in + (size_t)by * N * 36;
-        src += ((size_t)bx << log_c) * (WORDS_IN ? 32 : 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 e0 = (wv * 4 + (u32)i) * 64u;  // wave-uniform first slot of this instruction
-            const u32 e = e0 + lane;
-            const u32 rho = e >> log_c, cc = e & (u32)(C - 1);
-            const u32 r = __brev(rho) >> (32 - s);
-            const u32 g = cc + r * (u32)row_stride;
-            const u32 da = (u32)__builtin_amdgcn_readfirstlane((int)(lds_a + e0 * 16u)), db = (u32)__builtin_amdgcn_readfirstlane((int)(lds_b + e0 * 16u));
-            if constexpr (WORDS_IN) { glds16(src, g * 32u, da); glds16(src + 16, g * 32u, db); }
-            else { glds16(src, g * 16u, da); glds16(src + N * 16, g * 16u, db); }
-        }
-        if constexpr (!WORDS_IN) {  // the 4-byte plane: four consecutive elements of a row (C >= 4) per lane
-            const u32 e0 = wv * 256u;
-            const u32 e = e0 + lane * 4u;
-            const u32 rho = e >> log_c, cc = e & (u32)(C - 1);
-            const u32 r = __brev(rho) >> (32 - s);
-            const u32 g = cc + r * (u32)row_stride;
-            glds16(src + N * 32 - ((size_t)bx << log_c) * 12, g * 4u, (u32)__builtin_amdgcn_readfirstlane((int)(lds_c + e0 * 4u)));
-        }
-    };
-    // factor of the element x[u] holds (row m + bitrev2(u) R / 4 of the tile).  Rows u = 0, 1 are fetched a round ahead (18 registers beside the
-    // last round's four elements); rows 2, 3 at the start of the tile, under the products of rows 0, 1 (36 more would spill)
-    auto load_fac = [&](u32 bx, u32 by, int u, u32 m, u32 c) -> Fy<F> {
-        const u32 j = (bx << log_c) + c;
-        const u32 r = m + (u32)(((u & 1) << 1) | (u >> 1)) * (u32)(R >> LG);
-        const size_t idx = p.fac_blocks ? ((size_t)(by % p.fac_blocks) << log_n) + (size_t)j + (size_t)r * row_stride : ((size_t)r << log_ns) + (j & ((1u << log_ns) - 1u));
-        return load_direct_y<F>(p.fac, (size_t)p.fac_M, idx);
-    };
-
-    u32 w = blockIdx.x, bx = 0, by = 0;
-    Fy<F> f0 = fy_zero<F>(), f1 = fy_zero<F>(), f2 = fy_zero<F>(), f3 = fy_zero<F>();
-    if (w < total) {
-        coords(w, bx, by);
-        issue_dma(bx, by);
-        if constexpr (HAS_FAC) { f0 = load_fac(bx, by, 0, m0, c0); f1 = load_fac(bx, by, 1, m0, c0); f2 = load_fac(bx, by, 2, m0, c0); f3 = load_fac(bx, by, 3, m0, c0); }
-    }
-    if constexpr (TWM == 2) {
-        for (int i = tid; i < tw_n; i += (T >> LG)) lds_store_limbs_y<F>(tw_lo, tw_hi, pc + T, i, load_direct_y<F>(p.tile_tab, (size_t)(R >> 1), (size_t)(2 * i)));
-    } else {
-        for (int i = tid; i < tw_n; i += (T >> LG)) tw.put(i, twiddle_y<F>(p.z_lo, p.z_hi, (u32)i << (log_n - s), p.lo_bits));
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    while (w < total) {
-        // (m, c) pass through an empty asm statement once per tile: otherwise the compiler keeps the dozen 64-bit factor / output addresses that
-        // depend on them alone live across the whole loop and spills them (76 - 96 bytes of scratch per thread, reloaded behind vmcnt(0))
-        u32 m = m0, c = c0;
-        asm volatile("" : "+v"(m), "+v"(c));
-        const u32 j = (bx << log_c) + c;
-        const u32 k = j & ((1u << log_ns) - 1u);
-        const size_t blk = (POSTB && p.blocks) ? by % p.blocks : 0u;
-        uint4* out_a = RAW_OUT ? (uint4*)((char*)p.out + (size_t)by * N * 36) : p.out + (size_t)by * N * 2;
-        u32 base = (__brev(m) >> (32 - (s - LG))) << LG;
-        Fy<F> x[G];
-        // round 0: the thread's own four slots, filled by the DMA
-        auto own = [&](int u) -> Fy<F> {
-            const int idx = (int)(((base + (u32)u) << log_c) | c);
-            if constexpr (WORDS_IN) { const uint4 a = pa[idx], b = pb[idx]; return fy_load<F>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
-            else return lds_load_limbs_y<F>(pa, pb, pc, idx);
-        };
-        if constexpr (HAS_FAC && TRH_NTT_PFMODE == 0) { if constexpr (PF < 2) f1 = load_fac(bx, by, 1, m, c); f2 = load_fac(bx, by, 2, m, c); f3 = load_fac(bx, by, 3, m, c); }
-        x[0] = own(0); x[1] = own(1);
-        if constexpr (HAS_FAC) { x[0] = fy_mul(x[0], f0); x[1] = fy_mul(x[1], f1); }
-        x[2] = own(2); x[3] = own(3);
-        if constexpr (HAS_FAC) { x[2] = fy_mul(x[2], f2); x[3] = fy_mul(x[3], f3); }
-        round0_stage_y<F, LG, 0, true>(x, tw, s);
-        round0_stage_y<F, LG, 1, true>(x, tw, s);
-        const u32 wn = w + gridDim.x;
-        const bool has_next = wn < total;
-        u32 nbx = 0, nby = 0;
-        if (has_next) coords(wn, nbx, nby);
-        u32 L = 0;
-        int stl = 0, vb = 0;
-        for (int st = LG; st < s; st += LG) {
-#pragma unroll
-            for (int u = 0; u < G; ++u) lds_store_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c), x[u]);
-            __syncthreads();
-            stl = st + LG <= s ? st : s - LG;
-            vb = st - stl;
-            L = m & ((1u << stl) - 1u);
-            base = L | ((m >> stl) << (stl + LG));
-#pragma unroll
-            for (int u = 0; u < G; ++u) x[u] = lds_load_limbs_y<F>(pa, pb, pc, (int)(((base + ((u32)u << stl)) << log_c) | c));
-            if (st + LG >= s) {  // the last exchange read: once every wave has made it the buffer takes the next tile
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (has_next) {
-                    issue_dma(nbx, nby);
-                    if constexpr (HAS_FAC) { f0 = load_fac(nbx, nby, 0, m, c); if constexpr (PF >= 2) f1 = load_fac(nbx, nby, 1, m, c); }
-                }
-            }
-            if (0 >= vb) round_stage_y<F, LG, 0, true>(x, tw, L, stl, s, false, true);
-            if (1 >= vb) round_stage_y<F, LG, 1, true>(x, tw, L, stl, s, false, vb == 1);
-        }
-        // the next tile's elements have landed (this wave's; the barrier makes it every wave's) before the stores go out: they drain
-        // under the next tile's round 0
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // the remaining factor rows of the next tile go out BEFORE the stores: the memory counter retires in order, so a load issued behind
-        // the stores could not be waited for without waiting for them
-        if constexpr (HAS_FAC && TRH_NTT_PFMODE == 1) {
-            if (has_next) { if constexpr (PF < 2) f1 = load_fac(nbx, nby, 1, m, c); f2 = load_fac(nbx, nby, 2, m, c); f3 = load_fac(nbx, nby, 3, m, c); }
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const u32 rr = base + ((u32)u << stl);
-            const size_t dst = ((size_t)(j - k) << s) + k + ((size_t)rr << log_ns);
-            if constexpr (RAW_OUT) {
-                out_a[dst] = make_uint4((u32)x[u].l[0], (u32)x[u].l[1], (u32)x[u].l[2], (u32)x[u].l[3]);
-                out_a[N + dst] = make_uint4((u32)x[u].l[4], (u32)x[u].l[5], (u32)x[u].l[6], (u32)x[u].l[7]);
-                ((u32*)(out_a + 2 * N))[dst] = (u32)x[u].l[8];
-            } else {
-                Fy<F> y;
-                if (POSTB && p.post_blocks && p.last) y = fy_mul(x[u], load_direct_y<F>(p.post_blocks, (size_t)p.blocks << log_n, (blk << log_n) + dst));
-                else y = fy_norm(x[u]);
-                u32 wd[8];
-                fy_canonical_words(y, wd);
-                out_a[2 * dst] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-                out_a[2 * dst + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
-            }
-        }
-        w = wn; bx = nbx; by = nby;
-    }
-}
-
 template <class F>
 __global__ void __launch_bounds__(256) field_scale_periodic_kernel(uint4* __restrict__ a, size_t rows, size_t row_len, size_t active_len,
                                                                    const uint4* __restrict__ factors, u32 period) {
@@ -1086,24 +630,9 @@ void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
         if (P < 2) P = 2;
         int rem = log_n;
         for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
-        if (const char* e = getenv("TRH_NTT_PLAN")) {  // tuning knob: explicit pass sizes "8,8,6"
-            int v[8], cnt = 0, sum = 0;
-            for (const char* q = e; *q && cnt < 8;) { v[cnt] = atoi(q); sum += v[cnt++]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-            if (sum == log_n) { P = cnt; for (int p = 0; p < P; ++p) sizes[p] = v[p]; }
-        }
     }
     *n_passes = P; *tile_log = tlog;
 }
-bool lazy_enabled() {
-    static const int lazy = getenv("TRH_NTT_LAZY") ? atoi(getenv("TRH_NTT_LAZY")) : 1;
-    return lazy != 0;
-}
-// the signed 29-bit lazy passes (ntt_passy_kernel) instead of the unsigned 30-bit ones (ntt_passz_kernel); TRH_NTT_SIGNED=0 for A/B
-bool signed_enabled() {
-    static const int sg = getenv("TRH_NTT_SIGNED") ? atoi(getenv("TRH_NTT_SIGNED")) : 1;
-    return sg != 0 && lazy_enabled();
-}
-
 template <class F>
 int build_tables(int log_n, const u64 omega[4], const u64* scale, hipStream_t s, TwiddleEntry** out) {
     Ctx& c = ctx();
@@ -1135,25 +664,19 @@ int build_tables(int log_n, const u64 omega[4], const u64* scale, hipStream_t s,
     TRH_HIP_TRY(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
     const u32 cnt = 1u << (t->lo_bits > t->hi_bits ? t->lo_bits : t->hi_bits);
     hipLaunchKernelGGL((ntt_tables_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, s, d_pw, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits, t->hi_bits);
-    if (signed_enabled()) {
-        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, true>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
-        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, true>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
-    } else {
-        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, false>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
-        hipLaunchKernelGGL((ntt_tables_lazy_kernel<F, false>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
-    }
+    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->lo_bits) + 255) / 256), dim3(256), 0, s, t->lo.as<uint4>(), t->zlo.as<uint4>(), 1u << t->lo_bits);
+    hipLaunchKernelGGL((ntt_tables_lazy_kernel<F>), dim3(((1u << t->hi_bits) + 255) / 256), dim3(256), 0, s, t->hi.as<uint4>(), t->zhi.as<uint4>(), 1u << t->hi_bits);
     // direct inter-pass tables for the lazy passes (pass p >= 1 reads Ns * R entries, coalesced): up to 1 GiB per pass
-    static const int direct_on = getenv("TRH_NTT_DIRECT") ? atoi(getenv("TRH_NTT_DIRECT")) : 1;
     int sizes[8], P, tlog;
     plan_passes(log_n, sizes, &P, &tlog);
-    if (direct_on && lazy_enabled() && tlog == TILE_LOG && log_n >= TILE_LOG) {
+    if (tlog == TILE_LOG && log_n >= TILE_LOG) {
         int log_ns = sizes[0];
         for (int p = 1; p < P && rc == TRH_OK; ++p) {
             const size_t entries = (size_t)1 << (log_ns + sizes[p]);
-            const size_t entry_bytes = signed_enabled() ? 36 : 32;  // raw limbs for the signed passes
+            const size_t entry_bytes = 36;  // raw limbs
             if (entries * entry_bytes <= ((size_t)1 << 30) + ((size_t)1 << 27)) {
                 rc = t->direct[p].ensure(entries * entry_bytes);
-                if (rc == TRH_OK && signed_enabled()) {
+                if (rc == TRH_OK) {
                     const bool fold = scale && p == P - 1;
                     const u32* sw = (const u32*)t->scale;
                     hipLaunchKernelGGL((ntt_direct_table_y_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
@@ -1161,17 +684,13 @@ int build_tables(int log_n, const u64 omega[4], const u64* scale, hipStream_t s,
                                        fold ? 1 : 0);
                     if (fold) t->scaled = true;
                 }
-                else if (rc == TRH_OK)
-                    hipLaunchKernelGGL((ntt_direct_table_kernel<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits,
-                                       t->direct[p].as<uint4>(), log_ns, sizes[p], log_n - log_ns - sizes[p]);
             }
             log_ns += sizes[p];
         }
     }
-    static const int half_on = getenv("TRH_NTT_HALF") ? atoi(getenv("TRH_NTT_HALF")) : 1;  // 0: 9-stage passes with packed in-tile twiddles (A/B)
     bool nine = false;
     for (int p = 0; p < P; ++p) nine = nine || sizes[p] == 9;
-    if (rc == TRH_OK && half_on && nine && signed_enabled() && tlog == TILE_LOG && log_n >= TILE_LOG) {
+    if (rc == TRH_OK && nine && tlog == TILE_LOG && log_n >= TILE_LOG) {
         rc = t->tile9.ensure((size_t)256 * 36);
         if (rc == TRH_OK)
             hipLaunchKernelGGL((ntt_tile_table_y_kernel<F>), dim3(1), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, t->tile9.as<uint4>(), log_n, 9);
@@ -1195,10 +714,10 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     plan_passes((int)log_n, sizes, &P, &tlog);
     const size_t N = (size_t)1 << log_n;
     uint4* a = (uint4*)a_dev;
-    bool all_lazy = lazy_enabled() && tlog == TILE_LOG && (int)log_n >= TILE_LOG && P >= 2;
+    bool all_lazy = tlog == TILE_LOG && (int)log_n >= TILE_LOG && P >= 2;
     for (int p = 0; p < P; ++p) all_lazy = all_lazy && sizes[p] >= 2 && sizes[p] <= MAX_PASS_LOG;
-    if (scale && !(all_lazy && signed_enabled() && t->scaled)) { set_error("ntt: this size cannot take a factor in its tables (ntt_can_fold_scale)"); return TRH_EINVAL; }
-    if (all_lazy && signed_enabled()) {
+    if (scale && !(all_lazy && t->scaled)) { set_error("ntt: this size cannot take a factor in its tables (ntt_can_fold_scale)"); return TRH_EINVAL; }
+    if (all_lazy) {
         // signed-domain passes: caller's words -> raw nine-limb scratch -> ... -> caller's words (canonical)
         const size_t max_tmp = (size_t)2 << 30;
         size_t chunk = max_tmp / (N * 72);
@@ -1213,8 +732,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             int log_ns = 0;
             for (int p = 0; p < P; ++p) {
                 const int sp = sizes[p];
-                static const int grid_knob = getenv("TRH_NTT_GRID") ? atoi(getenv("TRH_NTT_GRID")) : -1;  // 0 tile-major, 1 batch-major, default: automatic
-                const int batch_major = grid_knob >= 0 ? (grid_knob && (N >> TILE_LOG) <= 65535) : (nb >= 8 && p > 0 && (N >> TILE_LOG) <= 65535);
+                const int batch_major = nb >= 8 && p > 0 && (N >> TILE_LOG) <= 65535;  // consecutive workgroups run the same tile of consecutive transforms: the inter-pass table's rows are re-read from the L2
                 const dim3 grid = batch_major ? dim3((unsigned)nb, (unsigned)(N >> TILE_LOG)) : dim3((unsigned)(N >> TILE_LOG), (unsigned)nb);
                 const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
                 NttFusion kf;
@@ -1229,54 +747,17 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 const bool fused = kf.in_dev || kf.pre || kf.post || kf.pre_blocks || kf.post_blocks;
                 const uint4* src = p == 0 ? base : (const uint4*)raw[(p - 1) & 1];
                 uint4* dst = p == P - 1 ? base : (uint4*)raw[p & 1];
-                const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1)), ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
+                const size_t ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
                 const size_t ldh = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 2));
                 const uint4* tile_tab = (sp == 9 && t->tile9.p) ? t->tile9.as<uint4>() : nullptr;
-                // persistent software-pipelined form (ntt_passp_kernel) for the shapes it takes: TRH_NTT_PIPE=1.  Off by default -- measured
-                // (profiles/r05_ntt_pipeline_ab.txt): 2^22 0.437 vs 0.439 ms, 2^24 +2 %, 320 x 2^18 +10 %, coset blocks +8 %; the waves wait less
-                // (SQ_WAIT_ANY -20 %) and the pass takes as long: what bounds it is VALU issue, not the load / store phases
-                static const int pipe_knob = getenv("TRH_NTT_PIPE") ? atoi(getenv("TRH_NTT_PIPE")) : 0;
-                static const int pipe_wg = getenv("TRH_NTT_PIPE_WG") ? atoi(getenv("TRH_NTT_PIPE_WG")) : 2;  // resident workgroups per CU
-                const bool pipe_ok = pipe_knob && log_n <= 26 && sp >= 4 && (sp <= 8 || tile_tab) && !kf.pre && !kf.post && (!kf.in_dev || kf.in_log == log_n) && (p == 0 || direct) &&
-                                     (N >> TILE_LOG) * nb < ((size_t)1 << 31);
-                if (pipe_ok) {
-                    NttPipeArgs pa;
-                    pa.in = (p == 0 && kf.in_dev) ? (const uint4*)kf.in_dev : src;
-                    pa.out = dst;
-                    pa.log_n = (int)log_n; pa.s = sp; pa.log_ns = log_ns; pa.last = (int)(p == P - 1); pa.words_in = (int)(p == 0); pa.raw_out = (int)(p < P - 1);
-                    pa.fac = p > 0 ? direct : (const uint4*)kf.pre_blocks;
-                    pa.fac_M = p > 0 ? (unsigned long long)1 << (log_ns + sp) : (unsigned long long)kf.blocks << log_n;
-                    pa.fac_blocks = (p == 0 && kf.pre_blocks) ? kf.blocks : 0u;
-                    pa.in_div = (p == 0 && kf.pre_blocks) ? kf.blocks : 1u;
-                    pa.post_blocks = (const uint4*)kf.post_blocks; pa.blocks = kf.blocks;
-                    pa.nb = (u32)nb; pa.batch_major = batch_major;
-                    pa.tile_tab = tile_tab; pa.z_lo = t->zlo.as<uint4>(); pa.z_hi = t->zhi.as<uint4>(); pa.lo_bits = t->lo_bits;
-                    if (!c.cu_count) TRH_HIP_TRY(hipDeviceGetAttribute(&c.cu_count, hipDeviceAttributeMultiprocessorCount, c.device));
-                    const size_t total = (N >> TILE_LOG) * nb, resident = (size_t)c.cu_count * (size_t)(pipe_wg > 0 ? pipe_wg : 2);
-                    const dim3 pgrid((unsigned)(total < resident ? total : resident));
-                    const size_t lds = sp <= 8 ? ldl : ldh;
-                    const int mode = (p == 0 ? 1 : 0) | (pa.fac ? 2 : 0) | ((p == P - 1 && kf.post_blocks) ? 4 : 0) | (p < P - 1 ? 8 : 0);
-#define TRH_LAUNCH_PASSP(TWM, MODE) hipLaunchKernelGGL((ntt_passp_kernel<F, TWM, MODE>), pgrid, dim3(TILE >> 2), lds, s, pa)
-#define TRH_LAUNCH_PASSP_MODES(TWM)                                                                                                                      \
-    do {                                                                                                                                                 \
-        if (mode == 9) TRH_LAUNCH_PASSP(TWM, 9); else if (mode == 11) TRH_LAUNCH_PASSP(TWM, 11); else if (mode == 10) TRH_LAUNCH_PASSP(TWM, 10);          \
-        else if (mode == 2) TRH_LAUNCH_PASSP(TWM, 2); else TRH_LAUNCH_PASSP(TWM, 6);                                                                     \
-    } while (0)
-                    if (sp <= 8) TRH_LAUNCH_PASSP_MODES(1); else TRH_LAUNCH_PASSP_MODES(2);
-#undef TRH_LAUNCH_PASSP_MODES
-#undef TRH_LAUNCH_PASSP
-                    log_ns += sp;
-                    continue;
-                }
 #define TRH_LAUNCH_PASSY(TWM, FUSE, LDS)                                                                                                       \
     hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWM, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
                        t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major, tile_tab)
                 if (sp <= 8 && !fused) TRH_LAUNCH_PASSY(1, false, ldl);
                 else if (sp <= 8) TRH_LAUNCH_PASSY(1, true, ldl);
-                else if (tile_tab && !fused) TRH_LAUNCH_PASSY(2, false, ldh);
-                else if (tile_tab) TRH_LAUNCH_PASSY(2, true, ldh);
-                else if (!fused) TRH_LAUNCH_PASSY(0, false, ldz);
-                else TRH_LAUNCH_PASSY(0, true, ldz);
+                else if (!tile_tab) { set_error("ntt: 9-stage pass without its tile table"); return TRH_EINVAL; }  // (build_tables makes one whenever a pass has nine stages)
+                else if (!fused) TRH_LAUNCH_PASSY(2, false, ldh);
+                else TRH_LAUNCH_PASSY(2, true, ldh);
 #undef TRH_LAUNCH_PASSY
                 log_ns += sp;
             }
@@ -1308,29 +789,8 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             const size_t tiles = N >> tile_log;
             const size_t lds = ((size_t)32 << tile_log) + ((size_t)32 << (sp - 1 > 0 ? sp - 1 : 0));
             const dim3 grid((unsigned)tiles, (unsigned)nb);
-            const bool lazy = lazy_enabled();
-            const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
-            NttFusion kf;  // what this pass fuses: input side on pass 0, output side on the last pass
-            if (fu && p == 0) {
-                kf.pre = fu->pre; kf.pre_period = fu->pre_period;
-                if (fu->in_dev) { kf.in_dev = (const char*)fu->in_dev + b0 * ((size_t)32 << fu->in_log); kf.in_log = fu->in_log; }
-            }
-            if (fu && p == P - 1) { kf.post = fu->post; kf.post_period = fu->post_period; }
-            const size_t ldz = ((size_t)36 << TILE_LOG) + ((size_t)32 << (sp - 1));
-            const bool fused = kf.in_dev || kf.pre || kf.post;
-            // (the tables are in the signed 2^261 form whenever the signed passes are on: the unsigned lazy kernel must not read them --
-            //  a mixed TRH_NTT_PLAN such as "10,4" then runs its passes canonically)
-            const bool lazy_pass = lazy && !signed_enabled() && tlog == TILE_LOG && (int)log_n >= TILE_LOG && sp >= 2 && sp <= MAX_PASS_LOG;
-            const size_t ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
-#define TRH_LAUNCH_PASSZ(TWL, FUSE, LDS)                                                                                                       \
-    hipLaunchKernelGGL((ntt_passz_kernel<F, 2, TILE_LOG, TWL, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, o, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
-                       t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), direct, kf)
-            if (lazy_pass && sp <= 8 && !fused) TRH_LAUNCH_PASSZ(true, false, ldl);
-            else if (lazy_pass && sp <= 8) TRH_LAUNCH_PASSZ(true, true, ldl);
-            else if (lazy_pass && !fused) TRH_LAUNCH_PASSZ(false, false, ldz);
-            else if (lazy_pass) TRH_LAUNCH_PASSZ(false, true, ldz);
-#undef TRH_LAUNCH_PASSZ
-            else if ((int)log_n >= TILE_LOG && sp >= 2)
+            // (sizes up to one tile: canonical passes; ntt_can_fuse is false here, so there is nothing fused to apply)
+            if ((int)log_n >= TILE_LOG && sp >= 2)
                 hipLaunchKernelGGL((ntt_passg_kernel<F, 2, TILE_LOG>), grid, dim3(TILE >> 2), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
             else
                 hipLaunchKernelGGL((ntt_pass_kernel<F>), grid, dim3(NTT_THREADS), lds, s, src, o, (int)log_n, sp, log_ns, t->lo.as<uint4>(), t->hi.as<uint4>(), t->lo_bits);
@@ -1347,18 +807,15 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
 bool ntt_can_fuse(uint32_t log_n) {
     int sizes[8], P, tlog;
     plan_passes((int)log_n, sizes, &P, &tlog);
-    if (!lazy_enabled() || tlog != TILE_LOG || (int)log_n < TILE_LOG) return false;
+    if (tlog != TILE_LOG || (int)log_n < TILE_LOG) return false;
     for (int p = 0; p < P; ++p) if (sizes[p] < 2 || sizes[p] > MAX_PASS_LOG) return false;  // every pass must be a lazy one
-    static const int fuse = getenv("TRH_NTT_FUSE") ? atoi(getenv("TRH_NTT_FUSE")) : 1;
-    return fuse != 0;
+    return true;
 }
 
 bool ntt_can_fold_scale(uint32_t log_n) {
-    static const int direct_on = getenv("TRH_NTT_DIRECT") ? atoi(getenv("TRH_NTT_DIRECT")) : 1;
-    static const int fold_on = getenv("TRH_NTT_FOLD_SCALE") ? atoi(getenv("TRH_NTT_FOLD_SCALE")) : 1;  // 0: the factor as a separate multiplication on the last store (A/B)
     int sizes[8], P, tlog;
     plan_passes((int)log_n, sizes, &P, &tlog);
-    return fold_on && direct_on && ntt_can_fuse(log_n) && signed_enabled() && P >= 2 && ((size_t)36 << log_n) <= ((size_t)1 << 30) + ((size_t)1 << 27);
+    return ntt_can_fuse(log_n) && P >= 2 && ((size_t)36 << log_n) <= ((size_t)1 << 30) + ((size_t)1 << 27);
 }
 
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu, const u64* scale) {
@@ -1371,20 +828,11 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
-#define TRH_PASSZ_ATTR(FIELD, TWL, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passz_kernel<FIELD, 2, TILE_LOG, TWL, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
-        TRH_PASSZ_ATTR(FpParams, true, false); TRH_PASSZ_ATTR(FpParams, true, true); TRH_PASSZ_ATTR(FpParams, false, false); TRH_PASSZ_ATTR(FpParams, false, true);
-        TRH_PASSZ_ATTR(FqParams, true, false); TRH_PASSZ_ATTR(FqParams, true, true); TRH_PASSZ_ATTR(FqParams, false, false); TRH_PASSZ_ATTR(FqParams, false, true);
-#undef TRH_PASSZ_ATTR
 #define TRH_PASSY_ATTR(FIELD, TWM, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passy_kernel<FIELD, 2, TILE_LOG, TWM, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
-        TRH_PASSY_ATTR(FpParams, 1, false); TRH_PASSY_ATTR(FpParams, 1, true); TRH_PASSY_ATTR(FpParams, 0, false); TRH_PASSY_ATTR(FpParams, 0, true);
-        TRH_PASSY_ATTR(FqParams, 1, false); TRH_PASSY_ATTR(FqParams, 1, true); TRH_PASSY_ATTR(FqParams, 0, false); TRH_PASSY_ATTR(FqParams, 0, true);
+        TRH_PASSY_ATTR(FpParams, 1, false); TRH_PASSY_ATTR(FpParams, 1, true);
+        TRH_PASSY_ATTR(FqParams, 1, false); TRH_PASSY_ATTR(FqParams, 1, true);
         TRH_PASSY_ATTR(FpParams, 2, false); TRH_PASSY_ATTR(FpParams, 2, true); TRH_PASSY_ATTR(FqParams, 2, false); TRH_PASSY_ATTR(FqParams, 2, true);
 #undef TRH_PASSY_ATTR
-#define TRH_PASSP_ATTR(FIELD, TWM, MODE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passp_kernel<FIELD, TWM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
-#define TRH_PASSP_ATTRS(FIELD, TWM) TRH_PASSP_ATTR(FIELD, TWM, 9); TRH_PASSP_ATTR(FIELD, TWM, 11); TRH_PASSP_ATTR(FIELD, TWM, 10); TRH_PASSP_ATTR(FIELD, TWM, 2); TRH_PASSP_ATTR(FIELD, TWM, 6)
-        TRH_PASSP_ATTRS(FpParams, 1); TRH_PASSP_ATTRS(FpParams, 2); TRH_PASSP_ATTRS(FqParams, 1); TRH_PASSP_ATTRS(FqParams, 2);
-#undef TRH_PASSP_ATTRS
-#undef TRH_PASSP_ATTR
         ctx().attr_done |= ATTR_NTT;
     }
     if (field == TRH_FP) return ntt_device_t<FpParams>(a_dev, log_n, omega, batch, s, fu, scale);
@@ -1432,7 +880,7 @@ int ntt_block_scale(int field, const void* in_dev, void* out_dev, size_t transfo
 
 // log2 of the factor between the lazy domain of the passes and the memory format's Montgomery radix 2^256: the pointwise factors
 // fused into the passes (EvaluationDomain, domain.hip) are multiplied by 2^this
-int ntt_lazy_shift() { return signed_enabled() ? 5 : 14; }
+int ntt_lazy_shift() { return 5; }
 
 void ntt_release_tables() {
     Ctx& c = ctx();

@@ -15,7 +15,7 @@ sc = torch.from_numpy(synth.field_elements(0x77, n).view(np.int64)).cuda()
 st = torch.cuda.current_stream().cuda_stream
 api.set_window_bits(cbits)
 for _ in range(2):
-    bases.msm_dev(sc, n, stream=st)
+    res = bases.msm_dev(sc, n, stream=st)
 api.set_timing(True)
 acc = {}
 reps = 5
@@ -29,4 +29,6 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(reps):
     bases.msm_dev(sc, n, stream=st)
 torch.cuda.synchronize(); wall = (time.perf_counter() - t) / reps * 1e3
-print(f"n={n} {curve}", {k: round(v, 3) for k, v in acc.items()}, f"wall {wall:.3f} ms  {n / wall / 1e3:.1f} Mpairs/s")
+res2 = bases.msm_dev(sc, n, stream=st)
+assert (res == res2).all()
+print(f"n={n} {curve}", {k: round(v, 3) for k, v in acc.items()}, f"wall {wall:.3f} ms  {n / wall / 1e3:.1f} Mpairs/s  point {int(res[0]):016x}{int(res[4]):016x}")
