@@ -123,14 +123,35 @@ TRAFFIC_SOURCE = ("profiles/traffic.json: HBM bytes per launch = (2 x FETCH_SIZE
                   "TCC_EA0_RDREQ_32B = 0); WRITE_SIZE as reported.  Read from the file, NOT measured in this run")
 
 
+_TRAFFIC_META = {}
+
+
 def load_traffic(name: str):
-    """PMC-derived HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    """PMC-derived HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/), or None.  An entry is either a number (rounds
+    1 - 5) or {"bytes", "build", "kernel", "vgpr", "isa_instructions"}: the library build and the kernel's ISA the counters were collected on."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(name)
+            ent = json.load(fh).get(name)
     except Exception:
         return None
+    if isinstance(ent, dict):
+        _TRAFFIC_META[name] = {k: v for k, v in ent.items() if k != "bytes"}
+        return ent.get("bytes")
+    if ent is not None:
+        _TRAFFIC_META[name] = {"build": None}
+    return ent
+
+
+def traffic_provenance(name: str, version: str):
+    """what the traffic figure of `name` was measured on, and whether that is this library: `traffic_stale` is True when the entry carries no
+    build id or another one than trh_version() -- the kernels may have changed since the counters were collected"""
+    meta = dict(_TRAFFIC_META.get(name) or {})
+    m = __import__("re").search(r"build ([0-9a-f]+)", version or "")
+    cur = m.group(1) if m else None
+    meta["library_build"] = cur
+    meta["traffic_stale"] = not (meta.get("build") and cur and meta["build"] == cur)
+    return meta
 
 
 Q_MOD = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001  # Pallas scalar field
@@ -326,8 +347,9 @@ def native_replay(timeout_s: float = 600.0):
         return {"error": repr(exc)[:300]}
 
 
-def e2e_summary(e2e, native):
-    """the proof-level totals as the LAST key of the line (the driver keeps the tail of stdout): one number per way of using the library"""
+def e2e_summary(e2e, native, ntt=None, sweep=None, scaling=None):
+    """the proof-level totals as the LAST key of the line (the driver keeps the tail of stdout): one number per way of using the library,
+    the secondary metric (BASELINE's metric names the 2^22 NTT) and BASELINE config 2 (the 2^20 MSM)"""
     m = e2e["modes"] if e2e else {}
     res, bat, lit = m.get("resident", {}), m.get("dropin-batched", {}), m.get("dropin", {})
     nat_ok = bool(native) and "error" not in native
@@ -349,6 +371,19 @@ def e2e_summary(e2e, native):
         "checked_against_oracle": sum(int(v.get("checked_against_oracle", 0)) for v in m.values()),
         "check": "ok" if m and all(str(v.get("check", "")).startswith("oracle limb-for-limb ok") for v in m.values()) and (not nat_ok or native.get("checks_failed") == 0) else "see e2e",
     }
+    first = (res.get("first_proof_in_process") or {}).get("gpu_ms_total")
+    if first and res.get("gpu_ms_total"):
+        out["first_proof_over_second"] = round(first / res["gpu_ms_total"], 4)
+    if ntt:
+        out["ntt_2_22_elems_per_s"] = ntt.get("value")
+        out["ntt_2_22_ms"] = ntt.get("ms_per_transform")
+        out["ntt_frac"] = (ntt.get("roofline") or {}).get("frac")
+    for ent in sweep or []:
+        if ent.get("op") == "msm" and ent.get("log_n") == 20:
+            out["msm_2_20_pairs_per_s"] = ent.get("value")
+            out["msm_2_20_ms"] = ent.get("ms")
+    if scaling:
+        out["e2e_scaling"] = scaling
     if native and "error" in native:
         out["native_error"] = native["error"]
     return out
@@ -444,7 +479,8 @@ def main():
     collective = {"backend": None, "world": world, "devices": [my_dev], "ok": True}
     # under a launcher (WORLD_SIZE set) the process group comes up at EVERY world size: a one-rank RCCL group on one MI355X is the
     # first contact of this code with RCCL that a one-GPU box allows (tests/test_gpu_native.py::test_bench_one_rank_rccl_first_contact)
-    launched = "WORLD_SIZE" in os.environ
+    # (a bare WORLD_SIZE=1 exported by a job scheduler, without a rendezvous address, is not a launcher: such a run benchmarks as one process)
+    launched = "WORLD_SIZE" in os.environ and ("MASTER_PORT" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ)
     if world > 1 or launched:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -748,6 +784,36 @@ def main():
                 import datetime
                 store.wait(["trh_single_process_done"], datetime.timedelta(seconds=900))  # longer than the child's own timeout
 
+    # ---- N > 1: one k = 18 resident proof PER GPU (the reference's multi-item workload is N independent proofs, /root/reference/src/test_utils.rs:37-54:
+    #      inputs.iter().map(create_proof)); replicas, no data-path collective -- only the MAX over ranks of the proof's GPU time.  Per rank:
+    #      ~25 GB of resident columns + 1.6 GB of fixed-base tables
+    e2e_scaling = None
+    if world > 1 and not args.no_sweep and not args.no_e2e:
+        torch.cuda.empty_cache()
+        mine, wall, err = -1.0, -1.0, None
+        try:
+            from tiny_ram_halo2_amd import replay
+            fence()
+            t0 = time.perf_counter()
+            r = replay.run(32, batch=64, hook=None, device=dev_index, verbose=False, columns="witness", keygen=False, gates_dir=os.path.join(ROOT, "tests", "golden"))
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3
+            mine = float(r["gpu_ms_total"])
+        except Exception as exc:  # every rank still takes part in the reductions below
+            err = repr(exc)[:300]
+        ok_all = -max_over_ranks(-(1.0 if mine > 0 else 0.0))  # MIN over ranks
+        slow = max_over_ranks(mine)
+        slow_wall = max_over_ranks(wall)
+        torch.cuda.empty_cache()
+        if rank == 0:
+            if ok_all > 0:
+                e2e_scaling = {"proofs_per_s": world / (slow * 1e-3), "ms_per_proof_slowest_rank": slow, "n_gpus": world,
+                               "mode": "one k = 18 TinyRamCircuit<32, 8> schedule replay per GPU, polynomials resident (replicas: no collective but the MAX over ranks)",
+                               "clock": "replay.py (Python mirror): HIP events around every step of the proof, summed",
+                               "wall_ms_slowest_rank_incl_host_input_generation": slow_wall, "ms_this_rank": mine}
+            else:
+                e2e_scaling = {"error": err or "a rank failed its replay", "n_gpus": world}
+
     if rank == 0:
         roof, valu = msm_roofline(n if n <= (1 << 25) else (1 << 25), acc, tm, load_traffic(f"msm_accumulate_2^{max(n - 1, 1).bit_length()}"))
         shape = f"2^{args.log_n} pairs per GPU; global size {world}*2^{args.log_n}" if mode == "weak" else f"2^{args.global_log_n} pairs in total, {n} per GPU"
@@ -783,8 +849,14 @@ def main():
             "secondary": ntt,
         }
         out["roofline"]["traffic_source"] = TRAFFIC_SOURCE
+        version = api.lib().trh_version().decode()
+        out["library"] = version
+        out["roofline"].update(traffic_provenance(f"msm_accumulate_2^{max(n - 1, 1).bit_length()}", version))
         if ntt is not None:
             ntt["roofline"]["traffic_source"] = TRAFFIC_SOURCE
+            ntt["roofline"].update(traffic_provenance(f"ntt_fp_2^{ln}", version))
+        for ent in sweep or []:
+            ent["roofline"].update(traffic_provenance(("msm_accumulate_2^%d" if ent["op"] == "msm" else "ntt_fp_2^%d") % ent["log_n"], version))
         if sweep is not None:
             out["sweep"] = sweep
         if e2e is not None:
@@ -810,7 +882,9 @@ def main():
                 failed.append(f"msm 2^{cpu_log_n} vs oracle")
             out["check"] = (f"oracle limb-for-limb ok (cpu_ref.best_multiexp, 2^{cpu_log_n}) + " + str(check)) if ok else "MISMATCH vs oracle"
         if e2e is not None:  # last key: the tail of the line is what the driver's record keeps
-            out["e2e_summary"] = e2e_summary(e2e, native_replay())
+            out["e2e_summary"] = e2e_summary(e2e, native_replay(), ntt, sweep)
+        elif e2e_scaling is not None:  # N > 1: one k = 18 proof per GPU (replicas), the proof-level scaling figure as the tail of the line
+            out["e2e_summary"] = e2e_summary(None, None, ntt, None, e2e_scaling)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1 or launched:

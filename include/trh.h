@@ -155,6 +155,9 @@ void trh_bases_destroy(trh_bases_t b);
  * group elements; MSMs over a sub-range (offset != 0 or n < len) keep using the per-window path.           */
 int trh_bases_precompute(trh_bases_t b, int window_bits);   /* must not run while an MSM over `b` is in flight on another context; the same holds for trh_bases_destroy */
 int trh_bases_precomputed_window_bits(trh_bases_t b); /* 0 when no table is attached */
+/* sizes the calling context's MSM scratch for batches of `batch` MSMs (commitments) over the first n bases of the set, without running one:
+ * setup-time, so that the first commitment batch of a process allocates nothing (see trh_domain_reserve) */
+int trh_bases_reserve(trh_bases_t b, size_t n, size_t batch);
 
 /* MSM over bases[offset .. offset+n) with host scalars (Params::commit / commit_lagrange) */
 int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n,
@@ -216,6 +219,10 @@ int trh_field_scale_rows_dev(int field, void* a_dev, size_t rows, size_t row_len
  * (or 2^extended_k) field elements stored back to back in device memory.                        */
 typedef struct trh_domain* trh_domain_t;
 int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain_t* out);
+/* Setup-time sizing, so that the FIRST proof of a process runs like every later one (the reference proves 1 - 10 circuits per process,
+ * /root/reference/src/test_utils.rs:37-54, and its user waits for the first): the transforms' twiddle / coset-block tables (also built by
+ * trh_domain_create) and their scratch for batches of `batch` polynomials, on the calling thread's context.                              */
+int trh_domain_reserve(trh_domain_t d, size_t batch);
 void trh_domain_destroy(trh_domain_t d);
 uint32_t trh_domain_extended_k(trh_domain_t d);
 /* which: 0 omega, 1 omega_inv, 2 extended_omega, 3 extended_omega_inv, 4 ifft_divisor,

@@ -171,6 +171,8 @@ public:
     trh_bases_t handle() const { return h_; }
     size_t len() const { return trh_bases_len(h_); }
     int precompute(int window_bits = 0) { check(trh_bases_precompute(h_, window_bits), "bases_precompute"); return trh_bases_precomputed_window_bits(h_); }
+    // setup-time: the calling context's MSM scratch for batches of `batch` MSMs over the first n bases (the first batch then allocates nothing)
+    void reserve(size_t n, size_t batch) const { check(trh_bases_reserve(h_, n, batch), "bases_reserve"); }
     std::vector<Affine> download() const { std::vector<Affine> v(len()); check(trh_bases_download(h_, 0, v.size(), (uint64_t*)v.data()), "bases_download"); return v; }
     Point msm(const std::vector<Limbs>& scalars, size_t offset = 0) const {
         Point out; check(trh_msm(h_, offset, (const uint64_t*)scalars.data(), scalars.size(), 1, (uint64_t*)&out), "msm"); return out;
@@ -217,6 +219,12 @@ public:
     const Bases& g() const { return g_; }
     const Bases& g_lagrange() const { return g_lagrange_; }
     const Bases& ipa_bases() const { return ipa_.handle() ? ipa_ : g_; }  // g || w || u with tables when precompute() built it
+    // setup-time sizing of the calling context's scratch for commit batches of `batch` columns and for the opening's round MSMs
+    void reserve(size_t batch) const {
+        g_.reserve(n + 1, batch);
+        g_lagrange_.reserve(n + 1, batch);
+        if (ipa_.handle()) ipa_.reserve(n + 2, 2);
+    }
 
     Curve curve;
     uint32_t k;
@@ -253,6 +261,8 @@ public:
     EvaluationDomain& operator=(const EvaluationDomain&) = delete;
     ~EvaluationDomain() { if (d_) trh_domain_destroy(d_); }
     size_t extended_len() const { return (size_t)1 << extended_k; }
+    // setup-time: tables and scratch of the per-column transforms for batches of `batch` polynomials on the calling context
+    void reserve(size_t batch) const { check(trh_domain_reserve(d_, batch), "domain_reserve"); }
     Limbs constant(int which) const { Limbs v; check(trh_domain_constant(d_, which, v.data()), "domain_constant"); return v; }
     Limbs get_omega() const { return constant(0); }
     Limbs get_extended_omega() const { return constant(2); }

@@ -224,3 +224,20 @@ def expr_to_tuple(e):
     if isinstance(e, expr.Product):
         return ("prod", expr_to_tuple(e.a), expr_to_tuple(e.b))
     return ("scaled", expr_to_tuple(e.e), e.value)
+
+
+# ---- library options are fixed while a context exists (trh_set_option / TRH_<NAME> read once): a test that needs another setting runs the
+#      computation in a fresh process and compares what it prints with this process's result -----------------------------------------------
+def run_with_options(script: str, env: dict, timeout: int = 600) -> str:
+    """runs `script` (python source; the repo root and tests/ are on sys.path) in a child process with `env` added; returns its stdout"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prologue = ("import sys\n" + "".join(f"sys.path.insert(0, {p!r})\n" for p in (os.path.join(root, "tests"), os.path.join(root, "oracle"), root)))
+    r = subprocess.run([sys.executable, "-c", prologue + script], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def point_hex(p) -> str:
+    return "".join(f"{int(v):016x}" for v in np.asarray(p, dtype=np.uint64).reshape(-1))

@@ -182,3 +182,49 @@ def test_integration_md_rust_block_matches_the_header():
         assert len(rargs) == len(cargs), f"{name}: {len(rargs)} arguments in INTEGRATION.md, {len(cargs)} in trh.h"
         assert rargs == cargs, f"{name}: argument kinds {rargs} in INTEGRATION.md vs {cargs} in trh.h"
         assert rret == cret, f"{name}: returns {rret} in INTEGRATION.md, {cret} in trh.h"
+
+
+OPTIONS_SCRIPT = r"""
+from tiny_ram_halo2_amd import api
+lib = api.lib()
+assert api.get_option("pool_mb") == 7 and api.get_option("reduce_q4") == 0      # the environment, read once
+assert api.get_option("stage_slot_mb") == 16                                     # 9999 is out of range: the default stays
+api.set_option("pool_mb", 123)
+assert api.get_option("pool_mb") == 123                                          # an explicit call overrides the environment
+import os
+os.environ["TRH_POOL_MB"] = "55"                                                 # not read again
+assert api.get_option("pool_mb") == 123
+for name, value in (("no_such_option", "1"), ("bin_sort", "2"), ("bin_sort", "x"), ("copy_threads", "65"), ("trace", "")):
+    assert lib.trh_set_option(name.encode(), value.encode()) == -1, (name, value)
+    assert name.encode() in lib.trh_last_error()
+assert lib.trh_set_option(None, b"1") == -1
+names = ["pool_mb", "stage_slot_mb", "copy_threads", "bases_cache", "force_no_peer", "roctx", "trace", "msm_chunk_gb", "sparse", "reduce_q4", "bin_sort", "selftest"]
+for n in names:
+    api.get_option(n)
+print("options ok", len(names))
+"""
+
+
+def test_options_are_parsed_once_and_settable_without_a_device():
+    """trh_set_option / trh_get_option (include/trh.h): TRH_<NAME> is read once, an explicit call overrides it, unknown names and values
+    out of range are TRH_EINVAL with the name in trh_last_error(); no device is needed.  (That options are fixed while a context exists
+    is a -m gpu test: tests/test_gpu_native.py.)"""
+    from common import run_with_options
+    out = run_with_options(OPTIONS_SCRIPT, {"TRH_POOL_MB": "7", "TRH_REDUCE_Q4": "0", "TRH_STAGE_SLOT_MB": "9999"})
+    assert "options ok 12" in out
+
+
+def test_no_getenv_outside_the_option_parser():
+    """the library reads the environment in ONE place (capi.hip opt_load_env): a getenv on a call path would race a setenv elsewhere in a
+    multi-threaded host"""
+    import glob
+    import re
+    hits = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "tiny-ram-halo2_amd", "csrc", "*"))):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for i, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bgetenv\s*\(", code):
+                hits.append((os.path.basename(f), i))
+    assert hits == [h for h in hits if h[0] == "capi.hip"] and len(hits) == 1, hits

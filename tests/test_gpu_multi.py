@@ -2,7 +2,7 @@
 times makes every shard its own context -- own stream, own pinned rings, own copy threads -- so the code that feeds and collects G
 devices runs for real, only the links are shared (the reference proves in one process, /root/reference/src/test_utils.rs:37-54).
   * host scalars into a range-sharded base set: one uploader thread per shard (csrc/capi.hip msm_sharded), same point as one context;
-  * TRH_FORCE_NO_PEER=1: device-resident scalars reach every shard through pinned host memory (stage_d2d_via_host), same point;
+  * option force_no_peer = 1 (a subprocess): device-resident scalars reach every shard through pinned host memory (stage_d2d_via_host), same point;
   * the block pool behind trh_malloc / trh_free with a tiny cap (TRH_POOL_MB=1, a subprocess): eviction, double free, trim.
 The group is [0] * 8 everywhere in the suite (trh_init_multi accepts only the list it was first given)."""
 import ctypes
@@ -99,35 +99,48 @@ def test_sharded_host_upload_is_not_serialised(group):
     b.destroy()
 
 
-def test_forced_no_peer_hand_over(group, monkeypatch):
-    """TRH_FORCE_NO_PEER=1: device-resident scalars are handed to EVERY shard through the destination context's pinned ring
-    (D2H on the caller's stream, H2D on the shard's, chained by events) -- the path a box without peer access takes; the point equals
-    the peer / same-device path's and the ring's byte counters moved"""
+NO_PEER_SCRIPT = r"""
+import numpy as np, torch
+from tiny_ram_halo2_amd import api, synth
+from common import point_hex
+G = 8
+api.init_multi([0] * G)
+assert api.get_option("force_no_peer") == 1 and api.lib().trh_group_peer_access() == 0
+api.set_shard_min(1 << 12)
+curve, n = "pallas", (1 << 21) + 77
+d = torch.from_numpy(synth.field_elements(0x5A4F, n).view(np.int64)).cuda()
+b = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+assert b.shards() == G
+api.io_stats(reset=True)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    d2 = d.clone()
+    got = b.msm_dev(d2, n, stream=s.cuda_stream)
+    again = b.msm_dev(d2, n, stream=s.cuda_stream)   # the ring is reused straight away
+assert (got == again).all()
+io = api.io_stats()   # shard 0 is the default context: its share went through its ring twice
+assert io["h2d_bytes"] >= 2 * (n // G) * 32 and io["d2h_bytes"] >= 2 * (n // G) * 32, io
+print("full", point_hex(got))
+lo, cnt = n // 5, n // 2
+print("part", point_hex(b.msm_dev(d[lo:lo + cnt].contiguous(), cnt, offset=lo)))
+"""
+
+
+def test_forced_no_peer_hand_over(group):
+    """option force_no_peer = 1 (a fresh process: options are fixed while a context exists): device-resident scalars are handed to EVERY
+    shard through the destination context's pinned ring (D2H on the caller's stream, H2D on the shard's, chained by events) -- the path
+    a box without peer access takes; the points equal the peer / same-device path's of this process and the ring's byte counters moved"""
+    from common import point_hex, run_with_options
     curve, n = "pallas", (1 << 21) + 77
-    sc = synth.field_elements(0x5A4F, n)
-    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    d = torch.from_numpy(synth.field_elements(0x5A4F, n).view(np.int64)).cuda()
     b = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
     assert b.shards() == G
     want = b.msm_dev(d, n)
-    api.io_stats(reset=True)
-    monkeypatch.setenv("TRH_FORCE_NO_PEER", "1")
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        d2 = d.clone()
-        got = b.msm_dev(d2, n, stream=s.cuda_stream)
-        again = b.msm_dev(d2, n, stream=s.cuda_stream)   # the ring is reused straight away
-    monkeypatch.delenv("TRH_FORCE_NO_PEER")
-    assert (got == want).all() and (again == want).all()
-    io = api.io_stats()   # shard 0 is the default context: its share went through its ring twice
-    assert io["h2d_bytes"] >= 2 * (n // G) * 32 and io["d2h_bytes"] >= 2 * (n // G) * 32, io
-    assert (b.msm_dev(d, n) == want).all()   # and the direct path still works afterwards
-    # a sub-range with an offset, forced again
-    monkeypatch.setenv("TRH_FORCE_NO_PEER", "1")
     lo, cnt = n // 5, n // 2
-    part = b.msm_dev(d[lo:lo + cnt].contiguous(), cnt, offset=lo)
-    monkeypatch.delenv("TRH_FORCE_NO_PEER")
-    assert (part == b.msm_dev(d[lo:lo + cnt].contiguous(), cnt, offset=lo)).all()
+    want_part = b.msm_dev(d[lo:lo + cnt].contiguous(), cnt, offset=lo)
     b.destroy()
+    out = dict(line.split() for line in run_with_options(NO_PEER_SCRIPT, {"TRH_FORCE_NO_PEER": "1"}).splitlines() if line.startswith(("full", "part")))
+    assert out["full"] == point_hex(want) and out["part"] == point_hex(want_part)
 
 
 POOL_SCRIPT = r"""

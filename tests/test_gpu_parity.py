@@ -392,26 +392,35 @@ def test_msm_witness_like_scalars(kind, log_n):
     assert (got[:8] == want).all()
 
 
-def test_msm_bin_sort_equals_chunked_passes(monkeypatch):
-    """the whole-bin LDS bucket sort and the chunked passes it replaces (TRH_NO_BIN_SORT=1; also its fallback for oversize bins)
-    sort the same entries: same point, single MSM and fixed-base batch"""
+BIN_SORT_SCRIPT = r"""
+import numpy as np
+from tiny_ram_halo2_amd import api, synth
+from common import point_hex
+api.init(0)
+assert api.get_option("bin_sort") == 0
+curve, n = "pallas", (1 << 20) + 7
+bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
+print("lone", point_hex(bases.msm_dev(api.DeviceBuffer.from_host(synth.field_elements(0xB175, n)), n)))
+m = 1 << 16
+small = api.Bases.generate(curve, 5, 9, m)
+small.precompute(0)
+print("batch", point_hex(small.msm_batch_dev(api.DeviceBuffer.from_host(synth.field_elements(0xB176, 4 * m)), m, 4)))
+"""
+
+
+def test_msm_bin_sort_equals_chunked_passes():
+    """the whole-bin LDS bucket sort and the chunked passes it replaces (option bin_sort = 0, a fresh process: options are fixed while a
+    context exists; also the fallback for oversize bins) sort the same entries: same point, single MSM and fixed-base batch"""
+    from common import point_hex, run_with_options
     curve, n = "pallas", (1 << 20) + 7
     bases = api.Bases.generate(curve, synth.BASE_S0, synth.BASE_D, n)
-    sc = synth.field_elements(0xB175, n)
-    d = api.DeviceBuffer.from_host(sc)
-    a = bases.msm_dev(d, n)
-    monkeypatch.setenv("TRH_NO_BIN_SORT", "1")
-    b = bases.msm_dev(d, n)
-    monkeypatch.delenv("TRH_NO_BIN_SORT")
-    assert (a == b).all()
+    a = bases.msm_dev(api.DeviceBuffer.from_host(synth.field_elements(0xB175, n)), n)
     m = 1 << 16
     small = api.Bases.generate(curve, 5, 9, m)
     small.precompute(0)
-    d4 = api.DeviceBuffer.from_host(synth.field_elements(0xB176, 4 * m))
-    a = small.msm_batch_dev(d4, m, 4)
-    monkeypatch.setenv("TRH_NO_BIN_SORT", "1")
-    b = small.msm_batch_dev(d4, m, 4)
-    assert (a == b).all()
+    b = small.msm_batch_dev(api.DeviceBuffer.from_host(synth.field_elements(0xB176, 4 * m)), m, 4)
+    out = dict(line.split() for line in run_with_options(BIN_SORT_SCRIPT, {"TRH_BIN_SORT": "0"}).splitlines() if line.startswith(("lone", "batch")))
+    assert out["lone"] == point_hex(a) and out["batch"] == point_hex(b)
 
 
 # ---------------------------------------------------------------------------------------

@@ -342,18 +342,3 @@ def test_extended_domain_as_coset_blocks(field, k, j):
     # without the division: h's own values in, h out
     d_hv = torch.from_numpy(np.ascontiguousarray(np.stack([h_ext[r::step] for r in range(D)])).view(np.int64)).cuda()
     assert (dom.blocks_to_quotient(d_hv, divide_by_vanishing=False).cpu().numpy().view(np.uint64) == h).all()
-
-
-def test_pipelined_ntt_passes_in_a_subprocess():
-    """TRH_NTT_PIPE=1 (read once per process): every signed pass it can take runs as the persistent software-pipelined ntt_passp_kernel
-    (LDS-DMA of tile t + 1 under the last round of tile t; round 5's A/B, off by default because it does not win) -- the transform and
-    domain tests of this file and of test_gpu_parity.py against the same oracles"""
-    import subprocess
-    import sys
-    if os.environ.get("TRH_NTT_PIPE_NESTED"):
-        pytest.skip("already inside the TRH_NTT_PIPE=1 run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TRH_NTT_PIPE="1", TRH_NTT_PIPE_NESTED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_poly.py"), os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "ntt or domain or coset or fft"], capture_output=True, text=True, timeout=1200, env=env, cwd=root)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -171,18 +171,3 @@ def test_unit_digits_and_tiny_columns_k14():
     for i in (0, 2, 4, 5, 7):
         assert (got[i] == lone).all(), i
     bases.destroy()
-
-
-def test_compact_pipeline_for_every_sparse_chunk_in_a_subprocess():
-    """TRH_SPARSE=2 (read once per process): chunks that are not flag-like go through the compact pipeline instead of the plain one (the
-    round-4 A/B switch; by default only the general columns of a flag-like chunk take it) -- the k = 14 cases above, same oracle checks"""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("TRH_SPARSE_NESTED"):
-        pytest.skip("already inside the TRH_SPARSE=2 run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TRH_SPARSE="2", TRH_SPARSE_NESTED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sparse.py"), "-q", "-x", "-m", "gpu", "-k", "k14"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

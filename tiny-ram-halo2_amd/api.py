@@ -96,6 +96,7 @@ _SIGNATURES = {
     "trh_bases_destroy": ([_vp], None),
     "trh_bases_precompute": ([_vp, ctypes.c_int], ctypes.c_int),
     "trh_bases_precomputed_window_bits": ([_vp], ctypes.c_int),
+    "trh_bases_reserve": ([_vp, ctypes.c_size_t, ctypes.c_size_t], ctypes.c_int),
     "trh_msm": ([_vp, ctypes.c_size_t, _u64p, ctypes.c_size_t, ctypes.c_int, _u64p], ctypes.c_int),
     "trh_msm_dev": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp, _u64p], ctypes.c_int),
     "trh_msm_dev_enqueue": ([_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, _vp], ctypes.c_int),
@@ -115,6 +116,7 @@ _SIGNATURES = {
     "trh_point_fft_dev": ([ctypes.c_int, _vp, ctypes.c_uint32, _u64p, _u64p, _vp], ctypes.c_int),
     "trh_domain_create": ([ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)], ctypes.c_int),
     "trh_domain_destroy": ([_vp], None),
+    "trh_domain_reserve": ([_vp, ctypes.c_size_t], ctypes.c_int),
     "trh_domain_extended_k": ([_vp], ctypes.c_uint32),
     "trh_domain_constant": ([_vp, ctypes.c_int, _u64p], ctypes.c_int),
     "trh_domain_lagrange_to_coeff": ([_vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <thread>
 
@@ -239,6 +240,38 @@ static void destroy_ctx(Ctx* c) {
 }
 
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s);
+
+// selftest.hip: the known-answer test of the device arithmetic, once per device and process, on the context just created (made current
+// for the calling thread while it runs).  On a mismatch the caller destroys the context and returns TRH_ESELFTEST.
+int selftest_run();
+static std::mutex g_selftest_mu;
+static std::set<int> g_selftest_done;
+static int selftest_once(Ctx* c) {
+    if (!opt().selftest) return TRH_OK;
+    std::lock_guard<std::mutex> lk(g_selftest_mu);
+    if (g_selftest_done.count(c->device)) return TRH_OK;
+    Ctx* prev = t_bound;
+    t_bound = c;
+    const int rc = selftest_run();
+    t_bound = prev;
+    if (rc == TRH_OK) g_selftest_done.insert(c->device);
+    return rc;
+}
+// create_ctx + self-test; a context that fails it never reaches the caller
+static int create_checked_ctx(int device, Ctx** out) {
+    Ctx* c = nullptr;
+    TRH_TRY(create_ctx(device, &c));
+    const int rc = selftest_once(c);
+    if (rc != TRH_OK) {
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", g_err);
+        destroy_ctx(c);
+        set_error("%s", msg);
+        return rc;
+    }
+    *out = c;
+    return TRH_OK;
+}
 
 namespace {
 
@@ -697,7 +730,7 @@ int trh_init(int device) {
         return TRH_EINVAL;
     }
     Ctx* c = nullptr;
-    int rc = create_ctx(device, &c);
+    int rc = create_checked_ctx(device, &c);
     if (rc != TRH_OK) {
         char msg[400];
         snprintf(msg, sizeof(msg), "%s", g_err);
@@ -726,7 +759,7 @@ int trh_init_multi(const int* devices, int n_devices) {
     if (g_default) made.push_back(g_default);
     for (int i = (int)made.size(); i < n_devices; ++i) {  // the same device may be listed more than once: two lanes on one GPU
         Ctx* c = nullptr;
-        const int rc = create_ctx(devices[i], &c);
+        const int rc = create_checked_ctx(devices[i], &c);
         if (rc != TRH_OK) {
             for (Ctx* m : made) if (m != g_default) destroy_ctx(m);
             char msg[400];
@@ -785,7 +818,7 @@ void trh_shutdown(void) {
 int trh_ctx_create(int device, trh_ctx_t* out) {
     if (!out) { set_error("ctx_create: null pointer"); return TRH_EINVAL; }
     Ctx* c = nullptr;
-    TRH_TRY(create_ctx(device, &c));
+    TRH_TRY(create_checked_ctx(device, &c));
     *out = static_cast<trh_ctx*>(c);
     return TRH_OK;
 }
@@ -932,6 +965,22 @@ int trh_bases_precompute(trh_bases_t b, int window_bits) {
     return TRH_OK;
 }
 int trh_bases_precomputed_window_bits(trh_bases_t b) { return b && b->d_table ? b->fb.c : 0; }
+
+int trh_bases_reserve(trh_bases_t b, size_t n, size_t batch) {
+    if (!b) { set_error("bases_reserve: null handle"); return TRH_EINVAL; }
+    if (n == 0 || n > b->n || batch == 0) { set_error("bases_reserve: n = %zu, batch = %zu over a set of %zu bases", n, batch, b->n); return TRH_EINVAL; }
+    if (!b->shards.empty()) return TRH_OK;  // every shard's context sizes itself at its first MSM
+    TRH_ENTER(0);
+    Range range("trh_bases_reserve");
+    TRH_TRY(single_device(b, "bases_reserve"));
+    Ctx& c = ctx();
+    if (c.msm.pending_curve >= 0) { set_error("bases_reserve: this context has an enqueued MSM that was not finished"); return TRH_EBUSY; }
+    TRH_TRY(c.msm.tails.ensure(batch * 32));
+    c.msm.reserve_only = true;
+    const int rc = msm_enqueue(b->curve, b->d_xy, lazy_bases(b, 0, nullptr), b->d_xy /* never read */, n, batch, n, 1, nullptr, fixed_base(b, 0, n), batch > 1 ? c.msm.tails.p : nullptr);
+    c.msm.reserve_only = false;
+    return rc;
+}
 
 int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n, int mont, uint64_t out[12]) {
     TRH_TRY(msm_args(bases, offset, scalars_host, n, 1, out));

@@ -124,6 +124,7 @@ struct MsmScratch {
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
     bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped, the combine takes the quad form
+    bool reserve_only = false;  // msm_enqueue sizes the scratch of the described launch and returns before the first kernel (trh_bases_reserve)
     bool no_sparse_vote = false;  // the sparse classifier is skipped and nothing else changes (the shards of a range-sharded MSM: its host synchronisation would hold back the other shards)
     void* sp_host = nullptr;    // pinned: the sparse path's list counters as read back, then the dense flags it sends down
     void* host_sums = nullptr;  // pinned mirror of window_sums
@@ -138,14 +139,6 @@ struct MsmScratch {
     u64 tile_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    // window-group pipeline of a lone large MSM (msm.hip): the sort of group g + 1 and the reduction of group g - 1 run on their own
-    // streams beside the accumulation of group g
-    static constexpr int MAX_GROUPS = 8;
-    hipStream_t g_sort = nullptr, g_tail = nullptr;
-    hipEvent_t g_front = nullptr, g_done = nullptr;
-    hipEvent_t g_sorted[MAX_GROUPS] = {}, g_acc[MAX_GROUPS] = {};
-    hipEvent_t g_t0[MAX_GROUPS] = {}, g_t1[MAX_GROUPS] = {};  // timing: around each group's accumulation launch
-    int g_timed = 0;                                          // groups of the last timed MSM (0: the single-stream pipeline)
 };
 
 // Host <-> device staging of the host-pointer entry points (hostio.hip): pinned slot rings + three streams.  Measured on the
@@ -307,6 +300,8 @@ int ntt_block_scale(int field, const void* in_dev, void* out_dev, size_t transfo
 bool ntt_can_fuse(uint32_t log_n);
 int ntt_lazy_shift();
 int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, hipStream_t s, const NttFusion* fu = nullptr, const u64* scale = nullptr);
+// the tables of that transform (built if this context does not hold them yet) and the scratch for `batch` transforms at a time, without running one
+int ntt_prepare(int field, uint32_t log_n, const u64 omega[4], const u64* scale, size_t batch, uint32_t blocks, hipStream_t s);
 // whether a transform of this size can take a constant factor (Montgomery words) in its last pass's table: ntt_device(..., scale) then returns a . scale
 bool ntt_can_fold_scale(uint32_t log_n);
 void ntt_release_tables();

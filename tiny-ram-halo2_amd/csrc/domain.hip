@@ -208,6 +208,23 @@ int check(const trh_domain* d, const void* a) {
     return TRH_OK;
 }
 
+// (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: one table per block count, built at first use (or by trh_domain_reserve)
+int pre_block_table(trh_domain* d, uint32_t n_blocks, hipStream_t s, const void** out) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->pre_sub.find(n_blocks);
+    if (it == d->pre_sub.end()) {
+        void* t = nullptr;
+        TRH_HIP_TRY(hipMalloc(&t, ntt_block_table_bytes(n_blocks, d->k)));
+        const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
+        int rc = ntt_block_table_build(d->field, t, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s);
+        if (rc == TRH_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("domain blocks: table kernel failed"); rc = TRH_EHIP; }  // complete before another context's stream may read it
+        if (rc != TRH_OK) { (void)hipFree(t); return rc; }
+        it = d->pre_sub.emplace(n_blocks, t).first;
+    }
+    *out = it->second;
+    return TRH_OK;
+}
+
 }  // namespace
 }  // namespace trh
 
@@ -215,6 +232,7 @@ using namespace trh;
 
 extern "C" {
 
+int trh_domain_reserve(trh_domain* d, size_t batch);
 int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain** out) {
     TRH_TRY(require_init());
     if (field != TRH_FP && field != TRH_FQ) { set_error("unknown field id %d", field); return TRH_EINVAL; }
@@ -230,7 +248,8 @@ int trh_domain_create(int field, uint32_t j, uint32_t k, trh_domain** out) {
     Range range("trh_domain_create");
     d->device = ctx().device;
     int rc = upload_tables(d);
-    if (rc != TRH_OK) { delete d; return rc; }
+    if (rc == TRH_OK) rc = trh_domain_reserve(d, 1);  // the transforms' tables now, not inside the first proof's steps
+    if (rc != TRH_OK) { trh_domain_destroy(d); return rc; }
     *out = d;
     return TRH_OK;
 }
@@ -249,6 +268,30 @@ int trh_domain_constant(trh_domain* d, int which, uint64_t out[4]) {
     const FeMem* src[8] = {&d->omega, &d->omega_inv, &d->extended_omega, &d->extended_omega_inv, &d->ifft_divisor, &d->extended_ifft_divisor,
                            &d->into_coset[1], &d->into_coset[2]};
     memcpy(out, src[which], 32);
+    return TRH_OK;
+}
+
+/* Tables and scratch of the per-column steps for batches of `batch` polynomials on the CALLING context (twiddle tables are per context,
+ * the coset-block tables per domain): lagrange_to_coeff, coeff_to_extended_blocks with j - 1 blocks, blocks_to_quotient.  What the first
+ * proof of a process would otherwise build and allocate inside its own steps (159.6 ms for the first proof against
+ * 151.1 for the second); trh_domain_create calls it with batch = 1 (tables only). */
+int trh_domain_reserve(trh_domain* d, size_t batch) {
+    if (!d) { set_error("domain_reserve: null handle"); return TRH_EINVAL; }
+    if (batch == 0) batch = 1;
+    TRH_ENTER(0);
+    Range range("trh_domain_reserve");
+    if (!ntt_can_fuse(d->k)) return TRH_OK;  // small domains: canonical passes, nothing lasting to build
+    hipStream_t s = nullptr;
+    const uint32_t D = d->j - 1, nblk = 1u << (d->extended_k - d->k);
+    TRH_TRY(ntt_prepare(d->field, d->k, (const u64*)&d->omega_inv, ntt_can_fold_scale(d->k) ? (const u64*)&d->ifft_divisor : nullptr, batch, 0, s));
+    if (D <= 8 && D <= nblk) {
+        TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
+        const void* pre = nullptr;
+        TRH_TRY(pre_block_table(d, D, s, &pre));
+        TRH_TRY(ntt_prepare(d->field, d->k, (const u64*)&d->omega, nullptr, batch * D, D, s));
+        TRH_TRY(ntt_prepare(d->field, d->k, (const u64*)&d->omega_inv, nullptr, D, D, s));
+    }
+    TRH_HIP_TRY(hipStreamSynchronize(s));
     return TRH_OK;
 }
 
@@ -342,22 +385,8 @@ int trh_domain_coeff_to_extended_blocks(trh_domain* d, const void* coeff_dev, vo
     (void)c;
     hipStream_t s = (hipStream_t)stream;
     TRH_TRY(d->field == TRH_FP ? build_blocks<FpParams>(d, s) : build_blocks<FqParams>(d, s));
-    // (zeta extended_omega^r)^j for r < n_blocks, j < 2^k: one table per block count, built at first use
     const void* pre_tab = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(d->mu);
-        auto it = d->pre_sub.find(n_blocks);
-        if (it == d->pre_sub.end()) {
-            void* t = nullptr;
-            TRH_HIP_TRY(hipMalloc(&t, ntt_block_table_bytes(n_blocks, d->k)));
-            const FeMem zm = d->into_coset[1], onem = d->into_coset[0];
-            int rc = ntt_block_table_build(d->field, t, n_blocks, d->k, (const u64*)&zm, (const u64*)&d->extended_omega, (const u64*)&onem, s);
-            if (rc == TRH_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("domain blocks: table kernel failed"); rc = TRH_EHIP; }  // complete before another context's stream may read it
-            if (rc != TRH_OK) { (void)hipFree(t); return rc; }
-            it = d->pre_sub.emplace(n_blocks, t).first;
-        }
-        pre_tab = it->second;
-    }
+    TRH_TRY(pre_block_table(d, n_blocks, s, &pre_tab));
     if (ntt_can_fuse(d->k) && ntt_lazy_shift() == 5) {  // the scaling rides on the loads of pass 0
         NttFusion fu;
         fu.in_dev = coeff_dev; fu.in_log = d->k;

@@ -249,76 +249,6 @@ __global__ void __launch_bounds__(PART_THREADS) msm_partition_kernel(const u32* 
     }
 }
 
-// The same partition with a small footprint (512 threads, the digits read twice -- the second time from the L2 -- instead of kept in
-// registers): a workgroup fits beside two waves per SIMD of the accumulation (window-group pipeline, msm_enqueue_t)
-constexpr int PARTL_THREADS = 512;
-__global__ void __launch_bounds__(PARTL_THREADS) msm_partition_lean_kernel(const u32* __restrict__ digits, u32* __restrict__ bin_cursor, u32* __restrict__ parted, size_t n,
-                                                                           int k2, u32 nbins, int idx_bits) {
-    extern __shared__ u32 lds[];
-    u32* stage = lds;
-    u32* cnt = lds + PART_TILE;
-    u32* lbase = cnt + nbins;
-    u32* gbase = lbase + nbins;
-    __shared__ u32 scan[PARTL_THREADS];
-    const int j = blockIdx.y;
-    const size_t t0 = (size_t)blockIdx.x * PART_TILE;
-    const size_t t1 = t0 + PART_TILE < n ? t0 + PART_TILE : n;
-    const u32* dg = digits + (size_t)j * n;
-    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
-    __syncthreads();
-    constexpr int PER = PART_TILE / PARTL_THREADS;
-#pragma unroll 8
-    for (int q = 0; q < PER; ++q) {
-        const size_t i = t0 + threadIdx.x + (size_t)q * PARTL_THREADS;
-        const u32 b = (i < t1 ? dg[i] : 0u) & ~SIGN_BIT;
-        if (b) atomicAdd(&cnt[(b - 1u) >> k2], 1u);
-    }
-    __syncthreads();
-    {
-        const u32 per = (nbins + PARTL_THREADS - 1) / PARTL_THREADS;
-        const u32 lo = threadIdx.x * per < nbins ? threadIdx.x * per : nbins, hi = lo + per < nbins ? lo + per : nbins;
-        u32 sum = 0;
-        for (u32 k = lo; k < hi; ++k) sum += cnt[k];
-        scan[threadIdx.x] = sum;
-        __syncthreads();
-        for (int off = 1; off < PARTL_THREADS; off <<= 1) {
-            const u32 v = ((int)threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
-            __syncthreads();
-            scan[threadIdx.x] += v;
-            __syncthreads();
-        }
-        u32 run = scan[threadIdx.x] - sum;
-        for (u32 k = lo; k < hi; ++k) {
-            const u32 v = cnt[k];
-            lbase[k] = run;
-            gbase[k] = v ? atomicAdd(&bin_cursor[(size_t)j * nbins + k], v) : 0u;
-            run += v;
-        }
-    }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < nbins; k += blockDim.x) cnt[k] = 0;
-    __syncthreads();
-    const u32 low_mask = (1u << k2) - 1u;
-#pragma unroll 8
-    for (int q = 0; q < PER; ++q) {
-        const size_t i = t0 + threadIdx.x + (size_t)q * PARTL_THREADS;
-        const u32 e = i < t1 ? dg[i] : 0u;
-        const u32 b = e & ~SIGN_BIT;
-        if (b) {
-            const u32 bm = b - 1u, bin = bm >> k2;
-            const u32 r = atomicAdd(&cnt[bin], 1u);
-            stage[lbase[bin] + r] = (u32)i | ((bm & low_mask) << idx_bits) | (e & SIGN_BIT);
-        }
-    }
-    __syncthreads();
-    u32* out = parted + (size_t)j * n;
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (u32 bin = wave; bin < nbins; bin += PARTL_THREADS / 64) {
-        const u32 c = cnt[bin], lb = lbase[bin], gb = gbase[bin];
-        for (u32 k = lane; k < c; k += 64) out[gb + k] = stage[lb + k];
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // 3b. bucket sort, chunk-parallel: the bin-grouped list is cut into fixed chunks of BS_CHUNK entries
 //     whatever the bin sizes (witness-like scalars put millions of entries into one bin), and every
@@ -499,63 +429,6 @@ __global__ void __launch_bounds__(BIN_THREADS) msm_bin_sort_kernel(const u32* __
     for (u32 i = threadIdx.x; i < count; i += BIN_THREADS) dst[i] = bstage[i];
 }
 
-// The whole-bin sort with a small footprint (512 threads, the bin read twice instead of held in registers), see msm_partition_lean_kernel
-constexpr int BINL_THREADS = 512;
-__global__ void __launch_bounds__(BINL_THREADS) msm_bin_sort_lean_kernel(const u32* __restrict__ parted, const u32* __restrict__ bin_starts, const u32* __restrict__ bin_ends,
-                                                                         u32* __restrict__ sorted, u32* __restrict__ starts, u32* __restrict__ ends, size_t n, int k2, u32 nbins,
-                                                                         int idx_bits, u32 nbk, const u32* __restrict__ oversize) {
-    if (oversize[blockIdx.y] != 0u) return;
-    extern __shared__ u32 bstage[];
-    __shared__ u32 cnt[128], tbase[128], wave0_total;
-    const int j = blockIdx.y;
-    const u32 bin = blockIdx.x;
-    const size_t wrow = j;
-    const u32 lo = bin_starts[wrow * nbins + bin], hi = bin_ends[wrow * nbins + bin];
-    const u32 count = hi - lo;
-    const u32 nsub = 1u << k2, low_mask = nsub - 1u, idx_mask = (1u << idx_bits) - 1u;
-    const u32* src = parted + wrow * n + lo;
-    u32* dst = sorted + wrow * n + lo;
-    const u32 lane = threadIdx.x & 63u;
-    if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
-    __syncthreads();
-#pragma unroll 8
-    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) atomicAdd(&cnt[(src[i] >> idx_bits) & low_mask], 1u);
-    __syncthreads();
-    u32 v = 0, x = 0;
-    if (threadIdx.x < 128) {
-        v = threadIdx.x < nsub ? cnt[threadIdx.x] : 0u;
-        x = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const u32 y = __shfl_up(x, off, 64);
-            if ((int)lane >= off) x += y;
-        }
-        if (threadIdx.x == 63) wave0_total = x;
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const u32 excl = x - v + (threadIdx.x >= 64 ? wave0_total : 0u);
-        tbase[threadIdx.x] = excl;
-        cnt[threadIdx.x] = 0;
-        if (threadIdx.x < nsub) {
-            const size_t b = wrow * (nbk + 1) + ((size_t)bin << k2) + threadIdx.x + 1u;
-            starts[b] = lo + excl;
-            ends[b] = lo + excl + v;
-        }
-        if (bin == 0 && threadIdx.x == 0) { starts[wrow * (nbk + 1)] = 0; ends[wrow * (nbk + 1)] = 0; }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) {
-        const u32 e = src[i];
-        const u32 sub = (e >> idx_bits) & low_mask;
-        const u32 r = atomicAdd(&cnt[sub], 1u);
-        bstage[tbase[sub] + r] = (e & idx_mask) | (e & SIGN_BIT);
-    }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < count; i += BINL_THREADS) dst[i] = bstage[i];
-}
-
 // per window: exclusive scan of the bucket counts -> starts / ends, cursor (in place of the counts).  Two launches over
 // 1024-bucket blocks (coalesced): block totals, then every block adds the totals before it to its own LDS scan -- one
 // workgroup per window walking 64 buckets per thread was a 0.18 ms latency chain at 2^16 buckets.
@@ -725,10 +598,10 @@ __device__ __forceinline__ XYZZz<BF> load_raw(const XYZZzMem* src) {
 }
 
 template <class BF>
-__device__ __forceinline__ void msm_accumulate_seg_body(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
-                                                        const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
-                                                        XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
-                                                        XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
+                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                                                                 XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
+                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
     const size_t z = blockIdx.z;  // batch item
     {
         const size_t Wz = gridDim.y;
@@ -839,24 +712,9 @@ __device__ __forceinline__ void msm_accumulate_seg_body(const uint4* __restrict_
     else if (cur_end == stop) store_raw(direct + (size_t)j * nb1 + B, acc);
     else store_raw(last + (size_t)j * nseg + t, acc);
 }
-template <class BF>
-__global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
-                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
-                                                                 XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
-                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
-    msm_accumulate_seg_body<BF>(bases_z, sorted, ends, seg_bucket, first, last, direct, n, nbk, nseg, seg_len);
-}
-// The same accumulation held to TWO waves per SIMD (the register allocation is padded so that a third does not fit): it issues at the
-// rate of three (measured: 14.24 against 14.20 ms at 2^24) and leaves a third of every SIMD's registers and the whole LDS to the sort
-// and reduction kernels of the neighbouring window groups (msm_enqueue_t, window-group pipeline).
-template <class BF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-msm_accumulate_seg2_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted, const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
-                           XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last, XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
-    asm volatile("" ::: "v175");  // next free VGPR = 176: three waves would need 528 of the SIMD's 512 registers (the attribute alone stops at 164 -> 168 allocated, which fits three)
-    msm_accumulate_seg_body<BF>(bases_z, sorted, ends, seg_bucket, first, last, direct, n, nbk, nseg, seg_len);
-}
-
+// (Round 6: holding this kernel to two waves per SIMD costs it nothing -- 14.24 against 14.20 ms at 2^24 -- but the sort and reduction kernels
+// of neighbouring window groups that were to use the freed registers and LDS take their VALU issue slots and memory queue entries from it one
+// for one: 17.7 against 16.9 ms per MSM.  profiles/r06_overlap_ab.txt; the pipeline is in the history at 780c803, not in the library.)
 constexpr u32 HEAVY_PIECES = 64;
 
 // buckets spanning more than HEAVY_PIECES segments (skewed scalars; the short top window of 255-bit
@@ -1618,6 +1476,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_TRY(L.sparse.ensure((size_t)chunk * SP_CNT * SP_PAD * 4 + (size_t)chunk * SP_PARTS * sizeof(XYZZzMem) + 64));
         if (!m.sp_host) TRH_HIP_TRY(hipHostMalloc(&m.sp_host, SP_MAX_CHUNK * SP_CNT * 4 + 4 + SP_MAX_CHUNK + 64, hipHostMallocDefault));
     }
+    if (m.reserve_only) return TRH_OK;  // trh_bases_reserve: the buffers above are what a launch of this shape needs
     const bool timing = c.timing && batch <= chunk && !sparse_ok;  // one pass over the phases
     if (timing && !m.ev[0]) for (int k = 0; k < 6; ++k) TRH_HIP_TRY(hipEventCreate(&m.ev[k]));
 
@@ -1735,8 +1594,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[2], s));
         if (b0 == 0 && !bases_z && !fb)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-        static const size_t exp_acc_lds = getenv("TRH_EXP_ACC_LDS") ? (size_t)atol(getenv("TRH_EXP_ACC_LDS")) : 0;  // EXPERIMENT: dynamic LDS caps the accumulation's workgroups per CU
-        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), exp_acc_lds, s, bz, L.sorted.as<u32>(),
+        hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
                            L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), nse, nbk, nseg, seg_len);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         {
@@ -1773,8 +1631,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // crowd each other out (2^24: reduction 0.43 -> 0.52 ms) and 2^17 lanes lose to 2^16 (IPA 13.9 against 13.0 ms).  Option
             // reduce_q4 = 0 keeps the one-thread-per-slice kernels everywhere
             const int q4_knob = opt().reduce_q4;
-            static const int q4_lanes_log = getenv("TRH_EXP_Q4_LANES_LOG") ? atoi(getenv("TRH_EXP_Q4_LANES_LOG")) : 16;  // EXPERIMENT
-            static const int q4_sets = getenv("TRH_EXP_Q4_SETS") ? atoi(getenv("TRH_EXP_Q4_SETS")) : 8;
+            constexpr int q4_lanes_log = 16, q4_sets = 8;  // (16 - 32 sets / 2^17 - 2^19 lanes lose at 2^18 .. 2^22: profiles/r06_q4_small_raw.txt)
             u32 q4_tpw = r_tpw;
             while (q4_tpw > 1024 && (size_t)q4_tpw * 4 * Ws * nb > ((size_t)1 << q4_lanes_log)) q4_tpw >>= 1;
             if (q4_knob && !compact && (size_t)Ws * nb <= (size_t)q4_sets && q4_tpw >= 64 && (size_t)q4_tpw * 4 * Ws * nb <= ((size_t)1 << q4_lanes_log) && nbk % q4_tpw == 0) {
@@ -1788,133 +1645,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
-        return TRH_OK;
-    };
-
-    // Window-group pipeline of a lone large MSM.  The windows are cut into G groups; the sort of group g + 1 (lean 512-thread forms of the
-    // partition and the bin sort) and the combine / reduction of group g - 1 (quad-lane forms, 115 - 121 registers) run on two
-    // high-priority streams beside the accumulation of group g, which is held to two waves per SIMD (msm_accumulate_seg2_kernel) so that
-    // a third of every SIMD's registers and the whole LDS stay free for them.  Exposed: the recode, the first group's sort, the last
-    // group's reduction.
-    const bool b0_convert_needed = !bases_z && !fb;
-    auto pipeline_groups = [&](const int* bounds, int G) -> int {
-        static const int exp_acc2 = getenv("TRH_EXP_ACC2") ? atoi(getenv("TRH_EXP_ACC2")) : 1;      // EXPERIMENT knobs
-        static const int exp_lean = getenv("TRH_EXP_LEAN") ? atoi(getenv("TRH_EXP_LEAN")) : 1;
-        static const int exp_tailq4 = getenv("TRH_EXP_TAILQ4") ? atoi(getenv("TRH_EXP_TAILQ4")) : 1;
-        static const int exp_prio = getenv("TRH_EXP_PRIO") ? atoi(getenv("TRH_EXP_PRIO")) : 1;
-        if (!m.g_sort) {
-            int lo_p = 0, hi_p = 0;
-            TRH_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-            TRH_HIP_TRY(hipStreamCreateWithPriority(&m.g_sort, hipStreamNonBlocking, exp_prio ? hi_p : lo_p));
-            TRH_HIP_TRY(hipStreamCreateWithPriority(&m.g_tail, hipStreamNonBlocking, exp_prio ? hi_p : lo_p));
-            TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_front, hipEventDisableTiming));
-            TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_done, hipEventDisableTiming));
-            for (int g = 0; g < MsmScratch::MAX_GROUPS; ++g) {
-                TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_sorted[g], hipEventDisableTiming));
-                TRH_HIP_TRY(hipEventCreateWithFlags(&m.g_acc[g], hipEventDisableTiming));
-                TRH_HIP_TRY(hipEventCreate(&m.g_t0[g]));
-                TRH_HIP_TRY(hipEventCreate(&m.g_t1[g]));
-            }
-            TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_bin_sort_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_CAP_MAX * 4));
-            TRH_HIP_TRY(hipFuncSetAttribute((const void*)msm_partition_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PART_TILE * 4 + 2048 * 12));
-        }
-        hipStream_t ss = m.g_sort, ts = m.g_tail;
-        const uint4* sc = (const uint4*)scalars_dev;
-        const u32 seg_len = seg_len0, nseg = nseg0, heavy_stride = heavy_stride0;
-        // reduction geometry of the quad-lane tails: the slices of the one-thread form
-        u32 q4_tpw = tpw;
-        while (q4_tpw > 64 && nbk % q4_tpw != 0) q4_tpw >>= 1;
-        const u32 q4_blocks = (q4_tpw + 63) / 64;
-        TRH_TRY(L.partials.ensure((size_t)Ws * (q4_blocks > rblocks ? q4_blocks : rblocks) * sizeof(XYZZzMem)));
-        TRH_TRY(L.heavy.ensure((size_t)G * heavy_stride * 4 + 16));
-        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[0], s));
-        {
-            auto up16 = [](size_t b) { return (u32)((b + 15) / 16); };
-            ZeroRanges zr{};
-            zr.p[0] = (uint4*)L.counts.p; zr.n16[0] = up16((size_t)Ws * nbins * 4 + 2 * (size_t)Ws * 4);
-            zr.p[1] = nullptr; zr.n16[1] = 0u;
-            zr.p[2] = (uint4*)L.heavy.p; zr.n16[2] = up16((size_t)G * heavy_stride * 4);
-            zr.p[3] = (uint4*)L.bucket_cnt.p; zr.n16[3] = up16((size_t)Ws * nb1 * 4);
-            const u32 most = zr.n16[3] > zr.n16[0] ? zr.n16[3] : zr.n16[0];
-            hipLaunchKernelGGL(msm_zero_ranges_kernel, dim3((most + 255) / 256 < 512 ? (most + 255) / 256 : 512), dim3(256), 0, s, zr);
-        }
-        unsigned gb = (unsigned)((n + 255) / 256);
-        if (gb > 2048) gb = 2048;
-        hipLaunchKernelGGL((msm_recode_kernel<SF>), dim3(gb, 1, 1), dim3(256), recode_use_lds ? recode_lds : 0, s, sc, n, mont, cb, W, L.digits.as<u32>(), L.counts.as<u32>(), k2, nbins,
-                           recode_use_lds, stride, 0, tails_dev ? (const uint4*)tails_dev : nullptr, (unsigned char*)nullptr, 14u, part_tiles);
-        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[1], s));
-        hipLaunchKernelGGL(msm_offsets_kernel, dim3(Ws, 1, 1), dim3(1024), 0, s, L.counts.as<u32>(), L.bin_starts.as<u32>(), nbins, oversize, bin_cap, (u32*)nullptr);
-        if (b0_convert_needed) hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
-        TRH_HIP_TRY(hipEventRecord(m.g_front, s));
-        TRH_HIP_TRY(hipStreamWaitEvent(ss, m.g_front, 0));
-        TRH_HIP_TRY(hipStreamWaitEvent(ts, m.g_front, 0));
-        const size_t part_lds = (size_t)PART_TILE * 4 + (size_t)nbins * 12;
-        const unsigned ptiles = (unsigned)((ns + PART_TILE - 1) / PART_TILE);
-        for (int g = 0; g < G; ++g) {
-            const size_t j0 = (size_t)bounds[g];
-            const unsigned wg = (unsigned)(bounds[g + 1] - bounds[g]);
-            u32* digits_g = L.digits.as<u32>() + j0 * n; u32* parted_g = L.parted.as<u32>() + j0 * n; u32* sorted_g = L.sorted.as<u32>() + j0 * n;
-            u32* counts_g = L.counts.as<u32>() + j0 * nbins; u32* bstarts_g = L.bin_starts.as<u32>() + j0 * nbins;
-            u32* starts_g = L.starts.as<u32>() + j0 * nb1; u32* ends_g = L.ends.as<u32>() + j0 * nb1; u32* bcnt_g = L.bucket_cnt.as<u32>() + j0 * nb1;
-            u32* segb_g = L.seg_bucket.as<u32>() + j0 * nseg; u32* over_g = oversize + j0;
-            XYZZzMem* first_g = L.first.as<XYZZzMem>() + j0 * nseg; XYZZzMem* last_g = L.last.as<XYZZzMem>() + j0 * nseg;
-            XYZZzMem* direct_g = L.direct.as<XYZZzMem>() + j0 * nb1; XYZZzMem* buckets_g = L.buckets.as<XYZZzMem>() + j0 * nbk;
-            u32* heavy_g = L.heavy.as<u32>() + (size_t)g * heavy_stride;
-            // ---- sort of group g
-            if (exp_lean) {
-                hipLaunchKernelGGL(msm_partition_lean_kernel, dim3(ptiles, wg, 1), dim3(PARTL_THREADS), part_lds, ss, digits_g, counts_g, parted_g, ns, k2, nbins, idx_bits);
-                hipLaunchKernelGGL(msm_bin_sort_lean_kernel, dim3(nbins, wg, 1), dim3(BINL_THREADS), (size_t)bin_cap * 4, ss, parted_g, bstarts_g, counts_g, sorted_g, starts_g, ends_g, ns, k2,
-                                   nbins, idx_bits, nbk, over_g);
-            } else {
-                hipLaunchKernelGGL(msm_partition_kernel, dim3(ptiles, wg, 1), dim3(PART_THREADS), part_lds, ss, digits_g, counts_g, parted_g, ns, k2, nbins, idx_bits, (const unsigned char*)nullptr);
-                hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, wg, 1), dim3(BIN_THREADS), (size_t)bin_cap * 4, ss, parted_g, bstarts_g, counts_g, sorted_g, starts_g, ends_g, ns, k2,
-                                   nbins, idx_bits, nbk, over_g);
-            }
-            {   // the chunked passes: return at once unless a bin of the window was too large for the LDS
-                const dim3 cgrid((unsigned)((ns + BS_CHUNK - 1) / BS_CHUNK), wg, 1);
-                hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, ss, parted_g, bstarts_g, counts_g, bcnt_g, sorted_g, ns, k2, nbins, idx_bits, nbk, over_g);
-                hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, wg, 1), dim3(RANGE_BLOCK), 0, ss, bcnt_g, segb_g, nbk, over_g);
-                hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, wg, 1), dim3(RANGE_BLOCK), 0, ss, bcnt_g, segb_g, starts_g, ends_g, nbk, over_g);
-                hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, ss, ends_g, segb_g, nbk, nseg, seg_len);
-                hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, ss, parted_g, bstarts_g, counts_g, bcnt_g, sorted_g, ns, k2, nbins, idx_bits, nbk, over_g);
-            }
-            TRH_HIP_TRY(hipEventRecord(m.g_sorted[g], ss));
-            // ---- accumulation of group g
-            TRH_HIP_TRY(hipStreamWaitEvent(s, m.g_sorted[g], 0));
-            if (timing) TRH_HIP_TRY(hipEventRecord(m.g_t0[g], s));
-            if (exp_acc2)
-                hipLaunchKernelGGL((msm_accumulate_seg2_kernel<BF>), dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, s, bz, sorted_g, ends_g, segb_g, first_g, last_g, direct_g, ns, nbk, nseg, seg_len);
-            else
-                hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, wg, 1), dim3(256), 0, s, bz, sorted_g, ends_g, segb_g, first_g, last_g, direct_g, ns, nbk, nseg, seg_len);
-            if (timing) TRH_HIP_TRY(hipEventRecord(m.g_t1[g], s));
-            TRH_HIP_TRY(hipEventRecord(m.g_acc[g], s));
-            // ---- combine / reduction of group g
-            TRH_HIP_TRY(hipStreamWaitEvent(ts, m.g_acc[g], 0));
-            const size_t pieces = ns / ((size_t)nbk * seg_len);
-            if (exp_tailq4 && nbk >= 4)
-                hipLaunchKernelGGL((msm_combine_q4_kernel<BF>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
-                                   nseg, seg_len, heavy_g, heavy_stride);
-            else if (pieces >= 3 && nbk >= 4)
-                hipLaunchKernelGGL((msm_combine_kernel<BF, 4>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
-                                   nseg, seg_len, heavy_g, heavy_stride);
-            else
-                hipLaunchKernelGGL((msm_combine_kernel<BF, 1>), dim3((unsigned)(((size_t)nbk + 255) / 256), wg, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, direct_g, buckets_g, nbk,
-                                   nseg, seg_len, heavy_g, heavy_stride);
-            hipLaunchKernelGGL((msm_combine_heavy_kernel<BF>), dim3(heavy_blocks0, 1, 1), dim3(256), 0, ts, starts_g, ends_g, first_g, last_g, buckets_g, nbk, nseg, seg_len, heavy_g, wg, heavy_stride);
-            if (exp_tailq4 && q4_tpw >= 64) {
-                XYZZzMem* partials_g = L.partials.as<XYZZzMem>() + j0 * q4_blocks;
-                hipLaunchKernelGGL((msm_reduce_q4_kernel<BF>), dim3(q4_blocks, wg, 1), dim3(256), 0, ts, buckets_g, partials_g, nbk, nbk / q4_tpw, q4_tpw);
-                hipLaunchKernelGGL((msm_window_sum_q4_kernel<BF>), dim3(wg, 1, 1), dim3(256), 0, ts, partials_g, m.window_sums.as<XYZZMem>() + j0, q4_blocks);
-            } else {
-                XYZZzMem* partials_g = L.partials.as<XYZZzMem>() + j0 * rblocks;
-                hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(rblocks, wg, 1), dim3(256), 0, ts, buckets_g, partials_g, nbk, slice, tpw);
-                hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(wg, 1, 1), dim3(256), 0, ts, partials_g, m.window_sums.as<XYZZMem>() + j0, rblocks);
-            }
-        }
-        TRH_HIP_TRY(hipEventRecord(m.g_done, ts));
-        TRH_HIP_TRY(hipStreamWaitEvent(s, m.g_done, 0));
-        if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
-        m.g_timed = timing ? G : 0;
         return TRH_OK;
     };
 
@@ -1986,28 +1716,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         }
         return TRH_OK;
     };
-    m.g_timed = 0;
-    int gbounds[MsmScratch::MAX_GROUPS + 1];
-    int G = 0;
-    if (!fb && batch == 1 && n && use_bin && Ws >= 4) {  // EXPERIMENT knob: TRH_EXP_GROUPS = number of groups, or explicit cut points "3,7,11"
-        if (const char* e = getenv("TRH_EXP_GROUPS")) {
-            if (strchr(e, ',')) {
-                gbounds[0] = 0; G = 1;
-                for (const char* q = e; *q && G < MsmScratch::MAX_GROUPS;) { gbounds[G++] = atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-                gbounds[G] = Ws;
-                for (int g = 0; g < G; ++g) if (gbounds[g + 1] <= gbounds[g]) G = 0;
-            } else {
-                G = atoi(e);
-                if (G > MsmScratch::MAX_GROUPS) G = MsmScratch::MAX_GROUPS;
-                if (G > Ws) G = Ws;
-                for (int g = 0; g <= G; ++g) gbounds[g] = (int)((size_t)Ws * g / G);
-            }
-        }
-    }
     for (size_t b0 = 0; n && b0 < batch; b0 += chunk) {
         const unsigned nb = (unsigned)(b0 + chunk <= batch ? chunk : batch - b0);
         if (sparse_ok) TRH_TRY(sparse_chunk(b0, nb));
-        else if (G >= 2) TRH_TRY(pipeline_groups(gbounds, G));
         else TRH_TRY(pipeline(b0, nb, PIPE_PLAIN, 0, 0));
     }
     TRH_HIP_TRY(hipGetLastError());
@@ -2038,18 +1749,7 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     TRH_HIP_TRY(hipStreamSynchronize(s));
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     hostcombine::combine_windows_batch<BF>((const uint64_t*)ws, m.pending_windows, m.pending_c, batch, (uint64_t*)out_xyz);  // one inversion for the whole batch
-    if (m.ev_valid && m.g_timed > 0) {  // window-group pipeline: sort = the exposed head, accumulate = first launch .. last launch, kernel = the sum of the launches
-        float t01 = 0, th = 0, ta = 0, tr = 0, tt = 0, ksum = 0;
-        const int G = m.g_timed;
-        TRH_HIP_TRY(hipEventElapsedTime(&t01, m.ev[0], m.ev[1]));
-        TRH_HIP_TRY(hipEventElapsedTime(&th, m.ev[1], m.g_t0[0]));
-        TRH_HIP_TRY(hipEventElapsedTime(&ta, m.g_t0[0], m.g_t1[G - 1]));
-        TRH_HIP_TRY(hipEventElapsedTime(&tr, m.g_t1[G - 1], m.ev[4]));
-        TRH_HIP_TRY(hipEventElapsedTime(&tt, m.ev[0], m.ev[4]));
-        for (int g = 0; g < G; ++g) { float t = 0; TRH_HIP_TRY(hipEventElapsedTime(&t, m.g_t0[g], m.g_t1[g])); ksum += t; }
-        c.last.total_ms = tt; c.last.digits_ms = t01; c.last.sort_ms = th; c.last.accumulate_ms = ta; c.last.reduce_ms = tr; c.last.accumulate_kernel_ms = ksum;
-    }
-    else if (m.ev_valid) {
+    if (m.ev_valid) {
         float t01, t12, t23, t34, tt, t25;
         TRH_HIP_TRY(hipEventElapsedTime(&t25, m.ev[2], m.ev[5]));
         c.last.accumulate_kernel_ms = t25;
@@ -2149,16 +1849,6 @@ void msm_release() {
     if (m.host_sums) (void)hipHostFree(m.host_sums);
     m.host_sums = nullptr; m.host_sums_cap = 0;
     for (int k = 0; k < 6; ++k) if (m.ev[k]) { (void)hipEventDestroy(m.ev[k]); m.ev[k] = nullptr; }
-    if (m.g_sort) { (void)hipStreamDestroy(m.g_sort); m.g_sort = nullptr; }
-    if (m.g_tail) { (void)hipStreamDestroy(m.g_tail); m.g_tail = nullptr; }
-    if (m.g_front) { (void)hipEventDestroy(m.g_front); m.g_front = nullptr; }
-    if (m.g_done) { (void)hipEventDestroy(m.g_done); m.g_done = nullptr; }
-    for (int g = 0; g < MsmScratch::MAX_GROUPS; ++g) {
-        if (m.g_sorted[g]) { (void)hipEventDestroy(m.g_sorted[g]); m.g_sorted[g] = nullptr; }
-        if (m.g_acc[g]) { (void)hipEventDestroy(m.g_acc[g]); m.g_acc[g] = nullptr; }
-        if (m.g_t0[g]) { (void)hipEventDestroy(m.g_t0[g]); m.g_t0[g] = nullptr; }
-        if (m.g_t1[g]) { (void)hipEventDestroy(m.g_t1[g]); m.g_t1[g] = nullptr; }
-    }
 }
 
 }  // namespace trh

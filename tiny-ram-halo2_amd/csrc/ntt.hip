@@ -839,6 +839,30 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
     return ntt_device_t<FqParams>(a_dev, log_n, omega, batch, s, fu, scale);
 }
 
+int ntt_prepare(int field, uint32_t log_n, const u64 omega[4], const u64* scale, size_t batch, uint32_t blocks, hipStream_t s) {
+    if (log_n == 0 || log_n > 27 || batch == 0) return TRH_OK;
+    Ctx& c = ctx();
+    TwiddleEntry* t = find_tables(field, (int)log_n, omega, scale);
+    if (!t) TRH_TRY(field == TRH_FP ? build_tables<FpParams>((int)log_n, omega, scale, s, &t) : build_tables<FqParams>((int)log_n, omega, scale, s, &t));
+    int sizes[8], P = 0, tlog = TILE_LOG;
+    plan_passes((int)log_n, sizes, &P, &tlog);
+    const size_t N = (size_t)1 << log_n;
+    if (ntt_can_fuse(log_n) && P >= 2) {  // the signed passes' raw scratch: the chunking of ntt_device_t
+        size_t chunk = ((size_t)2 << 30) / (N * 72);
+        if (chunk < 1) chunk = 1;
+        if (blocks) chunk = chunk < blocks ? blocks : chunk - chunk % blocks;
+        if (chunk > batch) chunk = batch;
+        return c.ntt_tmp.ensure(2 * chunk * N * 36);
+    }
+    if (P > 1) {
+        size_t chunk = ((size_t)2 << 30) / (N * 32);
+        if (chunk < 1) chunk = 1;
+        if (chunk > batch) chunk = batch;
+        return c.ntt_tmp.ensure(chunk * N * 32);
+    }
+    return TRH_OK;
+}
+
 int field_scale_periodic(int field, void* a_dev, size_t rows, size_t row_len, size_t active_len, const void* factors_dev, u32 period, hipStream_t s) {
     const size_t n = rows * active_len;
     if (!n) return TRH_OK;

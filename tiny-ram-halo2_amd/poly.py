@@ -115,6 +115,10 @@ class EvaluationDomain:
             self._h = h
         return self._h
 
+    def reserve(self, batch: int):
+        """trh_domain_reserve: tables and scratch of the per-column transforms for batches of `batch` polynomials (setup time)"""
+        api._check(api.lib().trh_domain_reserve(self.handle(), batch))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) is not None:
@@ -255,6 +259,15 @@ class Params:
                 pass
         self._ipa = None
         self.ipa_bases()
+
+    def reserve(self, batch: int):
+        """trh_bases_reserve over the resident sets: the calling context's MSM scratch for commit batches of `batch` columns and the
+        opening's round MSMs (setup time: the first batch of a process then allocates nothing)"""
+        for b in (self._g, self._g_lagrange):
+            api._check(api.lib().trh_bases_reserve(b.handle, self.n + 1, batch))
+        ipa = self.ipa_bases()
+        if ipa is not self._g:
+            api._check(api.lib().trh_bases_reserve(ipa.handle, self.n + 2, 2))
 
     def ipa_bases(self):
         """g || w || u as ONE resident set with fixed-base tables: `trh_ipa_create_proof` then runs every MSM of the opening in

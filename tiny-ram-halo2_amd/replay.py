@@ -237,6 +237,8 @@ def run(word_bits: int, batch: int = 64, hook=None, device: int = 0, verbose: bo
     if precompute:
         params.precompute()
         params.ipa_bases()  # the opening's resident set g || w || u with its own table
+        params.reserve(batch)  # keygen-time sizing of the scratch: the first proof of the process allocates and builds nothing inside its steps
+        dom.reserve(batch)
     torch.cuda.synchronize()
     precompute_ms = (time.perf_counter() - t_pre) * 1e3
 

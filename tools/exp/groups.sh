@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: drives the TRH_EXP_* knobs of the experiment build (git 780c803); the library no longer has them -- kept as the record of how profiles/r06_overlap_*.txt were made
 # EXPERIMENT (round 6): window-group pipeline of a lone MSM -- sort / reduction of neighbouring groups beside the accumulation
 cd ${GRAFT_REPO_ROOT:-.}
 run() { echo "== $*"; env "$@" python3 tools/msm_probe.py $LN pallas 0 0 2>&1 | tail -1; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: drives the TRH_EXP_* knobs of the experiment build (git 780c803); the library no longer has them -- kept as the record of how profiles/r06_overlap_*.txt were made
 # EXPERIMENT (round 6): window-group pipeline of a lone 2^24 MSM -- does the sort run UNDER the accumulation?
 #   tools/exp/overlap_ab.sh -> gpurun_out/overlap_ab/report.txt  (copied to profiles/r06_overlap_ab.txt)
 # Timelines come from rocprofv3 --kernel-trace alone (counter passes serialise dispatches); instruction counts from separate --pmc passes.

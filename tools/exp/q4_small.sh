@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: drives the TRH_EXP_* knobs of the experiment build (git 780c803); the library no longer has them -- kept as the record of how profiles/r06_overlap_*.txt were made
 # EXPERIMENT (round 6): quad-lane bucket reduction for a lone 2^20 .. 2^22 MSM (16 bucket sets)
 cd ${GRAFT_REPO_ROOT:-.}
 run() { echo "== LN=$LN $*"; env "$@" python3 tools/msm_probe.py $LN pallas 0 0 2>&1 | tail -1; }
