@@ -46,10 +46,29 @@ struct SplitMix {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// One step's time on the DEVICE: an event recorded on the (null) stream before the step and one after it, read once the second has
+// happened -- what replay.py's torch events measure.  (Until round 6 this was the host's clock between two stream synchronisations: every
+// step then started on an idle, down-clocked GPU and paid its own launch latency, 0.1 - 0.4 ms per step and ~5 ms per proof more than the
+// Python mirror reported for the same kernels: profiles/r06_driver_diff.md.  --host-clock keeps that clock for the comparison.)
+bool g_host_clock = false;
 struct Timer {
-    double t0;
-    Timer() { check(trh_stream_synchronize(nullptr), "sync"); t0 = now_ms(); }
-    double stop() { check(trh_stream_synchronize(nullptr), "sync"); return now_ms() - t0; }
+    double t0 = 0;
+    void *e0 = nullptr, *e1 = nullptr;
+    Timer() {
+        if (g_host_clock) { check(trh_stream_synchronize(nullptr), "sync"); t0 = now_ms(); return; }
+        check(trh_event_create(&e0), "event_create"); check(trh_event_create(&e1), "event_create");
+        check(trh_event_record(e0, nullptr), "event_record");
+    }
+    Timer(const Timer&) = delete;
+    Timer& operator=(const Timer&) = delete;
+    ~Timer() { trh_event_destroy(e0); trh_event_destroy(e1); }
+    double stop() {
+        if (g_host_clock) { check(trh_stream_synchronize(nullptr), "sync"); return now_ms() - t0; }
+        float ms = 0;
+        check(trh_event_record(e1, nullptr), "event_record");
+        check(trh_event_elapsed_ms(e0, e1, &ms), "event_elapsed_ms");
+        return (double)ms;
+    }
 };
 
 int failures = 0;
@@ -486,6 +505,7 @@ int main(int argc, char** argv) {
     bool overlap = false, pinned = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--overlap") { overlap = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
+    for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--host-clock") { g_host_clock = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--pinned") { pinned = true; for (int q = i; q + 1 < argc; ++q) argv[q] = argv[q + 1]; --argc; break; }
     for (int i = 1; i + 1 < argc; i += 2) {
         if (std::string(argv[i]) == "--word-bits") word_bits = std::atoi(argv[i + 1]);
@@ -927,9 +947,9 @@ int main(int argc, char** argv) {
         const double total = ms_lookup + ms_commit + ms_intt + ms_ext + ms_evals + ms_h + ms_commit_coeff + ms_ext_inv + ms_multiopen + ms_ipa;
         std::printf("{\"driver\": \"examples/replay.cpp\", \"word_bits\": %d, \"k\": %u, \"batch\": %zu, \"columns\": \"%s\", \"extended_domain\": \"5 of 8 coset blocks\", \"checks_failed\": %d, \"setup_ms\": %.3f, \"setup_tables_GB\": %.3f, \"keygen_ms\": %.3f, "
                     "\"ms\": {\"lookup_permute\": %.3f, \"commit_lagrange\": %.3f, \"lagrange_to_coeff\": %.3f, \"coeff_to_extended\": %.3f, \"evals\": %.3f, \"h_eval\": %.3f, \"commit\": %.3f, "
-                    "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f, \"column_loop_ms\": {\"step_by_step\": %.3f, \"two_contexts_overlapped\": %.3f}}\n",
+                    "\"extended_to_coeff\": %.3f, \"multiopen_folds\": %.3f, \"ipa\": %.3f}, \"ms_total\": %.3f, \"column_loop_ms\": {\"step_by_step\": %.3f, \"two_contexts_overlapped\": %.3f}, \"clock\": \"%s\"}\n",
                     word_bits, k, batch, witness ? "witness" : "random", failures, setup_ms, tables_gb, ms_keygen, ms_lookup, ms_commit, ms_intt, ms_ext, ms_evals, ms_h, ms_commit_coeff, ms_ext_inv, ms_multiopen, ms_ipa, total,
-                    loop_seq_ms, loop_ovl_ms);
+                    loop_seq_ms, loop_ovl_ms, g_host_clock ? "host clock between stream synchronisations" : "device events around every step (trh_event_*)");
         trh_shutdown();
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

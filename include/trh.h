@@ -421,6 +421,15 @@ size_t trh_pool_idle_bytes(void);
 int trh_memcpy_h2d(void* dev, const void* host, size_t bytes);
 int trh_memcpy_d2h(void* host, const void* dev, size_t bytes);
 int trh_stream_synchronize(void* stream);
+/* counters of the calling thread's context, by name.  "msm_lean_retries": MSMs of callers that vouched for uniformly random scalars (the
+ * opening's rounds) whose whole-bin LDS sort met a bin that did not fit and that were therefore run a second time with the chunked passes. */
+int trh_stat(const char* name, uint64_t* value);
+/* GPU-side timing without HIP headers: events recorded on a stream between the steps (a hipEvent_t each), read afterwards.
+ * trh_event_elapsed_ms waits for `end` and returns the device time between the two records. */
+int trh_event_create(void** out_event);
+int trh_event_record(void* event, void* stream);
+int trh_event_elapsed_ms(void* start, void* end, float* ms);
+void trh_event_destroy(void* event);
 
 /* ---- timing of the last MSM / NTT on this context (HIP events on the launch stream) -------- */
 typedef struct trh_timing {

@@ -57,15 +57,22 @@ def test_q4_point_ops_golden_and_edge_cases(curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("n", [1000, 4096, 1 << 14, 1 << 16])
-def test_msm_with_q4_reduction_vs_oracle(curve, n):
-    """sizes whose bucket sets are reduced by msm_reduce_q4_kernel (slices of one bucket: every quad's offset multiple meets its running sum,
-    the P + P branch) against cpu_ref.best_multiexp"""
-    sc = synth.field_elements(77 + n, n)
+@pytest.mark.parametrize("n,cbits,nb", [(1000, 8, 1), (4096, 10, 2), (1 << 14, 12, 6), (1 << 16, 14, 1), (1 << 16, 9, 3)])
+def test_msm_with_q4_reduction_vs_oracle(curve, n, cbits, nb):
+    """MSMs whose bucket set IS reduced by msm_reduce_q4_kernel / msm_window_sum_q4_kernel: a fixed-base table makes ONE bucket set per item
+    (Ws = 1), and the quad-lane gate of msm.hip takes launches of at most 8 sets whose slices give >= 64 quads -- here 2^(cbits - 1) buckets
+    in slices of one to a few buckets (the offset multiple meets its running sum: the P + P branch), for 1, 2, 3 and 6 items -- against
+    cpu_ref.best_multiexp.  (without the table these sizes have 26 - 32 windows and never reached the quad kernels.)  The same
+    cases run over the thread-per-slice kernels in test_thread_per_slice_reduction_in_a_subprocess."""
     bases = api.Bases.generate(curve, 5, 3, n)
-    got = bases.msm(sc)
-    want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, sc, bases.download(), threads=cpu_ref.hardware_threads()))
-    assert (np.asarray(got)[:8] == want).all()
+    assert bases.precompute(cbits) == cbits
+    assert api.get_option("reduce_q4") == (0 if os.environ.get("TRH_REDUCE_Q4_NESTED") else 1)
+    sc = synth.field_elements(77 + n + nb, nb * n)
+    got = bases.msm_batch_dev(api.DeviceBuffer.from_host(sc), n, nb)
+    host_bases = bases.download()
+    for i in range(nb):
+        want = cpu_ref.to_affine(curve, cpu_ref.best_multiexp(curve, sc[i * n:(i + 1) * n], host_bases, threads=cpu_ref.hardware_threads()))
+        assert (np.asarray(got[i])[:8] == want).all(), i
     bases.destroy()
 
 

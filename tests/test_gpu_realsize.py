@@ -115,6 +115,39 @@ def _ipa_case(curve, k, precompute):
         assert not ipa_verify_fast(*args, (v + 1) % fs.m, *tail, c_dev, f_dev)
 
 
+def test_ipa_skewed_polynomial_takes_the_chunked_sort_again():
+    """The opening's round MSMs promise the sort uniformly random scalars (dense_hint) and skip the launches of the chunked fallback behind
+    the whole-bin LDS sort; msm_finish checks the sort's "a bin did not fit" flags and repeats the MSM with the fallback when one is set.
+    A polynomial whose coefficients are all the SAME value with the digit 1 in every window of the table (and s(X) = 0) puts every entry
+    of round 0 into bucket 1 of one bin -- far above the LDS capacity: the retry must happen (trh_stat msm_lean_retries) and the transcript
+    must still be the oracle's, point for point."""
+    curve, k = "pallas", 14
+    cv = o.CURVES[curve]
+    fs = cv.scalar
+    n = 1 << k
+    g_l, w_l, u_l, params = _params(curve, k, 0x5E3D, precompute=True)
+    cbits = int(api.lib().trh_bases_precomputed_window_bits(params.ipa_bases().handle))
+    assert len(params.ipa_bases()) == n + 2 and cbits > 0
+    c0 = sum(1 << (cbits * j) for j in range(255 // cbits + 1)) % fs.m   # digit 1 in every window, no carries
+    lim = lambda v: np.array(fs.limbs(v), np.uint64)  # noqa: E731
+    p_l = np.tile(lim(c0), (n, 1))
+    s_l = np.zeros((n, 4), dtype=np.uint64)
+    rnd = random.Random(0x5E3D)
+    p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+    draws = [rnd.randrange(fs.m) for _ in range(2 * k)]
+    before = api.stat("msm_lean_retries")
+    it_dev = iter(draws)
+    t_dev = IntTranscript(fs)
+    c_dev, f_dev = ipa.create_proof_native(params, lambda: next(it_dev), t_dev, to_dev(p_l), p_blind, x3, s_l, s_blind)
+    assert api.stat("msm_lean_retries") > before, "the skewed round did not overflow a bin: the test no longer reaches the retry"
+    it_ref = iter(draws)
+    t_ref = LimbTranscript(fs)
+    c_ref, f_ref = cpu_ref.ipa_create_proof(curve, k, g_l, w_l[0], u_l[0], lambda: lim(next(it_ref)), t_ref, p_l, lim(p_blind), lim(x3), s_l, lim(s_blind))
+    assert (c_dev, f_dev) == (fs.from_limbs(c_ref), fs.from_limbs(f_ref))
+    for i, (a, b) in enumerate(zip(t_dev.log, t_ref.log)):
+        assert a == b, f"transcript item {i}"
+
+
 @pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 12), ("vesta", 18)])
 def test_multiopen_vs_cpp_oracle(curve, k):
     """poly::multiopen::create_proof on resident polynomials, transcript-identical to the oracle's restatement; k = 18 over Vesta is

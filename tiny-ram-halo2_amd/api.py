@@ -141,6 +141,11 @@ _SIGNATURES = {
     "trh_field_prefix_sum_dev": ([ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_poly_lincomb_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_size_t, _u64p, _vp, _vp], ctypes.c_int),
     "trh_poly_kate_division_dev": ([ctypes.c_int, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp], ctypes.c_int),
+    "trh_stat": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)], ctypes.c_int),
+    "trh_event_create": ([ctypes.POINTER(_vp)], ctypes.c_int),
+    "trh_event_record": ([_vp, _vp], ctypes.c_int),
+    "trh_event_elapsed_ms": ([_vp, _vp, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+    "trh_event_destroy": ([_vp], None),
     "trh_field_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_point_op_dev": ([ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp], ctypes.c_int),
     "trh_malloc": ([ctypes.POINTER(_vp), ctypes.c_size_t], ctypes.c_int),
@@ -184,7 +189,12 @@ def lib():
                            "there is no CPU fallback for the MSM/NTT path")
         _lib = ctypes.CDLL(LIB_PATH)
         for name, (argtypes, restype) in _SIGNATURES.items():
-            fn = getattr(_lib, name)
+            try:
+                fn = getattr(_lib, name)
+            except AttributeError:
+                if os.environ.get("TRH_LIB_PATH"):  # an older build loaded for a same-box A/B: entries added since are simply absent
+                    continue
+                raise
             fn.argtypes = argtypes
             fn.restype = restype
     return _lib
@@ -207,6 +217,12 @@ def set_option(name: str, value) -> None:
 def get_option(name: str) -> int:
     v = ctypes.c_long(0)
     _check(lib().trh_get_option(name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+def stat(name: str) -> int:
+    v = ctypes.c_uint64(0)
+    _check(lib().trh_stat(name.encode(), ctypes.byref(v)))
     return int(v.value)
 
 

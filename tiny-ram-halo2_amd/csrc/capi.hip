@@ -1262,6 +1262,42 @@ int trh_stream_synchronize(void* stream) {
     return TRH_OK;
 }
 
+/* GPU-side timing for hosts without a HIP toolchain of their own (the Rust shim, examples/replay.cpp): events recorded on a stream between
+ * the steps, read afterwards -- the time the device spent, without a host synchronisation (and the idle gap and clock ramp it causes)
+ * between the steps */
+int trh_event_create(void** out) {
+    if (!out) { set_error("event_create: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    hipEvent_t e = nullptr;
+    TRH_HIP_TRY(hipEventCreate(&e));
+    *out = (void*)e;
+    return TRH_OK;
+}
+int trh_event_record(void* event, void* stream) {
+    if (!event) { set_error("event_record: null event"); return TRH_EINVAL; }
+    TRH_ENTER(stream);
+    TRH_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return TRH_OK;
+}
+int trh_event_elapsed_ms(void* start, void* end, float* ms) {
+    if (!start || !end || !ms) { set_error("event_elapsed_ms: null pointer"); return TRH_EINVAL; }
+    TRH_TRY(require_init());
+    TRH_HIP_TRY(hipEventSynchronize((hipEvent_t)end));
+    TRH_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)end));
+    return TRH_OK;
+}
+void trh_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+int trh_stat(const char* name, uint64_t* value) {
+    if (!name || !value) { set_error("trh_stat: null pointer"); return TRH_EINVAL; }
+    TRH_ENTER(0);
+    if (strcmp(name, "msm_lean_retries") == 0) { *value = ctx().msm.lean_retries; return TRH_OK; }
+    set_error("trh_stat: unknown counter '%s'", name);
+    return TRH_EINVAL;
+}
+
 int trh_set_timing(int enabled) {
     TRH_TRY(require_init());
     Ctx* c = thread_ctx();

@@ -100,6 +100,12 @@ struct TwiddleEntry {
     u64 scale[4] = {0, 0, 0, 0};
 };
 
+// fixed-base table of an owned base set: table[j * n + i] = 2^(c j) * P_i (lazy affine form), j < W.  With it the
+// digits of ALL windows go into one bucket set: one reduction per MSM instead of W, no Horner over windows.
+struct MsmFixedBase {
+    const void* table;
+    int c, W;
+};
 struct MsmLane {         // scratch of one chunk of MSMs (leading dimension: batch item)
     DevBuf digits;       // W x n u32: bucket id | sign << 31
     DevBuf parted;       // W x n u32: entries grouped by level-1 bin (index | low bucket bits | sign)
@@ -124,6 +130,10 @@ struct MsmScratch {
     DevBuf window_sums;  // batch x W XYZZ
     MsmLane lane;
     bool dense_hint = false;    // the caller knows its scalars are full-size (the IPA's round MSMs): the sparse classifier is skipped, the combine takes the quad form
+    // lean sort (msm.hip): the enqueued MSM skipped the chunked fallback passes; msm_finish checks the flags and repeats it with them if needed
+    bool force_fallback = false, lean_pending = false;
+    struct { const void *bases_dev, *bases_z, *scalars_dev, *tails_dev; size_t n, batch, stride; int mont; bool has_fb; MsmFixedBase fb; } retry{};
+    unsigned lean_retries = 0;  // how often that happened on this context (tests)
     bool reserve_only = false;  // msm_enqueue sizes the scratch of the described launch and returns before the first kernel (trh_bases_reserve)
     bool no_sparse_vote = false;  // the sparse classifier is skipped and nothing else changes (the shards of a range-sharded MSM: its host synchronisation would hold back the other shards)
     void* sp_host = nullptr;    // pinned: the sparse path's list counters as read back, then the dense flags it sends down
@@ -180,7 +190,7 @@ struct Ctx {
     Stage stage;
     DevBuf pfft;  // curve-point FFT work array + twiddle scalars
     DevBuf scan, scan2;  // prefix-product block totals / batch-inversion running products
-    DevBuf ipa[7];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy), kept across proofs
+    DevBuf ipa[9];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy, the second halves of the p' / b ping-pong pairs), kept across proofs
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
     void* pinned_ring = nullptr;  // 64 x 2 KiB of pinned host memory mirroring the factor ring: constants are copied here first, so the
@@ -306,12 +316,6 @@ int ntt_prepare(int field, uint32_t log_n, const u64 omega[4], const u64* scale,
 bool ntt_can_fold_scale(uint32_t log_n);
 void ntt_release_tables();
 // msm.hip
-// fixed-base table of an owned base set: table[j * n + i] = 2^(c j) * P_i (lazy affine form), j < W.  With it the
-// digits of ALL windows go into one bucket set: one reduction per MSM instead of W, no Horner over windows.
-struct MsmFixedBase {
-    const void* table;
-    int c, W;
-};
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
                 size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr, const void* tails_dev = nullptr);
 int msm_fixed_base_windows(int c);

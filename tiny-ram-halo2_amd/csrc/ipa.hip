@@ -135,25 +135,34 @@ __global__ void __launch_bounds__(256) bases_fold_kernel(AffineMem* __restrict__
 // and a collapse with challenge u multiplies wgt[idx] by u on every index whose bit log2(half) is set.
 // So L_j = <p'[half..], G'[..half]> and R_j = <p'[..half], G'[half..]> are MSMs over the ORIGINAL
 // resident bases with the scalars below (zero outside their half), and G' is never materialised.
+// a round's constants travel as kernel arguments (a staged copy is a blit kernel and ~20 us of queue idle per round on the trace)
+struct IpaConsts { uint4 w[6]; };
 template <class F>
-__global__ void __launch_bounds__(256) ipa_weights_update_kernel(uint4* __restrict__ wgt, size_t n, u32 bit, const uint4* __restrict__ u) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n || !((idx >> bit) & 1u)) return;
-    st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), ld<F>(u)));
-}
-// out[0][idx] (scalars of L_j) and out[1][idx] (scalars of R_j)
+__device__ __forceinline__ Fe<F> ipa_const(const IpaConsts& c, int k) { return fe_load<F>(c.w[2 * k].x, c.w[2 * k].y, c.w[2 * k].z, c.w[2 * k].w, c.w[2 * k + 1].x, c.w[2 * k + 1].y, c.w[2 * k + 1].z, c.w[2 * k + 1].w); }
+// the folds of a round in one launch: p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] (i < half) and the generators' weights
+// (x u where bit log2(half) of the index is set); consts = (u^-1, u)
 template <class F>
-__global__ void __launch_bounds__(256) ipa_round_scalars_kernel(const uint4* __restrict__ p, const uint4* __restrict__ wgt, uint4* __restrict__ out, size_t n, size_t half, u32 bit, size_t stride) {
+__global__ void __launch_bounds__(256) ipa_round_update_kernel(uint4* __restrict__ p, uint4* __restrict__ b, uint4* __restrict__ wgt, size_t n, size_t half, u32 bit,
+                                                               const IpaConsts consts) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const size_t i = idx & (half - 1);
-    const bool hi = (idx >> bit) & 1u;
-    const Fe<F> v = fe_mul(ld<F>(wgt + 2 * idx), ld<F>(p + 2 * (hi ? i : half + i)));
-    const Fe<F> zero = fe_zero<F>();
-    st<F>(out + 2 * idx, hi ? zero : v);
-    st<F>(out + 2 * (stride + idx), hi ? v : zero);
+    const Fe<F> u = ipa_const<F>(consts, 1);
+    if ((idx >> bit) & 1u) st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), u));
+    if (idx < half) {
+        st<F>(p + 2 * idx, fe_add(ld<F>(p + 2 * idx), fe_mul(ld<F>(p + 2 * (half + idx)), ipa_const<F>(consts, 0))));
+        st<F>(b + 2 * idx, fe_add(ld<F>(b + 2 * idx), fe_mul(ld<F>(b + 2 * (half + idx)), u)));
+    }
 }
 
+// The folds of round j - 1 and the scalar rows of round j in ONE launch (round 6; two launches before):
+//   * the folds are applied ON THE FLY: p'_new[x] = p'[x] + u^-1 p'[hprev + x], b_new[x] = b[x] + u b[hprev + x] (x < hprev) are computed
+//     where this round's scalar rows read them and written once to the OTHER buffer of a ping-pong pair (a thread's reads are other
+//     threads' writes); the weights are updated in place (own index);
+//   * scalars of L_j (row 0) and R_j (row 1) over the bases g || w || u: v = wgt[idx] p'_new[...] on the half of the indices the row
+//     covers, 0 on the other.
+// consts = (u_prev^-1, u_prev); first = 1 in round 0 (nothing to fold yet: p' and b are read as they are and stay where they are).
+// (Measured and dropped: the two inner products and the tail scalars in the same launch behind a "last block" ticket -- every block's release
+//  fence and the last block's acquire made it 33 - 67 us against 29 us for the four launches of round 5.)
 // both inner products of an IPA round in one launch: partial[pair][block]
 template <class F>
 __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __restrict__ a0, const uint4* __restrict__ b0, const uint4* __restrict__ a1, const uint4* __restrict__ b1, size_t n,
@@ -173,12 +182,28 @@ __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __rest
     if (threadIdx.x == 0) st<F>(partial + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), sh[0]);
 }
 
-// The two tail scalars of both round MSMs without a trip to the host: [rand] W comes from the staged draws, [value z] U from the
-// inner products' partial sums (the host never needs `value`).  Block `side` writes row `side` of the scalar matrix.
-// (the round's constants travel as kernel arguments: a staged copy is a blit kernel and ~20 us of queue idle per round on the trace)
-struct IpaConsts { uint4 w[6]; };
 template <class F>
-__device__ __forceinline__ Fe<F> ipa_const(const IpaConsts& c, int k) { return fe_load<F>(c.w[2 * k].x, c.w[2 * k].y, c.w[2 * k].z, c.w[2 * k].w, c.w[2 * k + 1].x, c.w[2 * k + 1].y, c.w[2 * k + 1].z, c.w[2 * k + 1].w); }
+__global__ void __launch_bounds__(256) ipa_round_front_kernel(const uint4* __restrict__ p_old, const uint4* __restrict__ b_old, uint4* __restrict__ p_new, uint4* __restrict__ b_new,
+                                                              uint4* __restrict__ wgt, uint4* __restrict__ lrsc, size_t n, size_t half, u32 bit, size_t stride, int first,
+                                                              const IpaConsts consts) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const size_t hprev = half << 1;  // the previous round's half
+    const Fe<F> uinv = ipa_const<F>(consts, 0), u = ipa_const<F>(consts, 1);
+    auto pn = [&](size_t x) { return first ? ld<F>(p_old + 2 * x) : fe_add(ld<F>(p_old + 2 * x), fe_mul(ld<F>(p_old + 2 * (hprev + x)), uinv)); };  // x < hprev
+    Fe<F> w = ld<F>(wgt + 2 * idx);
+    if (!first && ((idx >> (bit + 1)) & 1u)) { w = fe_mul(w, u); st<F>(wgt + 2 * idx, w); }
+    const size_t i = idx & (half - 1);
+    const bool hi = (idx >> bit) & 1u;
+    const Fe<F> v = fe_mul(w, pn(hi ? i : half + i));
+    const Fe<F> zero = fe_zero<F>();
+    st<F>(lrsc + 2 * idx, hi ? zero : v);
+    st<F>(lrsc + 2 * (stride + idx), hi ? v : zero);
+    if (!first && idx < hprev) {  // the folded vectors, once
+        st<F>(p_new + 2 * idx, pn(idx));
+        st<F>(b_new + 2 * idx, fe_add(ld<F>(b_old + 2 * idx), fe_mul(ld<F>(b_old + 2 * (hprev + idx)), u)));
+    }
+}
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const IpaConsts consts /* rand_l, rand_r, z */,
                                                               uint4* __restrict__ lrsc, size_t n, size_t stride) {
@@ -196,20 +221,6 @@ __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __res
     if (threadIdx.x == 0) {
         st<F>(lrsc + 2 * (side * stride + n), side ? ipa_const<F>(consts, 1) : ipa_const<F>(consts, 0));
         st<F>(lrsc + 2 * (side * stride + n + 1), fe_mul(sh[0], ipa_const<F>(consts, 2)));
-    }
-}
-// the folds of a round in one launch: p'[i] += u^-1 p'[i + half], b[i] += u b[i + half] (i < half) and the generators' weights
-// (x u where bit log2(half) of the index is set); consts = (u^-1, u)
-template <class F>
-__global__ void __launch_bounds__(256) ipa_round_update_kernel(uint4* __restrict__ p, uint4* __restrict__ b, uint4* __restrict__ wgt, size_t n, size_t half, u32 bit,
-                                                               const IpaConsts consts) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const Fe<F> u = ipa_const<F>(consts, 1);
-    if ((idx >> bit) & 1u) st<F>(wgt + 2 * idx, fe_mul(ld<F>(wgt + 2 * idx), u));
-    if (idx < half) {
-        st<F>(p + 2 * idx, fe_add(ld<F>(p + 2 * idx), fe_mul(ld<F>(p + 2 * (half + idx)), ipa_const<F>(consts, 0))));
-        st<F>(b + 2 * idx, fe_add(ld<F>(b + 2 * idx), fe_mul(ld<F>(b + 2 * (half + idx)), u)));
     }
 }
 
@@ -243,21 +254,6 @@ int read_back(void* out, const void* dev, size_t bytes, hipStream_t s) {
     TRH_HIP_TRY(hipStreamSynchronize(s));
     memcpy(out, c.pinned_land, bytes);
     return TRH_OK;
-}
-
-template <class F>
-int inner_product2_t(const void* a0, const void* b0, const void* a1, const void* b1, size_t n, hipStream_t s, u64* out /* 2 x 4 */) {
-    Ctx& c = ctx();
-    unsigned blocks = (unsigned)((n + 255) / 256);
-    if (blocks > 512) blocks = 512;
-    if (blocks == 0) blocks = 1;
-    TRH_TRY(c.io.ensure((size_t)(2 * blocks + 2) * 32));
-    uint4* partial = c.io.as<uint4>();
-    uint4* result = partial + 4 * blocks;
-    hipLaunchKernelGGL((inner_product2_kernel<F>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)a0, (const uint4*)b0, (const uint4*)a1, (const uint4*)b1, n, partial);
-    hipLaunchKernelGGL((sum_partials_batch_kernel<F>), dim3(2), dim3(256), 0, s, partial, blocks, result);
-    TRH_HIP_TRY(hipGetLastError());
-    return read_back(out, result, 64, s);
 }
 
 // small per-call constant staged in the factor ring (see trh_field_scale_rows_dev)
@@ -348,13 +344,14 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
 
     // scratch kept in the context: a hipMalloc / hipFree pair per vector costs more than several rounds
     DevBuf* sc = ctx().ipa;
-    DevBuf &b = sc[0], &sp = sc[1], &pp = sc[2], &wgt = sc[3], &lrsc = sc[4], &gwu = sc[5], &gwuz = sc[6];
+    DevBuf &b = sc[0], &sp = sc[1], &pp = sc[2], &wgt = sc[3], &lrsc = sc[4], &gwu = sc[5], &gwuz = sc[6], &pp2 = sc[7], &b2 = sc[8];
     // A base set that holds g || w || u (n + 2 points) with fixed-base tables attached (trh_bases_precompute: Params are fixed for
     // the life of a proving key) lets every MSM of the opening run in fixed-base mode: one bucket set instead of one per window,
     // wide windows, no heavy top-window buckets and no Horner over windows on the host between two rounds.
     const bool with_u = gw->n == n + 2;
     const MsmFixedBase* fb = (with_u && gw->d_table) ? &gw->fb : nullptr;
     TRH_TRY(b.ensure(n * 32)); TRH_TRY(sp.ensure((n + 2) * 32)); TRH_TRY(pp.ensure(n * 32)); TRH_TRY(wgt.ensure(n * 32)); TRH_TRY(lrsc.ensure(2 * (n + 2) * 32));
+    TRH_TRY(pp2.ensure(n * 16 + 32)); TRH_TRY(b2.ensure(n * 16 + 32));  // the folded vectors have at most n / 2 entries
     if (!with_u) { TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * ZREC)); }
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
@@ -416,35 +413,44 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         ~WindowGuard() { slot = saved; }
     } window_guard(ctx().window_override, (!fb && k >= 16 && k <= 18) ? (int)k - 8 : 0);  // k = 20: the table's 15 is better again (60 vs 68 ms)
 
-    // per round: the scalar rows, both inner products and the tail scalars are three launches behind one staged 96-byte constant
-    // block (no host synchronisation before the MSM: the host never needs value_l / value_r), the MSM, the transcript, then ONE
-    // launch for the three folds.  (The first version had 14 small operations and two synchronisations per round.)
+    // per round three launches in front of the MSM (the previous round's folds applied on the fly + the scalar rows; both inner products; the tail
+    // scalars -- the round's constants travel as kernel arguments), the MSM, the transcript.  No host synchronisation before the MSM: the host
+    // never needs value_l / value_r.  (Round 5 had four launches here, the first version 14 small operations.)
     FeMem zm = stm(z);
     // TRH_TRACE bit 1: where the host's part of a round goes (averages over the rounds, microseconds, to stderr)
     const bool ipa_trace = (opt().trace & 2) != 0;
     double tr_acc[6] = {0, 0, 0, 0, 0, 0};
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const unsigned fblocks = (unsigned)((n + 255) / 256);
+    TRH_TRY(ctx().io.ensure((size_t)(2 * 512 + 2) * 32));
+    uint4* const partial = ctx().io.as<uint4>();
+    // p' and b live in ping-pong pairs from round 1 on (a round reads the vectors the previous one left and writes their folds to the other buffer)
+    void* p_cur = pp.p; void* b_cur = b.p;
+    void* p_nxt = pp2.p; void* b_nxt = b2.p;
+    Fe<SF> u_prev = fe_one<SF>(), u_prev_inv = fe_one<SF>();
     for (uint32_t j = 0; j < k; ++j) {
         const double t_round0 = ipa_trace ? tnow() : 0;
         const size_t half = (size_t)1 << (k - j - 1);
         const u32 bit = k - j - 1;
-        char* pph = (char*)pp.p + half * 32;
-        char* bh = (char*)b.p + half * 32;
-        // scalars of L_j (row 0) and R_j (row 1) over the bases g ‖ w ‖ u
-        hipLaunchKernelGGL((ipa_round_scalars_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pp.p, (const uint4*)wgt.p, (uint4*)lrsc.p, n, half, bit, stride);
         Fe<SF> rnd[2];
         rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
         {
+            FeMem cst[2] = {stm(u_prev_inv), stm(u_prev)};
+            IpaConsts kc{};
+            memcpy(&kc, cst, sizeof(cst));
+            hipLaunchKernelGGL((ipa_round_front_kernel<SF>), dim3(fblocks), dim3(256), 0, s, (const uint4*)p_cur, (const uint4*)b_cur, (uint4*)p_nxt, (uint4*)b_nxt, (uint4*)wgt.p, (uint4*)lrsc.p,
+                               n, half, bit, stride, j == 0 ? 1 : 0, kc);
+            if (j > 0) { void* t = p_cur; p_cur = p_nxt; p_nxt = t; t = b_cur; b_cur = b_nxt; b_nxt = t; }
+            // value_l = <p'[half ..], b[.. half]>, value_r = <p'[.. half], b[half ..]> over the folded vectors, then the tail scalars [rand] W, [value z] U
             unsigned blocks = (unsigned)((half + 255) / 256);
             if (blocks > 512) blocks = 512;
-            TRH_TRY(ctx().io.ensure((size_t)(2 * blocks + 2) * 32));
-            uint4* partial = ctx().io.as<uint4>();
-            hipLaunchKernelGGL((inner_product2_kernel<SF>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)pph, (const uint4*)b.p, (const uint4*)pp.p, (const uint4*)bh, half, partial);
-            FeMem cst[3] = {stm(rnd[0]), stm(rnd[1]), zm};
-            IpaConsts kc;
-            memcpy(&kc, cst, sizeof(cst));
-            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, kc, (uint4*)lrsc.p, n, stride);
+            hipLaunchKernelGGL((inner_product2_kernel<SF>), dim3(blocks, 2), dim3(256), 0, s, (const uint4*)((const char*)p_cur + half * 32), (const uint4*)b_cur, (const uint4*)p_cur,
+                               (const uint4*)((const char*)b_cur + half * 32), half, partial);
+            FeMem cst3[3] = {stm(rnd[0]), stm(rnd[1]), zm};
+            IpaConsts kt{};
+            memcpy(&kt, cst3, sizeof(cst3));
+            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, kt, (uint4*)lrsc.p, n, stride);
             TRH_HIP_TRY(hipGetLastError());
         }
         u64 lrb[24], lr[2][12];
@@ -463,24 +469,25 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const Fe<SF> u_j = fe_load<SF>(tmp);
         if (fe_is_zero(u_j)) { set_error("ipa_create_proof: round %u challenge is zero (the Rust prover's u_j.invert().unwrap() panics here)", j); return TRH_EINVAL; }
         const Fe<SF> u_inv = fe_inv(u_j);
-        {
-            FeMem cst[2] = {stm(u_inv), stm(u_j)};
-            IpaConsts kc{};
-            memcpy(&kc, cst, sizeof(cst));
-            hipLaunchKernelGGL((ipa_round_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)pp.p, (uint4*)b.p, (uint4*)wgt.p, n, half, bit, kc);
-            TRH_HIP_TRY(hipGetLastError());
-        }
+        u_prev = u_j; u_prev_inv = u_inv;  // folded into the next round's front launch (or by the launch behind the loop)
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
         if (ipa_trace) {
             const double t_end = tnow();
             tr_acc[0] += t_enq - t_round0; tr_acc[1] += t_fin - t_enq; tr_acc[2] += t_tr - t_fin; tr_acc[3] += t_end - t_tr; tr_acc[4] += t_end - t_round0;
         }
     }
+    if (k > 0) {  // the last round's fold: p'[0] += u^-1 p'[1] (b and the weights are not read again, the kernel folds them too)
+        FeMem cst[2] = {stm(u_prev_inv), stm(u_prev)};
+        IpaConsts kc{};
+        memcpy(&kc, cst, sizeof(cst));
+        hipLaunchKernelGGL((ipa_round_update_kernel<SF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)p_cur, (uint4*)b_cur, (uint4*)wgt.p, n, (size_t)1, 0u, kc);
+        TRH_HIP_TRY(hipGetLastError());
+    }
     if (ipa_trace)
         fprintf(stderr, "[trh ipa] k = %u, per round (us): enqueue %.1f, wait for the MSM (sync + host combine) %.1f, transcript callbacks %.1f, inversion + update launch %.1f, round %.1f\n",
                 k, tr_acc[0] / k, tr_acc[1] / k, tr_acc[2] / k, tr_acc[3] / k, tr_acc[4] / k);
     TRH_HIP_TRY(hipStreamSynchronize(s));
-    TRH_HIP_TRY(hipMemcpy(&tmp, pp.p, 32, hipMemcpyDeviceToHost));
+    TRH_HIP_TRY(hipMemcpy(&tmp, p_cur, 32, hipMemcpyDeviceToHost));
     FeMem fm = stm(f);
     tr->write_scalar(tr->ctx, (const u64*)&tmp);
     tr->write_scalar(tr->ctx, (const u64*)&fm);

@@ -485,28 +485,6 @@ __global__ void __launch_bounds__(RANGE_BLOCK) msm_bucket_ranges_kernel(u32* __r
     }
 }
 
-// seg_bucket[sg] = the bucket that holds entry sg * seg_len (first bucket whose end lies beyond it); one thread per
-// segment, binary search over the (L2-resident) bucket ends -- a single workgroup filling 10^5 segments was the
-// latency floor of small MSMs
-__global__ void __launch_bounds__(256) msm_seg_bucket_kernel(const u32* __restrict__ ends, u32* __restrict__ seg_bucket, u32 nbk, u32 nseg, u32 seg_len) {
-    const size_t z = blockIdx.z;
-    const size_t Wz = gridDim.y;
-    const int j = blockIdx.y;
-    const u32 nb1 = nbk + 1;
-    const u32* en = ends + (z * Wz + j) * nb1;
-    u32* sb = seg_bucket + (z * Wz + j) * nseg;
-    const u32 sg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sg >= nseg) return;
-    const u32 pos = sg * seg_len;
-    if (pos >= en[nbk]) return;  // beyond the last entry: never read
-    u32 lo = 0, hi = nbk;        // smallest b with en[b] > pos (en is non-decreasing, en[0] = 0)
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (en[mid] > pos) hi = mid; else lo = mid + 1;
-    }
-    sb[sg] = lo;
-}
-
 // ---------------------------------------------------------------------------------------
 // 4. accumulate
 // ---------------------------------------------------------------------------------------
@@ -599,13 +577,15 @@ __device__ __forceinline__ XYZZz<BF> load_raw(const XYZZzMem* src) {
 
 template <class BF>
 __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __restrict__ bases_z, const u32* __restrict__ sorted,
-                                                                 const u32* __restrict__ ends, const u32* __restrict__ seg_bucket,
+                                                                 const u32* __restrict__ ends,
                                                                  XYZZzMem* __restrict__ first, XYZZzMem* __restrict__ last,
-                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len) {
+                                                                 XYZZzMem* __restrict__ direct, size_t n, u32 nbk, u32 nseg, u32 seg_len,
+                                                                 const u32* __restrict__ lean_gate /* or null: lean sort -- a window whose bin sort gave up has no sorted list (msm_finish repeats the MSM) */) {
     const size_t z = blockIdx.z;  // batch item
+    if (lean_gate && lean_gate[z * gridDim.y + blockIdx.y] != 0u) return;
     {
         const size_t Wz = gridDim.y;
-        sorted += z * Wz * n; ends += z * Wz * (nbk + 1); seg_bucket += z * Wz * nseg;
+        sorted += z * Wz * n; ends += z * Wz * (nbk + 1);
         first += z * Wz * nseg; last += z * Wz * nseg; direct += z * Wz * (nbk + 1);
     }
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -617,7 +597,17 @@ __global__ void __launch_bounds__(256) msm_accumulate_seg_kernel(const uint4* __
     u32 pos = t * seg_len;
     if (pos >= total) return;
     const u32 stop = pos + seg_len < total ? pos + seg_len : total;
-    u32 B = seg_bucket[(size_t)j * nseg + t];
+    // the bucket that holds the segment's first entry: smallest b with en[b] > pos (en is non-decreasing, en[0] = 0, pos < total = en[nbk]).
+    // ~log2(nbk) L2-resident loads per thread (round 6: a kernel of its own until then -- 6 us of every small MSM's chain for the same loads)
+    u32 B;
+    {
+        u32 lo = 0, hi = nbk;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (en[mid] > pos) hi = mid; else lo = mid + 1;
+        }
+        B = lo;
+    }
     u32 cur_end = en[B];
     const u32* lst = sorted + (size_t)j * n;
     XYZZzMem* my_first = first + (size_t)j * nseg + t;
@@ -759,8 +749,10 @@ template <class BF, int G>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                           const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                           const XYZZzMem* __restrict__ direct, XYZZzMem* __restrict__ buckets,
-                                                          u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride) {
+                                                          u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride,
+                                                          const u32* __restrict__ lean_gate /* or null, see msm_accumulate_seg_kernel */) {
     const size_t z = blockIdx.z;  // batch item
+    if (lean_gate && lean_gate[z * gridDim.y + blockIdx.y] != 0u) return;
     {
         const size_t Wz = gridDim.y;
         starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
@@ -881,8 +873,10 @@ template <class BF>
 __global__ void __launch_bounds__(256) msm_combine_q4_kernel(const u32* __restrict__ starts, const u32* __restrict__ ends,
                                                              const XYZZzMem* __restrict__ first, const XYZZzMem* __restrict__ last,
                                                              const XYZZzMem* __restrict__ direct, XYZZzMem* __restrict__ buckets,
-                                                             u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride) {
+                                                             u32 nbk, u32 nseg, u32 seg_len, u32* __restrict__ heavy /* [0] = count, then list */, u32 heavy_stride,
+                                                             const u32* __restrict__ lean_gate /* or null, see msm_accumulate_seg_kernel */) {
     const size_t z = blockIdx.z;  // batch item
+    if (lean_gate && lean_gate[z * gridDim.y + blockIdx.y] != 0u) return;
     {
         const size_t Wz = gridDim.y;
         starts += z * Wz * (nbk + 1); ends += z * Wz * (nbk + 1); first += z * Wz * nseg; last += z * Wz * nseg;
@@ -955,7 +949,10 @@ __global__ void __launch_bounds__(256) msm_reduce_q4_kernel(const XYZZzMem* __re
 }
 // one block per window: the sum of `count` partials as 64 quads, handed over in the canonical form (lane q converts and stores coordinate q)
 template <class BF>
-__global__ void __launch_bounds__(256) msm_window_sum_q4_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+__global__ void __launch_bounds__(256) msm_window_sum_q4_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count,
+                                                                const u32* __restrict__ flag_src /* or null */, u32* __restrict__ flag_dst, u32 nflags) {
+    // (the sort's "a bin did not fit the LDS" flags ride to the host behind the window sums: see `lean_sort` in msm_enqueue_t)
+    if (flag_src && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < nflags) flag_dst[threadIdx.x] = flag_src[threadIdx.x];
     const size_t z = blockIdx.z;
     partials += z * (size_t)gridDim.x * count; window_sums += z * (size_t)gridDim.x;
     __shared__ Fy<BF> sh[256];
@@ -983,7 +980,9 @@ __global__ void __launch_bounds__(256) msm_window_sum_q4_kernel(const XYZZzMem* 
 
 // one block per window: sum `count` partials, hand the window sum over in the canonical form
 template <class BF>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count) {
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XYZZzMem* __restrict__ partials, XYZZMem* __restrict__ window_sums, u32 count,
+                                                             const u32* __restrict__ flag_src /* or null */, u32* __restrict__ flag_dst, u32 nflags) {
+    if (flag_src && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < nflags) flag_dst[threadIdx.x] = flag_src[threadIdx.x];
     const size_t z = blockIdx.z;  // batch item
     partials += z * (size_t)gridDim.x * count; window_sums += z * (size_t)gridDim.x;
     __shared__ XYZZz<BF> sh[256];
@@ -1444,7 +1443,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.bucket_cnt.ensure(chunk * Ws * nb1 * 4 + 16));
     TRH_TRY(L.ends.ensure(chunk * Ws * nb1 * 4));
     const unsigned range_blocks = (nb1 + RANGE_BLOCK - 1) / RANGE_BLOCK;  // <= 2^17 / 1024 + 1 = 129 < RANGE_BLOCK threads
-    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg0 > range_blocks ? nseg0 : range_blocks) * 4 + 16));
+    TRH_TRY(L.seg_bucket.ensure(chunk * Ws * range_blocks * 4 + 16));  // block totals of the chunked passes' range scan
     TRH_TRY(L.first.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
     TRH_TRY(L.last.ensure(chunk * Ws * nseg0 * sizeof(XYZZzMem)));
     TRH_TRY(L.direct.ensure(chunk * Ws * nb1 * sizeof(XYZZzMem)));
@@ -1453,8 +1452,14 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     TRH_TRY(L.partials.ensure(chunk * Ws * rblocks * sizeof(XYZZzMem)));
     if (!bases_z && !fb) TRH_TRY(m.bases_z.ensure(n * ZREC + ZREC));
     const uint4* bz = fb ? (const uint4*)fb->table : bases_z ? (const uint4*)bases_z : m.bases_z.as<uint4>();
-    TRH_TRY(m.window_sums.ensure(batch * Ws * sizeof(XYZZMem)));
-    const size_t hs = batch * Ws * sizeof(XYZZMem);
+    // Lean sort: a caller that vouches for uniformly random scalars (dense_hint: the IPA's rounds) gets the whole-bin LDS sort WITHOUT the four
+    // launches of the chunked fallback behind it (they return at once unless a bin overflowed the LDS: 19 us of a round's 680).  The "a bin
+    // did overflow" flags travel to the host behind the window sums, and msm_finish repeats the MSM with the fallback when one is set
+    // (the scalars must stay as they are until msm_finish: true of every caller that sets dense_hint).
+    const bool lean_sort = m.dense_hint && !m.force_fallback && use_bin && batch <= chunk && (size_t)batch * Ws <= 256 && n != 0;
+    const size_t flag_off = batch * Ws * sizeof(XYZZMem);
+    TRH_TRY(m.window_sums.ensure(flag_off + (lean_sort ? batch * Ws * 4 : 0)));
+    const size_t hs = flag_off + (lean_sort ? batch * Ws * 4 : 0);
     if (hs > m.host_sums_cap) {
         if (m.host_sums) (void)hipHostFree(m.host_sums);
         TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
@@ -1559,7 +1564,6 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             const size_t mh = (size_t)Ws * nseg / HEAVY_PIECES + 1;
             heavy_stride = (u32)(mh + 1);
             heavy_blocks = (unsigned)(mh < 256 ? mh : 256);
-            TRH_TRY(L.seg_bucket.ensure(chunk * Ws * (nseg > range_blocks ? nseg : range_blocks) * 4 + 16));
             TRH_TRY(L.first.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
             TRH_TRY(L.last.ensure(chunk * Ws * nseg * sizeof(XYZZzMem)));
             TRH_TRY(L.heavy.ensure(chunk * heavy_stride * 4));
@@ -1575,6 +1579,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             if (bin_sort)
                 hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(nbins, Ws, nb), dim3(BIN_THREADS), (size_t)bin_cap * 4, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                    L.sorted.as<u32>(), L.starts.as<u32>(), L.ends.as<u32>(), nse, k2, nbins, idx_bits, nbk, oversize);
+            if (!(lean_sort && bin_sort)) {
             if (!zero_fused) TRH_HIP_TRY(hipMemsetAsync(L.bucket_cnt.p, 0, (size_t)nb * Ws * nb1 * 4, s));
             hipLaunchKernelGGL((msm_bucket_pass_kernel<false>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), nse, k2, nbins, idx_bits, nbk, gate);
@@ -1582,9 +1587,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             hipLaunchKernelGGL(msm_bucket_block_sums_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), nbk, gate);
             hipLaunchKernelGGL(msm_bucket_ranges_kernel, dim3(range_blocks, Ws, nb), dim3(RANGE_BLOCK), 0, s, L.bucket_cnt.as<u32>(), L.seg_bucket.as<u32>(), L.starts.as<u32>(),
                                L.ends.as<u32>(), nbk, gate);
-            hipLaunchKernelGGL(msm_seg_bucket_kernel, dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, L.ends.as<u32>(), L.seg_bucket.as<u32>(), nbk, nseg, seg_len);
             hipLaunchKernelGGL((msm_bucket_pass_kernel<true>), cgrid, dim3(BS_THREADS), 0, s, L.parted.as<u32>(), L.bin_starts.as<u32>(), L.counts.as<u32>(),
                                L.bucket_cnt.as<u32>(), L.sorted.as<u32>(), nse, k2, nbins, idx_bits, nbk, gate);
+            }
             if (compact) {
                 unsigned gr = (entry_most + 255) / 256;
                 if (gr > 512) gr = 512;
@@ -1595,13 +1600,15 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (b0 == 0 && !bases_z && !fb)
             hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
         hipLaunchKernelGGL((msm_accumulate_seg_kernel<BF>), dim3((nseg + 255) / 256, Ws, nb), dim3(256), 0, s, bz, L.sorted.as<u32>(),
-                           L.ends.as<u32>(), L.seg_bucket.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), nse, nbk, nseg, seg_len);
+                           L.ends.as<u32>(), L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), nse, nbk, nseg, seg_len,
+                           (lean_sort && bin_sort) ? oversize : (const u32*)nullptr);
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[5], s));
         {
             const size_t pieces = compact ? 4 : ns / ((size_t)nbk * seg_len);  // expected pieces per bucket
 #define TRH_LAUNCH_COMBINE(G)                                                                                                                          \
     hipLaunchKernelGGL((msm_combine_kernel<BF, G>), dim3((unsigned)(((size_t)nbk * G + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(), \
-                       L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride)
+                       L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride, \
+                       (lean_sort && bin_sort) ? oversize : (const u32*)nullptr)
             // measured on the IPA opening at k = 18 (32 pieces per bucket): 24.0 ms with one lane per bucket, 23.0 with 4, 26.1 with 16
             // (idle lanes of the wider groups still occupy the SIMD)
             // sparse lists cut into short segments (adaptive): the few buckets that hold anything hold many pieces (an even-bits word column:
@@ -1613,7 +1620,8 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // it measured 0.52 -> 0.58 ms, full-size and word columns the same
             if (pieces >= 3 && nbk >= 4 && !compact && opt().reduce_q4 && m.dense_hint && (size_t)Ws * nb <= 8)
                 hipLaunchKernelGGL((msm_combine_q4_kernel<BF>), dim3((unsigned)(((size_t)nbk * 4 + 255) / 256), Ws, nb), dim3(256), 0, s, L.starts.as<u32>(), L.ends.as<u32>(),
-                                   L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride);
+                                   L.first.as<XYZZzMem>(), L.last.as<XYZZzMem>(), L.direct.as<XYZZzMem>(), L.buckets.as<XYZZzMem>(), nbk, nseg, seg_len, L.heavy.as<u32>(), heavy_stride,
+                                   (lean_sort && bin_sort) ? oversize : (const u32*)nullptr);
             else if (pieces >= 3 && nbk >= 4) TRH_LAUNCH_COMBINE(4);
             else TRH_LAUNCH_COMBINE(1);
 #undef TRH_LAUNCH_COMBINE
@@ -1638,10 +1646,12 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
                 const u32 q4_blocks = (q4_tpw + 63) / 64;
                 TRH_TRY(L.partials.ensure((size_t)chunk * Ws * q4_blocks * sizeof(XYZZzMem)));
                 hipLaunchKernelGGL((msm_reduce_q4_kernel<BF>), dim3(q4_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, nbk / q4_tpw, q4_tpw);
-                hipLaunchKernelGGL((msm_window_sum_q4_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, q4_blocks);
+                hipLaunchKernelGGL((msm_window_sum_q4_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, q4_blocks,
+                                   lean_sort ? oversize : (const u32*)nullptr, (u32*)((char*)m.window_sums.p + flag_off), (u32)(nb * Ws));
             } else {
             hipLaunchKernelGGL((msm_reduce_kernel<BF>), dim3(r_blocks, Ws, nb), dim3(256), 0, s, L.buckets.as<XYZZzMem>(), L.partials.as<XYZZzMem>(), nbk, r_slice, r_tpw);
-            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks);
+            hipLaunchKernelGGL((msm_window_sum_kernel<BF>), dim3(Ws, 1, nb), dim3(256), 0, s, L.partials.as<XYZZzMem>(), m.window_sums.as<XYZZMem>() + b0 * Ws, r_blocks,
+                               lean_sort ? oversize : (const u32*)nullptr, (u32*)((char*)m.window_sums.p + flag_off), (u32)(nb * Ws));
             }
         }
         if (timing) TRH_HIP_TRY(hipEventRecord(m.ev[4], s));
@@ -1730,6 +1740,13 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     m.pending_stream = s;
     m.pending_owner = nullptr;
     m.ev_valid = timing;
+    m.lean_pending = lean_sort;
+    if (lean_sort) {  // what msm_finish needs to run this MSM again with the chunked passes
+        m.retry.bases_dev = bases_dev; m.retry.bases_z = bases_z; m.retry.scalars_dev = scalars_dev; m.retry.tails_dev = tails_dev;
+        m.retry.n = n; m.retry.batch = batch; m.retry.stride = stride; m.retry.mont = mont;
+        m.retry.has_fb = fb != nullptr;
+        if (fb) m.retry.fb = *fb;
+    }
     return TRH_OK;
 }
 
@@ -1745,8 +1762,26 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
     Ctx& c = ctx();
     MsmScratch& m = c.msm;
     if (m.pending_curve != BF::ID || m.pending_batch != batch || m.pending_stream != s) { set_error("msm_finish: no matching MSM enqueued on this context and stream"); return TRH_EINVAL; }
+    const int curve_id = m.pending_curve;
     m.pending_curve = -1;  // whatever happens below, the context is free for the next MSM
     TRH_HIP_TRY(hipStreamSynchronize(s));
+    if (m.lean_pending) {  // the lean sort's promise: no bin overflowed the LDS of msm_bin_sort_kernel.  Otherwise: once more, with the chunked passes
+        m.lean_pending = false;
+        const u32* fl = (const u32*)((const char*)m.host_sums + batch * m.pending_windows * sizeof(XYZZMem));
+        bool over = false;
+        for (size_t q = 0; q < batch * (size_t)m.pending_windows; ++q) over = over || fl[q] != 0;
+        if (over) {
+            const bool hint = m.dense_hint;
+            m.force_fallback = true; m.dense_hint = true;
+            const int rc = msm_enqueue(curve_id, m.retry.bases_dev, m.retry.bases_z, m.retry.scalars_dev, m.retry.n, m.retry.batch, m.retry.stride, m.retry.mont, s,
+                                       m.retry.has_fb ? &m.retry.fb : nullptr, m.retry.tails_dev);
+            m.force_fallback = false; m.dense_hint = hint;
+            m.pending_curve = -1;
+            TRH_TRY(rc);
+            TRH_HIP_TRY(hipStreamSynchronize(s));
+            ++m.lean_retries;
+        }
+    }
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
     hostcombine::combine_windows_batch<BF>((const uint64_t*)ws, m.pending_windows, m.pending_c, batch, (uint64_t*)out_xyz);  // one inversion for the whole batch
     if (m.ev_valid) {
