@@ -23,4 +23,9 @@ for _ in range(reps):
     api.ntt_dev("fp", d, log_n, w, batch=batch, stream=st)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"ntt 2^{log_n} x{batch}: {ms:.4f} ms  {(1 << log_n) * batch / ms / 1e6:.2f} Gelem/s")
+import hashlib
+d2 = torch.from_numpy(a.view(np.int64).copy()).cuda()
+api.ntt_dev("fp", d2, log_n, w, batch=batch, stream=st)
+torch.cuda.synchronize()
+digest = hashlib.sha256(d2.cpu().numpy().tobytes()).hexdigest()[:16]
+print(f"ntt 2^{log_n} x{batch}: {ms:.4f} ms  {(1 << log_n) * batch / ms / 1e6:.2f} Gelem/s  output sha256 {digest}")
