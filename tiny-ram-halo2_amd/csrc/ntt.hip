@@ -454,9 +454,7 @@ __global__ void __launch_bounds__((1 << TLOG) >> LG) ntt_passy_kernel(const uint
     constexpr int G = 1 << LG, T = 1 << TLOG;
     // grid order: tile-major (x = tile, y = transform) or batch-major (x = transform, y = tile: consecutive workgroups run the SAME
     // tile of consecutive transforms, so the rows of the shared inter-pass twiddle table they read stay in L2)
-    u32 bx = batch_major == 1 ? blockIdx.y : blockIdx.x;
-    const u32 by = batch_major == 1 ? blockIdx.x : blockIdx.y;
-    if (batch_major == 2) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);  // EXPERIMENT: workgroup b runs on XCD b % 8 -- give each XCD a contiguous range of tiles
+    const u32 bx = batch_major ? blockIdx.y : blockIdx.x, by = batch_major ? blockIdx.x : blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = 1 << s;
     const int log_c = TLOG - s;
@@ -624,7 +622,9 @@ TwiddleEntry* find_tables(int field, int log_n, const u64 omega[4], const u64* s
 
 // pass plan: log_n split into passes of <= MAX_PASS_LOG stages on 2^tlog-element tiles
 void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
-    // (a 4096-element tile -- two passes for 2^19..2^22, all 160 KiB of LDS, one workgroup per CU -- measured equal: removed)
+    // (a 4096-element tile -- two passes for 2^19..2^22, all 160 KiB of LDS, one workgroup per CU -- measured equal: removed.  Round 6: 2^22 as
+    //  two 11-stage passes on the 2048-element tile, pass 0 reading 64-KiB-strided columns: 0.83 ms against 0.47 for 8 + 7 + 7, the fabric
+    //  fetches 4.8 x the bytes -- profiles/r06_ntt_11_11_ab.txt.)
     int P = 0, tlog = TILE_LOG;
     if (log_n <= TILE_LOG) { sizes[P++] = log_n; }
     else {
@@ -632,11 +632,6 @@ void plan_passes(int log_n, int* sizes, int* n_passes, int* tile_log) {
         if (P < 2) P = 2;
         int rem = log_n;
         for (int p = 0; p < P; ++p) { sizes[p] = (rem + (P - p) - 1) / (P - p); rem -= sizes[p]; }
-        if (const char* e = getenv("TRH_EXP_NTT_PLAN")) {  // EXPERIMENT (round 6): explicit pass sizes, e.g. "11,11"
-            int v[8], cnt = 0, sum = 0;
-            for (const char* q = e; *q && cnt < 8;) { v[cnt] = atoi(q); sum += v[cnt++]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-            if (sum == log_n) { P = cnt; for (int p = 0; p < P; ++p) sizes[p] = v[p]; }
-        }
     }
     *n_passes = P; *tile_log = tlog;
 }
@@ -695,12 +690,12 @@ int build_tables(int log_n, const u64 omega[4], const u64* scale, hipStream_t s,
             log_ns += sizes[p];
         }
     }
-    int nine = 0;
-    for (int p = 0; p < P; ++p) if (sizes[p] >= 9) nine = sizes[p];  // EXPERIMENT: passes of up to 11 stages share one tile table
+    bool nine = false;
+    for (int p = 0; p < P; ++p) nine = nine || sizes[p] == 9;
     if (rc == TRH_OK && nine && tlog == TILE_LOG && log_n >= TILE_LOG) {
-        rc = t->tile9.ensure(((size_t)1 << (nine - 1)) * 36);
+        rc = t->tile9.ensure((size_t)256 * 36);
         if (rc == TRH_OK)
-            hipLaunchKernelGGL((ntt_tile_table_y_kernel<F>), dim3(((1u << (nine - 1)) + 255) / 256), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, t->tile9.as<uint4>(), log_n, nine);
+            hipLaunchKernelGGL((ntt_tile_table_y_kernel<F>), dim3(1), dim3(256), 0, s, t->zlo.as<uint4>(), t->zhi.as<uint4>(), t->lo_bits, t->tile9.as<uint4>(), log_n, 9);
     }
     TRH_HIP_TRY(hipGetLastError());
     TRH_HIP_TRY(hipStreamSynchronize(s));  // pw is a stack buffer
@@ -722,7 +717,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
     const size_t N = (size_t)1 << log_n;
     uint4* a = (uint4*)a_dev;
     bool all_lazy = tlog == TILE_LOG && (int)log_n >= TILE_LOG && P >= 2;
-    for (int p = 0; p < P; ++p) all_lazy = all_lazy && sizes[p] >= 2 && sizes[p] <= (getenv("TRH_EXP_NTT_PLAN") ? 11 : MAX_PASS_LOG);
+    for (int p = 0; p < P; ++p) all_lazy = all_lazy && sizes[p] >= 2 && sizes[p] <= MAX_PASS_LOG;
     if (scale && !(all_lazy && t->scaled)) { set_error("ntt: this size cannot take a factor in its tables (ntt_can_fold_scale)"); return TRH_EINVAL; }
     if (all_lazy) {
         // signed-domain passes: caller's words -> raw nine-limb scratch -> ... -> caller's words (canonical)
@@ -739,9 +734,8 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
             int log_ns = 0;
             for (int p = 0; p < P; ++p) {
                 const int sp = sizes[p];
-                static const int exp_xcd = getenv("TRH_EXP_NTT_XCD") ? atoi(getenv("TRH_EXP_NTT_XCD")) : 0;  // EXPERIMENT: 1 = pass 0's tiles dealt out so that one XCD takes consecutive columns
-                const int batch_major = (exp_xcd && p == 0 && nb == 1 && ((N >> TILE_LOG) % 8) == 0) ? 2 : nb >= 8 && p > 0 && (N >> TILE_LOG) <= 65535;  // consecutive workgroups run the same tile of consecutive transforms: the inter-pass table's rows are re-read from the L2
-                const dim3 grid = batch_major == 1 ? dim3((unsigned)nb, (unsigned)(N >> TILE_LOG)) : dim3((unsigned)(N >> TILE_LOG), (unsigned)nb);
+                const int batch_major = nb >= 8 && p > 0 && (N >> TILE_LOG) <= 65535;  // consecutive workgroups run the same tile of consecutive transforms: the inter-pass table's rows are re-read from the L2
+                const dim3 grid = batch_major ? dim3((unsigned)nb, (unsigned)(N >> TILE_LOG)) : dim3((unsigned)(N >> TILE_LOG), (unsigned)nb);
                 const uint4* direct = t->direct[p].p ? t->direct[p].as<uint4>() : nullptr;
                 NttFusion kf;
                 if (fu && p == 0) {
@@ -757,7 +751,7 @@ int ntt_device_t(void* a_dev, uint32_t log_n, const u64 omega[4], size_t batch, 
                 uint4* dst = p == P - 1 ? base : (uint4*)raw[p & 1];
                 const size_t ldl = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 1));
                 const size_t ldh = ((size_t)36 << TILE_LOG) + ((size_t)36 << (sp - 2));
-                const uint4* tile_tab = (sp >= 9 && t->tile9.p) ? t->tile9.as<uint4>() : nullptr;
+                const uint4* tile_tab = (sp == 9 && t->tile9.p) ? t->tile9.as<uint4>() : nullptr;
 #define TRH_LAUNCH_PASSY(TWM, FUSE, LDS)                                                                                                       \
     hipLaunchKernelGGL((ntt_passy_kernel<F, 2, TILE_LOG, TWM, FUSE>), grid, dim3(TILE >> 2), LDS, s, src, dst, (int)log_n, sp, log_ns, t->zlo.as<uint4>(), \
                        t->zhi.as<uint4>(), t->lo_bits, (int)(p == P - 1), (int)(p > 0), (int)(p < P - 1), direct, kf, batch_major, tile_tab)
@@ -835,7 +829,7 @@ int ntt_device(int field, void* a_dev, uint32_t log_n, const u64 omega[4], size_
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_pass_kernel<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FpParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passg_kernel<FqParams, 2, TILE_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        const int z_lds = (36 << TILE_LOG) + (36 << 9);  // EXPERIMENT: 90 KiB for 11-stage passes (80 KiB: two workgroups per CU)
+        const int z_lds = (36 << TILE_LOG) + (32 << (MAX_PASS_LOG - 1));  // 80 KiB: two workgroups per CU
 #define TRH_PASSY_ATTR(FIELD, TWM, FUSE) TRH_HIP_TRY(hipFuncSetAttribute((const void*)ntt_passy_kernel<FIELD, 2, TILE_LOG, TWM, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, z_lds))
         TRH_PASSY_ATTR(FpParams, 1, false); TRH_PASSY_ATTR(FpParams, 1, true);
         TRH_PASSY_ATTR(FqParams, 1, false); TRH_PASSY_ATTR(FqParams, 1, true);
