@@ -1,11 +1,11 @@
-"""Timeline of the single-call host entries (TRH_IO_TRACE=1 makes csrc/hostio.hip print microseconds since the call began):
+"""Timeline of the single-call host entries (TRH_TRACE=1, read once per process, makes csrc/hostio.hip print microseconds since the call began):
 tools/io_trace_probe.py [log_n]  -- a full 2^log_n best_fft, then the zero-padded shape of coeff_to_extended (data in the first eighth)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-os.environ["TRH_IO_TRACE"] = "1"
+os.environ["TRH_TRACE"] = "1"
 import torch
 from tiny_ram_halo2_amd import api, synth
 import pasta as o
@@ -32,7 +32,6 @@ api.ntt_dev("fp", d, log_n, w); torch.cuda.synchronize()
 assert (d.cpu().numpy().view(np.uint64) == pad).all(), "zero-elided upload changed the transform"
 print("ok", file=sys.stderr)
 # the shapes of the k = 18 proof's literal drop-in: trh_msm over 2^18 + 1 host scalars, best_fft 2^18, zero-padded best_fft 2^21 (wall times, no trace)
-os.environ["TRH_IO_TRACE"] = "0"
 k = 18
 n = 1 << k
 bases = api.Bases.generate("vesta", synth.BASE_S0, synth.BASE_D, n + 1)
@@ -54,7 +53,6 @@ def padded():
 padded(); padded()
 print(f"k=18 shapes: trh_msm 2^18+1 host scalars {t(lambda: bases.msm(sc)):.3f} ms; best_fft 2^18 {t(lambda: api.best_fft_inplace('fp', col, w18, k)):.3f} ms; "
       f"zero-padded best_fft 2^21 {sum(padded() for _ in range(20)) / 20 * 1e3:.3f} ms", file=sys.stderr)
-os.environ["TRH_IO_TRACE"] = "1"
 print("--- trace: best_fft 2^18", file=sys.stderr)
 api.best_fft_inplace("fp", col, w18, k)
 print("--- trace: zero-padded best_fft 2^21", file=sys.stderr)

@@ -26,6 +26,15 @@ def main():
             subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], capture_output=True)
             for co in glob.glob(local + ".*amdgcn*"):
                 notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+                # static instruction count per kernel: lines of the disassembly between the kernel's label and the next one
+                counts, cur_fn = {}, None
+                for line in subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout.splitlines():
+                    m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+                    if m:
+                        cur_fn = m.group(1)
+                        counts[cur_fn] = 0
+                    elif cur_fn and re.match(r"^\s+[a-z_0-9]+(\s|$)", line) and not line.strip().startswith("s_code_end"):
+                        counts[cur_fn] += 1
                 cur = {}
                 for line in notes.splitlines():
                     m = re.match(r"\s+\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\S+)", line)
@@ -40,7 +49,8 @@ def main():
                         cur[key] = int(val)
                     if all(k in cur for k in ("short", "vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")):
                         prev = out.get(cur["short"])
-                        ent = {"vgpr": cur["vgpr_count"], "sgpr": cur["sgpr_count"], "scratch": cur["private_segment_fixed_size"], "lds": cur["group_segment_fixed_size"]}
+                        ent = {"vgpr": cur["vgpr_count"], "sgpr": cur["sgpr_count"], "scratch": cur["private_segment_fixed_size"], "lds": cur["group_segment_fixed_size"],
+                               "isa_instructions": counts.get(cur["mangled"].replace(".kd", ""), 0)}
                         if prev is None or ent["vgpr"] > prev["vgpr"]:
                             out[cur["short"]] = ent  # template instances that share a short name: the largest
                         cur = {}

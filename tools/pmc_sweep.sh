@@ -10,6 +10,7 @@ OUT=$REPO/gpurun_out/pmc_sweep_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+python3 -c "import sys; sys.path.insert(0, '$REPO'); from tiny_ram_halo2_amd import api; print(api.lib().trh_version().decode())" > $OUT/version.txt 2>/dev/null
 for lg in 20 22 26; do
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$OUT/msm${lg}_$( [ $c = FETCH_SIZE ] && echo fetch || echo write )

@@ -9,6 +9,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+# the library build the counters are collected on (bench.py flags a traffic figure whose build is not the running library's)
+python3 -c "import sys; sys.path.insert(0, '$REPO'); from tiny_ram_halo2_amd import api; print(api.lib().trh_version().decode())" > $OUT/version.txt 2>/dev/null
 ARGS="--gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-check --no-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- python3 $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1

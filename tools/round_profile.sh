@@ -38,17 +38,21 @@ if [ "$MODE" = collect ]; then
     # round 4: stall / instruction-cache counters of the accumulation, the reduction A/B, the column-sharded per-column phase on two contexts
     # (Python mirror and compiled driver), a lone commitment per witness class with and without the sparse-column path, the bank probe
     bash tools/pmc_stall.sh $TAG 24 > gpurun_out/msm_stall_counters_$TAG.txt 2>&1
-    bash tools/reduce_ab.sh > gpurun_out/reduce_ab_$TAG.txt 2>&1
     python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --devices 0,0 2>/dev/null | tail -1 > gpurun_out/replay_sharded_$TAG.json
     LD_LIBRARY_PATH=tiny-ram-halo2_amd ./examples/replay --word-bits 32 --columns witness --devices 0,0 2>/dev/null | tail -1 > gpurun_out/native_replay_sharded_$TAG.json
     (python3 tools/lone_sparse_probe.py 2>/dev/null | tail -1; TRH_SPARSE=0 python3 tools/lone_sparse_probe.py 2>/dev/null | tail -1) > gpurun_out/lone_sparse_probe_$TAG.txt
     [ -x tools/bank_probe ] && ./tools/bank_probe > gpurun_out/bank_probe_$TAG.txt 2>&1
     TRH_SPARSE=0 python3 -m tiny_ram_halo2_amd.replay --word-bits 32 --columns witness --no-keygen 2>/dev/null | tail -1 > gpurun_out/replay_witness_nosparse_$TAG.json
     python3 tools/io_trace_probe.py 22 2>&1 | grep -E "^full|^zero-padded|k=18 shapes" > gpurun_out/io_shapes_$TAG.txt
+    # round 6: PMC traffic at the sweep sizes with the build id beside it, the driver diff, the soak of the final build
+    # (tools/pmc_sweep.sh $TAG runs as its own gpurun call: its databases and this step's together exceed what one call brings back)
+    bash tools/driver_diff.sh $TAG > /dev/null 2>&1
     head -c 160 gpurun_out/bench_$TAG.json; echo
 else
     python3 tools/isa_regs.py | head -1
     python3 tools/summarize_prof.py gpurun_out/prof_$TAG "$TAG" | tail -2
+    [ -d gpurun_out/pmc_sweep_$TAG ] && python3 tools/summarize_sweep_pmc.py gpurun_out/pmc_sweep_$TAG "$TAG" | tail -3
+    [ -s gpurun_out/driver_diff_$TAG.md ] && echo "(driver diff table: gpurun_out/driver_diff_$TAG.md -- merge by hand into profiles/${TAG}_driver_diff.md)"
     for f in bench replay replay_witness replay_k10 native_replay native_replay_witness; do cp gpurun_out/${f}_$TAG.json profiles/; done
     for f in msm_sq_counters ntt_sq_counters; do grep -v "^\[" gpurun_out/${f}_$TAG.txt > profiles/${TAG}_$f.txt; done
     [ -f gpurun_out/microbench_$TAG.txt ] && cp gpurun_out/microbench_$TAG.txt profiles/
@@ -58,7 +62,7 @@ else
     [ -s gpurun_out/msm_valu_counters_$TAG.txt ] && grep -v "^\[" gpurun_out/msm_valu_counters_$TAG.txt > profiles/${TAG}_msm_valu_counters.txt
     [ -s gpurun_out/msm_2_20_kernel_stats_$TAG.txt ] && cp gpurun_out/msm_2_20_kernel_stats_$TAG.txt profiles/${TAG}_msm_2_20_kernel_stats.txt
     for f in replay_sharded native_replay_sharded replay_witness_nosparse; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done
-    for f in reduce_ab lone_sparse_probe bank_probe io_shapes; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/${TAG}_$f.txt; done
+    for f in lone_sparse_probe bank_probe io_shapes; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/${TAG}_$f.txt; done
     [ -s gpurun_out/msm_stall_counters_$TAG.txt ] && grep -v "^\[\|^tail:" gpurun_out/msm_stall_counters_$TAG.txt > profiles/${TAG}_msm_stall_counters_raw.txt
     ls profiles
 fi

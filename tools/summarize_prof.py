@@ -23,6 +23,23 @@ def short(name):
     return name.split("(")[0][-60:]
 
 
+def provenance(src_dir, root, kernel_key):
+    """{"build", "kernel", "vgpr", "isa_instructions"}: the library build the counters were collected on (version.txt written on the GPU box
+    by tools/profile.sh / tools/pmc_sweep.sh) and the kernel's ISA as tools/isa_regs.py reads it from the same sources' objects"""
+    import re as _re
+    build = None
+    try:
+        m = _re.search(r"build ([0-9a-f]+)", open(os.path.join(src_dir, "version.txt")).read())
+        build = m.group(1) if m else None
+    except Exception:
+        pass
+    try:
+        isa = json.load(open(os.path.join(root, "profiles", "isa_registers.json"))).get(kernel_key) or {}
+    except Exception:
+        isa = {}
+    return {"build": build, "kernel": kernel_key, "vgpr": isa.get("vgpr"), "isa_instructions": isa.get("isa_instructions")}
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     msm_log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 24
@@ -88,14 +105,14 @@ def main():
             f = v.get("FETCH_SIZE", (0, 0.0)); w = v.get("WRITE_SIZE", (0, 0.0))
             hbm = (2 * f[1] + w[1]) * 1024
             lines.append(f"| {name} | {grid} | {max(f[0], w[0])} | {f[1]:.0f} | {w[1]:.0f} | {hbm:.3e} |")
-            if name.startswith("msm_accumulate") and hbm > traffic.get(f"msm_accumulate_2^{msm_log_n}", 0):
-                traffic[f"msm_accumulate_2^{msm_log_n}"] = hbm  # the full-size launches (largest group)
+            if name.startswith("msm_accumulate") and hbm > (traffic.get(f"msm_accumulate_2^{msm_log_n}") or {}).get("bytes", 0):
+                traffic[f"msm_accumulate_2^{msm_log_n}"] = dict(bytes=hbm, **provenance(src, root, "msm_accumulate_seg_kernel<Fp>"))  # the full-size launches (largest group)
         # the NTT is several launches of one kernel per transform: sum over the passes of one transform
         passes = 1 if ntt_log_n <= 11 else max(2, -(-ntt_log_n // 9))  # mirrors the pass plan in csrc/ntt.hip
         ntt_total = passes * max([(2 * v.get("FETCH_SIZE", (0, 0.0))[1] + v.get("WRITE_SIZE", (0, 0.0))[1]) * 1024
                                   for (name, grid), v in pmc.items() if name.startswith("ntt_pass")] or [0])
         if ntt_total:
-            traffic[f"ntt_fp_2^{ntt_log_n}"] = ntt_total
+            traffic[f"ntt_fp_2^{ntt_log_n}"] = dict(bytes=ntt_total, **provenance(src, root, "ntt_passy_kernel<Fp>"))
             lines += ["", f"NTT 2^{ntt_log_n}: HBM bytes per transform ({passes} passes x per-launch average) = {ntt_total:.3e} "
                           f"(algorithmic {64 * (1 << ntt_log_n):.3e})"]
         with open(os.path.join(out_dir, f"{tag}_pmc.md"), "w") as fh:

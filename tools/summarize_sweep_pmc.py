@@ -20,6 +20,23 @@ def per_kernel(path, counter):
     return out
 
 
+def provenance(src_dir, root, kernel_key):
+    """{"build", "kernel", "vgpr", "isa_instructions"}: the library build the counters were collected on (version.txt written on the GPU box
+    by tools/profile.sh / tools/pmc_sweep.sh) and the kernel's ISA as tools/isa_regs.py reads it from the same sources' objects"""
+    import re as _re
+    build = None
+    try:
+        m = _re.search(r"build ([0-9a-f]+)", open(os.path.join(src_dir, "version.txt")).read())
+        build = m.group(1) if m else None
+    except Exception:
+        pass
+    try:
+        isa = json.load(open(os.path.join(root, "profiles", "isa_registers.json"))).get(kernel_key) or {}
+    except Exception:
+        isa = {}
+    return {"build": build, "kernel": kernel_key, "vgpr": isa.get("vgpr"), "isa_instructions": isa.get("isa_instructions")}
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +54,7 @@ def main():
         key = max(acc, key=lambda k: acc[k][1])  # the full-size launches
         hbm = (2 * acc[key][1] + w.get(key, (0, 0.0))[1]) * 1024
         per_launch = (1 << lg) if lg <= 25 else (1 << 25)
-        traffic[f"msm_accumulate_2^{lg}"] = hbm
+        traffic[f"msm_accumulate_2^{lg}"] = dict(bytes=hbm, **provenance(src, root, "msm_accumulate_seg_kernel<Fp>"))
         lines.append(f"| Pallas MSM 2^{lg} | {key[0]} | {acc[key][0]} | {acc[key][1]:.0f} | {w.get(key, (0, 0.0))[1]:.0f} | {hbm:.3e} | {96.0 * per_launch:.3e} | {hbm / (96.0 * per_launch):.1f} |")
     for lg in (20, 24):
         f = per_kernel(os.path.join(src, f"ntt{lg}_fetch"), "FETCH_SIZE")
@@ -50,7 +67,7 @@ def main():
         total = sum(v[0] * (2 * v[1] + w.get(k, (0, 0.0))[1]) * 1024 for k, v in passes.items())
         transforms = 7
         hbm = total / transforms
-        traffic[f"ntt_fp_2^{lg}"] = hbm
+        traffic[f"ntt_fp_2^{lg}"] = dict(bytes=hbm, **provenance(src, root, "ntt_passy_kernel<Fp>"))
         lines.append(f"| Fp NTT 2^{lg} | ntt_passy_kernel x {n_launch // transforms} passes | {n_launch} | {sum(v[0] * v[1] for v in passes.values()) / transforms:.0f} | "
                      f"{sum(w.get(k, (0, 0.0))[0] * w.get(k, (0, 0.0))[1] for k in passes) / transforms:.0f} | {hbm:.3e} | {64.0 * (1 << lg):.3e} | {hbm / (64.0 * (1 << lg)):.1f} |")
     with open(os.path.join(root, "profiles", f"{tag}_pmc_sweep.md"), "w") as fh:
