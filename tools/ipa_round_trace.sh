@@ -3,6 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OTHER=${1:-_ab/base/libtrh.so}
 export TMPDIR=/tmp
+export TRH_SELFTEST=0  # the self-test's own small launches (2^10 MSMs, 2^10 / 2^12 transforms) would be averaged into the per-kernel figures
 cd /tmp
 rm -rf $REPO/gpurun_out/ipa_tr_new $REPO/gpurun_out/ipa_tr_old
 rocprofv3 --kernel-trace -d $REPO/gpurun_out/ipa_tr_new -o t -- python3 $REPO/tools/ipa_probe.py 18 > /dev/null 2>&1

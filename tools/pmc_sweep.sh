@@ -9,6 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_sweep_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export TRH_SELFTEST=0  # the self-test's own small launches (2^10 MSMs, 2^10 / 2^12 transforms) would be averaged into the per-kernel figures
 cd /tmp
 python3 -c "import sys; sys.path.insert(0, '$REPO'); from tiny_ram_halo2_amd import api; print(api.lib().trh_version().decode())" > $OUT/version.txt 2>/dev/null
 for lg in 20 22 26; do

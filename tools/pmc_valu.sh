@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_valu_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export TRH_SELFTEST=0  # the self-test's own small launches (2^10 MSMs, 2^10 / 2^12 transforms) would be averaged into the per-kernel figures
 cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU -d $OUT/a -o pmc -- python3 $REPO/tools/msm_probe.py $LOGN pallas 0 0 > $OUT/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_CYCLES SQ_WAVES -d $OUT/b -o pmc -- python3 $REPO/tools/msm_probe.py $LOGN pallas 0 0 > $OUT/b.log 2>&1

@@ -6,6 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/trace_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export TRH_SELFTEST=0  # the self-test's own small launches (2^10 MSMs, 2^10 / 2^12 transforms) would be averaged into the per-kernel figures
 SCRIPT=$REPO/$1; shift
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python3 $SCRIPT "$@" > $OUT/log.txt 2>&1

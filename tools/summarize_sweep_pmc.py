@@ -62,10 +62,10 @@ def main():
         passes = {k: v for k, v in f.items() if k[0].startswith("ntt_pass")}
         if not passes:
             continue
-        # launches of one transform: every pass kernel launch / number of transforms run (the probe runs 2 warm-up + 5 timed = 7 transforms)
+        # launches of one transform: every pass kernel launch / number of transforms run (the probe runs 2 warm-up + 5 timed + 1 for the output digest = 8 transforms)
         n_launch = sum(v[0] for v in passes.values())
         total = sum(v[0] * (2 * v[1] + w.get(k, (0, 0.0))[1]) * 1024 for k, v in passes.items())
-        transforms = 7
+        transforms = 8
         hbm = total / transforms
         traffic[f"ntt_fp_2^{lg}"] = dict(bytes=hbm, **provenance(src, root, "ntt_passy_kernel<Fp>"))
         lines.append(f"| Fp NTT 2^{lg} | ntt_passy_kernel x {n_launch // transforms} passes | {n_launch} | {sum(v[0] * v[1] for v in passes.values()) / transforms:.0f} | "
