@@ -628,13 +628,6 @@ int main(int argc, char** argv) {
             dom.lagrange_to_coeff(cols.data(), b);
             ms_intt += t2.stop();
             if (done == 0) { first_coeff.resize(n); cols.download(first_coeff.data(), n * 32); }
-            check(trh_stream_synchronize(nullptr), "sync");
-            {   // keep the coefficient forms (device-to-device through the ABI's copy helpers would bounce over the host: one kernel instead)
-                const Limbs one = host::one(field);
-                (void)one;
-                std::vector<Limbs> unit(1, host::one(field));
-                for (size_t c = 0; c < b; ++c) lincomb(field, cols.at(c * n * 32), n, unit, coeff_all.at(((size_t)done + c) * n * 32));
-            }
             Timer t3;
             dom.coeff_to_extended_blocks(cols.data(), ext.data(), b, D);
             ms_ext += t3.stop();
@@ -646,6 +639,12 @@ int main(int argc, char** argv) {
                 Limbs acc{0, 0, 0, 0};
                 for (size_t i = n; i-- > 0;) acc = host::add(field, host::mul(field, acc, x_eval), first_coeff[i]);
                 expect(acc == evals[0], "eval_polynomial(column 0, x)");
+            }
+            {   // keep the coefficient forms for the multiopen argument (device-to-device through the ABI's copy helpers would bounce over the
+                // host: one kernel per column instead); behind the batch's timed steps
+                std::vector<Limbs> unit(1, host::one(field));
+                for (size_t c = 0; c < b; ++c) lincomb(field, cols.at(c * n * 32), n, unit, coeff_all.at(((size_t)done + c) * n * 32));
+                check(trh_stream_synchronize(nullptr), "sync");
             }
             last_b = b;
         }
