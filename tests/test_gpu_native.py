@@ -39,7 +39,8 @@ def test_native_multi_context():
 def test_bench_two_ranks_on_one_device():
     """the process-per-GPU harness (bench.py under torch.distributed.run, sharded.sharded_msm over the HIP path) with two ranks
     folded onto the GPUs present (gloo carries the 96-byte partials; the driver's scaling runs use RCCL): headline weak-scaling
-    step, the strong-scaling 2^26 leg and the single-process device-group leg all close their closed-form checks (exit code 0)"""
+    step, the strong-scaling 2^26 leg and the single-process device-group leg all close their closed-form checks (exit code 0), and the
+    proof-per-GPU leg reports its scaling figure"""
     import sys
     env = dict(os.environ, TRH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
@@ -51,6 +52,10 @@ def test_bench_two_ranks_on_one_device():
     assert out["config"]["pairs_total"] == 2 << 20
     assert out["strong"]["check"] == "closed-form ok" and out["strong"]["scaling"] == "strong"
     assert out["single_process"].get("check") == "closed-form ok", out["single_process"]
+    # round 6: one k = 18 resident proof per rank (the reference's N independent proofs, /root/reference/src/test_utils.rs:37-54), MAX over ranks
+    sc = out["e2e_summary"]["e2e_scaling"]
+    assert sc["n_gpus"] == 2 and sc["ms_per_proof_slowest_rank"] >= sc["ms_this_rank"] > 0 and abs(sc["proofs_per_s"] - 2e3 / sc["ms_per_proof_slowest_rank"]) < 1e-6, sc
+    assert out["e2e_summary"]["ntt_2_16_elems_per_s"] > 0 and 0 < out["e2e_summary"]["ntt_frac"] < 1
 
 
 @pytest.mark.parametrize("args", [["--word-bits", "16", "--batch", "32", "--devices", "0,0"], ["--word-bits", "32", "--batch", "32", "--max-columns", "120", "--devices", "0,0,0"]])

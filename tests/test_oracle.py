@@ -5,6 +5,8 @@ oracle/pasta.py (big-int) is pinned to the published pasta_curves constants; ora
 golden vectors.  The reference's own tests hold no value-level vectors for this path
 (/root/reference/src/test_utils.rs:6-71 asserts only that the verifier accepts).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -310,3 +312,16 @@ def test_fast_multiopen_and_verifier_vs_bigint():
     assert ipa_verify_fast(*fast_args, v, *fast_tail, c, f)
     assert not ipa_verify_fast(*fast_args, (v + 1) % fs.m, *fast_tail, c, f)
     assert not ipa_verify_fast(*fast_args, v, *fast_tail, c, (f + 1) % fs.m)
+
+
+def test_selftest_constants_are_what_the_oracle_generates(tmp_path):
+    """csrc/selftest_kat.h (the known answers trh_init's self-test compares the device with) is DATA generated by
+    tests/golden/make_selftest_kat.py from this oracle: regenerating it must reproduce the committed header byte for byte -- the library
+    carries no constant the oracle does not vouch for, and a change of either side cannot slip through unnoticed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "selftest_kat.h"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_selftest_kat.py"), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == open(os.path.join(root, "tiny-ram-halo2_amd", "csrc", "selftest_kat.h")).read()
