@@ -55,8 +55,6 @@ struct FpParams {  // Pallas base field = Vesta scalar field
     static constexpr u32 MOD[8] = {0x00000001u, 0x992d30edu, 0x094cf91bu, 0x224698fcu, 0u, 0u, 0u, 0x40000000u};
     static constexpr u32 ONE[8] = {0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // R mod p
     static constexpr u32 R2[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};   // R^2 mod p
-    static constexpr u32 TO_LAZY[8] = {0xc0000001u, 0x592d30ecu, 0x2301ace0u, 0x1ff35ab5u, 0xf76e59c1u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};   // 2^284 mod p
-    static constexpr u32 LAZY_ONE[8] = {0xffff0001u, 0x684030ecu, 0x10315feeu, 0x894a8fafu, 0xffffddb9u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};  // 2^270 mod p
     // pasta_curves ROOT_OF_UNITY (primitive 2^32-th root) and ZETA (cube root of unity), Montgomery form
     static constexpr u32 ROOT_OF_UNITY[8] = {0xbad6dbf0u, 0xa28db849u, 0xd3b539dfu, 0x9083cd03u, 0x9dc8448eu, 0xfba6b9cau, 0x7b89c6dau, 0x3ec92874u};
     static constexpr u32 ZETA[8] = {0x619a153du, 0x02021cf6u, 0x4980b78eu, 0x9e8c2697u, 0xc87a4666u, 0x2a676d5cu, 0xa7a17876u, 0x15d8049du};
@@ -68,8 +66,6 @@ struct FqParams {  // Vesta base field = Pallas scalar field
     static constexpr u32 MOD[8] = {0x00000001u, 0x8c46eb21u, 0x0994a8ddu, 0x224698fcu, 0u, 0u, 0u, 0x40000000u};
     static constexpr u32 ONE[8] = {0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
     static constexpr u32 R2[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
-    static constexpr u32 TO_LAZY[8] = {0xc0000001u, 0x4c46eb20u, 0xa682ee15u, 0x1fe16ec4u, 0xf76e59c1u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-    static constexpr u32 LAZY_ONE[8] = {0xffff0001u, 0xa125eb20u, 0x60b71c96u, 0x894a8f67u, 0xffffddb9u, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
     static constexpr u32 ROOT_OF_UNITY[8] = {0x8c9942deu, 0x21807742u, 0x21b60494u, 0xcc495789u, 0xb2efbee2u, 0xac2e5d27u, 0x7f2db056u, 0x0b79fa89u};
     static constexpr u32 ZETA[8] = {0x80111122u, 0x7c541a84u, 0x56ed29dau, 0x40630b9cu, 0x135b2b29u, 0x02c275fbu, 0x88245b10u, 0x121d29f8u};
     static constexpr u32 TO_LAZY29[8] = {0xfffff001u, 0x1d94db20u, 0xbf06d019u, 0xb8b6d862u, 0xfffffddbu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};   // 2^266 mod q
@@ -310,194 +306,6 @@ template <class F> TRH_HD Fe<F> fe_inv(const Fe<F>& a) {
 }
 
 // =========================================================================================
-// Lazy domain (used by the MSM accumulation only).
-//
-// Fz holds a residue in Montgomery form with R' = 2^270 = (2^30)^9 as nine normalised 30-bit limbs
-// whose VALUE is only bounded by 16 m, not reduced.  With nine uniform 30-bit reduction rounds
-//     fz_mul(a, b) = a b / 2^270 (mod m),   a, b < 16 m   ==>   result < m (1 + 2^-8)
-// (T < 2^8 m^2, so (T + Q m) / 2^270 < m (2^8 m / 2^270 + 1)), which means additions and
-// subtractions never need a modular reduction (a - b is computed as a + k m - b with k m >= bound(b))
-// and the multiply has no conditional subtraction, no 16-bit round and no realignment.
-// Operand bounds are tracked by hand at each call site (see curve.h).
-// =========================================================================================
-template <class F, int K> struct ToLazyLimb { static constexpr u32 v = limb30_of(F::TO_LAZY, K); };
-template <class F, int K> struct LazyOneLimb { static constexpr u32 v = limb30_of(F::LAZY_ONE, K); };
-
-template <class F>
-struct Fz {
-    u32 l[NLIMBS];
-};
-
-// limb `idx` of k * m (k small), computed at compile time
-template <class F> TRH_HD constexpr u32 kmod_limb(u32 k, int idx) {
-    u64 carry = 0;
-    u32 out = 0;
-    for (int i = 0; i <= idx; ++i) {
-        const u64 t = (u64)k * mod_limb<F>(i) + carry;
-        out = (u32)t & LIMB_MASK;
-        carry = t >> 30;
-    }
-    return out;
-}
-template <class F, u32 KM, int I> struct KModLimb { static constexpr u32 v = kmod_limb<F>(KM, I); };
-
-template <class F> TRH_HD Fz<F> fz_zero() {
-    Fz<F> r;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) r.l[i] = 0;
-    return r;
-}
-template <class F> TRH_HD Fz<F> fz_one() {
-    Fz<F> r;
-    r.l[0] = LazyOneLimb<F, 0>::v; r.l[1] = LazyOneLimb<F, 1>::v; r.l[2] = LazyOneLimb<F, 2>::v;
-    r.l[3] = LazyOneLimb<F, 3>::v; r.l[4] = LazyOneLimb<F, 4>::v; r.l[5] = LazyOneLimb<F, 5>::v;
-    r.l[6] = LazyOneLimb<F, 6>::v; r.l[7] = LazyOneLimb<F, 7>::v; r.l[8] = LazyOneLimb<F, 8>::v;
-    return r;
-}
-template <class F> TRH_HD bool fz_is_exact_zero(const Fz<F>& a) {
-    u32 o = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) o |= a.l[i];
-    return o == 0;
-}
-
-// nine uniform 30-bit rounds; result = value / 2^270 (mod m), < m (1 + 2^-8) for inputs < 2^8 m^2
-template <class F> TRH_HD Fz<F> fz_reduce(u64 (&acc)[18]) {
-    constexpr u32 P1 = ModLimb<F, 1>::v, P2 = ModLimb<F, 2>::v, P3 = ModLimb<F, 3>::v, P4 = ModLimb<F, 4>::v;
-    const u32 two14 = opaque_two14();
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const u32 q = (0u - (u32)acc[i]) & LIMB_MASK;
-        acc[i + 1] += ((acc[i] + LIMB_MASK) >> 30) + (u64)q * P1;
-        acc[i + 2] += (u64)q * P2;
-        acc[i + 3] += (u64)q * P3;
-        acc[i + 4] += (u64)q * P4;
-        acc[i + 8] += (u64)q * two14;
-    }
-    Fz<F> r;
-    u64 c = 0;
-#pragma unroll
-    for (int k = 0; k < NLIMBS; ++k) {
-        c += acc[9 + k];
-        r.l[k] = (u32)c & LIMB_MASK;
-        c >>= 30;
-    }
-    return r;
-}
-template <class F> TRH_HD Fz<F> fz_mul(const Fz<F>& a, const Fz<F>& b) {
-    u64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i)
-#pragma unroll
-        for (int j = 0; j < NLIMBS; ++j) acc[i + j] += (u64)a.l[i] * b.l[j];
-    return fz_reduce<F>(acc);
-}
-template <class F> TRH_HD Fz<F> fz_sqr(const Fz<F>& a) {
-    u64 acc[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) acc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        acc[2 * i] += (u64)a.l[i] * a.l[i];
-        const u32 a2 = a.l[i] << 1;
-#pragma unroll
-        for (int j = i + 1; j < NLIMBS; ++j) acc[i + j] += (u64)a2 * a.l[j];
-    }
-    return fz_reduce<F>(acc);
-}
-// a + b, no reduction (bound(a) + bound(b) must stay < 16 m)
-template <class F> TRH_HD Fz<F> fz_add(const Fz<F>& a, const Fz<F>& b) {
-    Fz<F> r;
-    u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        const u32 v = a.l[i] + b.l[i] + c;
-        r.l[i] = v & LIMB_MASK;
-        c = v >> 30;
-    }
-    return r;
-}
-// a + 2 b in one carry chain, no reduction (bound(a) + 2 bound(b) must stay < 16 m)
-template <class F> TRH_HD Fz<F> fz_add_dbl(const Fz<F>& a, const Fz<F>& b) {
-    Fz<F> r;
-    u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        const u32 v = a.l[i] + (b.l[i] << 1) + c;  // < 2^30 + 2^31 + 3
-        r.l[i] = v & LIMB_MASK;
-        c = v >> 30;
-    }
-    return r;
-}
-// a + KM * m - b  (KM * m must be >= bound(b)); result < bound(a) + KM m
-template <class F, u32 KM> TRH_HD Fz<F> fz_sub(const Fz<F>& a, const Fz<F>& b) {
-    Fz<F> r;
-    i32 c = 0;
-    const u32 km[NLIMBS] = {KModLimb<F, KM, 0>::v, KModLimb<F, KM, 1>::v, KModLimb<F, KM, 2>::v, KModLimb<F, KM, 3>::v, KModLimb<F, KM, 4>::v,
-                            KModLimb<F, KM, 5>::v, KModLimb<F, KM, 6>::v, KModLimb<F, KM, 7>::v, KModLimb<F, KM, 8>::v};
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) {
-        const i32 v = (i32)(a.l[i] + km[i]) - (i32)b.l[i] + c;
-        r.l[i] = (u32)v & LIMB_MASK;
-        c = v >> 30;
-    }
-    return r;
-}
-// value == 0 (mod m)?  value < 16 m, so it would be j m with j <= 16, whose low limb is j (m = 1 mod 2^30)
-template <class F> TRH_HD bool fz_is_zero_mod(const Fz<F>& a) {
-    const u32 j = a.l[0];
-    if (j > 16u) return false;
-    u64 carry = 0;
-    u32 diff = 0;
-    for (int i = 0; i < NLIMBS; ++i) {
-        const u64 t = (u64)j * mod_limb<F>(i) + carry;
-        diff |= ((u32)t & LIMB_MASK) ^ a.l[i];
-        carry = t >> 30;
-    }
-    return diff == 0;
-}
-// memory words <-> lazy limbs (same bit slicing as fe_load / fe_store; the value must be < 2^256)
-template <class F> TRH_HD Fz<F> fz_load(u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5, u32 w6, u32 w7) {
-    const Fe<F> t = fe_load<F>(w0, w1, w2, w3, w4, w5, w6, w7);
-    Fz<F> r;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) r.l[i] = t.l[i];
-    return r;
-}
-template <class F> TRH_HD void fz_store(const Fz<F>& a, u32* w) {
-    Fe<F> t;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) t.l[i] = a.l[i];
-    fe_store(t, w);
-}
-
-// canonical Montgomery-R element -> lazy domain (result < m (1 + 2^-8))
-template <class F> TRH_HD Fz<F> fz_from_fe(const Fe<F>& a) {
-    Fz<F> x, c;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) x.l[i] = a.l[i];
-    c.l[0] = ToLazyLimb<F, 0>::v; c.l[1] = ToLazyLimb<F, 1>::v; c.l[2] = ToLazyLimb<F, 2>::v;
-    c.l[3] = ToLazyLimb<F, 3>::v; c.l[4] = ToLazyLimb<F, 4>::v; c.l[5] = ToLazyLimb<F, 5>::v;
-    c.l[6] = ToLazyLimb<F, 6>::v; c.l[7] = ToLazyLimb<F, 7>::v; c.l[8] = ToLazyLimb<F, 8>::v;
-    return fz_mul(x, c);
-}
-// lazy (< 16 m) -> canonical Montgomery-R element: multiply by 2^256 mod m in the lazy domain
-template <class F> TRH_HD Fe<F> fz_to_fe(const Fz<F>& a) {
-    Fz<F> c;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) c.l[i] = one_limb<F>(i);
-    const Fz<F> t = fz_mul(a, c);  // < m (1 + 2^-8)
-    Fe<F> r;
-#pragma unroll
-    for (int i = 0; i < NLIMBS; ++i) r.l[i] = t.l[i];
-    fe_cond_sub(r);
-    return r;
-}
-
-
-// =========================================================================================
 // Signed lazy domain with 29-bit limbs (the MSM's bucket arithmetic, curve.h "XYZZz").
 //
 // Fy holds a residue in Montgomery form with R'' = 2^261 = (2^29)^9 as nine SIGNED 32-bit limbs.
@@ -508,7 +316,7 @@ template <class F> TRH_HD Fe<F> fz_to_fe(const Fz<F>& a) {
 //   * additions / subtractions that only feed a multiplication need no carry chain at all (fy_sub_lazy), and
 //   * a * b + c * d shares ONE Montgomery reduction (fy_mul2: y3 = R (Q - x3) - Y PPP of the mixed addition).
 // A reduction is more than half of a multiplication (45 of 126 multiply-adds and all of the 64-bit carry work), which is what
-// this buys over the 30-bit unsigned domain above (still used by the NTT, whose butterflies have no such pairs).
+// this buys over the unsigned 30-bit lazy domain of rounds 1 - 2 (R' = 2^270; removed in round 6 with the NTT passes that used it).
 // fy_mul(a, b) = a b / 2^261 (mod m) in (-|a b| / 2^261 - m, |a b| / 2^261]: |a|, |b| < 16 m gives (-3 m, 2 m).
 // =========================================================================================
 constexpr u32 YBITS = 29;

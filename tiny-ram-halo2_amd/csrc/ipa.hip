@@ -14,6 +14,7 @@
 #include <chrono>
 
 #include "ctx.h"
+#include "hostcombine.h"
 
 namespace trh {
 namespace {
@@ -468,7 +469,13 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const double t_tr = ipa_trace ? tnow() : 0;
         const Fe<SF> u_j = fe_load<SF>(tmp);
         if (fe_is_zero(u_j)) { set_error("ipa_create_proof: round %u challenge is zero (the Rust prover's u_j.invert().unwrap() panics here)", j); return TRH_EINVAL; }
-        const Fe<SF> u_inv = fe_inv(u_j);
+        // u_j^-1 on the host's 4 x 64-bit Montgomery code (hostcombine.h): the nine-limb form the device code uses costs the host three times as much
+        hostcombine::H uh;
+        memcpy(&uh, &tmp, 32);
+        const hostcombine::H uih = hostcombine::inv<SF>(uh);
+        FeMem uim;
+        memcpy(&uim, &uih, 32);
+        const Fe<SF> u_inv = fe_load<SF>(uim);
         u_prev = u_j; u_prev_inv = u_inv;  // folded into the next round's front launch (or by the launch behind the loop)
         f = fe_add(f, fe_add(fe_mul(rnd[0], u_inv), fe_mul(rnd[1], u_j)));
         if (ipa_trace) {

@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(256) k_field(u64* out, u32 seed) {
 }
 template <int MODE>
 __global__ void __launch_bounds__(256) k_lazy(u64* out, u32 seed) {
-    Fz<FpParams> x = fz_one<FpParams>(), y = fz_one<FpParams>();
+    Fy<FpParams> x = fy_one<FpParams>(), y = fy_one<FpParams>();
     x.l[0] += threadIdx.x + seed; y.l[1] ^= blockIdx.x;
     for (int i = 0; i < FITERS; ++i) {
-        if (MODE == 0) { const Fz<FpParams> t = fz_mul(x, y); x = y; y = t; }  // both operands vary
-        else if (MODE == 1) x = fz_sqr(x);
-        else if (MODE == 2) x = fz_add(x, y);
-        else x = fz_sub<FpParams, 8>(x, y);
+        if (MODE == 0) { const Fy<FpParams> t = fy_mul(x, y); x = y; y = t; }  // both operands vary
+        else if (MODE == 1) x = fy_sqr(x);
+        else if (MODE == 2) x = fy_add(x, y);
+        else x = fy_sub(x, y);
         if (MODE >= 2) { x.l[8] &= 0xffff; }
     }
     u64 r = 0;
@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(256) k_lazy(u64* out, u32 seed) {
 }
 __global__ void __launch_bounds__(256) k_madd_lazy(u64* out, u32 seed) {
     AffineZ<FpParams> g;
-    g.x = fz_one<FpParams>(); g.y = fz_one<FpParams>(); g.x.l[0] += 5; g.y.l[1] += 7;   // not a curve point: timing only
+    g.x = fy_one<FpParams>(); g.y = fy_one<FpParams>(); g.x.l[0] += 5; g.y.l[1] += 7;   // not a curve point: timing only
     XYZZz<FpParams> acc;
-    acc.x = g.y; acc.y = g.x; acc.zz = fz_one<FpParams>(); acc.zzz = fz_one<FpParams>();
+    acc.x = g.y; acc.y = g.x; acc.zz = fy_one<FpParams>(); acc.zzz = fy_one<FpParams>();
     acc.x.l[2] += threadIdx.x + seed;
     for (int i = 0; i < FITERS; ++i) xyzzz_madd(acc, g);
     u64 r = 0;
@@ -260,10 +260,10 @@ int main() {
     }
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<2>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fe_add", FITERS);
     run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_field<3>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fe_sub", FITERS);
-    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<0>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_mul (lazy R'=2^270)", FITERS);
-    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<1>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_sqr", FITERS);
-    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<2>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_add", FITERS);
-    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<3>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fz_sub", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<0>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fy_mul (signed lazy R''=2^261)", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<1>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fy_sqr", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<2>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fy_add", FITERS);
+    run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_lazy<3>, dim3(b), dim3(t), 0, 0, o, 1u); }, B, T, d_out, "fy_sub", FITERS);
     for (int blocks : {256 * 3, 256 * 6})
         run([](int b, int t, u64* o) { hipLaunchKernelGGL(k_madd_lazy, dim3(b), dim3(t), 0, 0, o, 1u); }, blocks, T, d_out, "xyzzz_madd (lazy)", FITERS);
     for (int blocks : {256 * 2, 256 * 4, 256 * 8})
