@@ -796,9 +796,9 @@ def main():
     if world > 1 and not args.no_sweep and not args.no_e2e:
         torch.cuda.empty_cache()
         mine, wall, err = -1.0, -1.0, None
+        fence()  # (outside the try: every rank reaches it whatever happens to its own replay)
         try:
             from tiny_ram_halo2_amd import replay
-            fence()
             t0 = time.perf_counter()
             r = replay.run(32, batch=64, hook=None, device=dev_index, verbose=False, columns="witness", keygen=False, gates_dir=os.path.join(ROOT, "tests", "golden"))
             torch.cuda.synchronize()
