@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 # build id = hash of the library's sources (trh_version() reports it)
 BUILD_ID := $(shell cat $(CSRC)/*.hip $(CSRC)/*.h include/trh.h | sha1sum | cut -c1-12)
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-result
-OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o $(CSRC)/hostio.o $(CSRC)/selftest.o
+OBJS := $(CSRC)/capi.o $(CSRC)/msm.o $(CSRC)/ntt.o $(CSRC)/ipa.o $(CSRC)/ipafold.o $(CSRC)/pointfft.o $(CSRC)/domain.o $(CSRC)/scan.o $(CSRC)/expr.o $(CSRC)/lookup.o $(CSRC)/hostio.o $(CSRC)/selftest.o
 HDRS := $(CSRC)/field.h $(CSRC)/curve.h $(CSRC)/curve_q4.h $(CSRC)/ctx.h $(CSRC)/hostcombine.h $(CSRC)/copypool.h $(CSRC)/devpool.h $(CSRC)/selftest_kat.h include/trh.h
 
 all: $(PKG)/libtrh.so oracle examples/replay tests/native/multi_ctx_test tests/native/libtrh_q4broken.so

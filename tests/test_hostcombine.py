@@ -81,3 +81,16 @@ def test_copy_pool_under_thread_sanitizer():
             r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
             assert r.returncode == 0 and "copypool: ok" in r.stdout, r.stdout + r.stderr
             assert "WARNING: ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_host_helper_under_thread_sanitizer():
+    """csrc/hosthelper.h (the thread that takes the second half of a batch's host Horners in msm_finish): jobs back to back and after the
+    helper fell asleep, shutdown in both states, two helpers side by side -- no report from -fsanitize=thread, then address + undefined"""
+    src = os.path.join(ROOT, "tests", "native", "hosthelper_test.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, san in (("tsan", "-fsanitize=thread"), ("asan", "-fsanitize=address,undefined")):
+            exe = os.path.join(tmp, "hosthelper_" + tag)
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-w", san, "-fno-omit-frame-pointer", src, "-o", exe, "-pthread"])
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "hosthelper: ok" in r.stdout, r.stdout + r.stderr
+            assert "WARNING: ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr

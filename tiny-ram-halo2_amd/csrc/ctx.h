@@ -43,6 +43,7 @@ struct Options {
     int reduce_q4 = 1;       // TRH_REDUCE_Q4      0: bucket reductions of small launches stay one thread per slice (no DPP-quad group law)
     int bin_sort = 1;        // TRH_BIN_SORT       0: the chunked bucket passes for every MSM (the path skewed scalars take anyway)
     int selftest = 1;        // TRH_SELFTEST       0: trh_init skips the known-answer self-test
+    int ipa_fold = 6;        // TRH_IPA_FOLD       rounds after which the IPA opening collapses its generators (ipafold.hip); 0: never
 };
 const Options& opt();
 
@@ -190,12 +191,18 @@ struct Ctx {
     Stage stage;
     DevBuf pfft;  // curve-point FFT work array + twiddle scalars
     DevBuf scan, scan2;  // prefix-product block totals / batch-inversion running products
-    DevBuf ipa[9];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy, the second halves of the p' / b ping-pong pairs), kept across proofs
+    DevBuf ipa[11];  // vectors of the IPA prover (b, s', p', weights, round scalars, g‖w‖u and its lazy copy, the second halves of the p' / b ping-pong pairs,
+                     // the generator fold's buckets and bucket lists -- ipafold.hip), kept across proofs
     DevBuf factors;  // ring of 16 small factor tables for the scale kernels
     unsigned factor_slot = 0;
     void* pinned_ring = nullptr;  // 64 x 2 KiB of pinned host memory mirroring the factor ring: constants are copied here first, so the
     void* pinned_land = nullptr;  // 4 KiB pinned landing area for the few words the host reads back per IPA round (a pageable target costs a staging copy)
     unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
+    void* pinned_fold = nullptr;  // pinned source of the generator fold's bucket lists (ipafold.hip)
+    size_t pinned_fold_cap = 0;
+    class HostHelper* helper = nullptr;  // host thread for the second half of a batch's Horners (hosthelper.h; msm_finish)
+    hipStream_t fold_stream = nullptr;  // the fold runs here, under the opening's next rounds (lowest priority)
+    hipEvent_t fold_ev[2] = {nullptr, nullptr};  // the opening's stream reached the fold's launch point / the folded generators are complete
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;
     void* lookup_scratch = nullptr;  // lookup.hip's buffers (opaque here)
@@ -315,6 +322,9 @@ int ntt_prepare(int field, uint32_t log_n, const u64 omega[4], const u64* scale,
 // whether a transform of this size can take a constant factor (Montgomery words) in its last pass's table: ntt_device(..., scale) then returns a . scale
 bool ntt_can_fold_scale(uint32_t log_n);
 void ntt_release_tables();
+// ipafold.hip: the IPA's generators after r collapses, from the fixed-base table of g || w || u
+bool ipa_fold_supported(const MsmFixedBase& fb, uint32_t k, uint32_t r);
+int ipa_fold_generators(int curve, const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const u64* u_mont, void* out_xy, void* out_z, hipStream_t s);
 // msm.hip
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
                 size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr, const void* tails_dev = nullptr);

@@ -138,43 +138,56 @@ template <class F> inline void combine_windows(const uint64_t* ws /* W x 16 u64 
     memcpy(out_xyz + 8, &consts<F>().one, 32);
 }
 
-// The same for `batch` MSMs at once (W window sums each, back to back): ONE field inversion for all of them (Montgomery's trick: prefix products of
-// the ZZZ's, one inversion, two multiplications per item on the way back).  An inversion is 255 squarings + ~130 multiplications = ~12 us here;
-// a batch of 64 commitments spent 0.8 ms of host time in them between two launches, an IPA round 24 us.
-template <class F> inline void combine_windows_batch(const uint64_t* ws /* batch x W x 16 u64 */, int W, int cb, size_t batch, uint64_t* out_xyz /* batch x 12 u64 */) {
-    if (batch == 1) { combine_windows<F>(ws, W, cb, out_xyz); return; }
+// Horner over one result's W window sums (XYZZ out, not normalised)
+template <class F> inline P horner(const uint64_t* w /* W x 16 u64 */, int W, int cb) {
+    P a = identity();
+    for (int j = W - 1; j >= 0; --j) {
+        if (!is_identity(a)) for (int k = 0; k < cb; ++k) a = pdbl<F>(a);
+        P s;
+        memcpy(&s, w + 16 * (size_t)j, sizeof(P));
+        a = padd<F>(a, s);
+    }
+    return a;
+}
+// nb points -> normalised Jacobian with ONE field inversion (Montgomery's trick: prefix products of the ZZZ's, one inversion, two multiplications
+// per item on the way back).  An inversion is 255 squarings + ~130 multiplications = ~12 us here; a batch of 64 commitments spent 0.8 ms of host
+// time in them between two launches, an IPA round 24 us.
+template <class F> inline void normalise_batch(const P* acc, size_t nb, uint64_t* out_xyz /* nb x 12 u64 */) {
     constexpr size_t CHUNK = 256;
-    P acc[CHUNK];
     H pre[CHUNK];
-    for (size_t b0 = 0; b0 < batch; b0 += CHUNK) {
-        const size_t nb = batch - b0 < CHUNK ? batch - b0 : CHUNK;
+    for (size_t b0 = 0; b0 < nb; b0 += CHUNK) {
+        const size_t cur = nb - b0 < CHUNK ? nb - b0 : CHUNK;
         H run = consts<F>().one;
-        for (size_t i = 0; i < nb; ++i) {
-            P a = identity();
-            const uint64_t* w = ws + (b0 + i) * (size_t)W * 16;
-            for (int j = W - 1; j >= 0; --j) {
-                if (!is_identity(a)) for (int k = 0; k < cb; ++k) a = pdbl<F>(a);
-                P s;
-                memcpy(&s, w + 16 * (size_t)j, sizeof(P));
-                a = padd<F>(a, s);
-            }
-            acc[i] = a;
+        for (size_t i = 0; i < cur; ++i) {
             pre[i] = run;                                   // product of the ZZZ's of the non-identity items before i
-            if (!is_identity(a)) run = mul<F>(run, a.zzz);
+            if (!is_identity(acc[b0 + i])) run = mul<F>(run, acc[b0 + i].zzz);
         }
         H inv_run = inv<F>(run);                            // (run = 1 when every item is the identity)
-        for (size_t i = nb; i-- > 0;) {
+        for (size_t i = cur; i-- > 0;) {
+            const P& a = acc[b0 + i];
             uint64_t* o = out_xyz + (b0 + i) * 12;
             memset(o, 0, 96);
-            if (is_identity(acc[i])) continue;
+            if (is_identity(a)) continue;
             const H zzz_inv = mul<F>(inv_run, pre[i]);
-            inv_run = mul<F>(inv_run, acc[i].zzz);
-            const H zz_inv = mul<F>(sqr<F>(zzz_inv), sqr<F>(acc[i].zz));
-            const H x = mul<F>(acc[i].x, zz_inv), y = mul<F>(acc[i].y, zzz_inv);
+            inv_run = mul<F>(inv_run, a.zzz);
+            const H zz_inv = mul<F>(sqr<F>(zzz_inv), sqr<F>(a.zz));
+            const H x = mul<F>(a.x, zz_inv), y = mul<F>(a.y, zzz_inv);
             memcpy(o, &x, 32);
             memcpy(o + 4, &y, 32);
             memcpy(o + 8, &consts<F>().one, 32);
         }
+    }
+}
+
+// `batch` MSMs at once (W window sums each, back to back): the Horners one after the other, one inversion for all of them
+template <class F> inline void combine_windows_batch(const uint64_t* ws /* batch x W x 16 u64 */, int W, int cb, size_t batch, uint64_t* out_xyz /* batch x 12 u64 */) {
+    if (batch == 1) { combine_windows<F>(ws, W, cb, out_xyz); return; }
+    constexpr size_t CHUNK = 256;
+    P acc[CHUNK];
+    for (size_t b0 = 0; b0 < batch; b0 += CHUNK) {
+        const size_t nb = batch - b0 < CHUNK ? batch - b0 : CHUNK;
+        for (size_t i = 0; i < nb; ++i) acc[i] = horner<F>(ws + (b0 + i) * (size_t)W * 16, W, cb);
+        normalise_batch<F>(acc, nb, out_xyz + b0 * 12);
     }
 }
 

@@ -25,6 +25,7 @@
 #include "ctx.h"
 #include "curve_q4.h"
 #include "hostcombine.h"
+#include "hosthelper.h"
 
 namespace trh {
 
@@ -1326,6 +1327,117 @@ __global__ void __launch_bounds__(256) msm_sparse_remap_kernel(u32* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Small MSMs in ONE launch (round 6).  Below ~2^13 pairs the pipeline above is a chain of ten launches whose kernels are each a few
+// dependent point operations on a nearly empty chip (an IPA round over 2^12 + 2 points: 230 us of kernels).  Here a workgroup owns one
+// (item, window): c = 5, 16 buckets x 16 lanes per bucket.
+//   digits    the window's signed digit of every scalar, taken from v + H (H = sum (2^(c-1) - 1) 2^(c j): the unsigned digits of v + H are the
+//             signed digits of v shifted by 2^(c-1) - 1 -- the same digit set as msm_recode_kernel's carry rule, without walking the windows
+//             below), counting sort by bucket in LDS
+//   add       the 16 lanes of a bucket split its list evenly and add their shares (mixed additions)
+//   combine   shuffle tree over the 16 lanes; then sum_b b B_b as a suffix scan over the 16 buckets and a tree over the suffix sums:
+//             8 + 4 full additions deep instead of 32 for running sums
+// and writes the window sum where msm_finish expects it (host Horner over the 52 windows as for every per-window MSM).
+// ---------------------------------------------------------------------------------------
+constexpr int SMALL_C = 5;
+constexpr u32 SMALL_NBK = 1u << (SMALL_C - 1);  // 16
+constexpr u32 SMALL_MAX_N = 8448;               // LDS: one byte + one u16 per scalar
+struct SmallBias { u32 w[9]; };
+
+template <class BF>
+__device__ __forceinline__ XYZZz<BF> shfl_down_point(const XYZZz<BF>& v, int off, int width) {
+    XYZZz<BF> o;
+#pragma unroll
+    for (int l = 0; l < NLIMBS; ++l) {
+        o.x.l[l] = __shfl_down(v.x.l[l], off, width); o.y.l[l] = __shfl_down(v.y.l[l], off, width);
+        o.zz.l[l] = __shfl_down(v.zz.l[l], off, width); o.zzz.l[l] = __shfl_down(v.zzz.l[l], off, width);
+    }
+    return o;
+}
+
+template <class SF, class BF>
+__global__ void __launch_bounds__(256) msm_small_kernel(const uint4* __restrict__ bases_z, const uint4* __restrict__ scalars, u32 n, int mont, size_t sstride,
+                                                        const uint4* __restrict__ tails, const SmallBias H, XYZZMem* __restrict__ window_sums) {
+    __shared__ signed char dig[SMALL_MAX_N];
+    __shared__ unsigned short list[SMALL_MAX_N];
+    __shared__ u32 hist[SMALL_NBK], cursor[SMALL_NBK], off[SMALL_NBK + 1];
+    __shared__ XYZZzMem bsum[SMALL_NBK];
+    const u32 j = blockIdx.x, z = blockIdx.y, W = gridDim.x, tid = threadIdx.x;
+    scalars += (size_t)z * sstride * 2;
+    if (tid < SMALL_NBK) hist[tid] = 0;
+    __syncthreads();
+    const u32 bit0 = SMALL_C * j, wi = bit0 >> 5, sh = bit0 & 31u;
+    for (u32 i = tid; i < n; i += 256) {
+        const uint4* src = (tails && i == n - 1) ? tails + 2 * z : scalars + 2 * (size_t)i;
+        const uint4 lo = src[0], hi = src[1];
+        u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (mont) fe_store(fe_from_mont(fe_load<SF>(w)), w);
+        // v + H as nine words; the window's bits are in words wi, wi + 1
+        u32 v[10];
+        u64 cy = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { cy += (u64)w[k] + H.w[k]; v[k] = (u32)cy; cy >>= 32; }
+        v[8] = (u32)cy + H.w[8]; v[9] = 0;
+        u32 a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if ((u32)k == wi) { a = v[k]; b = v[k + 1]; }
+        const u32 raw = (u32)((((u64)b << 32) | a) >> sh) & ((1u << SMALL_C) - 1u);
+        const int d = (int)raw - (int)(SMALL_NBK - 1);  // in [-15, 16]
+        dig[i] = (signed char)d;
+        if (d) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (u32 b = 0; b < SMALL_NBK; ++b) { off[b] = run; cursor[b] = run; run += hist[b]; }
+        off[SMALL_NBK] = run;
+    }
+    __syncthreads();
+    for (u32 i = tid; i < n; i += 256) {
+        const int d = dig[i];
+        if (d) list[atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u)] = (unsigned short)(i | (d < 0 ? 0x8000u : 0u));
+    }
+    __syncthreads();
+    const u32 b = tid >> 4, sl = tid & 15u;
+    XYZZz<BF> acc = xyzzz_identity<BF>();
+    {
+        const u32 start = off[b], cnt = off[b + 1] - start;
+        const u32 lo = start + cnt * sl / 16, hi = start + cnt * (sl + 1) / 16;
+        for (u32 e = lo; e < hi; ++e) {
+            const u32 ent = list[e];
+            const uint4* bp = bases_z + (size_t)(ent & 0x7FFFu) * (ZREC / 16);
+            const u32 neg = ent >> 15;
+            const uint4* yp = bp + 2 + (neg << 1);  // y, or -y for a negative digit
+            const uint4 qa = bp[0], qb = bp[1], qc = yp[0], qd = yp[1], qt = bp[6];
+            AffineZ<BF> p;
+            p.x.l[0] = (i32)qa.x; p.x.l[1] = (i32)qa.y; p.x.l[2] = (i32)qa.z; p.x.l[3] = (i32)qa.w;
+            p.x.l[4] = (i32)qb.x; p.x.l[5] = (i32)qb.y; p.x.l[6] = (i32)qb.z; p.x.l[7] = (i32)qb.w; p.x.l[8] = (i32)qt.x;
+            p.y.l[0] = (i32)qc.x; p.y.l[1] = (i32)qc.y; p.y.l[2] = (i32)qc.z; p.y.l[3] = (i32)qc.w;
+            p.y.l[4] = (i32)qd.x; p.y.l[5] = (i32)qd.y; p.y.l[6] = (i32)qd.z; p.y.l[7] = (i32)qd.w; p.y.l[8] = (i32)(neg ? qt.z : qt.y);
+            xyzzz_madd(acc, p);  // (identity bases, P + P and P - P inside)
+        }
+    }
+    for (int o = 8; o > 0; o >>= 1) {
+        const XYZZz<BF> other = shfl_down_point(acc, o, 16);
+        if ((int)sl < o) acc = xyzzz_add(acc, other);
+    }
+    if (sl == 0) store_raw(&bsum[b], acc);
+    __syncthreads();
+    if (tid >= 64) return;
+    // the first wave: lane b < 16 holds bucket b + 1's sum; S_b = sum of the buckets >= b (suffix scan), total = sum of the S_b = sum (b + 1) B_b
+    XYZZz<BF> v = tid < SMALL_NBK ? load_raw<BF>(&bsum[tid]) : xyzzz_identity<BF>();
+    for (int o = 1; o < (int)SMALL_NBK; o <<= 1) {
+        const XYZZz<BF> other = shfl_down_point(v, o, 16);
+        if (tid < SMALL_NBK && (int)tid + o < (int)SMALL_NBK) v = xyzzz_add(v, other);
+    }
+    for (int o = SMALL_NBK / 2; o > 0; o >>= 1) {
+        const XYZZz<BF> other = shfl_down_point(v, o, 16);
+        if ((int)tid < o) v = xyzzz_add(v, other);
+    }
+    if (tid == 0) store_xyzz(&window_sums[(size_t)z * W + j], xyzzz_to_canonical(v));
+}
+
 template <class BF> int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch);
 template <class BF> int point_sum_host_t(const u64* pts, size_t count, u64* out);
 
@@ -1361,6 +1473,36 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         if (rc != TRH_OK) return rc;
         memcpy(m.tile_sum, acc, 96);
         m.tile_sum_valid = true;
+        return TRH_OK;
+    }
+    if (!fb && n != 0 && n <= SMALL_MAX_N && batch <= 4 && c.window_override == 0 && !m.in_tile && !m.force_fallback) {  // one launch (msm_small_kernel)
+        const int W = num_windows(SMALL_C);
+        const size_t hs = batch * W * sizeof(XYZZMem);
+        TRH_TRY(m.window_sums.ensure(hs));
+        if (hs > m.host_sums_cap) {
+            if (m.host_sums) (void)hipHostFree(m.host_sums);
+            TRH_HIP_TRY(hipHostMalloc(&m.host_sums, hs + 4096, hipHostMallocDefault));
+            m.host_sums_cap = hs + 4096;
+        }
+        if (!bases_z) TRH_TRY(m.bases_z.ensure(n * ZREC + ZREC));
+        if (m.reserve_only) return TRH_OK;
+        if (!bases_z) {
+            hipLaunchKernelGGL((msm_convert_bases_kernel<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)bases_dev, m.bases_z.as<uint4>(), n);
+            bases_z = m.bases_z.p;
+        }
+        SmallBias H{};  // sum over the windows of (2^(c-1) - 1) 2^(c j), 9 x 32 bits
+        for (int j = 0; j < W; ++j) {
+            const u64 v = (u64)(SMALL_NBK - 1) << ((SMALL_C * j) & 31);
+            const int k = (SMALL_C * j) >> 5;
+            if (k < 9) H.w[k] |= (u32)v;
+            if (k + 1 < 9) H.w[k + 1] |= (u32)(v >> 32);
+        }
+        hipLaunchKernelGGL((msm_small_kernel<SF, BF>), dim3((unsigned)W, (unsigned)batch), dim3(256), 0, s, (const uint4*)bases_z, (const uint4*)scalars_dev, (u32)n, mont, stride,
+                           (const uint4*)tails_dev, H, m.window_sums.as<XYZZMem>());
+        TRH_HIP_TRY(hipGetLastError());
+        TRH_HIP_TRY(hipMemcpyAsync(m.host_sums, m.window_sums.p, hs, hipMemcpyDeviceToHost, s));
+        m.pending_curve = BF::ID; m.pending_windows = W; m.pending_c = SMALL_C; m.pending_batch = batch; m.pending_stream = s; m.pending_owner = nullptr;
+        m.ev_valid = false; m.lean_pending = false;
         return TRH_OK;
     }
     int cb = fb ? fb->c : choose_window_bits(n);
@@ -1783,6 +1925,19 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
         }
     }
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
+    if (m.pending_windows > 1 && batch >= 2 && batch <= 256) {
+        // Horner over the windows is ~250 doublings per result (70 us) and the results are independent: the upper half of the batch on the context's
+        // helper thread (hosthelper.h), the lower half here, then one inversion for all of them
+        if (!c.helper) c.helper = new HostHelper();
+        const int W = m.pending_windows, cb = m.pending_c;
+        hostcombine::P acc[256];
+        const size_t mid = batch / 2;
+        const uint64_t* w64 = (const uint64_t*)ws;
+        c.helper->start([&acc, w64, W, cb, mid, batch] { for (size_t i = mid; i < batch; ++i) acc[i] = hostcombine::horner<BF>(w64 + i * (size_t)W * 16, W, cb); });
+        for (size_t i = 0; i < mid; ++i) acc[i] = hostcombine::horner<BF>(w64 + i * (size_t)W * 16, W, cb);
+        c.helper->wait();
+        hostcombine::normalise_batch<BF>(acc, batch, (uint64_t*)out_xyz);
+    } else
     hostcombine::combine_windows_batch<BF>((const uint64_t*)ws, m.pending_windows, m.pending_c, batch, (uint64_t*)out_xyz);  // one inversion for the whole batch
     if (m.ev_valid) {
         float t01, t12, t23, t34, tt, t25;
