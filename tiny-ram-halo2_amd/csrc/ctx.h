@@ -135,6 +135,7 @@ struct MsmScratch {
     bool force_fallback = false, lean_pending = false;
     struct { const void *bases_dev, *bases_z, *scalars_dev, *tails_dev; size_t n, batch, stride; int mont; bool has_fb; MsmFixedBase fb; } retry{};
     unsigned lean_retries = 0;  // how often that happened on this context (tests)
+    size_t lean_off_n = 0; int lean_off_c = 0;  // the shape (pairs, window bits) whose lean sort last overflowed: the fallback launches are queued for it again
     bool reserve_only = false;  // msm_enqueue sizes the scratch of the described launch and returns before the first kernel (trh_bases_reserve)
     bool no_sparse_vote = false;  // the sparse classifier is skipped and nothing else changes (the shards of a range-sharded MSM: its host synchronisation would hold back the other shards)
     void* sp_host = nullptr;    // pinned: the sparse path's list counters as read back, then the dense flags it sends down

@@ -199,14 +199,20 @@ __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __rest
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_front_kernel(const uint4* __restrict__ p_old, const uint4* __restrict__ b_old, uint4* __restrict__ p_new, uint4* __restrict__ b_new,
                                                               uint4* __restrict__ wgt, uint4* __restrict__ lrsc, size_t n, size_t half, u32 bit, size_t stride, int first,
-                                                              const IpaConsts consts) {
+                                                              int wfresh /* the weights are all one and not in memory yet (rounds 0 and 1) */, const IpaConsts consts) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const size_t hprev = half << 1;  // the previous round's half
     const Fe<F> uinv = ipa_const<F>(consts, 0), u = ipa_const<F>(consts, 1);
     auto pn = [&](size_t x) { return first ? ld<F>(p_old + 2 * x) : fe_add(ld<F>(p_old + 2 * x), fe_mul(ld<F>(p_old + 2 * (hprev + x)), uinv)); };  // x < hprev
-    Fe<F> w = ld<F>(wgt + 2 * idx);
-    if (!first && ((idx >> (bit + 1)) & 1u)) { w = fe_mul(w, u); st<F>(wgt + 2 * idx, w); }
+    Fe<F> w;
+    if (wfresh) {  // round 0 reads no weights, round 1 writes them all
+        w = (!first && ((idx >> (bit + 1)) & 1u)) ? u : fe_one<F>();
+        if (!first) st<F>(wgt + 2 * idx, w);
+    } else {
+        w = ld<F>(wgt + 2 * idx);
+        if (!first && ((idx >> (bit + 1)) & 1u)) { w = fe_mul(w, u); st<F>(wgt + 2 * idx, w); }
+    }
     const size_t i = idx & (half - 1);
     const bool hi = (idx >> bit) & 1u;
     const Fe<F> v = fe_mul(w, pn(hi ? i : half + i));
@@ -218,6 +224,47 @@ __global__ void __launch_bounds__(256) ipa_round_front_kernel(const uint4* __res
         st<F>(b_new + 2 * idx, fe_add(ld<F>(b_old + 2 * idx), fe_mul(ld<F>(b_old + 2 * (hprev + idx)), u)));
     }
 }
+// dst[i] = a[i] + x s[i] (s may be null: a plain copy) and the block sums of dst[i] b[i], one pass: the opening's s(X) -> s' and p + xi s -> p'
+// with their values at x3 (consts = (x)).  ipa_fix_constant_kernel then subtracts the value from coefficient 0 -- on the device: the host never
+// needs s(x3) or p'(x3) (round 6; each was a synchronisation and two 32-byte copies before).
+template <class F>
+__global__ void __launch_bounds__(256) ipa_combine_eval_kernel(const uint4* __restrict__ a, const uint4* __restrict__ sv, const uint4* __restrict__ b, uint4* __restrict__ dst, size_t n,
+                                                               const IpaConsts consts, uint4* __restrict__ partial) {
+    __shared__ Fe<F> sh[256];
+    const Fe<F> x = ipa_const<F>(consts, 0);
+    Fe<F> acc = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fe<F> v = ld<F>(a + 2 * i);
+        if (sv) v = fe_add(v, fe_mul(ld<F>(sv + 2 * i), x));
+        st<F>(dst + 2 * i, v);
+        acc = fe_add(acc, fe_mul(v, ld<F>(b + 2 * i)));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st<F>(partial + 2 * blockIdx.x, sh[0]);
+}
+// one workgroup: vec[0] -= sum of the partials; with tail: vec[n] = consts[0] (the blind), vec[n + 1] = 0 (the scalar of u)
+template <class F>
+__global__ void __launch_bounds__(256) ipa_fix_constant_kernel(const uint4* __restrict__ partial, u32 count, uint4* __restrict__ vec, size_t n, int tail, const IpaConsts consts) {
+    __shared__ Fe<F> sh[256];
+    Fe<F> acc = fe_zero<F>();
+    for (u32 i = threadIdx.x; i < count; i += 256) acc = fe_add(acc, ld<F>(partial + 2 * i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st<F>(vec, fe_sub(ld<F>(vec), sh[0]));
+        if (tail) { st<F>(vec + 2 * n, ipa_const<F>(consts, 0)); st<F>(vec + 2 * (n + 1), fe_zero<F>()); }
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const IpaConsts consts /* rand_l, rand_r, z */,
                                                               uint4* __restrict__ lrsc, size_t n, size_t stride) {
@@ -356,6 +403,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     auto stm = [](const Fe<SF>& v) { FeMem m; fe_store(v, m); return m; };
     const Fe<SF> x3 = ld(x3_m), p_blind = ld(p_blind_m), s_blind = ld(s_blind_m);
 
+    ctx().msm.lean_off_n = 0;  // a shape whose lean sort overflowed keeps the fallback launches for the rest of ITS opening only (msm.hip lean_sort)
     // scratch kept in the context: a hipMalloc / hipFree pair per vector costs more than several rounds
     DevBuf* sc = ctx().ipa;
     DevBuf &b = sc[0], &sp = sc[1], &pp = sc[2], &wgt = sc[3], &lrsc = sc[4], &gwu = sc[5], &gwuz = sc[6], &pp2 = sc[7], &b2 = sc[8];
@@ -369,19 +417,24 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     if (!with_u) { TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * ZREC)); }
     FeMem x3m = stm(x3);
     TRH_TRY((powers_t<SF>(b.p, n, (const u64*)&x3m, s)));
-    // s(X) with s(x3) = 0, then its commitment over g ‖ w with the blind appended
-    TRH_HIP_TRY(hipMemcpyAsync(sp.p, s_poly_dev, n * 32, hipMemcpyDeviceToDevice, s));
+    // s'(X) = s(X) - s(x3), then its commitment over g ‖ w with the blind appended: one pass copies s and forms its value at x3, one workgroup
+    // subtracts it from coefficient 0 and appends the blind (and the zero scalar of u) -- no host turn before the MSM
     FeMem tmp;
-    TRH_TRY((inner_product_t<SF>(sp.p, b.p, n, s, (u64*)&tmp)));
-    const Fe<SF> s_at_x3 = fe_load<SF>(tmp);
-    TRH_HIP_TRY(hipMemcpy(&tmp, sp.p, 32, hipMemcpyDeviceToHost));
-    FeMem s0 = stm(fe_sub(fe_load<SF>(tmp), s_at_x3));
-    TRH_HIP_TRY(hipMemcpy(sp.p, &s0, 32, hipMemcpyHostToDevice));
-    FeMem sbm = stm(s_blind);
-    TRH_HIP_TRY(hipMemcpy((char*)sp.p + n * 32, &sbm, 32, hipMemcpyHostToDevice));
+    unsigned eblocks = (unsigned)((n + 255) / 256);
+    if (eblocks > 512) eblocks = 512;
+    TRH_TRY(ctx().io.ensure((size_t)(2 * 512 + 2) * 32));
+    {
+        IpaConsts k0{};
+        hipLaunchKernelGGL((ipa_combine_eval_kernel<SF>), dim3(eblocks), dim3(256), 0, s, (const uint4*)s_poly_dev, (const uint4*)nullptr, (const uint4*)b.p, (uint4*)sp.p, n, k0,
+                           ctx().io.as<uint4>());
+        FeMem sbm = stm(s_blind);
+        IpaConsts kb{};
+        memcpy(&kb, &sbm, 32);
+        hipLaunchKernelGGL((ipa_fix_constant_kernel<SF>), dim3(1), dim3(256), 0, s, (const uint4*)ctx().io.as<uint4>(), eblocks, (uint4*)sp.p, n, 1, kb);
+        TRH_HIP_TRY(hipGetLastError());
+    }
     u64 pt[12];
     if (fb) {  // the scalar of u is zero: the full-range (table) path
-        TRH_HIP_TRY(hipMemsetAsync((char*)sp.p + (n + 1) * 32, 0, 32, s));
         ctx().msm.dense_hint = true;  // s(X) is uniformly random: no sparse classification
         const int rc_s = msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 2, 1, n + 2, 1, s, fb);
         ctx().msm.dense_hint = false;
@@ -394,19 +447,21 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     const Fe<SF> xi = fe_load<SF>(tmp);
     tr->squeeze_challenge_scalar(tr->ctx, (u64*)&tmp);
     const Fe<SF> z = fe_load<SF>(tmp);
-    // p'(X) = p(X) + xi s(X) - v
-    TRH_HIP_TRY(hipMemcpyAsync(pp.p, p_poly_dev, n * 32, hipMemcpyDeviceToDevice, s));
-    TRH_TRY((axpy_t<SF>(pp.p, sp.p, n, stm(xi), s)));
-    TRH_TRY((inner_product_t<SF>(pp.p, b.p, n, s, (u64*)&tmp)));
-    const Fe<SF> v = fe_load<SF>(tmp);
-    TRH_HIP_TRY(hipMemcpy(&tmp, pp.p, 32, hipMemcpyDeviceToHost));
-    FeMem p0 = stm(fe_sub(fe_load<SF>(tmp), v));
-    TRH_HIP_TRY(hipMemcpy(pp.p, &p0, 32, hipMemcpyHostToDevice));
+    // p'(X) = p(X) + xi s'(X) - v, v its value at x3: the same two launches
+    {
+        FeMem xim = stm(xi);
+        IpaConsts kx{};
+        memcpy(&kx, &xim, 32);
+        hipLaunchKernelGGL((ipa_combine_eval_kernel<SF>), dim3(eblocks), dim3(256), 0, s, (const uint4*)p_poly_dev, (const uint4*)sp.p, (const uint4*)b.p, (uint4*)pp.p, n, kx,
+                           ctx().io.as<uint4>());
+        IpaConsts k0{};
+        hipLaunchKernelGGL((ipa_fix_constant_kernel<SF>), dim3(1), dim3(256), 0, s, (const uint4*)ctx().io.as<uint4>(), eblocks, (uint4*)pp.p, n, 0, k0);
+        TRH_HIP_TRY(hipGetLastError());
+    }
     Fe<SF> f = fe_add(fe_mul(s_blind, xi), p_blind);
     // weights of the original generators inside the (virtual) folded ones; the bases of the round MSMs are
     // g (n points) followed by w and u, so that [rand] W + [value z] U ride in the same MSM as the main sum
-    FeMem one_m = stm(fe_one<SF>());
-    TRH_TRY((powers_t<SF>(wgt.p, n, (const u64*)&one_m, s)));  // all ones
+    // (all ones at first: the front launch of round 0 takes them as such and round 1's writes them -- no fill)
     const void* round_xy = gw->d_xy;
     const void* round_z = nullptr;
     if (!with_u) {
@@ -451,7 +506,6 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     double tr_acc[6] = {0, 0, 0, 0, 0, 0};
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     unsigned fblocks = (unsigned)((n + 255) / 256);
-    TRH_TRY(ctx().io.ensure((size_t)(2 * 512 + 2) * 32));
     uint4* const partial = ctx().io.as<uint4>();
     // p' and b live in ping-pong pairs from round 1 on (a round reads the vectors the previous one left and writes their folds to the other buffer)
     void* p_cur = pp.p; void* b_cur = b.p;
@@ -506,7 +560,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             IpaConsts kc{};
             memcpy(&kc, cst, sizeof(cst));
             hipLaunchKernelGGL((ipa_round_front_kernel<SF>), dim3(fblocks), dim3(256), 0, s, (const uint4*)p_cur, (const uint4*)b_cur, (uint4*)p_nxt, (uint4*)b_nxt, (uint4*)wgt.p, (uint4*)lrsc.p,
-                               ncur, half, bit, stride, j == 0 ? 1 : 0, kc);
+                               ncur, half, bit, stride, j == 0 ? 1 : 0, (j <= 1 && !(fold_at && j >= switch_at)) ? 1 : 0, kc);
             if (j > 0) { void* t = p_cur; p_cur = p_nxt; p_nxt = t; t = b_cur; b_cur = b_nxt; b_nxt = t; }
             // value_l = <p'[half ..], b[.. half]>, value_r = <p'[.. half], b[half ..]> over the folded vectors, then the tail scalars [rand] W, [value z] U
             unsigned blocks = (unsigned)((half + 255) / 256);

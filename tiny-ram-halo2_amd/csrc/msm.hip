@@ -1356,7 +1356,7 @@ __device__ __forceinline__ XYZZz<BF> shfl_down_point(const XYZZz<BF>& v, int off
     return o;
 }
 
-template <class SF, class BF>
+template <class SF, class BF, bool Q4>
 __global__ void __launch_bounds__(256) msm_small_kernel(const uint4* __restrict__ bases_z, const uint4* __restrict__ scalars, u32 n, int mont, size_t sstride,
                                                         const uint4* __restrict__ tails, const SmallBias H, XYZZMem* __restrict__ window_sums) {
     __shared__ signed char dig[SMALL_MAX_N];
@@ -1418,24 +1418,60 @@ __global__ void __launch_bounds__(256) msm_small_kernel(const uint4* __restrict_
             xyzzz_madd(acc, p);  // (identity bases, P + P and P - P inside)
         }
     }
-    for (int o = 8; o > 0; o >>= 1) {
-        const XYZZz<BF> other = shfl_down_point(acc, o, 16);
-        if ((int)sl < o) acc = xyzzz_add(acc, other);
+    if constexpr (!Q4) {
+        for (int o = 8; o > 0; o >>= 1) {
+            const XYZZz<BF> other = shfl_down_point(acc, o, 16);
+            if ((int)sl < o) acc = xyzzz_add(acc, other);
+        }
+        if (sl == 0) store_raw(&bsum[b], acc);
+        __syncthreads();
+        if (tid >= 64) return;
+        // the first wave: lane b < 16 holds bucket b + 1's sum; S_b = sum of the buckets >= b (suffix scan), total = sum of the S_b = sum (b + 1) B_b
+        XYZZz<BF> v = tid < SMALL_NBK ? load_raw<BF>(&bsum[tid]) : xyzzz_identity<BF>();
+        for (int o = 1; o < (int)SMALL_NBK; o <<= 1) {
+            const XYZZz<BF> other = shfl_down_point(v, o, 16);
+            if (tid < SMALL_NBK && (int)tid + o < (int)SMALL_NBK) v = xyzzz_add(v, other);
+        }
+        for (int o = SMALL_NBK / 2; o > 0; o >>= 1) {
+            const XYZZz<BF> other = shfl_down_point(v, o, 16);
+            if ((int)tid < o) v = xyzzz_add(v, other);
+        }
+        if (tid == 0) store_xyzz(&window_sums[(size_t)z * W + j], xyzzz_to_canonical(v));
+    } else {
+        // the same sums with a point per DPP quad (curve_q4.h: an addition is five multiplication steps deep instead of fourteen products one after
+        // the other): 16 -> 8 partial sums per bucket in the plain form, those through LDS into quads -- 64 pairs on 256 lanes --, two more levels by
+        // shuffles between the quads of a bucket; then the 16 bucket sums on the 16 quads of the first wave: suffix scan + tree as above
+        __shared__ XYZZzMem pts[SMALL_NBK * 8];
+        {
+            const XYZZz<BF> other = shfl_down_point(acc, 8, 16);
+            if (sl < 8) { acc = xyzzz_add(acc, other); store_raw(&pts[b * 8 + sl], acc); }
+        }
+        __syncthreads();
+        const int q = (int)(tid & 3u);
+        const u32 g = tid >> 2;  // quad: bucket g >> 2, pair g & 3
+        auto shfl_fy = [](const Fy<BF>& a, int lanes) {
+            Fy<BF> r;
+#pragma unroll
+            for (int l = 0; l < NLIMBS; ++l) r.l[l] = __shfl_down(a.l[l], lanes);
+            return r;
+        };
+        Fy<BF> v = q4_add(q4_load<BF>(&pts[(g >> 2) * 8 + (g & 3u)], q), q4_load<BF>(&pts[(g >> 2) * 8 + (g & 3u) + 4], q), q);
+        // (a quad without a partner adds the identity: a lane past the wave's end would read itself back, and P + P takes the doubling's extra steps)
+        v = q4_add(v, q4_select((g & 3u) < 2, shfl_fy(v, 8), fy_zero<BF>()), q);   // pairs 0 and 1 of a bucket
+        v = q4_add(v, q4_select((g & 3u) == 0, shfl_fy(v, 4), fy_zero<BF>()), q);  // pair 0: the bucket's sum
+        if ((g & 3u) == 0) q4_store(&bsum[g >> 2], q, v);
+        __syncthreads();
+        if (tid >= 64) return;
+        v = q4_load<BF>(&bsum[g], q);  // quad g < 16 of the first wave: bucket g + 1
+        for (int o = 1; o < (int)SMALL_NBK; o <<= 1) v = q4_add(v, q4_select((int)g + o < (int)SMALL_NBK, shfl_fy(v, 4 * o), fy_zero<BF>()), q);
+        for (int o = SMALL_NBK / 2; o > 0; o >>= 1) v = q4_add(v, q4_select((int)g < o, shfl_fy(v, 4 * o), fy_zero<BF>()), q);
+        if (g == 0) {  // lane q holds coordinate q of the window sum
+            const bool id = q4_is_identity(v);
+            uint4* dst = (uint4*)&window_sums[(size_t)z * W + j] + 2 * q;
+            if (id) { dst[0] = make_uint4(0, 0, 0, 0); dst[1] = make_uint4(0, 0, 0, 0); }
+            else store_fe4(dst, fy_to_fe(v));
+        }
     }
-    if (sl == 0) store_raw(&bsum[b], acc);
-    __syncthreads();
-    if (tid >= 64) return;
-    // the first wave: lane b < 16 holds bucket b + 1's sum; S_b = sum of the buckets >= b (suffix scan), total = sum of the S_b = sum (b + 1) B_b
-    XYZZz<BF> v = tid < SMALL_NBK ? load_raw<BF>(&bsum[tid]) : xyzzz_identity<BF>();
-    for (int o = 1; o < (int)SMALL_NBK; o <<= 1) {
-        const XYZZz<BF> other = shfl_down_point(v, o, 16);
-        if (tid < SMALL_NBK && (int)tid + o < (int)SMALL_NBK) v = xyzzz_add(v, other);
-    }
-    for (int o = SMALL_NBK / 2; o > 0; o >>= 1) {
-        const XYZZz<BF> other = shfl_down_point(v, o, 16);
-        if ((int)tid < o) v = xyzzz_add(v, other);
-    }
-    if (tid == 0) store_xyzz(&window_sums[(size_t)z * W + j], xyzzz_to_canonical(v));
 }
 
 template <class BF> int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch);
@@ -1497,8 +1533,12 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             if (k < 9) H.w[k] |= (u32)v;
             if (k + 1 < 9) H.w[k + 1] |= (u32)(v >> 32);
         }
-        hipLaunchKernelGGL((msm_small_kernel<SF, BF>), dim3((unsigned)W, (unsigned)batch), dim3(256), 0, s, (const uint4*)bases_z, (const uint4*)scalars_dev, (u32)n, mont, stride,
-                           (const uint4*)tails_dev, H, m.window_sums.as<XYZZMem>());
+        if (opt().reduce_q4)
+            hipLaunchKernelGGL((msm_small_kernel<SF, BF, true>), dim3((unsigned)W, (unsigned)batch), dim3(256), 0, s, (const uint4*)bases_z, (const uint4*)scalars_dev, (u32)n, mont, stride,
+                               (const uint4*)tails_dev, H, m.window_sums.as<XYZZMem>());
+        else
+            hipLaunchKernelGGL((msm_small_kernel<SF, BF, false>), dim3((unsigned)W, (unsigned)batch), dim3(256), 0, s, (const uint4*)bases_z, (const uint4*)scalars_dev, (u32)n, mont, stride,
+                               (const uint4*)tails_dev, H, m.window_sums.as<XYZZMem>());
         TRH_HIP_TRY(hipGetLastError());
         TRH_HIP_TRY(hipMemcpyAsync(m.host_sums, m.window_sums.p, hs, hipMemcpyDeviceToHost, s));
         m.pending_curve = BF::ID; m.pending_windows = W; m.pending_c = SMALL_C; m.pending_batch = batch; m.pending_stream = s; m.pending_owner = nullptr;
@@ -1598,7 +1638,9 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     // launches of the chunked fallback behind it (they return at once unless a bin overflowed the LDS: 19 us of a round's 680).  The "a bin
     // did overflow" flags travel to the host behind the window sums, and msm_finish repeats the MSM with the fallback when one is set
     // (the scalars must stay as they are until msm_finish: true of every caller that sets dense_hint).
-    const bool lean_sort = m.dense_hint && !m.force_fallback && use_bin && batch <= chunk && (size_t)batch * Ws <= 256 && n != 0;
+    // (a shape that overflowed before -- k = 16: the 3-bit top window of the c = 14 table puts n / 5 extra entries into each of the buckets 1 .. 4 of
+    //  the shared set, every round -- is not tried again: the opening's rounds all have that shape and would each pay the MSM twice)
+    const bool lean_sort = m.dense_hint && !m.force_fallback && use_bin && batch <= chunk && (size_t)batch * Ws <= 256 && n != 0 && !(m.lean_off_n == n && m.lean_off_c == cb);
     const size_t flag_off = batch * Ws * sizeof(XYZZMem);
     TRH_TRY(m.window_sums.ensure(flag_off + (lean_sort ? batch * Ws * 4 : 0)));
     const size_t hs = flag_off + (lean_sort ? batch * Ws * 4 : 0);
@@ -1922,6 +1964,7 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
             TRH_TRY(rc);
             TRH_HIP_TRY(hipStreamSynchronize(s));
             ++m.lean_retries;
+            m.lean_off_n = m.retry.n; m.lean_off_c = m.pending_c;
         }
     }
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
