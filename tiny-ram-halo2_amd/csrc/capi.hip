@@ -985,7 +985,14 @@ int trh_bases_reserve(trh_bases_t b, size_t n, size_t batch) {
     c.msm.reserve_only = true;
     const int rc = msm_enqueue(b->curve, b->d_xy, lazy_bases(b, 0, nullptr), b->d_xy /* never read */, n, batch, n, 1, nullptr, fixed_base(b, 0, n), batch > 1 ? c.msm.tails.p : nullptr);
     c.msm.reserve_only = false;
-    return rc;
+    TRH_TRY(rc);
+    // the shape of an IPA opening's round MSMs -- two rows over the whole of a tabled set of 2^k + 2 points (g || w || u): the opening's own buffers too
+    if (batch == 2 && n == b->n && b->d_table && n > 2 && ((n - 2) & (n - 3)) == 0) {
+        uint32_t k = 0;
+        while (((size_t)1 << k) < n - 2) ++k;
+        TRH_TRY(ipa_reserve(b->curve, b, k));
+    }
+    return TRH_OK;
 }
 
 int trh_msm(trh_bases_t bases, size_t offset, const uint64_t* scalars_host, size_t n, int mont, uint64_t out[12]) {

@@ -21,6 +21,7 @@
 #include "../../include/trh.h"
 #include "curve.h"
 
+struct trh_bases;
 namespace trh { class CopyPool; }
 
 namespace trh {
@@ -325,6 +326,8 @@ bool ntt_can_fold_scale(uint32_t log_n);
 void ntt_release_tables();
 // ipafold.hip: the IPA's generators after r collapses, from the fixed-base table of g || w || u
 bool ipa_fold_supported(const MsmFixedBase& fb, uint32_t k, uint32_t r);
+int ipa_fold_reserve(const MsmFixedBase& fb, uint32_t k, uint32_t r);
+int ipa_reserve(int curve, const trh_bases* gw, uint32_t k);  // ipa.hip: the opening's vectors and the collapse's buffers, at setup time
 int ipa_fold_generators(int curve, const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const u64* u_mont, void* out_xy, void* out_z, hipStream_t s);
 // msm.hip
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,

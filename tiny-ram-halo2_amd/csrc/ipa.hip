@@ -15,6 +15,7 @@
 
 #include "ctx.h"
 #include "hostcombine.h"
+#include "hosthelper.h"
 
 namespace trh {
 namespace {
@@ -394,6 +395,21 @@ int axpy_t(void* y, const void* x, size_t n, const FeMem& c_mont, hipStream_t s)
 // device.  Host-side scalar arithmetic uses the shared field code; the transcript and the prover's
 // randomness are callbacks into the caller (BLAKE2b transcript and OsRng on the Rust side).
 // ---------------------------------------------------------------------------------------
+// the round after which the generators are collapsed (0: never -- no table, a small opening, or option ipa_fold = 0)
+uint32_t ipa_fold_level(const MsmFixedBase* fb, uint32_t k) {
+    const uint32_t fold_r = (uint32_t)(opt().ipa_fold % 10), fold_gap = (uint32_t)(opt().ipa_fold / 10);
+    return (fb && fold_r > 0 && fold_gap <= 4 && k >= 16 && ipa_fold_supported(*fb, k, fold_r)) ? fold_r : 0;
+}
+// the side stream and its events
+int ipa_fold_stream(Ctx& c) {
+    if (c.fold_stream) return TRH_OK;
+    int lo = 0, hi = 0;  // lo: the numerically greatest = lowest priority
+    TRH_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TRH_HIP_TRY(hipStreamCreateWithPriority(&c.fold_stream, hipStreamNonBlocking, lo));
+    for (hipEvent_t& e : c.fold_ev) TRH_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return TRH_OK;
+}
+
 template <class SF, class BF>
 int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t k, const void* p_poly_dev, const u64* p_blind_m, const u64* x3_m,
                        const void* s_poly_dev, const u64* s_blind_m, const trh_transcript_t* tr, trh_rng_scalar_fn rng, void* rng_ctx,
@@ -478,8 +494,8 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // points, a fraction of a full-size round each.  Only worth it where a full-size round costs much more than a small one.
     // The collapse is launched on a stream of its own after round r - 1 and the opening switches `gap` rounds later: those rounds still run
     // over the table (their kernels are latency chains that leave most of the chip idle), the collapse's million additions run under them.
-    const uint32_t fold_r = (uint32_t)(opt().ipa_fold % 10), fold_gap = (uint32_t)(opt().ipa_fold / 10);
-    const uint32_t fold_at = (fb && fold_r > 0 && fold_gap <= 4 && k >= 16 && ipa_fold_supported(*fb, k, fold_r)) ? fold_r : 0;
+    const uint32_t fold_gap = (uint32_t)(opt().ipa_fold / 10);
+    const uint32_t fold_at = ipa_fold_level(fb, k);
     const uint32_t switch_at = fold_at + fold_gap;
     struct FoldGuard {  // no return path leaves the side stream working on the context's buffers
         hipStream_t fs = nullptr; bool pending = false;
@@ -524,12 +540,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             TRH_TRY(gwu.ensure((m + 2) * 64)); TRH_TRY(gwuz.ensure((m + 2) * ZREC));
             hipStream_t fs = s;
             if (fold_gap) {
-                if (!c.fold_stream) {
-                    int lo = 0, hi = 0;  // lo: the numerically greatest = lowest priority
-                    TRH_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                    TRH_HIP_TRY(hipStreamCreateWithPriority(&c.fold_stream, hipStreamNonBlocking, lo));
-                    for (hipEvent_t& e : c.fold_ev) TRH_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                }
+                TRH_TRY(ipa_fold_stream(c));
                 fs = c.fold_stream;
                 TRH_HIP_TRY(hipEventRecord(c.fold_ev[0], s));  // behind whatever used these buffers last on the opening's stream
                 TRH_HIP_TRY(hipStreamWaitEvent(fs, c.fold_ev[0], 0));
@@ -624,6 +635,29 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
 }
 
 }  // namespace
+
+// what an opening over this base set allocates, at setup time (trh_bases_reserve): the first proof of a process then finds its vectors, the
+// collapse's buckets and the small MSM's landing area in place
+int ipa_reserve(int curve, const trh_bases* gw, uint32_t k) {
+    const size_t n = (size_t)1 << k;
+    Ctx& c = ctx();
+    DevBuf* sc = c.ipa;
+    TRH_TRY(sc[0].ensure(n * 32)); TRH_TRY(sc[1].ensure((n + 2) * 32)); TRH_TRY(sc[2].ensure(n * 32)); TRH_TRY(sc[3].ensure(n * 32)); TRH_TRY(sc[4].ensure(2 * (n + 2) * 32));
+    TRH_TRY(sc[7].ensure(n * 16 + 32)); TRH_TRY(sc[8].ensure(n * 16 + 32));
+    TRH_TRY(c.io.ensure((size_t)(2 * 512 + 2) * 32));
+    const MsmFixedBase* fb = gw->d_table ? &gw->fb : nullptr;
+    const uint32_t fold_at = ipa_fold_level(fb, k);
+    if (!fold_at) return TRH_OK;
+    const size_t m = (size_t)1 << (k - fold_at);
+    TRH_TRY(sc[5].ensure((m + 2) * 64)); TRH_TRY(sc[6].ensure((m + 2) * ZREC));
+    TRH_TRY(ipa_fold_reserve(*fb, k, fold_at));
+    if (opt().ipa_fold / 10) TRH_TRY(ipa_fold_stream(c));
+    if (!c.helper) c.helper = new HostHelper();  // msm_finish's second Horner thread
+    c.msm.reserve_only = true;
+    const int rc = msm_enqueue(curve, sc[5].p, sc[6].p, sc[4].p, m + 2, 2, m + 2, 1, nullptr);
+    c.msm.reserve_only = false;
+    return rc;
+}
 }  // namespace trh
 
 using namespace trh;

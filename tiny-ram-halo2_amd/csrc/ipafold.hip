@@ -118,16 +118,17 @@ __global__ void __launch_bounds__(256) ipa_fold_accumulate_kernel(const uint4* _
     fold_store_raw(out + ((size_t)b << log_m) + i, acc);
 }
 
-// 16 lanes per generator: lane = (sub-window s, slice q < 8).  Slice: running sums over its NB / 8 buckets, + (first id - 1) * (sum of
-// the slice); a shuffle tree over the eight slices; the high sub-window's sum doubled w0 times onto the low one; affine; both base formats.
+// 32 lanes per generator: lane = (sub-window s, slice q < 16).  Slice: running sums over its NB / 16 buckets, + (first id - 1) * (sum of the
+// slice); a shuffle tree over the sixteen slices; the high sub-window's sum doubled w0 times onto the low one.  The sum leaves as a raw point:
+// the inversion has a kernel of its own (in here every wave would walk the whole exponent for the two lanes that hold a result).
+// (First version: 16 lanes, slices of 16 buckets, the inversion inline -- 0.73 ms at k = 18, one wave per SIMD waiting on itself.)
 template <class BF>
-__global__ void __launch_bounds__(256) ipa_fold_reduce_kernel(const XYZZzMem* __restrict__ buckets, u32 log_m, u32 w0, u32 w1, uint4* __restrict__ out_xy,
-                                                              uint4* __restrict__ out_z) {
-    const u32 lane16 = threadIdx.x & 15u;
-    const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const u32 s = lane16 >> 3, q = lane16 & 7u;
+__global__ void __launch_bounds__(256) ipa_fold_reduce_kernel(const XYZZzMem* __restrict__ buckets, u32 log_m, u32 w0, u32 w1, XYZZzMem* __restrict__ sums) {
+    const u32 lane32 = threadIdx.x & 31u;
+    const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const u32 s = lane32 >> 4, q = lane32 & 15u;
     const u32 nb = 1u << ((s ? w1 : w0) - 1);
-    const u32 sl = nb >> 3;  // buckets per slice (w >= 4)
+    const u32 sl = nb >> 4;  // buckets per slice (w >= 5)
     const u32 first = (s ? (1u << (w0 - 1)) : 0u) + q * sl;  // row of the slice's first bucket
     XYZZz<BF> run = xyzzz_identity<BF>(), acc = xyzzz_identity<BF>();
     for (int k = (int)sl - 1; k >= 0; --k) {
@@ -144,28 +145,36 @@ __global__ void __launch_bounds__(256) ipa_fold_reduce_kernel(const XYZZzMem* __
         }
         acc = xyzzz_add(acc, sc);
     }
-    for (int d = 4; d > 0; d >>= 1) {
+    for (int d = 8; d > 0; d >>= 1) {
         XYZZz<BF> o;
 #pragma unroll
         for (int l = 0; l < NLIMBS; ++l) {
-            o.x.l[l] = __shfl_down(acc.x.l[l], d, 8); o.y.l[l] = __shfl_down(acc.y.l[l], d, 8);
-            o.zz.l[l] = __shfl_down(acc.zz.l[l], d, 8); o.zzz.l[l] = __shfl_down(acc.zzz.l[l], d, 8);
+            o.x.l[l] = __shfl_down(acc.x.l[l], d, 16); o.y.l[l] = __shfl_down(acc.y.l[l], d, 16);
+            o.zz.l[l] = __shfl_down(acc.zz.l[l], d, 16); o.zzz.l[l] = __shfl_down(acc.zzz.l[l], d, 16);
         }
-        if ((int)q + d < 8) acc = xyzzz_add(acc, o);
+        if ((int)q < d) acc = xyzzz_add(acc, o);
     }
-    if (lane16 == 8) for (u32 t = 0; t < w0; ++t) acc = xyzzz_dbl(acc);
+    if (lane32 == 16) for (u32 t = 0; t < w0; ++t) acc = xyzzz_dbl(acc);
     {
         XYZZz<BF> o;
 #pragma unroll
         for (int l = 0; l < NLIMBS; ++l) {
-            o.x.l[l] = __shfl_down(acc.x.l[l], 8, 16); o.y.l[l] = __shfl_down(acc.y.l[l], 8, 16);
-            o.zz.l[l] = __shfl_down(acc.zz.l[l], 8, 16); o.zzz.l[l] = __shfl_down(acc.zzz.l[l], 8, 16);
+            o.x.l[l] = __shfl_down(acc.x.l[l], 16, 32); o.y.l[l] = __shfl_down(acc.y.l[l], 16, 32);
+            o.zz.l[l] = __shfl_down(acc.zz.l[l], 16, 32); o.zzz.l[l] = __shfl_down(acc.zzz.l[l], 16, 32);
         }
-        if (lane16 != 0) return;
+        if (lane32 != 0) return;
         acc = xyzzz_add(acc, o);
     }
-    // affine in the lazy domain: 1 / zzz by Fermat with this domain's products (255 squarings + ~65 products: the moduli are 2^254 + a 126-bit
-    // number), 1 / zz = zzz^-2 zz^2.  (The canonical-domain fe_inv made this kernel 0.92 ms: its chain is the kernel's duration.)
+    fold_store_raw(sums + i, acc);
+}
+
+// a thread per generator: affine in the lazy domain -- 1 / zzz by Fermat with this domain's products (255 squarings + ~65 products: the moduli
+// are 2^254 + a 126-bit number), 1 / zz = zzz^-2 zz^2 -- and both base formats (64-byte affine, msm.hip's 128-byte record)
+template <class BF>
+__global__ void __launch_bounds__(64) ipa_fold_affine_kernel(const XYZZzMem* __restrict__ sums, size_t m, uint4* __restrict__ out_xy, uint4* __restrict__ out_z) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= m) return;
+    const XYZZz<BF> acc = fold_load_raw<BF>(sums + i);
     Affine<BF> a;
     if (xyzzz_is_identity(acc)) { a.x = fe_zero<BF>(); a.y = fe_zero<BF>(); }  // (never, for independent generators)
     else {
@@ -231,6 +240,21 @@ int fold_plan(const std::vector<hostcombine::H>& sc, int c, int W, u32 w0, u32 w
     return TRH_OK;
 }
 
+// buckets (+ the m sums between the reduction and the inversion), the bucket lists and their pinned source
+int fold_buffers(Ctx& c, const MsmFixedBase& fb, uint32_t k, uint32_t r, size_t plan_words, hipStream_t s) {
+    const size_t m = (size_t)1 << (k - r);
+    const u32 nbk = (1u << ((fb.c + 1) / 2 - 1)) + (1u << (fb.c / 2 - 1));
+    TRH_TRY(c.ipa[9].ensure((size_t)(nbk + 1) * m * sizeof(XYZZzMem)));
+    TRH_TRY(c.ipa[10].ensure(plan_words * 4));
+    if (c.pinned_fold_cap < plan_words * 4) {
+        if (c.pinned_fold) { TRH_HIP_TRY(hipStreamSynchronize(s)); (void)hipHostFree(c.pinned_fold); c.pinned_fold = nullptr; c.pinned_fold_cap = 0; }
+        const size_t want = plan_words * 4 + 4096;
+        TRH_HIP_TRY(hipHostMalloc(&c.pinned_fold, want, hipHostMallocDefault));
+        c.pinned_fold_cap = want;
+    }
+    return TRH_OK;
+}
+
 template <class SF, class BF>
 int ipa_fold_t(const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const u64* u_mont, void* out_xy, void* out_z, hipStream_t s) {
     using hostcombine::H;
@@ -255,20 +279,15 @@ int ipa_fold_t(const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const
     TRH_TRY(fold_plan(sc, fb.c, fb.W, w0, w1, plan, nbk));
     DevBuf& buckets = c.ipa[9];
     DevBuf& dplan = c.ipa[10];
-    TRH_TRY(buckets.ensure((size_t)nbk * m * sizeof(XYZZzMem)));
-    TRH_TRY(dplan.ensure(plan.size() * 4));
-    if (c.pinned_fold_cap < plan.size() * 4) {
-        if (c.pinned_fold) { TRH_HIP_TRY(hipStreamSynchronize(s)); (void)hipHostFree(c.pinned_fold); c.pinned_fold = nullptr; c.pinned_fold_cap = 0; }
-        const size_t want = plan.size() * 4 + 4096;
-        TRH_HIP_TRY(hipHostMalloc(&c.pinned_fold, want, hipHostMallocDefault));
-        c.pinned_fold_cap = want;
-    }
+    TRH_TRY(fold_buffers(c, fb, k, r, plan.size(), s));
+    XYZZzMem* const sums = (XYZZzMem*)buckets.p + (size_t)nbk * m;
     // (the previous opening's copy out of this buffer completed before that opening returned: it ends with a stream synchronisation)
     memcpy(c.pinned_fold, plan.data(), plan.size() * 4);
     TRH_HIP_TRY(hipMemcpyAsync(dplan.p, c.pinned_fold, plan.size() * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL((ipa_fold_accumulate_kernel<BF>), dim3((unsigned)(m / 256), nbk), dim3(256), 0, s, (const uint4*)fb.table, row, log_m, (const u32*)dplan.p, nbk,
                        (XYZZzMem*)buckets.p);
-    hipLaunchKernelGGL((ipa_fold_reduce_kernel<BF>), dim3((unsigned)(m / 16)), dim3(256), 0, s, (const XYZZzMem*)buckets.p, log_m, w0, w1, (uint4*)out_xy, (uint4*)out_z);
+    hipLaunchKernelGGL((ipa_fold_reduce_kernel<BF>), dim3((unsigned)(m / 8)), dim3(256), 0, s, (const XYZZzMem*)buckets.p, log_m, w0, w1, sums);
+    hipLaunchKernelGGL((ipa_fold_affine_kernel<BF>), dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const XYZZzMem*)sums, m, (uint4*)out_xy, (uint4*)out_z);
     TRH_HIP_TRY(hipGetLastError());
     return TRH_OK;
 }
@@ -276,8 +295,15 @@ int ipa_fold_t(const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const
 }  // namespace
 
 bool ipa_fold_supported(const MsmFixedBase& fb, uint32_t k, uint32_t r) {
-    // two sub-digits of 4 .. 8 bits per table window; t and the table level share an entry word; whole workgroups of generators
-    return fb.table && fb.c >= 8 && fb.c <= 16 && fb.W < 0x8000 && r >= 1 && r <= 10 && k >= r + 8;
+    // two sub-digits of 5 .. 8 bits per table window (sixteen slices of >= 1 bucket); t and the table level share an entry word; whole workgroups of generators
+    return fb.table && fb.c >= 10 && fb.c <= 16 && fb.W < 0x8000 && r >= 1 && r <= 10 && k >= r + 8;
+}
+
+// setup-time sizing of what ipa_fold_generators allocates (trh_bases_reserve over an opening's base set)
+int ipa_fold_reserve(const MsmFixedBase& fb, uint32_t k, uint32_t r) {
+    if (!ipa_fold_supported(fb, k, r)) return TRH_OK;
+    const u32 nbk = (1u << ((fb.c + 1) / 2 - 1)) + (1u << (fb.c / 2 - 1));
+    return fold_buffers(ctx(), fb, k, r, (size_t)nbk + 1 + ((size_t)2 << r) * fb.W, nullptr);
 }
 
 // G''[i] (i < 2^(k - r)) from the table of a base set with `row` points per level, after the r challenges u_mont (Montgomery words, round order):

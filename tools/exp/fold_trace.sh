@@ -26,3 +26,4 @@ for p in glob.glob("$REPO/gpurun_out/fold_tr/**/*.db", recursive=True):
         print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  gap {gap:7.1f}  st {sid}  {m.group(1) if m else name[:40]}")
         prev = e
 PY
+python3 $REPO/tools/exp/opening_phases.py $REPO/gpurun_out/fold_tr 18
