@@ -228,6 +228,45 @@ def test_msm_batch_dev():
         assert (got[k, :8] == want).all(), k
 
 
+SMALL_SCRIPT = r"""
+import numpy as np
+import cpu_ref
+from common import point_hex
+from tiny_ram_halo2_amd import api, synth
+api.init(0)
+for curve, n, batch in (("pallas", 1, 1), ("vesta", 777, 1), ("pallas", 4098, 2), ("vesta", 8448, 1), ("pallas", 3000, 4)):
+    b = api.Bases.from_host(curve, cpu_ref.gen_bases(curve, 91, 7, n, threads=4))
+    sc = synth.field_elements(0x5A11 + n, n * batch).reshape(batch, n, 4)
+    got = b.msm_batch_dev(api.DeviceBuffer.from_host(sc), n, batch)
+    print("case", curve, n, batch, "".join(point_hex(got[k]) for k in range(batch)))
+"""
+
+
+def test_msm_small_kernel_boundaries_batches_and_plain_sums():
+    """msm_small_kernel (one launch for MSMs of up to 8448 pairs in batches of up to four): the last size it takes and the first it does
+    not, batches of 2 - 4 (an IPA round over the collapsed generators is a batch of two over 2^12 + 2 points), against the oracle; then
+    the same cases in a child process with option reduce_q4 = 0 (the kernel's shuffle sums instead of its quad-lane sums): equal points"""
+    from common import point_hex, run_with_options
+    mine = {}
+    for curve, n, batch in (("pallas", 1, 1), ("vesta", 777, 1), ("pallas", 4098, 2), ("vesta", 8448, 1), ("pallas", 3000, 4), ("vesta", 8449, 2)):
+        bases_h = cpu_ref.gen_bases(curve, 91, 7, n, threads=4)
+        b = api.Bases.from_host(curve, bases_h)
+        sc = synth.field_elements(0x5A11 + n, n * batch).reshape(batch, n, 4)
+        got = b.msm_batch_dev(api.DeviceBuffer.from_host(sc), n, batch)
+        for k in range(batch):
+            want = aff(curve, cpu_ref.best_multiexp(curve, sc[k], bases_h, threads=8))
+            assert (got[k, :8] == want).all(), (curve, n, batch, k)
+        mine[(curve, n, batch)] = "".join(point_hex(got[k]) for k in range(batch))
+    out = run_with_options(SMALL_SCRIPT, {"TRH_REDUCE_Q4": "0"})
+    seen = 0
+    for line in out.splitlines():
+        if line.startswith("case"):
+            _, curve, n, batch, hexes = line.split()
+            assert mine[(curve, int(n), int(batch))] == hexes, line[:40]
+            seen += 1
+    assert seen == 5
+
+
 def test_point_sum_shards_equal_whole():
     """range-sharded MSM (the multi-GPU decomposition) == whole MSM"""
     curve, n, g = "pallas", 6000, 4

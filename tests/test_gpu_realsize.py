@@ -19,7 +19,7 @@ import torch
 
 import cpu_ref
 import pasta as o
-from common import LimbTranscript, ipa_verify_fast, multiopen_create_proof_fast
+from common import LimbTranscript, run_with_options, ipa_verify_fast, multiopen_create_proof_fast
 from tiny_ram_halo2_amd import api, ipa, multiopen, poly, synth
 
 pytestmark = pytest.mark.gpu
@@ -72,10 +72,12 @@ def test_ipa_native_vs_cpp_oracle(curve, k):
     _ipa_case(curve, k, precompute=False)
 
 
-@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("pallas", 16), ("vesta", 18)])
+@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("pallas", 16), ("vesta", 16), ("pallas", 17), ("vesta", 18)])
 def test_ipa_native_fixed_base_tables_vs_cpp_oracle(curve, k):
     """the same with Params that carry fixed-base tables: the opening then runs over ONE resident set g || w || u with its own table
-    (poly.Params.ipa_bases -> the n + 2 form of trh_ipa_create_proof) and every MSM of it in fixed-base mode"""
+    (poly.Params.ipa_bases -> the n + 2 form of trh_ipa_create_proof) and every MSM of it in fixed-base mode.  From k = 16 the generators are
+    collapsed after six rounds (csrc/ipafold.hip: table windows of 14, 15, 16 bits = sub-digits of 7 + 7, 8 + 7, 8 + 8 bits) and the other
+    rounds run over the 2^(k - 6) + 2 collapsed points through msm_small_kernel: every L_j, R_j must still be the literal prover's"""
     _ipa_case(curve, k, precompute=True)
 
 
@@ -281,3 +283,48 @@ def test_msm_2_26_as_8_logical_shards():
     finally:
         api.set_shard_min(1 << 62)  # later tests of the session create single-device sets again
         torch.cuda.synchronize()
+
+
+FOLD_SCRIPT = r"""
+import hashlib, random
+import numpy as np, torch
+import cpu_ref
+from tiny_ram_halo2_amd import api, ipa, poly, synth
+from common import DeviceTranscript
+import pasta as o
+api.init(0)
+curve, k = "pallas", 16
+fs = o.CURVES[curve].scalar
+n = 1 << k
+g_l = cpu_ref.gen_bases(curve, 29, 13, n, threads=8)
+w_l = cpu_ref.gen_bases(curve, 515152, 1, 1, threads=1)
+u_l = cpu_ref.gen_bases(curve, 626263, 1, 1, threads=1)
+params = poly.Params(curve, k, g_l, g_l, w_l, u=u_l, precompute=True)
+params.reserve(2)
+p_l, s_l = synth.field_elements(0xF01D, n), synth.field_elements(0xF01E, n)
+rnd = random.Random(0xF01D)
+p_blind, s_blind, x3 = rnd.randrange(fs.m), rnd.randrange(fs.m), rnd.randrange(fs.m)
+draws = [rnd.randrange(fs.m) for _ in range(2 * k)]
+p_dev = torch.from_numpy(np.ascontiguousarray(p_l, dtype=np.uint64).view(np.int64).copy()).cuda()
+for rep in range(2):   # twice: the second opening reuses the collapse's buffers and streams
+    it = iter(draws)
+    tr = DeviceTranscript(fs.m)
+    c, f = ipa.create_proof_native(params, lambda: next(it), tr, p_dev, p_blind, x3, s_l, s_blind)
+    h = hashlib.sha256(repr((c, f, tr.log)).encode()).hexdigest()
+    print("digest", h)
+print("fold", api.get_option("ipa_fold"))
+"""
+
+
+def test_ipa_generator_collapse_levels_agree():
+    """option ipa_fold (csrc/ipa.hip: the round after which the generators are collapsed, + 10 x the rounds the collapse may run on its
+    own stream before the opening switches to the collapsed set): never, after 4 / 6 / 7 rounds, and with the switch one / two / three rounds
+    behind the collapse -- the same transcript, twice in every process.  (The default is checked against the literal prover above.)"""
+    digests = {}
+    for fold in ("0", "6", "4", "7", "16", "25", "36"):
+        out = run_with_options(FOLD_SCRIPT, {"TRH_IPA_FOLD": fold}, timeout=900)
+        d = [line.split()[1] for line in out.splitlines() if line.startswith("digest")]
+        assert len(d) == 2 and d[0] == d[1], (fold, d)
+        assert ("fold " + fold) in out
+        digests[fold] = d[0]
+    assert len(set(digests.values())) == 1, digests
