@@ -55,24 +55,72 @@ template <class F> inline H sub(const H& a, const H& b) {
     return Consts<F>::sub_raw(add_raw(a, consts<F>().m), b);  // a + m < 2^256
 }
 template <class F> inline H dbl(const H& a) { return add<F>(a, a); }
-// Montgomery product a b / 2^256 mod m (CIOS)
+// Montgomery product a b / 2^256 mod m (CIOS, unrolled).  Both moduli are 2^254 + a 126-bit number: limbs (m0, m1, 0, 2^62), so a reduction
+// round is two multiplications and a shift instead of four multiplications.
+#define TRH_HC_REDUCE_ROUND                                                       \
+    {                                                                             \
+        const uint64_t q = t0 * inv;                                              \
+        u128 c = ((u128)q * m0 + t0) >> 64;                                       \
+        c += (u128)q * m1 + t1; t0 = (uint64_t)c; c >>= 64;                       \
+        c += t2; t1 = (uint64_t)c; c >>= 64;                                      \
+        c += ((u128)q << 62) + t3; t2 = (uint64_t)c; c >>= 64;                    \
+        c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                 \
+    }
 template <class F> inline H mul(const H& a, const H& b) {
     const H& m = consts<F>().m;
-    const uint64_t inv = consts<F>().inv;
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) { c += (u128)t[j] + (u128)a.l[i] * b.l[j]; t[j] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-        const uint64_t q = t[0] * inv;
-        c = ((u128)t[0] + (u128)q * m.l[0]) >> 64;
-        for (int j = 1; j < 4; ++j) { c += (u128)t[j] + (u128)q * m.l[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64); t[5] = 0;
-    }
-    H r = {{t[0], t[1], t[2], t[3]}};
-    return (t[4] || geq(r, m)) ? Consts<F>::sub_raw(r, m) : r;
+    const uint64_t inv = consts<F>().inv, m0 = m.l[0], m1 = m.l[1];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#define TRH_HC_ROUND(ai)                                                          \
+    {                                                                             \
+        u128 c = (u128)(ai) * b.l[0] + t0; t0 = (uint64_t)c; c >>= 64;            \
+        c += (u128)(ai) * b.l[1] + t1; t1 = (uint64_t)c; c >>= 64;                \
+        c += (u128)(ai) * b.l[2] + t2; t2 = (uint64_t)c; c >>= 64;                \
+        c += (u128)(ai) * b.l[3] + t3; t3 = (uint64_t)c; c >>= 64;                \
+        c += t4; t4 = (uint64_t)c; t5 = (uint64_t)(c >> 64);                      \
+    }                                                                             \
+    TRH_HC_REDUCE_ROUND
+    TRH_HC_ROUND(a.l[0]) TRH_HC_ROUND(a.l[1]) TRH_HC_ROUND(a.l[2]) TRH_HC_ROUND(a.l[3])
+#undef TRH_HC_ROUND
+    H r = {{t0, t1, t2, t3}};
+    return (t4 || geq(r, m)) ? Consts<F>::sub_raw(r, m) : r;
 }
-template <class F> inline H sqr(const H& a) { return mul<F>(a, a); }
+// a^2 / 2^256 mod m: the six cross products once, doubled, plus the four squares (10 multiplications for the 8-limb square), then four reduction rounds
+template <class F> inline H sqr(const H& a) {
+    const H& m = consts<F>().m;
+    const uint64_t inv = consts<F>().inv, m0 = m.l[0], m1 = m.l[1];
+    uint64_t w[8];
+    {
+        u128 c = (u128)a.l[0] * a.l[1]; w[1] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[0] * a.l[2]; w[2] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[0] * a.l[3]; w[3] = (uint64_t)c; w[4] = (uint64_t)(c >> 64);
+        c = (u128)a.l[1] * a.l[2] + w[3]; w[3] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[1] * a.l[3] + w[4]; w[4] = (uint64_t)c; w[5] = (uint64_t)(c >> 64);
+        c = (u128)a.l[2] * a.l[3] + w[5]; w[5] = (uint64_t)c; w[6] = (uint64_t)(c >> 64);
+        w[7] = w[6] >> 63; w[6] = (w[6] << 1) | (w[5] >> 63); w[5] = (w[5] << 1) | (w[4] >> 63); w[4] = (w[4] << 1) | (w[3] >> 63);
+        w[3] = (w[3] << 1) | (w[2] >> 63); w[2] = (w[2] << 1) | (w[1] >> 63); w[1] <<= 1;
+        c = (u128)a.l[0] * a.l[0]; w[0] = (uint64_t)c; c >>= 64;
+        c += w[1]; w[1] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[1] * a.l[1] + w[2]; w[2] = (uint64_t)c; c >>= 64;
+        c += w[3]; w[3] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[2] * a.l[2] + w[4]; w[4] = (uint64_t)c; c >>= 64;
+        c += w[5]; w[5] = (uint64_t)c; c >>= 64;
+        c += (u128)a.l[3] * a.l[3] + w[6]; w[6] = (uint64_t)c; c >>= 64;
+        w[7] += (uint64_t)c;
+    }
+    // Montgomery reduction of the 512-bit square, a word at a time: (t0 .. t3) is the running low part, the high words enter one per round
+    uint64_t t0 = w[0], t1 = w[1], t2 = w[2], t3 = w[3], t4 = 0, t5 = 0, carry = 0;
+#define TRH_HC_SQ_ROUND(hi)                                                       \
+    {                                                                             \
+        u128 c = (u128)(hi) + carry; t4 = (uint64_t)c; t5 = (uint64_t)(c >> 64);  \
+        TRH_HC_REDUCE_ROUND                                                       \
+        carry = t4;                                                               \
+    }
+    TRH_HC_SQ_ROUND(w[4]) TRH_HC_SQ_ROUND(w[5]) TRH_HC_SQ_ROUND(w[6]) TRH_HC_SQ_ROUND(w[7])
+#undef TRH_HC_SQ_ROUND
+    H r = {{t0, t1, t2, t3}};
+    return (carry || geq(r, m)) ? Consts<F>::sub_raw(r, m) : r;
+}
+#undef TRH_HC_REDUCE_ROUND
 template <class F> inline H inv(const H& a) {  // a^(m - 2); inv(0) = 0
     H e = consts<F>().m;
     e.l[0] -= 2;  // the low limb ends in ...00000001: no borrow

@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(256) inner_product2_kernel(const uint4* __rest
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_front_kernel(const uint4* __restrict__ p_old, const uint4* __restrict__ b_old, uint4* __restrict__ p_new, uint4* __restrict__ b_new,
                                                               uint4* __restrict__ wgt, uint4* __restrict__ lrsc, size_t n, size_t half, u32 bit, size_t stride, int first,
-                                                              int wfresh /* the weights are all one and not in memory yet (rounds 0 and 1) */, const IpaConsts consts) {
+                                                              int wfresh /* the weights are all one and not in memory yet (rounds 0 and 1) */,
+                                                              int canon /* the scalar rows leave in canonical form (the small-MSM kernel would convert every scalar in each of its 104 workgroups) */,
+                                                              const IpaConsts consts) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const size_t hprev = half << 1;  // the previous round's half
@@ -216,7 +218,8 @@ __global__ void __launch_bounds__(256) ipa_round_front_kernel(const uint4* __res
     }
     const size_t i = idx & (half - 1);
     const bool hi = (idx >> bit) & 1u;
-    const Fe<F> v = fe_mul(w, pn(hi ? i : half + i));
+    Fe<F> v = fe_mul(w, pn(hi ? i : half + i));
+    if (canon) v = fe_from_mont(v);
     const Fe<F> zero = fe_zero<F>();
     st<F>(lrsc + 2 * idx, hi ? zero : v);
     st<F>(lrsc + 2 * (stride + idx), hi ? v : zero);
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(256) ipa_fix_constant_kernel(const uint4* __re
 
 template <class F>
 __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __restrict__ partial, u32 count, const IpaConsts consts /* rand_l, rand_r, z */,
-                                                              uint4* __restrict__ lrsc, size_t n, size_t stride) {
+                                                              uint4* __restrict__ lrsc, size_t n, size_t stride, int canon /* as ipa_round_front_kernel */) {
     __shared__ Fe<F> sh[256];
     const u32 side = blockIdx.x;
     const uint4* p = partial + 2 * (size_t)side * count;
@@ -281,8 +284,10 @@ __global__ void __launch_bounds__(256) ipa_round_tails_kernel(const uint4* __res
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        st<F>(lrsc + 2 * (side * stride + n), side ? ipa_const<F>(consts, 1) : ipa_const<F>(consts, 0));
-        st<F>(lrsc + 2 * (side * stride + n + 1), fe_mul(sh[0], ipa_const<F>(consts, 2)));
+        Fe<F> r = side ? ipa_const<F>(consts, 1) : ipa_const<F>(consts, 0), vz = fe_mul(sh[0], ipa_const<F>(consts, 2));
+        if (canon) { r = fe_from_mont(r); vz = fe_from_mont(vz); }
+        st<F>(lrsc + 2 * (side * stride + n), r);
+        st<F>(lrsc + 2 * (side * stride + n + 1), vz);
     }
 }
 
@@ -566,12 +571,13 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             ncur = m; stride = m + 2; fblocks = (unsigned)((m + 255) / 256);
             round_xy = gwu.p; round_z = gwuz.p; round_fb = nullptr;
         }
+        const int canon = (fold_at && j >= switch_at) ? 1 : 0;  // the rounds over the collapsed generators
         {
             FeMem cst[2] = {stm(u_prev_inv), stm(u_prev)};
             IpaConsts kc{};
             memcpy(&kc, cst, sizeof(cst));
             hipLaunchKernelGGL((ipa_round_front_kernel<SF>), dim3(fblocks), dim3(256), 0, s, (const uint4*)p_cur, (const uint4*)b_cur, (uint4*)p_nxt, (uint4*)b_nxt, (uint4*)wgt.p, (uint4*)lrsc.p,
-                               ncur, half, bit, stride, j == 0 ? 1 : 0, (j <= 1 && !(fold_at && j >= switch_at)) ? 1 : 0, kc);
+                               ncur, half, bit, stride, j == 0 ? 1 : 0, (j <= 1 && !(fold_at && j >= switch_at)) ? 1 : 0, canon, kc);
             if (j > 0) { void* t = p_cur; p_cur = p_nxt; p_nxt = t; t = b_cur; b_cur = b_nxt; b_nxt = t; }
             // value_l = <p'[half ..], b[.. half]>, value_r = <p'[.. half], b[half ..]> over the folded vectors, then the tail scalars [rand] W, [value z] U
             unsigned blocks = (unsigned)((half + 255) / 256);
@@ -581,12 +587,12 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             FeMem cst3[3] = {stm(rnd[0]), stm(rnd[1]), zm};
             IpaConsts kt{};
             memcpy(&kt, cst3, sizeof(cst3));
-            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, kt, (uint4*)lrsc.p, ncur, stride);
+            hipLaunchKernelGGL((ipa_round_tails_kernel<SF>), dim3(2), dim3(256), 0, s, partial, blocks, kt, (uint4*)lrsc.p, ncur, stride, canon);
             TRH_HIP_TRY(hipGetLastError());
         }
         u64 lrb[24], lr[2][12];
         ctx().msm.dense_hint = true;  // p' . w: full-size values on half the rows
-        const int rc_r = msm_enqueue(curve, round_xy, round_z, lrsc.p, ncur + 2, 2, stride, 1, s, round_fb);
+        const int rc_r = msm_enqueue(curve, round_xy, round_z, lrsc.p, ncur + 2, 2, stride, canon ? 0 : 1, s, round_fb);
         ctx().msm.dense_hint = false;
         TRH_TRY(rc_r);
         const double t_enq = ipa_trace ? tnow() : 0;
