@@ -317,11 +317,11 @@ print("fold", api.get_option("ipa_fold"))
 
 
 def test_ipa_generator_collapse_levels_agree():
-    """option ipa_fold (csrc/ipa.hip: the round after which the generators are collapsed, + 10 x the rounds the collapse may run on its
-    own stream before the opening switches to the collapsed set): never, after 4 / 6 / 7 rounds, and with the switch one / two / three rounds
-    behind the collapse -- the same transcript, twice in every process.  (The default is checked against the literal prover above.)"""
+    """option ipa_fold (csrc/ipa.hip: the round after which the generators are collapsed; 1 = the library's choice): never, the default, after
+    4 / 7 / 8 rounds (collapsed sets of 2^12, 2^9, 2^8 points here) -- the same transcript, twice in every process (the second opening reuses
+    the collapse's buffers).  (The default is checked against the literal prover above.)"""
     digests = {}
-    for fold in ("0", "6", "4", "7", "16", "25", "36"):
+    for fold in ("0", "1", "4", "7", "8"):
         out = run_with_options(FOLD_SCRIPT, {"TRH_IPA_FOLD": fold}, timeout=900)
         d = [line.split()[1] for line in out.splitlines() if line.startswith("digest")]
         assert len(d) == 2 and d[0] == d[1], (fold, d)

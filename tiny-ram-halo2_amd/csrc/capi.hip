@@ -45,7 +45,7 @@ const OptField* opt_fields(size_t* count) {
         {"bases_cache", 0, &g_opt.bases_cache, 0, 1},        {"force_no_peer", 0, &g_opt.force_no_peer, 0, 1},   {"roctx", 0, &g_opt.roctx, 0, 1},
         {"trace", 0, &g_opt.trace, 0, 3},                    {"msm_chunk_gb", 1, &g_opt.msm_chunk_gb, 1, 256},   {"sparse", 0, &g_opt.sparse, 0, 1},
         {"reduce_q4", 0, &g_opt.reduce_q4, 0, 1},            {"bin_sort", 0, &g_opt.bin_sort, 0, 1},             {"selftest", 0, &g_opt.selftest, 0, 1},
-        {"ipa_fold", 0, &g_opt.ipa_fold, 0, 99},
+        {"ipa_fold", 0, &g_opt.ipa_fold, 0, 10},
     };
     *count = sizeof(f) / sizeof(f[0]);
     return f;
@@ -235,9 +235,7 @@ static void destroy_ctx(Ctx* c) {
         }
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    if (c->fold_stream) (void)hipStreamDestroy(c->fold_stream);
     delete c->helper; c->helper = nullptr;
-    for (hipEvent_t& e : c->fold_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     c->inited = false;
     if (t_bound == c) t_bound = nullptr;

@@ -44,7 +44,7 @@ struct Options {
     int reduce_q4 = 1;       // TRH_REDUCE_Q4      0: bucket reductions of small launches stay one thread per slice (no DPP-quad group law)
     int bin_sort = 1;        // TRH_BIN_SORT       0: the chunked bucket passes for every MSM (the path skewed scalars take anyway)
     int selftest = 1;        // TRH_SELFTEST       0: trh_init skips the known-answer self-test
-    int ipa_fold = 6;        // TRH_IPA_FOLD       rounds after which the IPA opening collapses its generators (ipafold.hip); 0: never
+    int ipa_fold = 1;        // TRH_IPA_FOLD       rounds after which the IPA opening collapses its generators (ipafold.hip); 0: never, 1: the library's choice
 };
 const Options& opt();
 
@@ -203,8 +203,6 @@ struct Ctx {
     void* pinned_fold = nullptr;  // pinned source of the generator fold's bucket lists (ipafold.hip)
     size_t pinned_fold_cap = 0;
     class HostHelper* helper = nullptr;  // host thread for the second half of a batch's Horners (hosthelper.h; msm_finish)
-    hipStream_t fold_stream = nullptr;  // the fold runs here, under the opening's next rounds (lowest priority)
-    hipEvent_t fold_ev[2] = {nullptr, nullptr};  // the opening's stream reached the fold's launch point / the folded generators are complete
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;
     void* lookup_scratch = nullptr;  // lookup.hip's buffers (opaque here)

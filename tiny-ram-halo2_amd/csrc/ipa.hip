@@ -156,19 +156,6 @@ __global__ void __launch_bounds__(256) ipa_round_update_kernel(uint4* __restrict
     }
 }
 
-// weights of the collapsed generators G'' (ipafold.hip) when the opening switches to them some rounds AFTER the collapse's level r: the rounds
-// r .. sw - 2 in between have multiplied the weight of every index whose bit (top - c) is set by their challenge consts[c] (the challenge of
-// round sw - 1 is applied by the front launch of round sw, like every round's)
-template <class F>
-__global__ void __launch_bounds__(256) ipa_weights_init_kernel(uint4* __restrict__ wgt, size_t m, int count, u32 top, const IpaConsts consts) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= m) return;
-    Fe<F> w = fe_one<F>();
-    for (int c = 0; c < count; ++c)
-        if ((idx >> (top - c)) & 1u) w = fe_mul(w, ipa_const<F>(consts, c));
-    st<F>(wgt + 2 * idx, w);
-}
-
 // The folds of round j - 1 and the scalar rows of round j in ONE launch (round 6; two launches before):
 //   * the folds are applied ON THE FLY: p'_new[x] = p'[x] + u^-1 p'[hprev + x], b_new[x] = b[x] + u b[hprev + x] (x < hprev) are computed
 //     where this round's scalar rows read them and written once to the OTHER buffer of a ping-pong pair (a thread's reads are other
@@ -400,19 +387,12 @@ int axpy_t(void* y, const void* x, size_t n, const FeMem& c_mont, hipStream_t s)
 // device.  Host-side scalar arithmetic uses the shared field code; the transcript and the prover's
 // randomness are callbacks into the caller (BLAKE2b transcript and OsRng on the Rust side).
 // ---------------------------------------------------------------------------------------
-// the round after which the generators are collapsed (0: never -- no table, a small opening, or option ipa_fold = 0)
+// the round after which the generators are collapsed (0: never -- no table, a small opening, or option ipa_fold = 0).  Option 1 = the measured
+// choice: after six rounds, later where the collapsed set would not fit msm_small_kernel (k = 18: 5 / 6 / 7 / 8 rounds -> 9.3 / 9.0 / 9.2 / 9.6 ms)
 uint32_t ipa_fold_level(const MsmFixedBase* fb, uint32_t k) {
-    const uint32_t fold_r = (uint32_t)(opt().ipa_fold % 10), fold_gap = (uint32_t)(opt().ipa_fold / 10);
-    return (fb && fold_r > 0 && fold_gap <= 4 && k >= 16 && ipa_fold_supported(*fb, k, fold_r)) ? fold_r : 0;
-}
-// the side stream and its events
-int ipa_fold_stream(Ctx& c) {
-    if (c.fold_stream) return TRH_OK;
-    int lo = 0, hi = 0;  // lo: the numerically greatest = lowest priority
-    TRH_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    TRH_HIP_TRY(hipStreamCreateWithPriority(&c.fold_stream, hipStreamNonBlocking, lo));
-    for (hipEvent_t& e : c.fold_ev) TRH_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    return TRH_OK;
+    uint32_t r = (uint32_t)opt().ipa_fold;
+    if (r == 1) r = k > 19 ? k - 13 : 6;
+    return (fb && r > 0 && k >= 16 && ipa_fold_supported(*fb, k, r)) ? r : 0;
 }
 
 template <class SF, class BF>
@@ -497,18 +477,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // Hybrid (round 6, ipafold.hip): the first r rounds run over the 2^k original bases with the folds as weights (a full-size fixed-base MSM each);
     // then the generators are collapsed for real -- r folds at once from the table -- and the remaining k - r rounds are MSMs over m + 2 = 2^(k - r) + 2
     // points, a fraction of a full-size round each.  Only worth it where a full-size round costs much more than a small one.
-    // The collapse is launched on a stream of its own after round r - 1 and the opening switches `gap` rounds later: those rounds still run
-    // over the table (their kernels are latency chains that leave most of the chip idle), the collapse's million additions run under them.
-    const uint32_t fold_gap = (uint32_t)(opt().ipa_fold / 10);
     const uint32_t fold_at = ipa_fold_level(fb, k);
-    const uint32_t switch_at = fold_at + fold_gap;
-    struct FoldGuard {  // no return path leaves the side stream working on the context's buffers
-        hipStream_t fs = nullptr; bool pending = false;
-        ~FoldGuard() { if (pending) (void)hipStreamSynchronize(fs); }
-    } fold_guard;
     const MsmFixedBase* round_fb = fb;
     size_t ncur = n;  // generators of the round MSMs
-    u64 u_hist[16 * 4];  // the challenges the collapse and the switch need
+    u64 u_hist[16 * 4];  // the challenges the collapse needs
 
     // the round MSMs are batches of two with half of the scalars zero: their time is the latency of the sort / reduction chain,
     // which narrow windows shorten (measured: k = 18 -> c = 10 gives 24.4 ms against 26.7 at the table's 15; k = 14 -> 8)
@@ -539,45 +511,23 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         Fe<SF> rnd[2];
         rng(rng_ctx, (u64*)&tmp); rnd[0] = fe_load<SF>(tmp);
         rng(rng_ctx, (u64*)&tmp); rnd[1] = fe_load<SF>(tmp);
-        if (fold_at && j == fold_at) {  // G'' || w || u from the table, after the challenges of rounds 0 .. r - 1
-            Ctx& c = ctx();
+        if (fold_at && j == fold_at) {  // G'' || w || u from the table, after the challenges of rounds 0 .. r - 1; from here on the rounds are MSMs over m + 2 points
+            // (inline: on a stream of its own under the next full-size rounds the collapse gained nothing -- profiles/r06_ipa_fold_overlap_ab.txt)
             const size_t m = (size_t)1 << (k - fold_at);
             TRH_TRY(gwu.ensure((m + 2) * 64)); TRH_TRY(gwuz.ensure((m + 2) * ZREC));
-            hipStream_t fs = s;
-            if (fold_gap) {
-                TRH_TRY(ipa_fold_stream(c));
-                fs = c.fold_stream;
-                TRH_HIP_TRY(hipEventRecord(c.fold_ev[0], s));  // behind whatever used these buffers last on the opening's stream
-                TRH_HIP_TRY(hipStreamWaitEvent(fs, c.fold_ev[0], 0));
-                fold_guard.fs = fs; fold_guard.pending = true;
-            }
-            TRH_TRY(ipa_fold_generators(curve, *fb, gw->n, k, fold_at, u_hist, gwu.p, gwuz.p, fs));
-            TRH_HIP_TRY(hipMemcpyAsync((char*)gwu.p + m * 64, (const char*)gw->d_xy + n * 64, 2 * 64, hipMemcpyDeviceToDevice, fs));
-            TRH_HIP_TRY(hipMemcpyAsync((char*)gwuz.p + m * ZREC, (const char*)fb->table + n * ZREC, 2 * ZREC, hipMemcpyDeviceToDevice, fs));  // level 0 of the table = the bases
-            if (fold_gap) TRH_HIP_TRY(hipEventRecord(c.fold_ev[1], fs));
-        }
-        if (fold_at && j == switch_at) {  // from here on the rounds are MSMs over the m + 2 points
-            const size_t m = (size_t)1 << (k - fold_at);
-            if (fold_gap) {
-                TRH_HIP_TRY(hipStreamWaitEvent(s, ctx().fold_ev[1], 0));
-                fold_guard.pending = false;  // s is ordered behind the side stream from here on (and the opening ends with a synchronisation of s)
-            }
-            // the weights: one, times the challenges of the rounds r .. sw - 2 on their index bits (round sw - 1's is applied by this round's front launch)
-            IpaConsts kw{};
-            const int cnt = fold_gap > 1 ? (int)fold_gap - 1 : 0;
-            memcpy(&kw, u_hist + 4 * fold_at, (size_t)cnt * 32);
-            hipLaunchKernelGGL((ipa_weights_init_kernel<SF>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (uint4*)wgt.p, m, cnt, (u32)(k - fold_at - 1), kw);
-            TRH_HIP_TRY(hipGetLastError());
+            TRH_TRY(ipa_fold_generators(curve, *fb, gw->n, k, fold_at, u_hist, gwu.p, gwuz.p, s));
+            TRH_HIP_TRY(hipMemcpyAsync((char*)gwu.p + m * 64, (const char*)gw->d_xy + n * 64, 2 * 64, hipMemcpyDeviceToDevice, s));
+            TRH_HIP_TRY(hipMemcpyAsync((char*)gwuz.p + m * ZREC, (const char*)fb->table + n * ZREC, 2 * ZREC, hipMemcpyDeviceToDevice, s));  // level 0 of the table = the bases
             ncur = m; stride = m + 2; fblocks = (unsigned)((m + 255) / 256);
             round_xy = gwu.p; round_z = gwuz.p; round_fb = nullptr;
         }
-        const int canon = (fold_at && j >= switch_at) ? 1 : 0;  // the rounds over the collapsed generators
+        const int canon = (fold_at && j >= fold_at) ? 1 : 0;  // the rounds over the collapsed generators
         {
             FeMem cst[2] = {stm(u_prev_inv), stm(u_prev)};
             IpaConsts kc{};
             memcpy(&kc, cst, sizeof(cst));
             hipLaunchKernelGGL((ipa_round_front_kernel<SF>), dim3(fblocks), dim3(256), 0, s, (const uint4*)p_cur, (const uint4*)b_cur, (uint4*)p_nxt, (uint4*)b_nxt, (uint4*)wgt.p, (uint4*)lrsc.p,
-                               ncur, half, bit, stride, j == 0 ? 1 : 0, (j <= 1 && !(fold_at && j >= switch_at)) ? 1 : 0, canon, kc);
+                               ncur, half, bit, stride, j == 0 ? 1 : 0, (j <= 1 || (fold_at && j - fold_at <= 1)) ? 1 : 0, canon, kc);
             if (j > 0) { void* t = p_cur; p_cur = p_nxt; p_nxt = t; t = b_cur; b_cur = b_nxt; b_nxt = t; }
             // value_l = <p'[half ..], b[.. half]>, value_r = <p'[.. half], b[half ..]> over the folded vectors, then the tail scalars [rand] W, [value z] U
             unsigned blocks = (unsigned)((half + 255) / 256);
@@ -657,7 +607,6 @@ int ipa_reserve(int curve, const trh_bases* gw, uint32_t k) {
     const size_t m = (size_t)1 << (k - fold_at);
     TRH_TRY(sc[5].ensure((m + 2) * 64)); TRH_TRY(sc[6].ensure((m + 2) * ZREC));
     TRH_TRY(ipa_fold_reserve(*fb, k, fold_at));
-    if (opt().ipa_fold / 10) TRH_TRY(ipa_fold_stream(c));
     if (!c.helper) c.helper = new HostHelper();  // msm_finish's second Horner thread
     c.msm.reserve_only = true;
     const int rc = msm_enqueue(curve, sc[5].p, sc[6].p, sc[4].p, m + 2, 2, m + 2, 1, nullptr);

@@ -295,8 +295,8 @@ int ipa_fold_t(const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const
 }  // namespace
 
 bool ipa_fold_supported(const MsmFixedBase& fb, uint32_t k, uint32_t r) {
-    // two sub-digits of 5 .. 8 bits per table window (sixteen slices of >= 1 bucket); t and the table level share an entry word; whole workgroups of generators
-    return fb.table && fb.c >= 10 && fb.c <= 16 && fb.W < 0x8000 && r >= 1 && r <= 10 && k >= r + 8;
+    // two sub-digits of 5 .. 9 bits per table window (sixteen slices of >= 1 bucket); t and the table level share an entry word; whole workgroups of generators
+    return fb.table && fb.c >= 10 && fb.c <= 18 && fb.W < 0x8000 && r >= 2 && r <= 10 && k >= r + 8;
 }
 
 // setup-time sizing of what ipa_fold_generators allocates (trh_bases_reserve over an opening's base set)
