@@ -73,8 +73,8 @@ const char* trh_version(void);       /* "trh <version> (gfx950, build <hash of t
  * setenv elsewhere in the process is undefined behaviour, so no entry point of this library calls getenv after that).  Options are
  * process-wide and fixed while any context exists: call before trh_init, or after trh_shutdown (TRH_EBUSY otherwise).  Values are
  * decimal integers.  Names (defaults): pool_mb (4096), stage_slot_mb (16), copy_threads (-1 = by core count), bases_cache (0),
- * force_no_peer (0), roctx (1), trace (0; bit 0 host-pointer entries, bit 1 IPA rounds), msm_chunk_gb (4), sparse (1), reduce_q4 (1),
- * bin_sort (1), selftest (1) -- see DESIGN.md section 8.                                                                            */
+ * force_no_peer (0), ipa_fold (1 = the library's choice of the round after which an opening collapses its generators; 0 never), trace (0; bit 0
+ * host-pointer entries, bit 1 IPA rounds), msm_chunk_gb (4), sparse (1), reduce_q4 (1), bin_sort (1), selftest (1) -- DESIGN.md section 8.   */
 int trh_set_option(const char* name, const char* value);
 int trh_get_option(const char* name, long* value);
 

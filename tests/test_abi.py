@@ -198,7 +198,7 @@ for name, value in (("no_such_option", "1"), ("bin_sort", "2"), ("bin_sort", "x"
     assert lib.trh_set_option(name.encode(), value.encode()) == -1, (name, value)
     assert name.encode() in lib.trh_last_error()
 assert lib.trh_set_option(None, b"1") == -1
-names = ["pool_mb", "stage_slot_mb", "copy_threads", "bases_cache", "force_no_peer", "roctx", "trace", "msm_chunk_gb", "sparse", "reduce_q4", "bin_sort", "selftest"]
+names = ["pool_mb", "stage_slot_mb", "copy_threads", "bases_cache", "force_no_peer", "ipa_fold", "trace", "msm_chunk_gb", "sparse", "reduce_q4", "bin_sort", "selftest"]
 for n in names:
     api.get_option(n)
 print("options ok", len(names))

@@ -72,12 +72,13 @@ def test_ipa_native_vs_cpp_oracle(curve, k):
     _ipa_case(curve, k, precompute=False)
 
 
-@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("pallas", 16), ("vesta", 16), ("pallas", 17), ("vesta", 18)])
+@pytest.mark.parametrize("curve,k", [("vesta", 10), ("pallas", 10), ("vesta", 14), ("pallas", 15), ("pallas", 16), ("vesta", 16), ("pallas", 17), ("vesta", 18)])
 def test_ipa_native_fixed_base_tables_vs_cpp_oracle(curve, k):
     """the same with Params that carry fixed-base tables: the opening then runs over ONE resident set g || w || u with its own table
-    (poly.Params.ipa_bases -> the n + 2 form of trh_ipa_create_proof) and every MSM of it in fixed-base mode.  From k = 16 the generators are
-    collapsed after six rounds (csrc/ipafold.hip: table windows of 14, 15, 16 bits = sub-digits of 7 + 7, 8 + 7, 8 + 8 bits) and the other
-    rounds run over the 2^(k - 6) + 2 collapsed points through msm_small_kernel: every L_j, R_j must still be the literal prover's"""
+    (poly.Params.ipa_bases -> the n + 2 form of trh_ipa_create_proof) and every MSM of it in fixed-base mode.  Up to k = 13 the set is small enough for msm_small_kernel and the opening leaves the
+    table alone (level 0 of it serves as the base records); from k = 14 the generators are collapsed to 2^12 after k - 12 rounds
+    (csrc/ipafold.hip: table windows of 12 .. 16 bits = sub-digits of 6 + 6 .. 8 + 8 bits) and the other rounds run over the 2^12 + 2 collapsed
+    points through msm_small_kernel: every L_j, R_j must still be the literal prover's"""
     _ipa_case(curve, k, precompute=True)
 
 

@@ -42,10 +42,9 @@ struct OptField { const char* name; int kind; void* p; long lo, hi; };  // kind 
 const OptField* opt_fields(size_t* count) {
     static const OptField f[] = {
         {"pool_mb", 1, &g_opt.pool_mb, 0, 1 << 20},          {"stage_slot_mb", 1, &g_opt.stage_slot_mb, 1, 256}, {"copy_threads", 0, &g_opt.copy_threads, -1, 64},
-        {"bases_cache", 0, &g_opt.bases_cache, 0, 1},        {"force_no_peer", 0, &g_opt.force_no_peer, 0, 1},   {"roctx", 0, &g_opt.roctx, 0, 1},
+        {"bases_cache", 0, &g_opt.bases_cache, 0, 1},        {"force_no_peer", 0, &g_opt.force_no_peer, 0, 1},   {"ipa_fold", 0, &g_opt.ipa_fold, 0, 10},
         {"trace", 0, &g_opt.trace, 0, 3},                    {"msm_chunk_gb", 1, &g_opt.msm_chunk_gb, 1, 256},   {"sparse", 0, &g_opt.sparse, 0, 1},
         {"reduce_q4", 0, &g_opt.reduce_q4, 0, 1},            {"bin_sort", 0, &g_opt.bin_sort, 0, 1},             {"selftest", 0, &g_opt.selftest, 0, 1},
-        {"ipa_fold", 0, &g_opt.ipa_fold, 0, 10},
     };
     *count = sizeof(f) / sizeof(f[0]);
     return f;
@@ -146,7 +145,6 @@ roctx_push_fn g_roctx_push = nullptr;
 roctx_pop_fn g_roctx_pop = nullptr;
 std::once_flag g_roctx_once;
 void roctx_resolve() {
-    if (!opt().roctx) return;
     void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return;

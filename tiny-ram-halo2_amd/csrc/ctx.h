@@ -37,7 +37,6 @@ struct Options {
     int copy_threads = -1;   // TRH_COPY_THREADS   host threads per staging direction and context (-1: by core count)
     int bases_cache = 0;     // TRH_BASES_CACHE    1: trh_best_multiexp_* keeps base sets it has seen twice (full-content hash)
     int force_no_peer = 0;   // TRH_FORCE_NO_PEER  1: the device group hands device-resident scalars over through pinned host memory
-    int roctx = 1;           // TRH_ROCTX          0: no roctx ranges around the primitives
     int trace = 0;           // TRH_TRACE          bit 0: timeline of the single-call host entries, bit 1: host side of the IPA's rounds (stderr)
     long msm_chunk_gb = 4;   // TRH_MSM_CHUNK_GB   scratch budget of one chunk of a batched MSM (GiB per digit array set)
     int sparse = 1;          // TRH_SPARSE         0: flag-like chunks of a fixed-base batch take the plain pipeline (no unit path)
@@ -330,6 +329,7 @@ int ipa_fold_generators(int curve, const MsmFixedBase& fb, size_t row, uint32_t 
 // msm.hip
 int msm_enqueue(int curve, const void* bases_dev, const void* bases_z_or_null, const void* scalars_dev, size_t n, size_t batch,
                 size_t scalar_stride_elems, int mont, hipStream_t s, const MsmFixedBase* fb = nullptr, const void* tails_dev = nullptr);
+size_t msm_small_max_pairs();  // the largest MSM msm_small_kernel takes (batches of up to four, no window override)
 int msm_fixed_base_windows(int c);
 bool msm_fixed_base_fits(size_t n, int c);
 int msm_build_table(int curve, const void* bases_dev, size_t n, int c, void* table_dev, hipStream_t s);

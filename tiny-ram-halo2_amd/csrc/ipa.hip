@@ -391,8 +391,8 @@ int axpy_t(void* y, const void* x, size_t n, const FeMem& c_mont, hipStream_t s)
 // choice: after six rounds, later where the collapsed set would not fit msm_small_kernel (k = 18: 5 / 6 / 7 / 8 rounds -> 9.3 / 9.0 / 9.2 / 9.6 ms)
 uint32_t ipa_fold_level(const MsmFixedBase* fb, uint32_t k) {
     uint32_t r = (uint32_t)opt().ipa_fold;
-    if (r == 1) r = k > 19 ? k - 13 : 6;
-    return (fb && r > 0 && k >= 16 && ipa_fold_supported(*fb, k, r)) ? r : 0;
+    if (r == 1) r = k >= 14 ? k - 12 : 0;  // down to 2^12 generators
+    return (fb && r > 0 && k >= 14 && ipa_fold_supported(*fb, k, r)) ? r : 0;
 }
 
 template <class SF, class BF>
@@ -413,6 +413,10 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
     // wide windows, no heavy top-window buckets and no Horner over windows on the host between two rounds.
     const bool with_u = gw->n == n + 2;
     const MsmFixedBase* fb = (with_u && gw->d_table) ? &gw->fb : nullptr;
+    // A set small enough for msm_small_kernel does not use its table: one launch + a host Horner beats the fixed-base pipeline's chain of ten
+    // launches (k = 10: 3.3 -> 2.1 ms per opening, k = 13: 5.4 -> 3.7); level 0 of the table is the set in the accumulation's record format
+    const void* small_z = nullptr;
+    if (fb && n + 2 <= msm_small_max_pairs() && ctx().window_override == 0) { small_z = fb->table; fb = nullptr; }
     TRH_TRY(b.ensure(n * 32)); TRH_TRY(sp.ensure((n + 2) * 32)); TRH_TRY(pp.ensure(n * 32)); TRH_TRY(wgt.ensure(n * 32)); TRH_TRY(lrsc.ensure(2 * (n + 2) * 32));
     TRH_TRY(pp2.ensure(n * 16 + 32)); TRH_TRY(b2.ensure(n * 16 + 32));  // the folded vectors have at most n / 2 entries
     if (!with_u) { TRH_TRY(gwu.ensure((n + 2) * 64)); TRH_TRY(gwuz.ensure((n + 2) * ZREC)); }
@@ -440,7 +444,9 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         const int rc_s = msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 2, 1, n + 2, 1, s, fb);
         ctx().msm.dense_hint = false;
         TRH_TRY(rc_s);
-    } else
+    } else if (small_z)
+    TRH_TRY(msm_enqueue(curve, gw->d_xy, small_z, sp.p, n + 2, 1, n + 2, 1, s));
+    else
     TRH_TRY(msm_enqueue(curve, gw->d_xy, gw->d_z, sp.p, n + 1, 1, n + 1, 1, s));
     TRH_TRY(msm_finish(curve, s, pt, 1));
     tr->write_point(tr->ctx, pt);
@@ -471,7 +477,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
         TRH_TRY(msm_convert_bases(curve, gwu.p, gwuz.p, n + 2, s));
         round_xy = gwu.p; round_z = gwuz.p;
     } else if (!fb) {
-        round_z = gw->d_z;  // the handle's converted copy when it has one; otherwise the MSM converts per call
+        round_z = small_z ? small_z : gw->d_z;  // the handle's converted copy when it has one; otherwise the MSM converts per call
     }
     size_t stride = n + 2;
     // Hybrid (round 6, ipafold.hip): the first r rounds run over the 2^k original bases with the folds as weights (a full-size fixed-base MSM each);
@@ -521,7 +527,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             ncur = m; stride = m + 2; fblocks = (unsigned)((m + 255) / 256);
             round_xy = gwu.p; round_z = gwuz.p; round_fb = nullptr;
         }
-        const int canon = (fold_at && j >= fold_at) ? 1 : 0;  // the rounds over the collapsed generators
+        const int canon = (!round_fb && ncur + 2 <= msm_small_max_pairs() && ctx().window_override == 0) ? 1 : 0;  // this round's MSM is msm_small_kernel's
         {
             FeMem cst[2] = {stm(u_prev_inv), stm(u_prev)};
             IpaConsts kc{};

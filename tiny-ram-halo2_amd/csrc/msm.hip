@@ -2026,6 +2026,7 @@ int point_sum_host_t(const u64* pts, size_t count, u64* out) {
 
 }  // namespace
 
+size_t msm_small_max_pairs() { return SMALL_MAX_N; }
 int msm_fixed_base_windows(int c) { return num_windows(c); }
 // the partitioned entries pack 7 low bucket bits above the flat table index
 bool msm_fixed_base_fits(size_t n, int c) {
