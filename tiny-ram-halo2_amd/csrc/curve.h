@@ -170,7 +170,7 @@ template <class F> TRH_HD XYZZ<F> xyzz_from_jacobian(const Jacobian<F>& j) {
 // Coordinates are NORMALISED Fy values (signed, |x| < 4 m, |y| < 1.5 m, zz, zzz in (-0.02 m, 1.02 m) -- loose enough: the
 // arithmetic tolerates 16 m); identity <=> zz is exactly zero.  AffineZ coordinates are in [0, 1.01 m); identity <=> x and y
 // exactly zero.  Differences that only feed one multiplication stay lazy (no carry chain), and every y3 = A B - C D shares one
-// Montgomery reduction (fy_mul2).  The exceptional cases of the full addition (P + P, P + (-P)) go through the canonical formulas.
+// Montgomery reduction (fy_mul2).  The exceptional cases of the full addition (P + P, P + (-P)) are a doubling / the identity in this domain too.
 // ---------------------------------------------------------------------------------------
 template <class F>
 struct AffineZ {
@@ -273,7 +273,13 @@ template <class F> TRH_HD XYZZz<F> xyzzz_add(const XYZZz<F>& a, const XYZZz<F>& 
     const Fy<F> U1 = fy_mul(a.x, b.zz), U2 = fy_mul(b.x, a.zz);
     const Fy<F> S1 = fy_mul(a.y, b.zzz), S2 = fy_mul(b.y, a.zzz);
     const Fy<F> P = fy_sub(U2, U1), R = fy_sub(S2, S1);
-    if (fy_is_zero_mod(P)) return xyzzz_from_canonical(xyzz_add(xyzzz_to_canonical(a), xyzzz_to_canonical(b)));
+    if (fy_is_zero_mod(P)) {
+        // same x: b is a (the sum is 2 a) or -a (the identity).  In this domain (round 6): through the canonical formulas every inlined copy of
+        // this function carried ~11 000 instructions of conversions and canonical arithmetic for a case that almost never runs -- msm_reduce_kernel
+        // was 84 581 instructions long, 660 KiB against a 64 KiB instruction cache
+        if (fy_is_zero_mod(R)) return xyzzz_dbl(a);
+        return xyzzz_identity<F>();
+    }
     const Fy<F> PP = fy_sqr(P), PPP = fy_mul(P, PP), Q = fy_mul(U1, PP);
     XYZZz<F> r;
     r.x = fy_sqr_sub_sub2(R, PPP, Q);
