@@ -47,6 +47,10 @@ if [ "$MODE" = collect ]; then
     # round 6: PMC traffic at the sweep sizes with the build id beside it, the driver diff, the soak of the final build
     # (tools/pmc_sweep.sh $TAG runs as its own gpurun call: its databases and this step's together exceed what one call brings back)
     bash tools/driver_diff.sh $TAG > /dev/null 2>&1
+    # round 6, second half: the opening with its generators collapsed -- timeline around the collapse + where the opening's time goes, and the opening by size
+    # with the collapse (default) and without (ipa_fold = 0)
+    bash tools/exp/fold_trace.sh > gpurun_out/ipa_opening_timeline_$TAG.txt 2>&1
+    (for k in 10 12 13 14 15 16 17 18 19; do for f in 1 0; do echo -n "k $k ipa_fold $f: "; TRH_IPA_FOLD=$f python3 tools/ipa_probe.py $k 2>&1 | tail -1; done; done) > gpurun_out/ipa_opening_by_k_$TAG.txt 2>&1
     head -c 160 gpurun_out/bench_$TAG.json; echo
 else
     python3 tools/isa_regs.py | head -1
@@ -64,5 +68,6 @@ else
     for f in replay_sharded native_replay_sharded replay_witness_nosparse; do [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json profiles/; done
     for f in lone_sparse_probe bank_probe io_shapes; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/${TAG}_$f.txt; done
     [ -s gpurun_out/msm_stall_counters_$TAG.txt ] && grep -v "^\[\|^tail:" gpurun_out/msm_stall_counters_$TAG.txt > profiles/${TAG}_msm_stall_counters_raw.txt
+    for f in ipa_opening_timeline ipa_opening_by_k; do [ -s gpurun_out/${f}_$TAG.txt ] && cp gpurun_out/${f}_$TAG.txt profiles/${TAG}_$f.txt; done
     ls profiles
 fi
