@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 import torch
 from tiny_ram_halo2_amd import api, permutation, poly, synth
 MOD = {"fp": poly._MODULUS["fp"], "fq": poly._MODULUS["fq"]}
-KINDS = ["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products", "sparse", "padded", "sharded"]
+KINDS = ["msm", "msm", "ntt", "lookup", "blocks", "hostio", "products", "sparse", "padded", "sharded", "opening"]
 GROUP = 8  # the suite's device group is [0] * 8 (trh_init_multi accepts only the list it was first given)
 rng = random.Random(1)  # re-seeded by run()
 cpu_ref = None          # the oracle module when a test hands it over
@@ -228,6 +228,45 @@ def trial(which, fails):
         if not ok:
             fails.append(which)
             print("PADDED MISMATCH", field, k, data, flush=True)
+    elif which == "opening":
+        # round 6: the IPA opening over a tabled g || w || u (k <= 13: msm_small_kernel from round 0 on level 0 of the table; k >= 14: k - 12 full-size
+        # fixed-base rounds, the generator collapse of ipafold.hip, the other rounds over 2^12 + 2 points) against the same opening without tables
+        # (per-window MSMs over the original generators in every round): the same transcript, item for item
+        import hashlib
+        from tiny_ram_halo2_amd import ipa
+        curve = rng.choice(["pallas", "vesta"])
+        sf = api.SCALAR_FIELD[curve]
+        k = rng.choice([rng.randrange(1, 9), rng.randrange(9, 14), rng.randrange(14, 17)])
+        n = 1 << k
+        g = api.Bases.generate(curve, rng.randrange(1, 1 << 40), rng.randrange(1, 1 << 30), n + 1).download()
+        u = api.Bases.generate(curve, rng.randrange(1, 1 << 40), 1, 1).download()
+        p_h = scalars(sf, n, rng.choice(["uniform", "uniform", "small", "edge"]))
+        s_h = scalars(sf, n, "uniform")
+        m = MOD[sf]
+        p_blind, s_blind, x3 = rng.randrange(m), rng.randrange(m), rng.randrange(1, m)
+        draws = [rng.randrange(1, m) for _ in range(2 * k)]
+
+        class Tr:
+            def __init__(self):
+                self.h, self.items = hashlib.blake2b(b"soak"), []
+            def write_point(self, jac):
+                b = np.ascontiguousarray(jac, dtype=np.uint64)[:8].tobytes(); self.h.update(b"P" + b); self.items.append(b)
+            def write_scalar(self, l):
+                b = np.ascontiguousarray(l, dtype=np.uint64).tobytes(); self.h.update(b"S" + b); self.items.append(b)
+            def squeeze_challenge_scalar(self):
+                self.h.update(b"C")
+                return int.from_bytes(self.h.digest()[:40], "little") % (m - 1) + 1
+
+        outs = []
+        for tables in (True, False):
+            params = poly.Params(curve, k, g[:n], g[:n], g[n:n + 1], u=u, precompute=tables)
+            it = iter(draws)
+            tr = Tr()
+            cf = ipa.create_proof_native(params, lambda: next(it), tr, torch.from_numpy(p_h.view(np.int64)).cuda(), p_blind, x3, s_h, s_blind)
+            outs.append((cf, tr.items))
+        if outs[0] != outs[1]:
+            fails.append(which)
+            print("OPENING MISMATCH", curve, k, flush=True)
     elif which == "sharded":
         # round 4: a base set range-sharded over the device group: host scalars (one uploader thread per shard), page-locked host scalars,
         # device scalars with and without the forced no-peer hand-over, random sub-ranges -- against the same MSM on one context
