@@ -201,6 +201,7 @@ struct Ctx {
     unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
     void* pinned_fold = nullptr;  // pinned source of the generator fold's bucket lists (ipafold.hip)
     size_t pinned_fold_cap = 0;
+    bool helper_failed = false;
     class HostHelper* helper = nullptr;  // host thread for the second half of a batch's Horners (hosthelper.h; msm_finish)
     std::vector<TwiddleEntry*> twiddles;
     u64 stamp = 0;

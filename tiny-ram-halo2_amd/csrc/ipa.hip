@@ -613,7 +613,9 @@ int ipa_reserve(int curve, const trh_bases* gw, uint32_t k) {
     const size_t m = (size_t)1 << (k - fold_at);
     TRH_TRY(sc[5].ensure((m + 2) * 64)); TRH_TRY(sc[6].ensure((m + 2) * ZREC));
     TRH_TRY(ipa_fold_reserve(*fb, k, fold_at));
-    if (!c.helper) c.helper = new HostHelper();  // msm_finish's second Horner thread
+    if (!c.helper && !c.helper_failed) {  // msm_finish's second Horner thread
+        try { c.helper = new HostHelper(); } catch (...) { c.helper_failed = true; }
+    }
     c.msm.reserve_only = true;
     const int rc = msm_enqueue(curve, sc[5].p, sc[6].p, sc[4].p, m + 2, 2, m + 2, 1, nullptr);
     c.msm.reserve_only = false;

@@ -1968,10 +1968,12 @@ int msm_finish_t(hipStream_t s, u64* out_xyz, size_t batch) {
         }
     }
     const XYZZMem* ws = (const XYZZMem*)m.host_sums;
-    if (m.pending_windows > 1 && batch >= 2 && batch <= 256) {
+    if (m.pending_windows > 1 && batch >= 2 && batch <= 256 && !c.helper && !c.helper_failed) {
+        try { c.helper = new HostHelper(); } catch (...) { c.helper_failed = true; }  // no thread to be had: the Horners run one after the other below
+    }
+    if (m.pending_windows > 1 && batch >= 2 && batch <= 256 && c.helper) {
         // Horner over the windows is ~250 doublings per result (70 us) and the results are independent: the upper half of the batch on the context's
         // helper thread (hosthelper.h), the lower half here, then one inversion for all of them
-        if (!c.helper) c.helper = new HostHelper();
         const int W = m.pending_windows, cb = m.pending_c;
         hostcombine::P acc[256];
         const size_t mid = batch / 2;
