@@ -4,8 +4,8 @@
 // Why: the host side of a per-window MSM is a Horner over the window sums -- ~250 doublings per result, 70 us in hostcombine.h's 4 x 64-bit
 // code -- and the results of a batch are independent.  An IPA round over the collapsed generators (ipafold.hip) waits for two of them while
 // the GPU idles: with the second one on this thread the round's host turn is one Horner long instead of two.  A condition-variable wake-up
-// costs 30 - 50 us, most of what there is to win, so the thread spins for a while after every job (jobs of an opening arrive every ~250 us)
-// and goes to sleep when nothing came.
+// costs 30 - 50 us, most of what there is to win, so the thread spins for a millisecond or two after every job (jobs of an opening arrive every
+// 0.2 - 0.6 ms) and goes to sleep when nothing came.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -53,7 +53,7 @@ class HostHelper {
     void loop() {
         unsigned seen = 0;
         for (;;) {
-            for (int spin = 0; spin < 200000 && posted.load(std::memory_order_acquire) == seen; ++spin) {
+            for (int spin = 0; spin < 30000 && posted.load(std::memory_order_acquire) == seen; ++spin) {  // ~1 - 2 ms
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
