@@ -6,7 +6,7 @@
 // cost a full 2^k MSM (0.62 ms at k = 18) however short p' has become.  After r rounds the folded generators are
 //     G''[i] = sum over t < 2^r of s_t G[i + t m],     m = 2^(k - r),     s_t = product of u_j over the set bits (r - 1 - j) of t,
 // i.e. m sums of 2^r points whose 2^r SCALARS ARE THE SAME for every i.  With the table T[j][x] = 2^(c j) G[x] each s_t splits into W
-// chunks of c bits, each chunk into two signed sub-digits of <= 8 bits, and
+// chunks of c bits, each chunk into two signed sub-digits of <= 9 bits (8 + 8 for the c = 16 table of k = 18), and
 //     G''[i] = sum over sub-windows s of 2^(shift_s) * sum over d of d * B[s][d][i],
 //     B[s][d][i] = sum over the (t, j) whose sub-digit (j, s) is +-d of +-T[j][i + t m].
 // The lists of (t, j, sign) per bucket (s, d) do not depend on i: the host builds them from the 2^r scalars (a counting sort of 2^r W 2
@@ -269,7 +269,7 @@ int ipa_fold_t(const MsmFixedBase& fb, size_t row, uint32_t k, uint32_t r, const
         H u;
         memcpy(&u, u_mont + 4 * j, 32);
         const size_t bit = (size_t)1 << (r - 1 - j);
-        // every index whose bits below `bit`... are still zero and whose bits above are any: the indices built so far are the multiples of 2 bit
+        // the indices built so far are the multiples of 2 * bit: each gets its sibling with `bit` set
         for (size_t t = 0; t < sc.size(); t += 2 * bit) sc[t + bit] = hostcombine::mul<SF>(sc[t], u);
     }
     const H one_plain = {{1, 0, 0, 0}};
