@@ -1590,9 +1590,11 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
     if (tpw > nbk) tpw = nbk;
     const u32 slice = nbk / tpw;
     const u32 rblocks = (tpw + 255) / 256;
-    // segment length: enough segments to fill the chip (>= ~2^19 threads) but at most 128 entries each
+    // segment length: enough segments to fill the chip (>= ~2^18 threads) but at most 128 entries each
     u32 seg_len0 = 128;
-    while (seg_len0 > 16 && (size_t)W * n * chunk / seg_len0 < ((size_t)1 << 19)) seg_len0 >>= 1;  // W * n == Ws * ns
+    // (2^18, round 6: an opening's full-size round -- 2 x 4.2 M digit slots, half of them empty -- takes segments of 32 instead of 16: four pieces per
+    //  bucket for the combine instead of eight, k = 18 opening 8.2 -> 8.0 ms; 2^20 .. 2^22 MSMs and lone commitments unchanged; 2^17 loses: 9.0 ms)
+    while (seg_len0 > 16 && (size_t)W * n * chunk / seg_len0 < ((size_t)1 << 18)) seg_len0 >>= 1;  // W * n == Ws * ns
     const u32 nseg0 = (u32)((ns + seg_len0 - 1) / seg_len0);
     // a heavy bucket spans > HEAVY_PIECES segments, so there are fewer than W * nseg / HEAVY_PIECES of them
     const size_t max_heavy = (size_t)Ws * nseg0 / HEAVY_PIECES + 1;
