@@ -1825,7 +1825,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
             // crowd each other out (2^24: reduction 0.43 -> 0.52 ms) and 2^17 lanes lose to 2^16 (IPA 13.9 against 13.0 ms).  Option
             // reduce_q4 = 0 keeps the one-thread-per-slice kernels everywhere
             const int q4_knob = opt().reduce_q4;
-            constexpr int q4_lanes_log = 16, q4_sets = 8;  // (16 - 32 sets / 2^17 - 2^19 lanes lose at 2^18 .. 2^22: profiles/r06_q4_small_raw.txt)
+            constexpr int q4_lanes_log = 16, q4_sets = 8;  // (16 - 32 sets / 2^17 - 2^19 lanes lose at 2^18 .. 2^22: profiles/r06_q4_small_raw.txt; 2^15 / 2^14 lanes: opening 8.2 -> 8.6 ms)
             u32 q4_tpw = r_tpw;
             while (q4_tpw > 1024 && (size_t)q4_tpw * 4 * Ws * nb > ((size_t)1 << q4_lanes_log)) q4_tpw >>= 1;
             if (q4_knob && !compact && (size_t)Ws * nb <= (size_t)q4_sets && q4_tpw >= 64 && (size_t)q4_tpw * 4 * Ws * nb <= ((size_t)1 << q4_lanes_log) && nbk % q4_tpw == 0) {
