@@ -422,7 +422,9 @@ int trh_memcpy_h2d(void* dev, const void* host, size_t bytes);
 int trh_memcpy_d2h(void* host, const void* dev, size_t bytes);
 int trh_stream_synchronize(void* stream);
 /* counters of the calling thread's context, by name.  "msm_lean_retries": MSMs of callers that vouched for uniformly random scalars (the
- * opening's rounds) whose whole-bin LDS sort met a bin that did not fit and that were therefore run a second time with the chunked passes. */
+ * opening's rounds) whose whole-bin LDS sort met a bin that did not fit and that were therefore run a second time with the chunked passes;
+ * "msm_small_launches": MSMs that ran as ONE launch (up to 8448 pairs, batches of up to four); "ipa_generator_collapses": openings that
+ * collapsed their generators from the fixed-base table (option ipa_fold). */
 int trh_stat(const char* name, uint64_t* value);
 /* GPU-side timing without HIP headers: events recorded on a stream between the steps (a hipEvent_t each), read afterwards.
  * trh_event_elapsed_ms waits for `end` and returns the device time between the two records. */

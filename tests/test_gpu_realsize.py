@@ -97,7 +97,11 @@ def _ipa_case(curve, k, precompute):
 
     it_dev = iter(draws)
     t_dev = IntTranscript(fs)
+    collapses, small = api.stat("ipa_generator_collapses"), api.stat("msm_small_launches")
     c_dev, f_dev = ipa.create_proof_native(params, lambda: next(it_dev), t_dev, to_dev(p_l), p_blind, x3, s_l, s_blind)
+    if precompute and api.get_option("ipa_fold") == 1:   # the paths the docstrings name were taken, not silently fallen back from
+        assert api.stat("ipa_generator_collapses") - collapses == (1 if k >= 14 else 0)
+        assert api.stat("msm_small_launches") - small == (12 if k >= 14 else k + 1)   # the rounds over 2^12 + 2 points / every MSM of a small opening
     it_ref = iter(draws)
     t_ref = LimbTranscript(fs)
     c_ref, f_ref = cpu_ref.ipa_create_proof(curve, k, g_l, w_l[0], u_l[0], lambda: lim(next(it_ref)), t_ref, p_l, lim(p_blind), lim(x3), s_l, lim(s_blind))

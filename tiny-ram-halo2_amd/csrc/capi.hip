@@ -1303,6 +1303,8 @@ int trh_stat(const char* name, uint64_t* value) {
     if (!name || !value) { set_error("trh_stat: null pointer"); return TRH_EINVAL; }
     TRH_ENTER(0);
     if (strcmp(name, "msm_lean_retries") == 0) { *value = ctx().msm.lean_retries; return TRH_OK; }
+    if (strcmp(name, "msm_small_launches") == 0) { *value = ctx().msm.small_launches; return TRH_OK; }
+    if (strcmp(name, "ipa_generator_collapses") == 0) { *value = ctx().ipa_collapses; return TRH_OK; }
     set_error("trh_stat: unknown counter '%s'", name);
     return TRH_EINVAL;
 }

@@ -135,6 +135,7 @@ struct MsmScratch {
     bool force_fallback = false, lean_pending = false;
     struct { const void *bases_dev, *bases_z, *scalars_dev, *tails_dev; size_t n, batch, stride; int mont; bool has_fb; MsmFixedBase fb; } retry{};
     unsigned lean_retries = 0;  // how often that happened on this context (tests)
+    u64 small_launches = 0;     // MSMs that ran as one msm_small_kernel launch (tests: the path was taken, not fallen back from)
     size_t lean_off_n = 0; int lean_off_c = 0;  // the shape (pairs, window bits) whose lean sort last overflowed: the fallback launches are queued for it again
     bool reserve_only = false;  // msm_enqueue sizes the scratch of the described launch and returns before the first kernel (trh_bases_reserve)
     bool no_sparse_vote = false;  // the sparse classifier is skipped and nothing else changes (the shards of a range-sharded MSM: its host synchronisation would hold back the other shards)
@@ -201,6 +202,7 @@ struct Ctx {
     unsigned pinned_slot = 0;     // asynchronous upload never reads a caller's stack buffer and needs no synchronisation
     void* pinned_fold = nullptr;  // pinned source of the generator fold's bucket lists (ipafold.hip)
     size_t pinned_fold_cap = 0;
+    u64 ipa_collapses = 0;      // openings that collapsed their generators (ipafold.hip; tests)
     bool helper_failed = false;
     class HostHelper* helper = nullptr;  // host thread for the second half of a batch's Horners (hosthelper.h; msm_finish)
     std::vector<TwiddleEntry*> twiddles;

@@ -526,6 +526,7 @@ int ipa_create_proof_t(int curve, const trh_bases* gw, const u64* u_xy, uint32_t
             TRH_HIP_TRY(hipMemcpyAsync((char*)gwuz.p + m * ZREC, (const char*)fb->table + n * ZREC, 2 * ZREC, hipMemcpyDeviceToDevice, s));  // level 0 of the table = the bases
             ncur = m; stride = m + 2; fblocks = (unsigned)((m + 255) / 256);
             round_xy = gwu.p; round_z = gwuz.p; round_fb = nullptr;
+            ++ctx().ipa_collapses;
         }
         const int canon = (!round_fb && ncur + 2 <= msm_small_max_pairs() && ctx().window_override == 0) ? 1 : 0;  // this round's MSM is msm_small_kernel's
         {

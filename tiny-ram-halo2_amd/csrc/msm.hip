@@ -1543,6 +1543,7 @@ int msm_enqueue_t(const void* bases_dev, const void* bases_z, const void* scalar
         TRH_HIP_TRY(hipMemcpyAsync(m.host_sums, m.window_sums.p, hs, hipMemcpyDeviceToHost, s));
         m.pending_curve = BF::ID; m.pending_windows = W; m.pending_c = SMALL_C; m.pending_batch = batch; m.pending_stream = s; m.pending_owner = nullptr;
         m.ev_valid = false; m.lean_pending = false;
+        ++m.small_launches;
         return TRH_OK;
     }
     int cb = fb ? fb->c : choose_window_bits(n);
