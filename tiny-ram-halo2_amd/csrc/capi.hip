@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <set>
@@ -428,6 +429,12 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
     const size_t ntiles = cut.size() - 1;
     uint64_t acc[24];
     memset(acc, 0, sizeof(acc));
+    // option trace, bit 0: where the call's time goes (microseconds since here, stderr)
+    const bool tr_on = (opt().trace & 1) != 0;
+    const auto tr_t0 = std::chrono::steady_clock::now();
+    auto tr_mark = [&](const char* what) {
+        if (tr_on) fprintf(stderr, "[trh msm] %9.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr_t0).count(), what);
+    };
     for (size_t t = 0; t < ntiles; ++t) {  // both device buffers at their final size before anything is in flight (a growing DevBuf frees)
         size_t longest = 0;
         for (size_t u = t & 1; u < ntiles; u += 2) longest = cut[u + 1] - cut[u] > longest ? cut[u + 1] - cut[u] : longest;
@@ -443,6 +450,7 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
             TRH_TRY(stage_h2d(c, st.ring_out[slot].p, bases_host + 8 * off, cur * 64, st.us, true));
         }
         TRH_HIP_TRY(hipEventRecord(st.ev_up[slot], st.us));
+        tr_mark("scalars handed to the upload stream");
         if (t > 0) {  // the previous range finished under this upload
             TRH_TRY(msm_finish(curve, st.cs, acc + 12, 1));
             TRH_TRY(point_sum_host(curve, acc, 2, acc));
@@ -454,8 +462,10 @@ int msm_host_tiled(int curve, const uint64_t* coeffs, const uint64_t* bases_host
         // 3 * 2^21 pairs); only a forced range length (TRH_HOST_TILE_LOG, a test switch) sends a tabled set down the per-window path
         const MsmFixedBase* fb = (!bases_host && ntiles == 1) ? fixed_base(res, offset, n) : nullptr;
         TRH_TRY(msm_enqueue(curve, bdev, bz, st.ring_in[slot].p, cur, 1, cur, mont, st.cs, fb));
+        tr_mark("MSM enqueued");
     }
     TRH_TRY(msm_finish(curve, st.cs, acc + 12, 1));
+    tr_mark("MSM finished");
     if (ntiles > 1) TRH_TRY(point_sum_host(curve, acc, 2, acc));
     memcpy(out, ntiles > 1 ? acc : acc + 12, 96);
     return scope.finish();

@@ -180,12 +180,15 @@ class CopyPool {
 // last bytes do (a download: the caller waits for the copy out of the last chunk; an upload whose host copies are the slower side).
 // The fill / drain of a 16 MiB ring cost 0.25 ms each on a 128 MiB best_fft; uniformly small slots lose to the per-slot hand-over.
 // No chunk is ever larger than a slot (TRH_STAGE_SLOT_MB may be as small as 1: slots no larger than the short chunk are not graded).
-inline void chunk_plan(size_t bytes, size_t slot, bool head, bool tail, std::vector<size_t>& out) {
+// tiny_tail (bytes, 0 = none): a last chunk of that size in front of everything else that is cut off the end -- for transfers whose zero chunks are
+// elided and whose last bytes are NOT zero (a witness column: zero padding, then a few blinding rows): the padding in front of it then elides whole.
+inline void chunk_plan(size_t bytes, size_t slot, bool head, bool tail, std::vector<size_t>& out, size_t tiny_tail = 0) {
     out.clear();
     if (!slot) return;
     const size_t small = (size_t)2 << 20, mid = (size_t)6 << 20;
     size_t left = bytes;
     std::vector<size_t> back;
+    if (tiny_tail && tiny_tail < slot && left > 4 * tiny_tail) { back.push_back(tiny_tail); left -= tiny_tail; }
     if (slot > small) {
         if (head && left > 2 * small) { out.push_back(small); left -= small; if (slot > mid && left > mid + small) { out.push_back(mid); left -= mid; } }
         if (tail && left > 2 * small) { back.push_back(small); left -= small; if (slot > mid && left > mid + small) { back.push_back(mid); left -= mid; } }

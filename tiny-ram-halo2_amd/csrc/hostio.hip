@@ -152,7 +152,7 @@ int stage_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStre
         // a lone transfer starts (and ends) with short chunks: the copy into slot i + 1 hides under the DMA of slot i, and nothing hides the
         // first copy; inside a batch the previous call's DMA is still running, so a transfer that fits one slot is not split
         std::vector<size_t> plan;
-        chunk_plan(bytes, st.slot, !part_of_batch, !part_of_batch && !head_only, plan);
+        chunk_plan(bytes, st.slot, !part_of_batch, !part_of_batch && !head_only, plan, (zero_elide && !part_of_batch) ? (size_t)256 << 10 : 0);
         size_t off = 0;
         for (const size_t cur : plan) {
             if (speculate && cur >= ((size_t)1 << 20) && probe_zero((const char*)src_host + off, cur)) {
